@@ -1,0 +1,139 @@
+/*
+ * ro_render.c -- CPU oracle (test infrastructure): mesh depth render + masked depth likelihood.
+ *
+ * The reference renders with OpenGL (SICAD::superimpose, src/roft-lib/src/SICAD.cpp:924-1066;
+ * projection :1634-1637; view :1723-1735 with the OpenGL->camera flip of ROFTFilter.cpp:198;
+ * fragment shader src/roft-lib/shader/shader_model.frag:30-52).  GL is not available here, so this
+ * is a restatement of the *contract* of that pipeline, not of a GPU driver's rasteriser:
+ *   - tile of (W/d) x (H/d) pixels, intrinsics divided by d (ROFTFilter.cpp:191-197);
+ *   - pixel (i, j) (column i, row j from the top) is sampled at its centre: the ray through
+ *     u = i + 0.5, v = j + 0.5 with u = fx X / Z + cx, v = fy Y / Z + cy (this is what the
+ *     projection matrix + vertical flip at SICAD.cpp:1052 amount to);
+ *   - value = eye-space Z of the nearest surface (depth test LESS, both faces, no culling,
+ *     SICAD.cpp:271-272), perspective-correct (1/Z interpolated linearly in screen space, which
+ *     is what linearising gl_FragCoord.z yields); background = 0;
+ *   - model matrix = translation * rotation(angle, axis) in float (SICAD.cpp:986-989).
+ * Deviations (documented, only silhouette pixels are affected): edges are inclusive instead of
+ * GL's top-left rule; triangles with a vertex at Z <= near (0.001) are dropped instead of clipped;
+ * depth-buffer quantisation is not modelled.
+ *
+ * All per-pixel arithmetic is IEEE float with a fixed operation order (build with
+ * -ffp-contract=off) so that an independent implementation following the same spec can be
+ * compared bit for bit.
+ *
+ * Likelihood: ROFTFilter::pick_best_alternative  src/roft-lib/src/ROFTFilter.cpp:553-577.
+ */
+#include "roft_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+void ro_render_depth(const ro_mesh* mesh, const double x[3], const double q[4],
+                     const ro_camera* cam, int divider, float* tile)
+{
+    const int w = cam->width / divider, h = cam->height / divider;
+    const float fx = (float)(cam->fx / divider), fy = (float)(cam->fy / divider);
+    const float cx = (float)(cam->cx / divider), cy = (float)(cam->cy / divider);
+    double Rd[9];
+    ro_quat_to_rotmat(q, Rd);
+    float R[9], t[3];
+    for (int i = 0; i < 9; i++) R[i] = (float)Rd[i];
+    for (int i = 0; i < 3; i++) t[i] = (float)x[i];
+
+    const size_t npix = (size_t)w * h;
+    for (size_t i = 0; i < npix; i++) tile[i] = INFINITY;
+
+    /* camera-frame vertices and their projections */
+    float* cam_z = (float*)malloc(sizeof(float) * mesh->n_verts);
+    float* sx = (float*)malloc(sizeof(float) * mesh->n_verts);
+    float* sy = (float*)malloc(sizeof(float) * mesh->n_verts);
+    for (int i = 0; i < mesh->n_verts; i++) {
+        const float* p = mesh->verts + (size_t)3 * i;
+        float X = ((R[0] * p[0] + R[1] * p[1]) + R[2] * p[2]) + t[0];
+        float Y = ((R[3] * p[0] + R[4] * p[1]) + R[5] * p[2]) + t[1];
+        float Z = ((R[6] * p[0] + R[7] * p[1]) + R[8] * p[2]) + t[2];
+        cam_z[i] = Z;
+        if (Z > 0.001f) {
+            sx[i] = (fx * X) / Z + cx;
+            sy[i] = (fy * Y) / Z + cy;
+        } else {
+            sx[i] = sy[i] = 0.0f;
+        }
+    }
+
+    for (int k = 0; k < mesh->n_tris; k++) {
+        const int32_t* tri = mesh->tris + (size_t)3 * k;
+        const int i0 = tri[0], i1 = tri[1], i2 = tri[2];
+        const float z0 = cam_z[i0], z1 = cam_z[i1], z2 = cam_z[i2];
+        if (!(z0 > 0.001f && z1 > 0.001f && z2 > 0.001f)) continue;
+        const float x0 = sx[i0], y0 = sy[i0], x1 = sx[i1], y1 = sy[i1], x2 = sx[i2], y2 = sy[i2];
+        const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+        if (area == 0.0f || !(area == area)) continue;
+        float minx = fminf(x0, fminf(x1, x2)), maxx = fmaxf(x0, fmaxf(x1, x2));
+        float miny = fminf(y0, fminf(y1, y2)), maxy = fmaxf(y0, fmaxf(y1, y2));
+        /* pixel centres i + 0.5 inside [min, max] */
+        float fi0 = ceilf(minx - 0.5f), fi1 = floorf(maxx - 0.5f);
+        float fj0 = ceilf(miny - 0.5f), fj1 = floorf(maxy - 0.5f);
+        if (fi0 < 0.0f) fi0 = 0.0f;
+        if (fj0 < 0.0f) fj0 = 0.0f;
+        if (fi1 > (float)(w - 1)) fi1 = (float)(w - 1);
+        if (fj1 > (float)(h - 1)) fj1 = (float)(h - 1);
+        if (!(fi0 <= fi1) || !(fj0 <= fj1)) continue;
+        const int ia = (int)fi0, ib = (int)fi1, ja = (int)fj0, jb = (int)fj1;
+        const float iz0 = 1.0f / z0, iz1 = 1.0f / z1, iz2 = 1.0f / z2;
+        for (int j = ja; j <= jb; j++) {
+            const float py = (float)j + 0.5f;
+            for (int i = ia; i <= ib; i++) {
+                const float px = (float)i + 0.5f;
+                /* edge functions; w_k is the weight of vertex k */
+                float w0 = (x2 - x1) * (py - y1) - (y2 - y1) * (px - x1);
+                float w1 = (x0 - x2) * (py - y2) - (y0 - y2) * (px - x2);
+                float w2 = (x1 - x0) * (py - y0) - (y1 - y0) * (px - x0);
+                int inside = (area > 0.0f) ? (w0 >= 0.0f && w1 >= 0.0f && w2 >= 0.0f)
+                                           : (w0 <= 0.0f && w1 <= 0.0f && w2 <= 0.0f);
+                if (!inside) continue;
+                float b0 = w0 / area, b1 = w1 / area, b2 = w2 / area;
+                float iz = (b0 * iz0 + b1 * iz1) + b2 * iz2;
+                float z = 1.0f / iz;
+                if (!(z > 0.0f)) continue;
+                float* dst = tile + (size_t)j * w + i;
+                if (z < *dst) *dst = z;
+            }
+        }
+    }
+    for (size_t i = 0; i < npix; i++)
+        if (tile[i] == INFINITY) tile[i] = 0.0f;
+    free(cam_z);
+    free(sx);
+    free(sy);
+}
+
+double ro_depth_likelihood(const ro_camera* cam, const float* depth, const uint8_t* mask,
+                           const float* tile, int divider, long* samples_out)
+{
+    const int W = cam->width, H = cam->height, w = W / divider;
+    double error = 0.0;
+    long samples = 0;
+    size_t rank = 0;
+    /* cv::findNonZero order, every second entry (`k += 2`, ROFTFilter.cpp:556) */
+    for (int v = 0; v < H; v++) {
+        for (int u = 0; u < W; u++) {
+            if (mask[(size_t)v * W + u] == 0) continue;
+            if ((rank & 1) == 0) {
+                float d = depth[(size_t)v * W + u];
+                float r = tile[(size_t)(v / divider) * w + (u / divider)];
+                if ((d > 0) && (d < 2.0) && (r != 0.0)) {
+                    error += fabsf(d - r);
+                    samples++;
+                }
+            }
+            rank++;
+        }
+    }
+    if (samples_out) *samples_out = samples;
+    if (samples == 0) return DBL_MAX;
+    /* outlier_rejection_gain_ is a `const bool` (ROFTFilter.h:64): 0.01 -> true -> 1.0 */
+    return (error / samples) / 1.0;
+}

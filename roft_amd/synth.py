@@ -1,0 +1,264 @@
+"""Seeded synthetic Fast-YCB / HO-3D shaped streams.
+
+Produces, per object, exactly what the reference's Dataset* sources hand to the tracker
+(App. B of SURVEY.md): depth frames (f32 metres, H x W), forward optical flow frames
+(CV_32FC2 grid 1 or CV_16SC2 S10.5 grid 4), segmentation masks and 6D pose measurements delivered
+on the reference's 5 fps / 6-frame-delay schedule
+(src/roft-lib/src/DatasetImageSegmentationDelayed.cpp:42-63), plus ground truth.
+
+Objects are boxes (ray/box intersection is analytic, so frames are generated with a handful of
+vectorised torch ops on CPU or GPU); the matching render mesh is a subdivided box of ~8k
+vertices / ~16k triangles like the reference's YCB meshes (src/roft-lib/meshes/DOPE/*.obj).
+torch is used here only as an array library.
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+FLOW_S16C2 = 11  # OpenCV type codes stored in the reference's .float flow files
+FLOW_F32C2 = 13
+
+CRACKER_BOX_HALF_EXTENTS = (0.082, 0.1065, 0.036)  # 003_cracker_box.obj extents / 2
+
+
+@dataclass
+class Camera:
+    width: int
+    height: int
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+
+    @staticmethod
+    def shape_a():  # 640x480, config/config_ho3d.cfg
+        return Camera(640, 480, 614.7142806307731, 614.7142806307731, 320.0, 240.0)
+
+    @staticmethod
+    def shape_b():  # 1280x720, config/config_fast_ycb.cfg:5-10
+        return Camera(1280, 720, 1229.4285612615463, 1229.4285612615463, 640.0, 360.0)
+
+    def scaled(self, s):
+        return Camera(self.width // s, self.height // s, self.fx / s, self.fy / s, self.cx / s, self.cy / s)
+
+
+def box_mesh(half_extents, n=36):
+    """Subdivided box: 6 faces x (n+1)^2 vertices, 12 n^2 triangles (n=36 -> 8214 / 15552)."""
+    hx, hy, hz = half_extents
+    verts, tris = [], []
+    lin = np.linspace(-1.0, 1.0, n + 1)
+    a, b = np.meshgrid(lin, lin, indexing="ij")
+    a, b = a.ravel(), b.ravel()
+    idx = np.arange((n + 1) * (n + 1)).reshape(n + 1, n + 1)
+    q = np.stack([idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()], 1)
+    face_tris = np.concatenate([q[:, [0, 1, 2]], q[:, [0, 2, 3]]], 0)
+    for axis in range(3):
+        for sgn in (-1.0, 1.0):
+            p = np.zeros((a.size, 3))
+            p[:, axis] = sgn
+            p[:, (axis + 1) % 3] = a
+            p[:, (axis + 2) % 3] = b
+            base = sum(v.shape[0] for v in verts)
+            verts.append(p * np.array([hx, hy, hz]))
+            tris.append(face_tris + base)
+    return np.concatenate(verts).astype(np.float32), np.concatenate(tris).astype(np.int32)
+
+
+def quat_mul(a, b):
+    w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3]
+    x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2]
+    y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1]
+    z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]
+    return np.array([w, x, y, z])
+
+
+def quat_exp(r):
+    n = np.linalg.norm(r)
+    if n == 0.0:
+        return np.array([1.0, 0.0, 0.0, 0.0])
+    return np.concatenate([[math.cos(n / 2)], math.sin(n / 2) * r / n])
+
+
+def quat_to_rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+@dataclass
+class Trajectory:
+    """Ground truth per frame: position x, quaternion q (w,x,y,z), twist [v_O, w] with v_O the
+    velocity of the object point instantaneously at the camera origin (the state of the
+    reference's velocity filter, cf. CartesianQuaternionMeasurement.cpp:410)."""
+    x: np.ndarray
+    q: np.ndarray
+    twist: np.ndarray
+
+
+def make_trajectory(seed, n_frames, dt=1.0 / 30.0, speed=1.0):
+    rng = np.random.default_rng(seed)
+    x0 = np.array([rng.uniform(-0.12, 0.12), rng.uniform(-0.08, 0.08), rng.uniform(0.6, 0.85)])
+    A = rng.uniform(0.03, 0.08, 3) * speed
+    f = rng.uniform(0.2, 0.6, 3)
+    ph = rng.uniform(0, 2 * math.pi, 3)
+    w0 = rng.uniform(0.3, 1.2, 3) * rng.choice([-1.0, 1.0], 3) * speed
+    fw = rng.uniform(0.15, 0.5, 3)
+    phw = rng.uniform(0, 2 * math.pi, 3)
+    q = quat_exp(rng.normal(0, 0.6, 3))
+
+    def omega(t):
+        return w0 * np.sin(2 * math.pi * fw * t + phw)
+
+    xs, qs, tw = [], [], []
+    for k in range(n_frames):
+        t = k * dt
+        x = x0 + A * np.sin(2 * math.pi * f * t + ph)
+        xd = A * 2 * math.pi * f * np.cos(2 * math.pi * f * t + ph)
+        w = omega(t)
+        xs.append(x)
+        qs.append(q / np.linalg.norm(q))
+        tw.append(np.concatenate([xd - np.cross(w, x), w]))
+        q = quat_mul(quat_exp(omega(t + dt / 2) * dt), q)
+    return Trajectory(np.array(xs), np.array(qs), np.array(tw))
+
+
+@dataclass
+class Stream:
+    camera: Camera
+    flow_type: int
+    flow_grid: int
+    flow_scale: float
+    half_extents: tuple
+    depth: torch.Tensor       # [F, H, W] f32
+    flow: torch.Tensor        # [F, H/g, W/g, 2] f32 | i16; frame 0 is absent (zeros, flow_valid[0]=0)
+    flow_valid: np.ndarray    # [F] bool
+    mask_gt: torch.Tensor     # [F, H, W] u8 {0,255}
+    mask_delivery: np.ndarray  # [F] int: index into mask_gt delivered at that frame, -1 = none
+    pose_valid: np.ndarray    # [F] bool
+    pose_meas: np.ndarray     # [F, 7] x, q(wxyz) (delayed content)
+    gt: Trajectory = None
+    dt: float = 1.0 / 30.0
+    mesh: tuple = field(default=None, repr=False)
+
+    @property
+    def n_frames(self):
+        return self.depth.shape[0]
+
+
+def _render_box(cam, half, x, R, device):
+    """Ray/box slab intersection.  Returns depth Z of the box surface [H, W] (inf = miss)."""
+    u = torch.arange(cam.width, device=device, dtype=torch.float64)
+    v = torch.arange(cam.height, device=device, dtype=torch.float64)
+    dx = ((u - cam.cx) / cam.fx)[None, :].expand(cam.height, cam.width)
+    dy = ((v - cam.cy) / cam.fy)[:, None].expand(cam.height, cam.width)
+    d = torch.stack([dx, dy, torch.ones_like(dx)], -1)           # camera-frame ray, d.z = 1
+    Rt = torch.as_tensor(R.T, device=device, dtype=torch.float64)
+    o = -(Rt @ torch.as_tensor(x, device=device, dtype=torch.float64))
+    dl = d @ Rt.T                                                 # R^T d
+    h = torch.as_tensor(half, device=device, dtype=torch.float64)
+    inv = 1.0 / torch.where(dl.abs() < 1e-12, torch.full_like(dl, 1e-12), dl)
+    t1 = (-h - o) * inv
+    t2 = (h - o) * inv
+    tn = torch.minimum(t1, t2).amax(-1)
+    tf = torch.maximum(t1, t2).amin(-1)
+    hit = (tn <= tf) & (tn > 1e-3)
+    return torch.where(hit, tn, torch.full_like(tn, float("inf")))
+
+
+def make_stream(seed, n_frames, camera=None, flow_type=FLOW_F32C2, half_extents=CRACKER_BOX_HALF_EXTENTS,
+                device="cpu", background_z=1.5, mask_period=6, pose_period=6, depth_noise=1e-3,
+                depth_dropout=0.02, flow_invalid=0.005, pose_noise_x=0.005, pose_noise_rot=math.radians(2.0),
+                pose_outlier_prob=0.10, pose_drop_prob=0.03, mask_dilate=1, speed=1.0, mesh_n=36):
+    cam = camera or Camera.shape_a()
+    dt = 1.0 / 30.0
+    gt = make_trajectory(seed, n_frames, dt, speed)
+    rng = np.random.default_rng(seed + 7919)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    H, W = cam.height, cam.width
+    grid = 4 if flow_type == FLOW_S16C2 else 1
+    scale = 32.0 if flow_type == FLOW_S16C2 else 1.0
+
+    depths, masks, flows = [], [], []
+    z_prev = None
+    for k in range(n_frames):
+        R = quat_to_rot(gt.q[k])
+        zb = _render_box(cam, half_extents, gt.x[k], R, device)
+        hit = torch.isfinite(zb)
+        z_clean = torch.where(hit, zb, torch.full_like(zb, background_z))
+        masks.append((hit.to(torch.uint8) * 255))
+        noise = torch.randn(H, W, generator=g, dtype=torch.float32).to(device) * depth_noise
+        drop = (torch.rand(H, W, generator=g) < depth_dropout).to(device)
+        depths.append(torch.where(drop, torch.zeros((), device=device), z_clean.float() + noise))
+
+        if k == 0:
+            flows.append(torch.zeros(H // grid, W // grid, 2, device=device,
+                                     dtype=torch.int16 if flow_type == FLOW_S16C2 else torch.float32))
+        else:
+            # forward flow of frame k-1 pixels: back-project with the clean depth of frame k-1,
+            # move object points rigidly with the GT motion, re-project.
+            zp, hp = z_prev
+            u = torch.arange(W, device=device, dtype=torch.float64)[None, :].expand(H, W)
+            v = torch.arange(H, device=device, dtype=torch.float64)[:, None].expand(H, W)
+            P = torch.stack([(u - cam.cx) / cam.fx * zp, (v - cam.cy) / cam.fy * zp, zp], -1)
+            Rp = torch.as_tensor(quat_to_rot(gt.q[k - 1]), device=device)
+            Rk = torch.as_tensor(R, device=device)
+            xp = torch.as_tensor(gt.x[k - 1], device=device)
+            xk = torch.as_tensor(gt.x[k], device=device)
+            Pn = (P - xp) @ Rp @ Rk.T + xk           # R_k R_{k-1}^T (P - x_{k-1}) + x_k
+            un = cam.fx * Pn[..., 0] / Pn[..., 2] + cam.cx
+            vn = cam.fy * Pn[..., 1] / Pn[..., 2] + cam.cy
+            fl = torch.stack([torch.where(hp, un - u, torch.zeros_like(u)),
+                              torch.where(hp, vn - v, torch.zeros_like(v))], -1).float()
+            if flow_type == FLOW_S16C2:
+                fl = fl[grid // 2::grid, grid // 2::grid]
+                fl = torch.clamp(torch.round(fl * scale), -32768, 32767).to(torch.int16)
+            else:
+                bad = torch.rand(H, W, generator=g).to(device)
+                fl = torch.where((bad < flow_invalid / 2)[..., None], torch.full_like(fl, float("nan")), fl)
+                fl = torch.where(((bad >= flow_invalid / 2) & (bad < flow_invalid))[..., None],
+                                 torch.full_like(fl, 1e10), fl)
+            flows.append(fl.contiguous())
+        z_prev = (z_clean, hit)
+
+    mask_gt = torch.stack(masks)
+    if mask_dilate > 0:  # crude segmentation noise: the network mask is a bit fatter than GT
+        k = 2 * mask_dilate + 1
+        mask_gt = torch.nn.functional.max_pool2d(mask_gt[:, None].float(), k, 1, mask_dilate)[:, 0].to(torch.uint8)
+
+    # delivery schedules: frame h delivers the content of frame max(h - D, 0) iff (h - D) % D == 0
+    mask_delivery = np.full(n_frames, -1, np.int64)
+    pose_valid = np.zeros(n_frames, bool)
+    pose_meas = np.zeros((n_frames, 7))
+    pose_meas[:, 3] = 1.0
+    for h in range(n_frames):
+        if mask_period > 0 and (h - mask_period) % mask_period == 0:
+            mask_delivery[h] = max(h - mask_period, 0)
+        if pose_period > 0 and (h - pose_period) % pose_period == 0:
+            src = max(h - pose_period, 0)
+            if h > 0 and rng.uniform() < pose_drop_prob:
+                continue  # dropped detection (all-zero row in poses.txt = invalid)
+            outlier = h > 0 and rng.uniform() < pose_outlier_prob
+            sx = 0.05 if outlier else pose_noise_x
+            sr = math.radians(30.0) if outlier else pose_noise_rot
+            xm = gt.x[src] + rng.normal(0, sx, 3)
+            qm = quat_mul(quat_exp(rng.normal(0, sr / math.sqrt(3), 3)), gt.q[src])
+            pose_valid[h] = True
+            pose_meas[h, :3] = xm
+            pose_meas[h, 3:] = qm / np.linalg.norm(qm)
+
+    flow_valid = np.ones(n_frames, bool)
+    flow_valid[0] = False
+    return Stream(cam, flow_type, grid, scale, tuple(half_extents), torch.stack(depths).contiguous(),
+                  torch.stack(flows).contiguous(), flow_valid, mask_gt.contiguous(), mask_delivery,
+                  pose_valid, pose_meas, gt, dt, box_mesh(half_extents, mesh_n))
+
+
+def initial_pose_from_stream(stream):
+    """The reference initialises the filter from the first DOPE pose (test/test.sh:120-123)."""
+    m = np.zeros(13)
+    m[6:9] = stream.pose_meas[0, :3]
+    m[9:13] = stream.pose_meas[0, 3:]
+    return m
