@@ -1,0 +1,230 @@
+/*
+ * roft_engine.h -- C ABI of the MI355X-native ROFT filtering engine (libroft_hip.so).
+ *
+ * This is the drop-in boundary for the per-frame filtering hot path of hsp-iit/roft
+ * (`src/roft-lib`).  Plain C types only: pointers, sizes, POD structs.  Every entry point returns
+ * an int status (ROFT_OK == 0, negative = error; nothing throws across the ABI) and
+ * roft_last_error_string() describes the last failure of the calling thread.
+ * Citations are relative to the reference checkout (hsp-iit/roft v1.2.1).
+ *
+ * Two levels:
+ *  (1) operator-level entry points -- one per reference operator, host buffers in / host buffers
+ *      out, used by the C++ facade classes in include/ROFT/ and by the parity tests:
+ *        roft_flow_measurement   <- ImageOpticalFlowMeasurement<T>::freeze
+ *                                   include/ROFT/ImageOpticalFlowMeasurement.hpp:231-283
+ *        roft_kf_predict         <- bfl::KFPrediction over SpatialVelocityModel
+ *                                   src/roft-lib/src/SpatialVelocityModel.cpp:15-27
+ *        roft_skf_correct        <- SKFCorrection::correctStep  src/roft-lib/src/SKFCorrection.cpp:37-153
+ *        roft_mask_propagate     <- ImageSegmentationOFAidedSource<T>::map + cv::remap
+ *                                   include/ROFT/ImageSegmentationOFAidedSource.hpp:215,225,234-281
+ *        roft_ukf_predict        <- bfl::UKFPrediction over CartesianQuaternionModel::motion
+ *                                   src/roft-lib/src/CartesianQuaternionModel.cpp:86-141
+ *        roft_ukf_correct        <- ROFT::UKFCorrection::correctStep over CartesianQuaternionMeasurement
+ *                                   src/roft-lib/src/UKFCorrection.cpp:54-133,
+ *                                   src/roft-lib/src/CartesianQuaternionMeasurement.cpp:357-487
+ *        roft_render_depth       <- SICAD::superimpose(poses, ..., depth)  src/roft-lib/src/SICAD.cpp:924-1066
+ *        roft_depth_likelihood   <- ROFTFilter::pick_best_alternative inner loop
+ *                                   src/roft-lib/src/ROFTFilter.cpp:553-577
+ *  (2) the batched engine -- ROFTFilter::filtering_step (src/roft-lib/src/ROFTFilter.cpp:255-452)
+ *      for many objects at once with all filter state resident in HBM:
+ *        roft_engine_create / roft_object_add / roft_frame_submit / roft_step / roft_get_state.
+ */
+#ifndef ROFT_ENGINE_H
+#define ROFT_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ROFT_OK 0
+#define ROFT_ERR_INVALID (-1)  /* bad argument */
+#define ROFT_ERR_DEVICE (-2)   /* HIP runtime error / no device */
+#define ROFT_ERR_CAPACITY (-3) /* caller buffer too small */
+#define ROFT_ERR_STATE (-4)    /* call order violated */
+
+/* OpenCV matrix type codes of the reference's .float flow files
+ * (src/roft-lib/src/OpticalFlowUtilities.cpp:38-62) */
+#define ROFT_FLOW_S16C2 11 /* CV_16SC2: S10.5 fixed point, scale 32, grid 4 (NVOF 1.0) */
+#define ROFT_FLOW_F32C2 13 /* CV_32FC2: float pixels, grid 1 (NVOF 2.0) */
+
+/* measurement types of CartesianQuaternionMeasurement (CartesianQuaternionMeasurement.h:54) */
+#define ROFT_MEAS_NONE 0
+#define ROFT_MEAS_VELOCITY 1
+#define ROFT_MEAS_POSE 2
+#define ROFT_MEAS_POSE_VELOCITY 3
+
+/* memory kind of image pointers handed to the engine */
+#define ROFT_MEM_HOST 0
+#define ROFT_MEM_DEVICE 1
+
+typedef struct {
+    int width, height;
+    double fx, fy, cx, cy;
+} roft_camera;
+
+typedef struct {
+    const void* data; /* rows*cols interleaved (dx,dy), row-major */
+    int type;         /* ROFT_FLOW_* */
+    int cols, rows;
+    int grid;    /* image width / cols (DatasetImageOpticalFlow.cpp:46) */
+    float scale; /* 32 for S16C2 else 1 (DatasetImageOpticalFlow.cpp:48-50) */
+    int valid;
+} roft_flow;
+
+typedef struct {
+    double alpha, beta, kappa;
+} roft_ut_params;
+
+typedef struct {
+    const float* verts; /* n_verts x 3 (object frame, metres) */
+    int n_verts;
+    const int32_t* tris; /* n_tris x 3 */
+    int n_tris;
+} roft_mesh;
+
+const char* roft_last_error_string(void);
+/* number of visible HIP devices (0 when there is none); never fails */
+int roft_device_count(void);
+
+/* ---- (1) operator level: host buffers, device 0 ----------------------------------------- */
+
+/* uv: 2 ints per kept point (u, v); y: 2N; H: 2N x 6 row-major; *n_out = N.
+ * ROFT_ERR_CAPACITY if more than `capacity` points are kept. */
+int roft_flow_measurement(const roft_camera* cam, const uint8_t* prev_mask, const float* prev_depth,
+                          const roft_flow* flow, double dt, float radius, double depth_max,
+                          int capacity, int32_t* uv, double* y, double* H, int* n_out);
+
+int roft_kf_predict(const double x[6], const double P[36], const double Qdiag[6], double x_out[6],
+                    double P_out[36]);
+
+/* *status_out: 0 corrected, 1 measurement empty (corr = pred, SKFCorrection.cpp:61-69) */
+int roft_skf_correct(const double x_pred[6], const double P_pred[36], int N, const double* y,
+                     const double* H, const double Rdiag[2], int reweight, double x_out[6],
+                     double P_out[36], int* status_out);
+
+/* mask (W*H u8) is propagated in place through flows[0..n_flows) (chronological); only the last
+ * `frames_between` flows are used when frames_between > 0. */
+int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int n_flows,
+                        int frames_between);
+
+int roft_pose_process_noise(const double psd_lin_acc[3], const double sigma_ang_vel[3], double T,
+                            double Q[81]);
+int roft_ukf_predict(const double mean[13], const double P[144], const double Q[81], double T,
+                     const roft_ut_params* ut, double mean_out[13], double P_out[144]);
+/* meas: [v w] | [x q] | [v w x q] with q = (w,x,y,z); Rdiag in the same order.
+ * *status_out: 0 corrected, 1 no measurement, 2 singular innovation covariance (corr = pred) */
+int roft_ukf_correct(const double mean[13], const double P[144], int type, const double* meas,
+                     const double* Rdiag, const roft_ut_params* ut, double mean_out[13],
+                     double P_out[144], int* status_out);
+
+/* tile: (H/divider) x (W/divider) float, 0 = background */
+int roft_render_depth(const roft_mesh* mesh, const double x[3], const double q[4],
+                      const roft_camera* cam, int divider, float* tile);
+/* *L_out = mean |depth - render| over every second mask pixel, DBL_MAX if no sample */
+int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint8_t* mask,
+                          const float* tile, int divider, double* L_out, long* samples_out);
+
+/* ---- (2) batched engine --------------------------------------------------------------------- */
+
+typedef struct roft_engine roft_engine;
+
+/* Mirrors the keys of config/config_fast_ycb.cfg consumed by ROFTFilter's constructor
+ * (src/roft-lib/src/ROFTFilter.cpp:32-201, wiring src/roft/src/main.cpp:286-325). */
+typedef struct {
+    roft_camera cam;
+    int flow_type;  /* ROFT_FLOW_* of every flow frame of this engine */
+    int flow_grid;
+    float flow_scale;
+    double sample_time;
+    roft_ut_params ut;
+    double depth_maximum;       /* measurement_model.velocity.depth_maximum */
+    double subsampling_radius;  /* measurement_model.velocity.subsampling_radius */
+    int flow_weighting;         /* measurement_model.velocity.weight_flow */
+    int use_pose, use_pose_resync, use_velocity; /* measurement_model.use_* */
+    int outlier_rejection;                       /* outlier_rejection.enable */
+    int flow_aided_segmentation;                 /* segmentation_dataset.flow_aided */
+    int mask_frames_between;                     /* original_fps / desired_fps of the mask source */
+    int pose_frames_between;                     /* original_fps / desired_fps of the pose source */
+    int max_objects;
+    int device;                                  /* HIP device ordinal */
+} roft_config;
+
+typedef struct {
+    double p_mean0[13];     /* v w x q(wxyz): initial_condition.pose */
+    double p_cov0_diag[12];
+    double v_mean0[6];      /* initial_condition.velocity */
+    double v_cov0_diag[6];
+    double p_sigma_ang_vel[3]; /* kinematic_model.pose.sigma_angular */
+    double p_psd_lin_acc[3];   /* kinematic_model.pose.sigma_linear  */
+    double v_q_diag[6];        /* kinematic_model.velocity.{sigma_linear, sigma_angular} */
+    double p_meas_cov_v[3], p_meas_cov_w[3], p_meas_cov_x[3], p_meas_cov_q[3];
+    double v_meas_cov_flow[2];
+    roft_mesh mesh;            /* host pointers; copied */
+} roft_object_desc;
+
+/* One object's inputs for one frame.  Image pointers are HOST or DEVICE memory according to
+ * mem_kind.  DEVICE buffers are used in place (zero copy) and must stay valid and unmodified for
+ * the next ROFT_RETAIN_FRAMES steps (previous depth, buffered flows and the outlier-rejection
+ * features of ROFTFilter.cpp:624-646 are references into them).  HOST buffers are copied into the
+ * engine's own ring before roft_frame_submit returns. */
+#define ROFT_RETAIN_FRAMES 8
+typedef struct {
+    double dt;            /* RGB stamp delta; <= 0 means cfg.sample_time */
+    const float* depth;   /* H x W metres, 0 = invalid; required */
+    const void* flow;     /* flow frame or NULL when absent (first frame) */
+    const uint8_t* mask;  /* newly delivered mask or NULL */
+    int pose_valid;       /* newly delivered pose measurement? */
+    double pose_x[3];
+    double pose_q[4];     /* (w,x,y,z) */
+    int mem_kind;
+} roft_frame_input;
+
+typedef struct {
+    double pose[13];   /* v w x q */
+    double twist[6];   /* v_O, w */
+    int n_flow_points; /* N of the velocity stage, -1 if it did not run */
+    int outlier_selected; /* -1 no test this frame, 0 pose+velocity kept, 1 velocity-only chosen */
+    double outlier_L[2];
+} roft_object_output;
+
+int roft_default_config(roft_config* cfg, int width, int height, int flow_type);
+int roft_default_object(roft_object_desc* obj);
+
+int roft_engine_create(const roft_config* cfg, roft_engine** out);
+int roft_engine_destroy(roft_engine* e);
+int roft_object_add(roft_engine* e, const roft_object_desc* desc, int* obj_id);
+
+/* inputs: one entry per object, in obj_id order.  Enqueues uploads and builds the frame program. */
+int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inputs);
+/* Enqueues every kernel of ROFTFilter::filtering_step for all objects; returns without waiting. */
+int roft_step(roft_engine* e);
+int roft_sync(roft_engine* e);
+/* Blocks until the last step has finished.  Any of the output pointers may be NULL. */
+int roft_get_state(roft_engine* e, int obj_id, double pose13[13], double P12[144], double twist6[6],
+                   double Pv[36]);
+/* outputs of the last finished step for all objects (n_objects entries) */
+int roft_get_outputs(roft_engine* e, roft_object_output* outs, int n_outs);
+/* current propagated, binarised mask (H*W u8, {0,255}) of one object -> host buffer */
+int roft_get_mask(roft_engine* e, int obj_id, uint8_t* mask_out);
+
+/* Device-side log of the per-frame outputs (what ROFTFilter logs per frame, ROFTFilter.cpp:386-394):
+ * a ring of n_frames x n_objects records written by the step itself, read back in one copy. */
+int roft_engine_enable_log(roft_engine* e, int n_frames);
+int roft_engine_get_log(roft_engine* e, int first_frame, int n_frames, roft_object_output* outs);
+
+/* HIP stream the engine enqueues on (as void*), for timing with hipEvents */
+void* roft_engine_stream(roft_engine* e);
+
+/* Per-kernel timing of the last roft_step, measured with HIP events on the engine's stream when
+ * enabled (adds event records between launches).  names/ms arrays are owned by the engine. */
+int roft_engine_enable_timing(roft_engine* e, int enable);
+int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, const float** ms_out,
+                           const int** launches_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

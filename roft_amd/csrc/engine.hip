@@ -1,0 +1,1146 @@
+// engine.hip -- host side of libroft_hip.so: the C ABI of include/roft_engine.h.
+//
+// (2) the batched engine mirrors ROFTFilter::filtering_step (src/roft-lib/src/ROFTFilter.cpp:255-452)
+//     as a per-frame *program*: the data-dependent control flow of the reference that depends only
+//     on the delivery schedule (is a pose / mask / flow present this frame, how many buffered
+//     velocities are replayed by the re-sync, ROFTFilter.cpp:327-367 and
+//     CartesianQuaternionMeasurement.cpp:92-348) is resolved here on the host into one FrameCtrl
+//     block per object; everything that depends on image content or filter state (is the new mask
+//     empty, N < 3, the outlier decision) is resolved inside the kernels.  A frame is therefore one
+//     small H2D copy plus a fixed sequence of batched launches on one HIP stream, no D2H sync.
+// (1) the operator-level entry points run the same kernels on a private one-object context.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "roft_device.h"
+
+using namespace roft;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                      \
+    do {                                                                                                   \
+        hipError_t _e = (expr);                                                                            \
+        if (_e != hipSuccess)                                                                              \
+            return fail(ROFT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t ensure(size_t count, bool zero = false)
+    {
+        if (count <= n && p) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), std::max<size_t>(count, 1) * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return e; }
+        n = count;
+        if (zero) e = hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T));
+        return e;
+    }
+};
+
+size_t flow_bytes(const DevFlowFmt& f)
+{
+    return (size_t)f.cols * f.rows * 2 * (f.type == ROFT_FLOW_S16C2 ? sizeof(int16_t) : sizeof(float));
+}
+
+DevCamera make_cam(const roft_camera& c)
+{
+    DevCamera d;
+    d.W = c.width;
+    d.H = c.height;
+    d.wpr = c.width / 32;
+    d.divider = (c.width == 640) ? 2 : 4;  // ROFTFilter.cpp:191-193
+    d.fx = c.fx; d.fy = c.fy; d.cx = c.cx; d.cy = c.cy;
+    return d;
+}
+
+int check_geometry(int W, int H)
+{
+    if (W <= 0 || H <= 0 || (W % 32) != 0 || (((size_t)W * H) % 64) != 0)
+        return fail(ROFT_ERR_INVALID, "image width must be a multiple of 32 and width*height a multiple of 64");
+    if ((size_t)W * H >= (1u << 24))
+        return fail(ROFT_ERR_INVALID, "width*height must be < 2^24 (float-accumulated sampling index, hpp:237)");
+    if ((size_t)(W / 32) * H * 4 + (H + 1) * 4 + 64 > 160 * 1024 - 256)
+        return fail(ROFT_ERR_INVALID, "mask bit plane does not fit the 160 KiB LDS of a CU");
+    return ROFT_OK;
+}
+
+// Device arrays for n objects of one geometry
+struct Arrays {
+    EngineArrays a{};
+    DevBuf<ObjParams> params;
+    DevBuf<ObjState> state;
+    DevBuf<FrameCtrl> ctrl;
+    DevBuf<uint32_t> planes;
+    DevBuf<int32_t> map;
+    DevBuf<FlowRec> cand, recs;
+    DevBuf<double> norms;
+    DevBuf<uint32_t> feat_pix;
+    DevBuf<float> feat_depth;
+    DevBuf<uint32_t> zbuf;
+    DevBuf<roft_object_output> log;
+
+    int alloc(int n_obj, const DevCamera& cam, const DevFlowFmt& ffmt, int radius)
+    {
+        a.n_obj = n_obj;
+        a.cam = cam;
+        a.ffmt = ffmt;
+        a.plane_words = (size_t)cam.wpr * cam.H;
+        const size_t npix = (size_t)cam.W * cam.H;
+        a.cand_cap = (int)((npix + radius - 1) / std::max(radius, 1)) + 8;
+        a.feat_cap = (int)(npix / 2 + 8);
+        a.tile_w = cam.W / cam.divider;
+        a.tile_h = cam.H / cam.divider;
+        HIP_TRY(params.ensure(n_obj, true));
+        HIP_TRY(state.ensure(n_obj, true));
+        HIP_TRY(ctrl.ensure(n_obj, true));
+        HIP_TRY(planes.ensure((size_t)n_obj * (kPlaneSlots + 2) * 2 * a.plane_words, true));
+        HIP_TRY(map.ensure((size_t)n_obj * npix, true));
+        HIP_TRY(cand.ensure((size_t)n_obj * a.cand_cap));
+        HIP_TRY(recs.ensure((size_t)n_obj * a.cand_cap));
+        HIP_TRY(norms.ensure((size_t)n_obj * a.cand_cap));
+        HIP_TRY(feat_pix.ensure((size_t)n_obj * a.feat_cap));
+        HIP_TRY(feat_depth.ensure((size_t)n_obj * a.feat_cap));
+        HIP_TRY(zbuf.ensure((size_t)n_obj * 2 * a.tile_w * a.tile_h));
+        a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
+        a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
+        a.zbuf = zbuf.p;
+        a.out_log = nullptr;
+        a.log_cap = 0;
+        a.max_tris = 0;
+        return ROFT_OK;
+    }
+};
+
+void init_state(ObjState& st)
+{
+    std::memset(&st, 0, sizeof(st));
+    st.bbox[0] = INT32_MAX; st.bbox[1] = INT32_MAX; st.bbox[2] = -1; st.bbox[3] = -1;
+    st.n_flow_points = -1;
+    st.outlier_selected = -1;
+}
+
+void clear_ctrl(FrameCtrl& c)
+{
+    std::memset(&c, 0, sizeof(c));
+    c.outlier_step = -1;
+}
+
+}  // namespace
+
+// =================================================================================================
+// batched engine
+// =================================================================================================
+
+struct HostObject {
+    // schedule-driven mirrors of the reference's source / measurement-model state machines
+    int frame_idx = 0;
+    bool seg_available = false;        // ImageSegmentationOFAidedSource::segmentation_available_
+    bool of_first_frame = true;        // ...::is_first_frame_
+    bool flow_first_frame = true;      // ImageOpticalFlowMeasurement::is_first_frame_
+    bool features_initialized = false; // ROFTFilter::outlier_rejection_features_initialized_
+    std::deque<const void*> flow_hist; // last valid flows, newest at front
+    std::deque<int> vel_buf;           // twist_hist slots (CartesianQuaternionMeasurement::buffer_velocities_)
+    int last_meas_slot = 0;            // slot of measurement_.head<6>()
+    const float* depth_prev = nullptr;
+    // engine-owned copies of HOST inputs
+    DevBuf<float> depth_ring[kPlaneSlots];
+    DevBuf<unsigned char> flow_ring[kPlaneSlots];
+    DevBuf<uint8_t> mask_stage;
+    DevBuf<float> verts;
+    DevBuf<int32_t> tris;
+};
+
+struct roft_engine {
+    roft_config cfg{};
+    Arrays arr;
+    hipStream_t stream = nullptr;
+    std::vector<HostObject*> objs;
+    std::vector<ObjParams> h_params;
+    // pinned staging ring for FrameCtrl blocks
+    static constexpr int kStage = 8;
+    FrameCtrl* stage[kStage] = {};
+    hipEvent_t stage_ev[kStage] = {};
+    int stage_idx = 0;
+    FrameCtrl* cur = nullptr;  // staging block of the submitted, not yet stepped frame
+    bool submitted = false;
+    int max_steps = 0;
+    bool any_new_mask = false, any_outlier = false, any_feat0 = false, any_feat1 = false;
+    int frame_counter = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> tev;
+    std::vector<std::string> tnames_s;
+    std::vector<const char*> tnames;
+    std::vector<float> tms;
+    std::vector<int> tlaunches;
+    std::vector<int> tmark;  // kernel id per event interval
+};
+
+extern "C" {
+
+const char* roft_last_error_string(void) { return g_last_error.c_str(); }
+
+int roft_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int roft_default_config(roft_config* c, int width, int height, int flow_type)
+{
+    if (!c) return fail(ROFT_ERR_INVALID, "null config");
+    std::memset(c, 0, sizeof(*c));
+    c->cam.width = width;
+    c->cam.height = height;
+    if (width == 640) {  // config/config_ho3d.cfg shape (fx..cy are read from cam_K.json there)
+        c->cam.fx = c->cam.fy = 614.7142806307731;
+        c->cam.cx = 320.0; c->cam.cy = 240.0;
+    } else {             // config/config_fast_ycb.cfg:5-10
+        c->cam.fx = c->cam.fy = 1229.4285612615463 * width / 1280.0;
+        c->cam.cx = width / 2.0; c->cam.cy = height / 2.0;
+    }
+    c->flow_type = flow_type;
+    c->flow_grid = (flow_type == ROFT_FLOW_S16C2) ? 4 : 1;
+    c->flow_scale = (flow_type == ROFT_FLOW_S16C2) ? 32.0f : 1.0f;
+    c->sample_time = 1.0 / 30.0;
+    c->ut.alpha = 1.0; c->ut.beta = 2.0; c->ut.kappa = 0.0;
+    c->depth_maximum = 2.0;
+    c->subsampling_radius = 35.0;
+    c->flow_weighting = 1;
+    c->use_pose = c->use_pose_resync = c->use_velocity = 1;
+    c->outlier_rejection = 1;
+    c->flow_aided_segmentation = 1;
+    c->mask_frames_between = 6;
+    c->pose_frames_between = 6;
+    c->max_objects = 64;
+    c->device = 0;
+    return ROFT_OK;
+}
+
+int roft_default_object(roft_object_desc* o)
+{
+    if (!o) return fail(ROFT_ERR_INVALID, "null object");
+    std::memset(o, 0, sizeof(*o));
+    o->p_mean0[9] = 1.0;
+    for (int i = 0; i < 12; ++i) o->p_cov0_diag[i] = 1e-3;
+    for (int i = 0; i < 6; ++i) { o->v_cov0_diag[i] = 1e-3; o->v_q_diag[i] = 0.1; }
+    for (int i = 0; i < 3; ++i) {
+        o->p_sigma_ang_vel[i] = 1.0;  // test/test.sh:70
+        o->p_psd_lin_acc[i] = 1.0;
+        o->p_meas_cov_v[i] = 0.1;
+        o->p_meas_cov_w[i] = 1e-4;
+        o->p_meas_cov_x[i] = 1e-3;
+        o->p_meas_cov_q[i] = 1e-4;    // test/test.sh:71
+    }
+    o->v_meas_cov_flow[0] = o->v_meas_cov_flow[1] = 1.0;
+    return ROFT_OK;
+}
+
+int roft_engine_create(const roft_config* cfg, roft_engine** out)
+{
+    if (!cfg || !out) return fail(ROFT_ERR_INVALID, "null argument");
+    if (roft_device_count() <= cfg->device) return fail(ROFT_ERR_DEVICE, "no such HIP device (the engine has no CPU path)");
+    if (int rc = check_geometry(cfg->cam.width, cfg->cam.height)) return rc;
+    if (cfg->max_objects <= 0) return fail(ROFT_ERR_INVALID, "max_objects must be positive");
+    if (cfg->flow_type != ROFT_FLOW_S16C2 && cfg->flow_type != ROFT_FLOW_F32C2)
+        return fail(ROFT_ERR_INVALID, "flow_type must be ROFT_FLOW_S16C2 or ROFT_FLOW_F32C2");
+    if (cfg->flow_grid <= 0 || cfg->cam.width % cfg->flow_grid) return fail(ROFT_ERR_INVALID, "bad flow grid");
+    if (cfg->mask_frames_between > kMaxFlowHist)
+        return fail(ROFT_ERR_INVALID, "mask_frames_between > 6 is not supported");
+    if (cfg->pose_frames_between + 2 > kTwistRing) return fail(ROFT_ERR_INVALID, "pose_frames_between too large");
+    HIP_TRY(hipSetDevice(cfg->device));
+    roft_engine* e = new roft_engine();
+    e->cfg = *cfg;
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    DevFlowFmt ff;
+    ff.type = cfg->flow_type;
+    ff.grid = cfg->flow_grid;
+    ff.cols = cfg->cam.width / cfg->flow_grid;
+    ff.rows = cfg->cam.height / cfg->flow_grid;
+    ff.scale = cfg->flow_scale;
+    const int radius = (int)(size_t)cfg->subsampling_radius;
+    if (radius <= 0) { delete e; return fail(ROFT_ERR_INVALID, "subsampling_radius must be >= 1"); }
+    if (int rc = e->arr.alloc(cfg->max_objects, make_cam(cfg->cam), ff, radius)) { delete e; return rc; }
+    e->arr.a.n_obj = 0;
+    for (int i = 0; i < roft_engine::kStage; ++i) {
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects));
+        HIP_TRY(hipEventCreateWithFlags(&e->stage_ev[i], hipEventDisableTiming));
+    }
+    e->h_params.resize(cfg->max_objects);
+    *out = e;
+    return ROFT_OK;
+}
+
+int roft_engine_destroy(roft_engine* e)
+{
+    if (!e) return ROFT_OK;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto* o : e->objs) delete o;
+    for (int i = 0; i < roft_engine::kStage; ++i) {
+        if (e->stage[i]) (void)hipHostFree(e->stage[i]);
+        if (e->stage_ev[i]) (void)hipEventDestroy(e->stage_ev[i]);
+    }
+    for (auto ev : e->tev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return ROFT_OK;
+}
+
+int roft_object_add(roft_engine* e, const roft_object_desc* d, int* obj_id)
+{
+    if (!e || !d) return fail(ROFT_ERR_INVALID, "null argument");
+    if ((int)e->objs.size() >= e->cfg.max_objects) return fail(ROFT_ERR_CAPACITY, "max_objects reached");
+    if (e->frame_counter > 0) return fail(ROFT_ERR_STATE, "objects must be added before the first frame");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int id = (int)e->objs.size();
+    HostObject* o = new HostObject();
+    ObjParams& p = e->h_params[id];
+    std::memset(&p, 0, sizeof(p));
+    for (int i = 0; i < 3; ++i) {
+        p.sigma_ang_vel[i] = d->p_sigma_ang_vel[i];
+        p.psd_lin_acc[i] = d->p_psd_lin_acc[i];
+        p.R_v[i] = d->p_meas_cov_v[i]; p.R_w[i] = d->p_meas_cov_w[i];
+        p.R_x[i] = d->p_meas_cov_x[i]; p.R_q[i] = d->p_meas_cov_q[i];
+    }
+    for (int i = 0; i < 6; ++i) p.v_q[i] = d->v_q_diag[i];
+    p.r_flow[0] = d->v_meas_cov_flow[0];
+    p.r_flow[1] = d->v_meas_cov_flow[1];
+    if (d->mesh.n_verts > 0 && d->mesh.n_tris > 0) {
+        HIP_TRY(o->verts.ensure((size_t)3 * d->mesh.n_verts));
+        HIP_TRY(o->tris.ensure((size_t)3 * d->mesh.n_tris));
+        HIP_TRY(hipMemcpy(o->verts.p, d->mesh.verts, sizeof(float) * 3 * d->mesh.n_verts, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(o->tris.p, d->mesh.tris, sizeof(int32_t) * 3 * d->mesh.n_tris, hipMemcpyHostToDevice));
+        p.verts = o->verts.p; p.tris = o->tris.p;
+        p.n_verts = d->mesh.n_verts; p.n_tris = d->mesh.n_tris;
+        e->arr.a.max_tris = std::max(e->arr.a.max_tris, d->mesh.n_tris);
+    } else if (e->cfg.outlier_rejection && e->cfg.use_pose) {
+        delete o;
+        return fail(ROFT_ERR_INVALID, "outlier rejection needs a mesh");
+    }
+    HIP_TRY(hipMemcpy(e->arr.params.p + id, &p, sizeof(p), hipMemcpyHostToDevice));
+    // initialization_step (ROFTFilter.cpp:216-237)
+    ObjState* st = new ObjState();
+    init_state(*st);
+    for (int i = 0; i < 6; ++i) { st->v_mean[i] = d->v_mean0[i]; st->v_cov[i * 6 + i] = d->v_cov0_diag[i]; }
+    PoseBelief b{};
+    for (int i = 0; i < 13; ++i) b.mean[i] = d->p_mean0[i];
+    for (int i = 0; i < 12; ++i) b.cov[i * 12 + i] = d->p_cov0_diag[i];
+    st->belief[B_CORR] = b;
+    st->belief[B_PRED] = b;
+    st->belief[B_BUF] = b;
+    hipError_t err = hipMemcpy(e->arr.state.p + id, st, sizeof(ObjState), hipMemcpyHostToDevice);
+    delete st;
+    HIP_TRY(err);
+    e->objs.push_back(o);
+    e->arr.a.n_obj = (int)e->objs.size();
+    if (obj_id) *obj_id = id;
+    return ROFT_OK;
+}
+
+static void build_pose_program(roft_engine* e, HostObject& o, const roft_frame_input& in, FrameCtrl& c)
+{
+    const roft_config& cfg = e->cfg;
+    const int slot = o.frame_idx % kTwistRing;
+    c.twist_slot = slot;
+    int n = 0;
+    auto add = [&](StepDesc sd) { if (n < kMaxSteps) c.steps[n++] = sd; };
+
+    // CartesianQuaternionMeasurement::freeze(Standard)  (cpp:176-347)
+    const bool has_vel = cfg.use_velocity != 0;
+    const bool is_pose = cfg.use_pose && in.pose_valid;
+    int type = ROFT_MEAS_NONE;
+    if (has_vel && is_pose) type = ROFT_MEAS_POSE_VELOCITY;
+    else if (has_vel) type = ROFT_MEAS_VELOCITY;
+    else if (is_pose) type = ROFT_MEAS_POSE;
+    if (has_vel) {
+        o.vel_buf.push_back(slot);
+        while ((int)o.vel_buf.size() > kTwistRing - 2) o.vel_buf.pop_front();  // only the last D+1 are ever used
+        o.last_meas_slot = slot;
+    }
+    for (int i = 0; i < 3; ++i) c.pose_x[i] = in.pose_x[i];
+    for (int i = 0; i < 4; ++i) c.pose_q[i] = in.pose_q[i];
+
+    StepDesc sd{};
+    sd.op = 1;
+    sd.src = B_CORR;
+    sd.do_predict = 1;
+    sd.twist_slot = slot;
+    if (type == ROFT_MEAS_POSE_VELOCITY) {
+        if (cfg.use_pose_resync) {
+            // ROFTFilter.cpp:331-354: roll back to the belief buffered at the previous pose arrival and
+            // replay the buffered velocities (PopBufferedMeasurement, cpp:97-154)
+            bool first = true;
+            bool pose_pending = true;
+            for (;;) {
+                if (cfg.pose_frames_between > 0)
+                    while ((int)o.vel_buf.size() > cfg.pose_frames_between + 1) o.vel_buf.pop_front();
+                if (o.vel_buf.empty()) { o.vel_buf.push_back(o.last_meas_slot); break; }
+                const int ts = o.vel_buf.front();
+                o.vel_buf.pop_front();
+                o.last_meas_slot = ts;
+                StepDesc r{};
+                r.op = 1;
+                r.do_predict = 1;
+                r.twist_slot = ts;
+                r.src = first ? B_BUF : B_CORR;
+                r.save_corr_to_buf = first ? 1 : 0;
+                if (pose_pending) {
+                    pose_pending = false;
+                    if (cfg.outlier_rejection) {
+                        r.n_corr = 2;
+                        r.type[0] = ROFT_MEAS_POSE_VELOCITY; r.dst[0] = B_ALT0;
+                        r.type[1] = ROFT_MEAS_VELOCITY;      r.dst[1] = B_ALT1;
+                        c.outlier_step = n;
+                    } else {
+                        r.n_corr = 1;
+                        r.type[0] = ROFT_MEAS_POSE_VELOCITY; r.dst[0] = B_CORR;
+                    }
+                } else {
+                    r.n_corr = 1;
+                    r.type[0] = ROFT_MEAS_VELOCITY; r.dst[0] = B_CORR;
+                }
+                add(r);
+                first = false;
+            }
+            c.buffer_features_after = 1;
+        } else {
+            if (cfg.outlier_rejection) {
+                sd.n_corr = 2;
+                sd.type[0] = ROFT_MEAS_POSE_VELOCITY; sd.dst[0] = B_ALT0;
+                sd.type[1] = ROFT_MEAS_VELOCITY;      sd.dst[1] = B_ALT1;
+                c.outlier_step = n;
+                c.features_current = 1;
+            } else {
+                sd.n_corr = 1;
+                sd.type[0] = ROFT_MEAS_POSE_VELOCITY; sd.dst[0] = B_CORR;
+            }
+            add(sd);
+        }
+    } else if (type != ROFT_MEAS_NONE) {
+        sd.n_corr = 1;
+        sd.type[0] = type; sd.dst[0] = B_CORR;
+        add(sd);
+    } else {
+        sd.n_corr = 0;  // p_corr = p_pred (ROFTFilter.cpp:366-367)
+        sd.dst[0] = B_CORR;
+        add(sd);
+    }
+    c.n_steps = n;
+}
+
+int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inputs)
+{
+    if (!e || !inputs) return fail(ROFT_ERR_INVALID, "null argument");
+    if (n_inputs != (int)e->objs.size()) return fail(ROFT_ERR_INVALID, "one input per object required");
+    if (e->submitted) return fail(ROFT_ERR_STATE, "previous frame not stepped yet");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const roft_config& cfg = e->cfg;
+    const size_t npix = (size_t)cfg.cam.width * cfg.cam.height;
+    const size_t fbytes = flow_bytes(e->arr.a.ffmt);
+
+    const int si = e->stage_idx;
+    HIP_TRY(hipEventSynchronize(e->stage_ev[si]));  // staging block free again?
+    FrameCtrl* blk = e->stage[si];
+    e->max_steps = 0;
+    e->any_new_mask = e->any_outlier = e->any_feat0 = e->any_feat1 = false;
+
+    for (int id = 0; id < n_inputs; ++id) {
+        HostObject& o = *e->objs[id];
+        const roft_frame_input& in = inputs[id];
+        FrameCtrl& c = blk[id];
+        clear_ctrl(c);
+        if (!in.depth) return fail(ROFT_ERR_INVALID, "cannot continue without a continuous depth stream (ROFTFilter.cpp:261-266)");
+        c.dt = (in.dt > 0.0) ? in.dt : cfg.sample_time;
+        const int rs = o.frame_idx % kPlaneSlots;
+
+        // ---- inputs to device memory
+        const float* d_depth;
+        const void* d_flow = nullptr;
+        const uint8_t* d_mask = nullptr;
+        if (in.mem_kind == ROFT_MEM_DEVICE) {
+            d_depth = in.depth;
+            d_flow = in.flow;
+            d_mask = in.mask;
+        } else {
+            HIP_TRY(o.depth_ring[rs].ensure(npix));
+            HIP_TRY(hipMemcpyAsync(o.depth_ring[rs].p, in.depth, npix * sizeof(float), hipMemcpyHostToDevice, e->stream));
+            d_depth = o.depth_ring[rs].p;
+            if (in.flow) {
+                HIP_TRY(o.flow_ring[rs].ensure(fbytes));
+                HIP_TRY(hipMemcpyAsync(o.flow_ring[rs].p, in.flow, fbytes, hipMemcpyHostToDevice, e->stream));
+                d_flow = o.flow_ring[rs].p;
+            }
+            if (in.mask) {
+                HIP_TRY(o.mask_stage.ensure(npix));
+                HIP_TRY(hipMemcpyAsync(o.mask_stage.p, in.mask, npix, hipMemcpyHostToDevice, e->stream));
+                d_mask = o.mask_stage.p;
+            }
+        }
+
+        // ---- ImageSegmentationOFAidedSource::step_frame (hpp:127-231), schedule part
+        c.slot_prev = (o.frame_idx + kPlaneSlots - 1) % kPlaneSlots;
+        c.slot_cur = rs;
+        c.has_new_mask = d_mask ? 1 : 0;
+        c.new_mask = d_mask;
+        c.first_mask = 0;
+        if (d_mask && !o.seg_available) { o.seg_available = true; c.first_mask = 1; }
+        if (!o.seg_available)
+            return fail(ROFT_ERR_STATE, "no segmentation mask delivered yet: the first frame must carry one");
+        const bool valid_flow = d_flow && !o.of_first_frame;
+        o.of_first_frame = false;
+        if (valid_flow) {
+            o.flow_hist.push_front(d_flow);
+            while ((int)o.flow_hist.size() > kMaxFlowHist) o.flow_hist.pop_back();
+        }
+        c.flow_valid = valid_flow ? 1 : 0;
+        for (int j = 0; j < kMaxFlowHist; ++j) c.flow[j] = j < (int)o.flow_hist.size() ? o.flow_hist[j] : nullptr;
+        if (!valid_flow) c.flow[0] = d_flow;  // (unused by the mask stage then)
+        if (c.has_new_mask) e->any_new_mask = true;
+
+        // ---- ImageOpticalFlowMeasurement::freeze state machine (hpp:217-229)
+        bool data_in = true;  // segmentation is available at this point
+        if (!d_flow || o.flow_first_frame) {
+            o.flow_first_frame = false;
+            data_in = false;
+        }
+        c.vel_stage = data_in ? 1 : 0;
+        c.depth_prev = o.depth_prev;
+        c.depth_cur = d_depth;
+        if (data_in) c.flow[0] = d_flow;
+        o.depth_prev = d_depth;
+
+        // ---- outlier-rejection features on the first frame (ROFTFilter.cpp:313-322)
+        if (cfg.use_pose_resync && !o.features_initialized) {
+            c.buffer_features_before = 1;
+            o.features_initialized = true;
+        }
+        build_pose_program(e, o, in, c);
+        e->max_steps = std::max(e->max_steps, c.n_steps);
+        if (c.outlier_step >= 0) e->any_outlier = true;
+        if (c.buffer_features_before || c.features_current) e->any_feat0 = true;
+        if (c.buffer_features_after) e->any_feat1 = true;
+        o.frame_idx++;
+    }
+    e->cur = blk;
+    e->submitted = true;
+    return ROFT_OK;
+}
+
+static void tmark(roft_engine* e, const char* name)
+{
+    if (!e->timing) return;
+    // one event after each (group of) launch(es); names resolved in roft_engine_get_timing
+    size_t idx = e->tmark.size();
+    if (e->tev.size() <= idx + 1) {
+        while (e->tev.size() <= idx + 1) {
+            hipEvent_t ev;
+            (void)hipEventCreate(&ev);
+            e->tev.push_back(ev);
+        }
+    }
+    int id = -1;
+    for (size_t i = 0; i < e->tnames_s.size(); ++i)
+        if (e->tnames_s[i] == name) id = (int)i;
+    if (id < 0) { e->tnames_s.push_back(name); id = (int)e->tnames_s.size() - 1; }
+    e->tmark.push_back(id);
+    (void)hipEventRecord(e->tev[idx + 1], e->stream);
+}
+
+int roft_step(roft_engine* e)
+{
+    if (!e) return fail(ROFT_ERR_INVALID, "null engine");
+    if (!e->submitted) return fail(ROFT_ERR_STATE, "roft_frame_submit must precede roft_step");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const EngineArrays& a = e->arr.a;
+    hipStream_t s = e->stream;
+    const int si = e->stage_idx;
+    HIP_TRY(hipMemcpyAsync(a.ctrl, e->cur, sizeof(FrameCtrl) * a.n_obj, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipEventRecord(e->stage_ev[si], s));
+    e->stage_idx = (si + 1) % roft_engine::kStage;
+
+    if (e->timing) {
+        e->tmark.clear();
+        if (e->tev.empty()) { hipEvent_t ev; (void)hipEventCreate(&ev); e->tev.push_back(ev); }
+        (void)hipEventRecord(e->tev[0], s);
+    }
+    const int radius = (int)(size_t)e->cfg.subsampling_radius;
+    if (e->any_new_mask) { launch_mask_ingest(a, s); tmark(e, "mask_ingest"); }
+    launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, s);
+    tmark(e, "mask_propagate");
+    launch_flow_measure(a, e->cfg.depth_maximum, radius, s);
+    tmark(e, "flow_measure");
+    launch_skf(a, e->cfg.flow_weighting, s);
+    tmark(e, "skf");
+    if (e->any_feat0) { launch_features(a, 0, s); tmark(e, "features"); }
+    for (int k = 0; k < e->max_steps; ++k) {
+        launch_ukf_step(a, k, e->cfg.ut, s);
+        tmark(e, "ukf_step");
+        if (k == 0 && e->any_outlier) { launch_outlier(a, s); tmark(e, "outlier_render_likelihood"); }
+    }
+    if (e->any_feat1) { launch_features(a, 1, s); tmark(e, "features"); }
+    if (a.out_log) { launch_collect_outputs(a, e->frame_counter, s); tmark(e, "collect_outputs"); }
+    HIP_TRY(hipGetLastError());
+    e->frame_counter++;
+    e->submitted = false;
+    return ROFT_OK;
+}
+
+int roft_sync(roft_engine* e)
+{
+    if (!e) return fail(ROFT_ERR_INVALID, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ROFT_OK;
+}
+
+int roft_get_state(roft_engine* e, int id, double pose13[13], double P12[144], double twist6[6], double Pv[36])
+{
+    if (!e || id < 0 || id >= (int)e->objs.size()) return fail(ROFT_ERR_INVALID, "bad object id");
+    if (int rc = roft_sync(e)) return rc;
+    ObjState* st = new ObjState();
+    hipError_t err = hipMemcpy(st, e->arr.state.p + id, sizeof(ObjState), hipMemcpyDeviceToHost);
+    if (err == hipSuccess) {
+        if (pose13) std::memcpy(pose13, st->belief[B_CORR].mean, sizeof(double) * 13);
+        if (P12) std::memcpy(P12, st->belief[B_CORR].cov, sizeof(double) * 144);
+        if (twist6) std::memcpy(twist6, st->v_mean, sizeof(double) * 6);
+        if (Pv) std::memcpy(Pv, st->v_cov, sizeof(double) * 36);
+    }
+    delete st;
+    HIP_TRY(err);
+    return ROFT_OK;
+}
+
+int roft_get_outputs(roft_engine* e, roft_object_output* outs, int n_outs)
+{
+    if (!e || !outs || n_outs != (int)e->objs.size()) return fail(ROFT_ERR_INVALID, "bad arguments");
+    if (int rc = roft_sync(e)) return rc;
+    std::vector<ObjState> st(n_outs);
+    HIP_TRY(hipMemcpy(st.data(), e->arr.state.p, sizeof(ObjState) * n_outs, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n_outs; ++i) {
+        std::memcpy(outs[i].pose, st[i].belief[B_CORR].mean, sizeof(double) * 13);
+        std::memcpy(outs[i].twist, st[i].v_mean, sizeof(double) * 6);
+        outs[i].n_flow_points = st[i].n_flow_points;
+        outs[i].outlier_selected = st[i].outlier_selected;
+        outs[i].outlier_L[0] = st[i].outlier_L[0];
+        outs[i].outlier_L[1] = st[i].outlier_L[1];
+    }
+    return ROFT_OK;
+}
+
+int roft_engine_enable_log(roft_engine* e, int n_frames)
+{
+    if (!e || n_frames <= 0) return fail(ROFT_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(e->arr.log.ensure((size_t)n_frames * e->cfg.max_objects, true));
+    e->arr.a.out_log = e->arr.log.p;
+    e->arr.a.log_cap = n_frames;
+    return ROFT_OK;
+}
+
+int roft_engine_get_log(roft_engine* e, int first_frame, int n_frames, roft_object_output* outs)
+{
+    if (!e || !outs || !e->arr.a.out_log) return fail(ROFT_ERR_INVALID, "log not enabled");
+    if (int rc = roft_sync(e)) return rc;
+    const int n_obj = e->arr.a.n_obj;
+    for (int f = 0; f < n_frames; ++f) {
+        const int slot = (first_frame + f) % e->arr.a.log_cap;
+        HIP_TRY(hipMemcpy(outs + (size_t)f * n_obj, e->arr.a.out_log + (size_t)slot * n_obj,
+                          sizeof(roft_object_output) * n_obj, hipMemcpyDeviceToHost));
+    }
+    return ROFT_OK;
+}
+
+int roft_get_mask(roft_engine* e, int id, uint8_t* mask_out)
+{
+    if (!e || !mask_out || id < 0 || id >= (int)e->objs.size()) return fail(ROFT_ERR_INVALID, "bad arguments");
+    HostObject& o = *e->objs[id];
+    if (o.frame_idx == 0) return fail(ROFT_ERR_STATE, "no frame processed yet");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const EngineArrays& a = e->arr.a;
+    const int slot = (o.frame_idx - 1) % kPlaneSlots;
+    const size_t npix = (size_t)a.cam.W * a.cam.H;
+    DevBuf<uint8_t> tmp;
+    HIP_TRY(tmp.ensure(npix));
+    launch_planes_to_mask(nullptr, a.planes + plane_offset(a, id, slot, 1), (int)npix, tmp.p, e->stream);
+    HIP_TRY(hipMemcpyAsync(mask_out, tmp.p, npix, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return ROFT_OK;
+}
+
+void* roft_engine_stream(roft_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int roft_engine_enable_timing(roft_engine* e, int enable)
+{
+    if (!e) return fail(ROFT_ERR_INVALID, "null engine");
+    e->timing = enable != 0;
+    return ROFT_OK;
+}
+
+int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, const float** ms_out,
+                           const int** launches_out)
+{
+    if (!e || !n_out) return fail(ROFT_ERR_INVALID, "null argument");
+    if (int rc = roft_sync(e)) return rc;
+    const size_t nk = e->tnames_s.size();
+    e->tms.assign(nk, 0.f);
+    e->tlaunches.assign(nk, 0);
+    for (size_t i = 0; i < e->tmark.size(); ++i) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e->tev[i], e->tev[i + 1]));
+        e->tms[e->tmark[i]] += ms;
+        e->tlaunches[e->tmark[i]] += 1;
+    }
+    e->tnames.clear();
+    for (auto& s : e->tnames_s) e->tnames.push_back(s.c_str());
+    *n_out = (int)nk;
+    if (names_out) *names_out = e->tnames.data();
+    if (ms_out) *ms_out = e->tms.data();
+    if (launches_out) *launches_out = e->tlaunches.data();
+    return ROFT_OK;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// operator level: one-object context on device 0
+// =================================================================================================
+namespace {
+
+struct OpCtx {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    Arrays arr;
+    int W = 0, H = 0, ftype = 0, fgrid = 0, radius = 0;
+    DevBuf<unsigned char> b0, b1, b2, b3, b4, b5;  // generic scratch
+    bool ready = false;
+
+    int prepare(const roft_camera& cam, int ftype_, int fgrid_, float fscale, int radius_)
+    {
+        if (roft_device_count() <= 0) return fail(ROFT_ERR_DEVICE, "no HIP device (libroft_hip has no CPU path)");
+        if (int rc = check_geometry(cam.width, cam.height)) return rc;
+        HIP_TRY(hipSetDevice(0));
+        if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        DevFlowFmt ff;
+        ff.type = ftype_;
+        ff.grid = std::max(fgrid_, 1);
+        ff.cols = cam.width / ff.grid;
+        ff.rows = cam.height / ff.grid;
+        ff.scale = fscale;
+        if (!ready || W != cam.width || H != cam.height || radius != radius_) {
+            if (int rc = arr.alloc(1, make_cam(cam), ff, std::max(radius_, 1))) return rc;
+            W = cam.width; H = cam.height; radius = radius_;
+            ready = true;
+        }
+        arr.a.cam = make_cam(cam);
+        arr.a.ffmt = ff;
+        arr.a.n_obj = 1;
+        ObjState st;
+        init_state(st);
+        HIP_TRY(hipMemcpyAsync(arr.state.p, &st, sizeof(st), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        return ROFT_OK;
+    }
+};
+
+OpCtx& op()
+{
+    static OpCtx c;
+    return c;
+}
+
+int upload_ctrl(OpCtx& c, const FrameCtrl& fc)
+{
+    HIP_TRY(hipMemcpyAsync(c.arr.ctrl.p, &fc, sizeof(fc), hipMemcpyHostToDevice, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));  // fc lives on the caller's stack
+    return ROFT_OK;
+}
+
+template <class T>
+int to_dev(DevBuf<unsigned char>& b, const T* src, size_t count, hipStream_t s)
+{
+    HIP_TRY(b.ensure(std::max<size_t>(count * sizeof(T), 16)));
+    if (count) HIP_TRY(hipMemcpyAsync(b.p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    return ROFT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int roft_flow_measurement(const roft_camera* cam, const uint8_t* prev_mask, const float* prev_depth,
+                          const roft_flow* flow, double dt, float radius, double depth_max, int capacity,
+                          int32_t* uv, double* y, double* H, int* n_out)
+{
+    if (!cam || !prev_mask || !prev_depth || !flow || !flow->data || !n_out) return fail(ROFT_ERR_INVALID, "null argument");
+    OpCtx& c = op();
+    std::lock_guard<std::mutex> lk(c.mu);
+    const int r = (int)(size_t)radius;
+    if (r <= 0) return fail(ROFT_ERR_INVALID, "radius must be >= 1");
+    if (int rc = c.prepare(*cam, flow->type, flow->grid, flow->scale, r)) return rc;
+    const size_t npix = (size_t)cam->width * cam->height;
+    if (int rc = to_dev(c.b0, prev_mask, npix, c.stream)) return rc;
+    if (int rc = to_dev(c.b1, prev_depth, npix, c.stream)) return rc;
+    if (int rc = to_dev(c.b2, (const unsigned char*)flow->data, flow_bytes(c.arr.a.ffmt), c.stream)) return rc;
+    FrameCtrl fc;
+    clear_ctrl(fc);
+    fc.dt = dt;
+    fc.has_new_mask = 1;
+    fc.new_mask = c.b0.p;
+    fc.slot_prev = kSlotNew;  // the ingested planes are "the previous frame's mask"
+    fc.slot_cur = 0;
+    fc.depth_prev = reinterpret_cast<const float*>(c.b1.p);
+    fc.flow[0] = c.b2.p;
+    fc.vel_stage = 1;
+    if (int rc = upload_ctrl(c, fc)) return rc;
+    launch_mask_ingest(c.arr.a, c.stream);
+    launch_flow_measure(c.arr.a, depth_max, r, c.stream);
+    int n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, &c.arr.state.p->n_flow_points, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    HIP_TRY(hipGetLastError());
+    *n_out = n;
+    if (n > capacity) return fail(ROFT_ERR_CAPACITY, "more flow points than the caller's capacity");
+    if (n > 0 && uv && y && H) {
+        HIP_TRY(c.b3.ensure(sizeof(int32_t) * 2 * n));
+        HIP_TRY(c.b4.ensure(sizeof(double) * 2 * n));
+        HIP_TRY(c.b5.ensure(sizeof(double) * 12 * n));
+        launch_expand_yh(c.arr.a.recs, &c.arr.state.p->n_flow_points, c.arr.a.cam, dt, reinterpret_cast<int32_t*>(c.b3.p),
+                         reinterpret_cast<double*>(c.b4.p), reinterpret_cast<double*>(c.b5.p), n, c.stream);
+        HIP_TRY(hipMemcpyAsync(uv, c.b3.p, sizeof(int32_t) * 2 * n, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(y, c.b4.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipMemcpyAsync(H, c.b5.p, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+    }
+    // leave the one-object context clean for the next call
+    ObjState st;
+    init_state(st);
+    HIP_TRY(hipMemcpy(c.arr.state.p, &st, sizeof(st), hipMemcpyHostToDevice));
+    return ROFT_OK;
+}
+
+static int op_simple_prepare(OpCtx& c)
+{
+    if (roft_device_count() <= 0) return fail(ROFT_ERR_DEVICE, "no HIP device (libroft_hip has no CPU path)");
+    HIP_TRY(hipSetDevice(0));
+    if (!c.stream) HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    return ROFT_OK;
+}
+
+int roft_kf_predict(const double x[6], const double P[36], const double Qdiag[6], double x_out[6], double P_out[36])
+{
+    if (!x || !P || !Qdiag || !x_out || !P_out) return fail(ROFT_ERR_INVALID, "null argument");
+    OpCtx& c = op();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (int rc = op_simple_prepare(c)) return rc;
+    double in[48];
+    std::memcpy(in, x, 48);
+    std::memcpy(in + 6, P, 288);
+    std::memcpy(in + 42, Qdiag, 48);
+    if (int rc = to_dev(c.b0, in, 48, c.stream)) return rc;
+    HIP_TRY(c.b1.ensure(sizeof(double) * 42));
+    double* d = reinterpret_cast<double*>(c.b0.p);
+    double* o = reinterpret_cast<double*>(c.b1.p);
+    launch_kf_predict(d, d + 6, d + 42, o, o + 6, c.stream);
+    double out[42];
+    HIP_TRY(hipMemcpyAsync(out, o, sizeof(out), hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    std::memcpy(x_out, out, 48);
+    std::memcpy(P_out, out + 6, 288);
+    return ROFT_OK;
+}
+
+int roft_skf_correct(const double x_pred[6], const double P_pred[36], int N, const double* y, const double* H,
+                     const double Rdiag[2], int reweight, double x_out[6], double P_out[36], int* status_out)
+{
+    if (!x_pred || !P_pred || !Rdiag || !x_out || !P_out || (N > 0 && (!y || !H))) return fail(ROFT_ERR_INVALID, "null argument");
+    OpCtx& c = op();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (int rc = op_simple_prepare(c)) return rc;
+    double in[44];
+    std::memcpy(in, x_pred, 48);
+    std::memcpy(in + 6, P_pred, 288);
+    in[42] = Rdiag[0]; in[43] = Rdiag[1];
+    if (int rc = to_dev(c.b0, in, 44, c.stream)) return rc;
+    const int n = std::max(N, 0);
+    if (int rc = to_dev(c.b1, y, (size_t)2 * n, c.stream)) return rc;
+    if (int rc = to_dev(c.b2, H, (size_t)12 * n, c.stream)) return rc;
+    HIP_TRY(c.b3.ensure(sizeof(double) * std::max(n, 1)));
+    HIP_TRY(c.b4.ensure(sizeof(double) * 44));
+    double* d = reinterpret_cast<double*>(c.b0.p);
+    double* o = reinterpret_cast<double*>(c.b4.p);
+    launch_skf_arrays(d, d + 6, N, reinterpret_cast<double*>(c.b1.p), reinterpret_cast<double*>(c.b2.p), d + 42, reweight,
+                      reinterpret_cast<double*>(c.b3.p), o, o + 6, reinterpret_cast<int*>(o + 42), c.stream);
+    double out[44];
+    HIP_TRY(hipMemcpyAsync(out, o, sizeof(out), hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    HIP_TRY(hipGetLastError());
+    std::memcpy(x_out, out, 48);
+    std::memcpy(P_out, out + 6, 288);
+    if (status_out) std::memcpy(status_out, out + 42, sizeof(int));
+    return ROFT_OK;
+}
+
+int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int n_flows, int frames_between)
+{
+    if (!mask || (n_flows > 0 && !flows)) return fail(ROFT_ERR_INVALID, "null argument");
+    int start = 0;
+    if (frames_between > 0) start = std::max(0, n_flows - frames_between);
+    const int used = n_flows - start;
+    if (used > kMaxFlowHist) return fail(ROFT_ERR_INVALID, "more than 6 flow frames per propagation are not supported");
+    OpCtx& c = op();
+    std::lock_guard<std::mutex> lk(c.mu);
+    roft_camera cam{W, H, 1.0, 1.0, 0.0, 0.0};
+    const roft_flow* f0 = used > 0 ? &flows[start] : nullptr;
+    if (int rc = c.prepare(cam, f0 ? f0->type : ROFT_FLOW_F32C2, f0 ? f0->grid : 1, f0 ? f0->scale : 1.0f, 35)) return rc;
+    const size_t npix = (size_t)W * H;
+    const size_t fb = flow_bytes(c.arr.a.ffmt);
+    if (int rc = to_dev(c.b0, mask, npix, c.stream)) return rc;
+    HIP_TRY(c.b1.ensure(fb * std::max(used, 1)));
+    FrameCtrl fc;
+    clear_ctrl(fc);
+    for (int j = 0; j < used; ++j) {
+        const roft_flow& f = flows[start + j];
+        if (f.type != f0->type || f.cols != f0->cols || f.rows != f0->rows || !f.data)
+            return fail(ROFT_ERR_INVALID, "all flow frames must share one format");
+        HIP_TRY(hipMemcpyAsync(c.b1.p + fb * j, f.data, fb, hipMemcpyHostToDevice, c.stream));
+        fc.flow[used - 1 - j] = c.b1.p + fb * j;  // [0] = newest
+    }
+    fc.has_new_mask = 1;
+    fc.new_mask = c.b0.p;
+    fc.force_mode = 3;
+    fc.slot_prev = 1;
+    fc.slot_cur = 0;
+    fc.flow_valid = 0;
+    // decide_mode() uses fbuf_n + flow_valid as the number of buffered flows
+    ObjState st;
+    init_state(st);
+    st.fbuf_n = used;
+    HIP_TRY(hipMemcpyAsync(c.arr.state.p, &st, sizeof(st), hipMemcpyHostToDevice, c.stream));
+    if (int rc = upload_ctrl(c, fc)) return rc;
+    launch_mask_ingest(c.arr.a, c.stream);
+    launch_mask_propagate(c.arr.a, frames_between, 1, c.stream);
+    HIP_TRY(c.b2.ensure(npix));
+    launch_planes_to_mask(c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 0), c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 1),
+                          (int)npix, c.b2.p, c.stream);
+    HIP_TRY(hipMemcpyAsync(mask, c.b2.p, npix, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    HIP_TRY(hipGetLastError());
+    return ROFT_OK;
+}
+
+int roft_pose_process_noise(const double psd[3], const double sig_w[3], double T, double Q[81])
+{
+    if (!psd || !sig_w || !Q) return fail(ROFT_ERR_INVALID, "null argument");
+    // parameter packing only (CartesianQuaternionModel.cpp:127-141); the filter kernels build Q(T) themselves
+    std::memset(Q, 0, sizeof(double) * 81);
+    for (int i = 0; i < 3; ++i) {
+        Q[i * 9 + i] = psd[i] * T;
+        Q[(3 + i) * 9 + (3 + i)] = sig_w[i];
+        Q[(6 + i) * 9 + (6 + i)] = psd[i] * (std::pow(T, 3.0) / 3.0);
+        Q[i * 9 + (6 + i)] = psd[i] * (std::pow(T, 2.0) / 2.0);
+        Q[(6 + i) * 9 + i] = psd[i] * (std::pow(T, 2.0) / 2.0);
+    }
+    return ROFT_OK;
+}
+
+static int op_ukf(const double mean[13], const double P[144], const double* Q81, double T, int type, const double* meas,
+                  const double* Rdiag, const roft_ut_params* ut, double mean_out[13], double P_out[144], int* status)
+{
+    OpCtx& c = op();
+    std::lock_guard<std::mutex> lk(c.mu);
+    roft_camera cam{64, 64, 1.0, 1.0, 0.0, 0.0};
+    if (!c.ready) { if (int rc = c.prepare(cam, ROFT_FLOW_F32C2, 1, 1.0f, 35)) return rc; }
+    else { if (int rc = op_simple_prepare(c)) return rc; }
+    ObjState* st = new ObjState();
+    init_state(*st);
+    std::memcpy(st->belief[B_CORR].mean, mean, sizeof(double) * 13);
+    std::memcpy(st->belief[B_CORR].cov, P, sizeof(double) * 144);
+    ObjParams prm;
+    std::memset(&prm, 0, sizeof(prm));
+    FrameCtrl fc;
+    clear_ctrl(fc);
+    fc.dt = T;
+    fc.n_steps = 1;
+    StepDesc& sd = fc.steps[0];
+    sd.op = 1;
+    sd.src = B_CORR;
+    if (Q81) {
+        if (int rc = to_dev(c.b0, Q81, 81, c.stream)) { delete st; return rc; }
+        prm.q_override = reinterpret_cast<const double*>(c.b0.p);
+        sd.do_predict = 1;
+        sd.n_corr = 0;
+        sd.dst[0] = B_SPARE;
+    } else {
+        sd.do_predict = 0;
+        sd.n_corr = 1;
+        sd.type[0] = type;
+        sd.dst[0] = B_SPARE;
+        sd.twist_slot = 0;
+        int k = 0;
+        const bool has_vel = (type == ROFT_MEAS_VELOCITY || type == ROFT_MEAS_POSE_VELOCITY);
+        const bool has_pose = (type == ROFT_MEAS_POSE || type == ROFT_MEAS_POSE_VELOCITY);
+        if (has_vel) {
+            for (int i = 0; i < 6; ++i) st->twist_hist[0][i] = meas[i];
+            for (int i = 0; i < 3; ++i) prm.R_v[i] = Rdiag[k++];
+            for (int i = 0; i < 3; ++i) prm.R_w[i] = Rdiag[k++];
+        }
+        if (has_pose) {
+            const double* pm = meas + (has_vel ? 6 : 0);
+            for (int i = 0; i < 3; ++i) fc.pose_x[i] = pm[i];
+            for (int i = 0; i < 4; ++i) fc.pose_q[i] = pm[3 + i];
+            for (int i = 0; i < 3; ++i) prm.R_x[i] = Rdiag[k++];
+            for (int i = 0; i < 3; ++i) prm.R_q[i] = Rdiag[k++];
+        }
+    }
+    hipError_t err = hipMemcpyAsync(c.arr.state.p, st, sizeof(ObjState), hipMemcpyHostToDevice, c.stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(c.arr.params.p, &prm, sizeof(prm), hipMemcpyHostToDevice, c.stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
+    if (err != hipSuccess) { delete st; HIP_TRY(err); }
+    c.arr.a.n_obj = 1;
+    if (int rc = upload_ctrl(c, fc)) { delete st; return rc; }
+    launch_ukf_step(c.arr.a, 0, *ut, c.stream);
+    err = hipMemcpyAsync(st, c.arr.state.p, sizeof(ObjState), hipMemcpyDeviceToHost, c.stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
+    if (err == hipSuccess) err = hipGetLastError();
+    if (err == hipSuccess) {
+        std::memcpy(mean_out, st->belief[B_SPARE].mean, sizeof(double) * 13);
+        std::memcpy(P_out, st->belief[B_SPARE].cov, sizeof(double) * 144);
+        if (status) *status = st->ukf_status & 0xF;
+    }
+    delete st;
+    HIP_TRY(err);
+    return ROFT_OK;
+}
+
+int roft_ukf_predict(const double mean[13], const double P[144], const double Q[81], double T, const roft_ut_params* ut,
+                     double mean_out[13], double P_out[144])
+{
+    if (!mean || !P || !Q || !ut || !mean_out || !P_out) return fail(ROFT_ERR_INVALID, "null argument");
+    return op_ukf(mean, P, Q, T, 0, nullptr, nullptr, ut, mean_out, P_out, nullptr);
+}
+
+int roft_ukf_correct(const double mean[13], const double P[144], int type, const double* meas, const double* Rdiag,
+                     const roft_ut_params* ut, double mean_out[13], double P_out[144], int* status_out)
+{
+    if (!mean || !P || !ut || !mean_out || !P_out) return fail(ROFT_ERR_INVALID, "null argument");
+    if (type != ROFT_MEAS_NONE && (!meas || !Rdiag)) return fail(ROFT_ERR_INVALID, "null measurement");
+    if (type < ROFT_MEAS_NONE || type > ROFT_MEAS_POSE_VELOCITY) return fail(ROFT_ERR_INVALID, "bad measurement type");
+    return op_ukf(mean, P, nullptr, 0.0, type, meas, Rdiag, ut, mean_out, P_out, status_out);
+}
+
+int roft_render_depth(const roft_mesh* mesh, const double x[3], const double q[4], const roft_camera* cam, int divider,
+                      float* tile)
+{
+    if (!mesh || !mesh->verts || !mesh->tris || !x || !q || !cam || !tile || divider <= 0)
+        return fail(ROFT_ERR_INVALID, "bad argument");
+    OpCtx& c = op();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (int rc = op_simple_prepare(c)) return rc;
+    DevCamera dc = make_cam(*cam);
+    dc.divider = divider;
+    const int n = (dc.W / divider) * (dc.H / divider);
+    if (int rc = to_dev(c.b0, mesh->verts, (size_t)3 * mesh->n_verts, c.stream)) return rc;
+    if (int rc = to_dev(c.b1, mesh->tris, (size_t)3 * mesh->n_tris, c.stream)) return rc;
+    double xq[7] = {x[0], x[1], x[2], q[0], q[1], q[2], q[3]};
+    if (int rc = to_dev(c.b2, xq, 7, c.stream)) return rc;
+    HIP_TRY(c.b3.ensure(sizeof(uint32_t) * n));
+    HIP_TRY(c.b4.ensure(sizeof(float) * n));
+    HIP_TRY(hipStreamSynchronize(c.stream));  // xq lives on this stack frame
+    launch_render(reinterpret_cast<const float*>(c.b0.p), reinterpret_cast<const int32_t*>(c.b1.p), mesh->n_tris,
+                  reinterpret_cast<const double*>(c.b2.p), dc, reinterpret_cast<uint32_t*>(c.b3.p),
+                  reinterpret_cast<float*>(c.b4.p), c.stream);
+    HIP_TRY(hipMemcpyAsync(tile, c.b4.p, sizeof(float) * n, hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));
+    HIP_TRY(hipGetLastError());
+    return ROFT_OK;
+}
+
+int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint8_t* mask, const float* tile, int divider,
+                          double* L_out, long* samples_out)
+{
+    if (!cam || !depth || !mask || !tile || !L_out || divider <= 0) return fail(ROFT_ERR_INVALID, "bad argument");
+    OpCtx& c = op();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (int rc = c.prepare(*cam, ROFT_FLOW_F32C2, 1, 1.0f, 35)) return rc;
+    c.arr.a.cam.divider = divider;
+    c.arr.a.tile_w = cam->width / divider;
+    c.arr.a.tile_h = cam->height / divider;
+    const size_t npix = (size_t)cam->width * cam->height;
+    const size_t tpix = (size_t)c.arr.a.tile_w * c.arr.a.tile_h;
+    if (tpix * 2 > c.arr.zbuf.n) HIP_TRY(c.arr.zbuf.ensure(tpix * 2));
+    c.arr.a.zbuf = c.arr.zbuf.p;
+    if (int rc = to_dev(c.b0, mask, npix, c.stream)) return rc;
+    if (int rc = to_dev(c.b1, depth, npix, c.stream)) return rc;
+    // tile -> z-buffer bit pattern (0 = background -> +inf), used for both alternatives
+    std::vector<uint32_t> zb(tpix * 2);
+    for (size_t i = 0; i < tpix; ++i) {
+        uint32_t bits;
+        std::memcpy(&bits, &tile[i], 4);
+        if (tile[i] == 0.0f) bits = 0x7F800000u;
+        zb[i] = bits;
+        zb[tpix + i] = bits;
+    }
+    HIP_TRY(hipMemcpyAsync(c.arr.zbuf.p, zb.data(), zb.size() * 4, hipMemcpyHostToDevice, c.stream));
+    FrameCtrl fc;
+    clear_ctrl(fc);
+    fc.has_new_mask = 1;
+    fc.new_mask = c.b0.p;
+    fc.slot_cur = kSlotNew;
+    fc.depth_cur = reinterpret_cast<const float*>(c.b1.p);
+    fc.buffer_features_before = 1;
+    fc.outlier_step = 0;
+    if (int rc = upload_ctrl(c, fc)) return rc;
+    launch_mask_ingest(c.arr.a, c.stream);
+    launch_features(c.arr.a, 0, c.stream);
+    // likelihood only (the z-buffers are already filled)
+    launch_outlier_only(c.arr.a, c.stream);
+    ObjState* st = new ObjState();
+    hipError_t err = hipMemcpyAsync(st, c.arr.state.p, sizeof(ObjState), hipMemcpyDeviceToHost, c.stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
+    if (err == hipSuccess) err = hipGetLastError();
+    if (err == hipSuccess) {
+        *L_out = st->outlier_L[0];
+        if (samples_out) *samples_out = (long)st->outlier_cnt[0];
+    }
+    delete st;
+    // restore the default tile geometry of this context
+    c.arr.a.cam = make_cam(*cam);
+    c.arr.a.tile_w = cam->width / c.arr.a.cam.divider;
+    c.arr.a.tile_h = cam->height / c.arr.a.cam.divider;
+    c.ready = false;  // zbuf may have been re-sized: force a clean re-allocation next time
+    HIP_TRY(err);
+    return ROFT_OK;
+}
+
+}  // extern "C"

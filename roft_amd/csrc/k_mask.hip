@@ -1,0 +1,278 @@
+// k_mask.hip -- segmentation mask kernels (gfx950).
+//
+// Reference behaviour reproduced (hsp-iit/roft v1.2.1):
+//   ImageSegmentationOFAidedSource<T>::step_frame / map   include/ROFT/ImageSegmentationOFAidedSource.hpp:127-281
+//   cv::remap(mask_, mask_, map, INTER_LINEAR, BORDER_CONSTANT) with an integer map (:215, :225)
+//   ImageSegmentationMeasurement::freeze threshold (>1 -> 255)  src/roft-lib/src/ImageSegmentationMeasurement.cpp:65
+//
+// MI355X design: a mask lives in HBM as two 1-bit planes (W*H/8 bytes each instead of W*H):
+//   nz  = raw value != 0  (what cv::findNonZero sees inside the OF-aided source)
+//   obj = raw value  > 1  (what every consumer sees after the threshold)
+// The reference's "later writer wins" scatter in row-major source order is order-free here:
+// the winner is the source with the LARGEST linear index, i.e. an atomicMax on a W*H int32 map
+// whose zero value doubles as "unmapped -> sample mask(0,0)" exactly like the zero-initialised
+// cv::Mat map (:237).  The gather kernel clears the entries it consumed, so the map is never
+// memset.
+#include "roft_device.h"
+
+namespace roft {
+
+// (int)float as evaluated by the reference's x86-64 build (cvttss2si): NaN / out of range give
+// INT_MIN, which then fails the `< 0` bounds test.  AMD's v_cvt_i32_f32 would saturate / give 0.
+__device__ __forceinline__ int trunc_int_x86(float x)
+{
+    if (!(x > -2147483904.0f && x < 2147483648.0f)) return INT32_MIN;
+    return (int)x;
+}
+
+__device__ __forceinline__ void flow_at(const void* data, const DevFlowFmt& f, int row, int col, float& dx,
+                                        float& dy)
+{
+    size_t idx = ((size_t)row * (size_t)f.cols + (size_t)col);
+    if (f.type == ROFT_FLOW_S16C2) {
+        short2 p = reinterpret_cast<const short2*>(data)[idx];
+        dx = (float)p.x / f.scale;
+        dy = (float)p.y / f.scale;
+    } else {
+        float2 p = reinterpret_cast<const float2*>(data)[idx];
+        dx = p.x / f.scale;
+        dy = p.y / f.scale;
+    }
+}
+
+// ---- ingest: raw u8 mask -> (nz, obj) bit planes + non-zero count -------------------------------
+// grid: (ceil(W*H/64/4), n_obj), block 256 = 4 waves; each wave converts 64 consecutive pixels per
+// iteration (coalesced byte loads, one ballot per plane).
+__global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a)
+{
+    const int obj = blockIdx.y;
+    const FrameCtrl& c = a.ctrl[obj];
+    if (!c.has_new_mask) return;
+    const uint8_t* src = c.new_mask;
+    uint32_t* nz = a.planes + plane_offset(a, obj, kSlotNew, 0);
+    uint32_t* ob = a.planes + plane_offset(a, obj, kSlotNew, 1);
+    const int lane = threadIdx.x & 63;
+    const size_t npix = (size_t)a.cam.W * a.cam.H;
+    const size_t wave_global = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+    int count = 0;
+    for (size_t base = wave_global * 64; base < npix; base += nwaves * 64) {
+        const size_t p = base + lane;
+        uint8_t v = (p < npix) ? src[p] : 0;
+        unsigned long long bnz = __ballot(v != 0);
+        unsigned long long bob = __ballot(v > 1);
+        if (lane == 0) {
+            // W % 32 == 0, so linear pixel index / 32 is the plane word index
+            reinterpret_cast<uint2*>(nz)[base >> 6] = make_uint2((uint32_t)bnz, (uint32_t)(bnz >> 32));
+            reinterpret_cast<uint2*>(ob)[base >> 6] = make_uint2((uint32_t)bob, (uint32_t)(bob >> 32));
+            count += __popcll(bnz);
+        }
+    }
+    if (lane == 0 && count) atomicAdd(&a.state[obj].new_mask_count, count);
+}
+
+// ---- mode decision + scatter ----------------------------------------------------------------
+// mode 0: copy (no flow, no usable new mask); 1: propagate last mask through this frame's flow,
+// mask(0,0) forced to 0 (hpp:221-226); 2: new mask chased through the buffered flows (hpp:211-219)
+__device__ __forceinline__ int decide_mode(const FrameCtrl& c, const ObjState& st, int& src_slot, int& n_flows)
+{
+    const int n_avail = st.fbuf_n + (c.flow_valid ? 1 : 0);
+    if (c.force_mode == 3) {  // operator level: map() + remap() of the given mask through n flows
+        src_slot = kSlotNew;
+        n_flows = n_avail < kMaxFlowHist ? n_avail : kMaxFlowHist;
+        return 2;
+    }
+    if (c.has_new_mask && !c.first_mask && st.new_mask_count > 0) {
+        src_slot = kSlotNew;
+        n_flows = n_avail < kMaxFlowHist ? n_avail : kMaxFlowHist;
+        return 2;
+    }
+    src_slot = (c.has_new_mask && c.first_mask) ? kSlotNew : c.slot_prev;
+    n_flows = 1;
+    return c.flow_valid ? 1 : 0;
+}
+
+// grid: (ceil(words/256), n_obj); thread = one 32-pixel word of the source nz plane
+__global__ __launch_bounds__(256) void mask_scatter_kernel(EngineArrays a, int frames_between)
+{
+    const int obj = blockIdx.y;
+    const FrameCtrl& c = a.ctrl[obj];
+    const ObjState& st = a.state[obj];
+    int src_slot, n_flows;
+    const int mode = decide_mode(c, st, src_slot, n_flows);
+    if (mode == 0) return;
+    if (frames_between > 0 && n_flows > frames_between) n_flows = frames_between;
+
+    __shared__ int s_bbox[4];
+    if (threadIdx.x < 4) s_bbox[threadIdx.x] = (threadIdx.x < 2) ? INT32_MAX : -1;
+    __syncthreads();
+
+    const int W = a.cam.W, H = a.cam.H;
+    const size_t widx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = -1, by1 = -1;
+    if (widx < a.plane_words) {
+        uint32_t bits = a.planes[plane_offset(a, obj, src_slot, 0) + widx];
+        if (mode == 1 && widx == 0) bits &= ~1u;  // mask_.at<uchar>(0,0) = 0
+        const int py = (int)(widx / a.cam.wpr);
+        const int px0 = (int)(widx % a.cam.wpr) * 32;
+        int32_t* map = a.map + (size_t)obj * W * H;
+        while (bits) {
+            const int b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            const int px = px0 + b;
+            float t_x = (float)px, t_y = (float)py;
+            bool error = false;
+            // flows in chronological order: oldest buffered first (c.flow[n_flows-1]) ... current
+            for (int j = n_flows - 1; j >= 0; --j) {
+                const int ix = trunc_int_x86(t_x), iy = trunc_int_x86(t_y);
+                if (ix < 0 || ix >= W || iy < 0 || iy >= H) { error = true; break; }
+                float dx, dy;
+                flow_at(c.flow[j], a.ffmt, trunc_int_x86(t_y / (float)a.ffmt.grid),
+                        trunc_int_x86(t_x / (float)a.ffmt.grid), dx, dy);
+                t_x += dx;
+                t_y += dy;
+            }
+            const int ix = trunc_int_x86(t_x), iy = trunc_int_x86(t_y);
+            if (error || ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
+            atomicMax(&map[(size_t)iy * W + ix], py * W + px);
+            bx0 = min(bx0, ix); bx1 = max(bx1, ix);
+            by0 = min(by0, iy); by1 = max(by1, iy);
+        }
+    }
+    if (bx1 >= 0) {
+        atomicMin(&s_bbox[0], bx0); atomicMin(&s_bbox[1], by0);
+        atomicMax(&s_bbox[2], bx1); atomicMax(&s_bbox[3], by1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_bbox[2] >= 0) {
+        int* bb = a.state[obj].bbox;
+        atomicMin(&bb[0], s_bbox[0]); atomicMin(&bb[1], s_bbox[1]);
+        atomicMax(&bb[2], s_bbox[2]); atomicMax(&bb[3], s_bbox[3]);
+    }
+}
+
+// grid: (ceil(W*H/64/4), n_obj); each wave produces 64 output pixels (two plane words) per step
+__global__ __launch_bounds__(256) void mask_gather_kernel(EngineArrays a, int frames_between)
+{
+    const int obj = blockIdx.y;
+    const FrameCtrl& c = a.ctrl[obj];
+    ObjState& st = a.state[obj];
+    int src_slot, n_flows;
+    const int mode = decide_mode(c, st, src_slot, n_flows);
+    const uint32_t* snz = a.planes + plane_offset(a, obj, src_slot, 0);
+    const uint32_t* sob = a.planes + plane_offset(a, obj, src_slot, 1);
+    uint32_t* dnz = a.planes + plane_offset(a, obj, c.slot_cur, 0);
+    uint32_t* dob = a.planes + plane_offset(a, obj, c.slot_cur, 1);
+    const int W = a.cam.W;
+    const size_t npix = (size_t)W * a.cam.H;
+    const int lane = threadIdx.x & 63;
+    const size_t wave_global = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t nwaves = (size_t)gridDim.x * 4;
+
+    // background = mask(0,0) of the source: forced to 0 in mode 1
+    bool bg_nz = false, bg_ob = false;
+    if (mode == 2) { bg_nz = snz[0] & 1u; bg_ob = sob[0] & 1u; }
+    const int bx0 = st.bbox[0], by0 = st.bbox[1], bx1 = st.bbox[2], by1 = st.bbox[3];
+    int32_t* map = a.map + (size_t)obj * npix;
+
+    for (size_t base = wave_global * 64; base < npix; base += nwaves * 64) {
+        const size_t word2 = base >> 6;
+        if (mode == 0) {
+            if (lane == 0) {
+                reinterpret_cast<uint2*>(dnz)[word2] = reinterpret_cast<const uint2*>(snz)[word2];
+                reinterpret_cast<uint2*>(dob)[word2] = reinterpret_cast<const uint2*>(sob)[word2];
+            }
+            continue;
+        }
+        const size_t p = base + lane;
+        const int y = (int)(p / W), x = (int)(p % W);
+        bool nzb = bg_nz, obb = bg_ob;
+        // the 64 pixels of a wave lie in one row (W % 64 == 0) -> wave-uniform row test
+        if (y >= by0 && y <= by1 && x >= bx0 && x <= bx1) {
+            const int m = map[p];
+            if (m != 0) {
+                map[p] = 0;
+                nzb = (snz[m >> 5] >> (m & 31)) & 1u;
+                obb = (sob[m >> 5] >> (m & 31)) & 1u;
+            }
+        }
+        unsigned long long b1 = __ballot(nzb);
+        unsigned long long b2 = __ballot(obb);
+        if (lane == 0) {
+            reinterpret_cast<uint2*>(dnz)[word2] = make_uint2((uint32_t)b1, (uint32_t)(b1 >> 32));
+            reinterpret_cast<uint2*>(dob)[word2] = make_uint2((uint32_t)b2, (uint32_t)(b2 >> 32));
+        }
+    }
+}
+
+// bookkeeping after the gather: flow buffer count, reset per-frame scratch state
+__global__ void mask_finish_kernel(EngineArrays a, int frames_between)
+{
+    const int obj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (obj >= a.n_obj) return;
+    const FrameCtrl& c = a.ctrl[obj];
+    ObjState& st = a.state[obj];
+    int src_slot, n_flows;
+    const int mode = decide_mode(c, st, src_slot, n_flows);
+    int n_avail = st.fbuf_n + (c.flow_valid ? 1 : 0);
+    if (n_avail > kMaxFlowHist) n_avail = kMaxFlowHist;
+    st.fbuf_n = (mode == 2) ? 0 : n_avail;
+    st.mask_mode = mode;
+    st.new_mask_count = 0;
+    st.outlier_selected = -1;
+    st.bbox[0] = INT32_MAX; st.bbox[1] = INT32_MAX; st.bbox[2] = -1; st.bbox[3] = -1;
+}
+
+// no flow-aided segmentation: the delivered mask is used as is, otherwise the last one persists
+__global__ __launch_bounds__(256) void mask_plain_kernel(EngineArrays a)
+{
+    const int obj = blockIdx.y;
+    const FrameCtrl& c = a.ctrl[obj];
+    const int src_slot = c.has_new_mask ? kSlotNew : c.slot_prev;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.plane_words) return;
+    for (int which = 0; which < 2; ++which)
+        a.planes[plane_offset(a, obj, c.slot_cur, which) + i] = a.planes[plane_offset(a, obj, src_slot, which) + i];
+}
+
+void launch_mask_ingest(const EngineArrays& a, hipStream_t s)
+{
+    const size_t waves = ((size_t)a.cam.W * a.cam.H + 63) / 64;
+    int gx = (int)((waves + 3) / 4);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(mask_ingest_kernel, dim3(gx, a.n_obj), dim3(256), 0, s, a);
+}
+
+void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s)
+{
+    if (!flow_aided) {
+        hipLaunchKernelGGL(mask_plain_kernel, dim3((unsigned)((a.plane_words + 255) / 256), a.n_obj), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(mask_finish_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frames_between);
+        return;
+    }
+    hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)((a.plane_words + 255) / 256), a.n_obj), dim3(256), 0, s, a,
+                       frames_between);
+    const size_t waves = ((size_t)a.cam.W * a.cam.H + 63) / 64;
+    int gx = (int)((waves + 3) / 4);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(mask_gather_kernel, dim3(gx, a.n_obj), dim3(256), 0, s, a, frames_between);
+    hipLaunchKernelGGL(mask_finish_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frames_between);
+}
+
+// ---- plane -> u8 mask (operator-level output / roft_get_mask) --------------------------------
+__global__ __launch_bounds__(256) void plane_to_mask_kernel(const uint32_t* nz, const uint32_t* ob, int npix,
+                                                            uint8_t* mask)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npix) return;
+    const bool o = (ob[p >> 5] >> (p & 31)) & 1u;
+    const bool n = nz ? ((nz[p >> 5] >> (p & 31)) & 1u) : false;
+    mask[p] = o ? 255 : (n ? 1 : 0);
+}
+
+void launch_planes_to_mask(const uint32_t* nz, const uint32_t* ob, int npix, uint8_t* mask, hipStream_t s)
+{
+    hipLaunchKernelGGL(plane_to_mask_kernel, dim3((npix + 255) / 256), dim3(256), 0, s, nz, ob, npix, mask);
+}
+
+}  // namespace roft

@@ -1,0 +1,290 @@
+// k_render.hip -- depth render of the object mesh + masked depth likelihood + outlier decision
+// (gfx950).
+//
+// Reference:
+//   ROFTFilter::correct_outlier_rejection / pick_best_alternative / buffer_outlier_rejection_features
+//                                               src/roft-lib/src/ROFTFilter.cpp:467-676
+//   SICAD::superimpose (OpenGL) contract         src/roft-lib/src/SICAD.cpp:924-1066,1601-1656,
+//                                               src/roft-lib/shader/shader_model.frag:30-52
+//
+// MI355X design.
+//  * No OpenGL: a compute rasteriser, one thread per triangle, min-depth resolved with atomicMin on
+//    the IEEE bits of the (positive) eye-space Z -- order independent, so the tile is bit-identical
+//    from run to run.  Per-pixel arithmetic is IEEE float with the operation order of the render
+//    contract in oracle/ro_render.c (this file is built with -ffp-contract=off).
+//  * The reference copies the whole depth frame and mask when a pose arrives and scans them six
+//    frames later (findNonZero, every second pixel).  Here the "features" are extracted once into
+//    a compact (pixel, depth) list indexed by rank/2, so the likelihood is a dense reduction over
+//    ~N_mask/2 samples and the frame itself need not be retained.
+#include "roft_device.h"
+
+namespace roft {
+
+constexpr int kFeatThreads = 512;
+
+__device__ int block_exclusive_scan_r(int v, int* s_wave, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < nw; ++w) { int t = s_wave[w]; s_wave[w] = run; run += t; }
+        s_wave[16] = run;
+    }
+    __syncthreads();
+    const int res = s_wave[wave] + inc - v;
+    *total = s_wave[16];
+    __syncthreads();
+    return res;
+}
+
+// phase 0: before the UKF steps (first frame / non-resync outlier rejection uses the current frame)
+// phase 1: after them (re-buffer at pose re-sync frames, ROFTFilter.cpp:353)
+__global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a, int phase)
+{
+    __shared__ int s_wave[17];
+    __shared__ int s_carry;
+    const int obj = blockIdx.x;
+    const FrameCtrl& c = a.ctrl[obj];
+    const bool run = (phase == 0) ? (c.buffer_features_before || c.features_current) : c.buffer_features_after;
+    if (!run) return;
+    const int W = a.cam.W, H = a.cam.H, wpr = a.cam.wpr;
+    const uint32_t* plane = a.planes + plane_offset(a, obj, c.slot_cur, 1);
+    const float* depth = c.depth_cur;
+    uint32_t* fpix = a.feat_pix + (size_t)obj * a.feat_cap;
+    float* fdep = a.feat_depth + (size_t)obj * a.feat_cap;
+
+    int carry = 0;
+    for (int r0 = 0; r0 < H; r0 += blockDim.x) {
+        const int r = r0 + threadIdx.x;
+        int cnt = 0;
+        if (r < H)
+            for (int w = 0; w < wpr; ++w) cnt += __popc(plane[(size_t)r * wpr + w]);
+        int total;
+        int rank = carry + block_exclusive_scan_r(cnt, s_wave, &total);
+        carry += total;
+        if (r < H && cnt) {
+            for (int w = 0; w < wpr; ++w) {
+                uint32_t bits = plane[(size_t)r * wpr + w];
+                while (bits) {
+                    const int b = __builtin_ctz(bits);
+                    bits &= bits - 1;
+                    if ((rank & 1) == 0) {   // `k += 2` over findNonZero order (ROFTFilter.cpp:556)
+                        const int u = w * 32 + b;
+                        const int slot = rank >> 1;
+                        if (slot < a.feat_cap) {
+                            fpix[slot] = (uint32_t)(r * W + u);
+                            fdep[slot] = depth[(size_t)r * W + u];
+                        }
+                    }
+                    ++rank;
+                }
+            }
+        }
+    }
+    if (threadIdx.x == 0) a.state[obj].n_feat = min((carry + 1) / 2, a.feat_cap);
+    (void)s_carry;
+}
+
+void launch_features(const EngineArrays& a, int phase, hipStream_t s)
+{
+    hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), 0, s, a, phase);
+}
+
+// ---- rasteriser ---------------------------------------------------------------------------------
+struct RenderPose {
+    float R[9];
+    float t[3];
+};
+
+__device__ __forceinline__ RenderPose make_pose(const double* x, const double* q)
+{
+    RenderPose p;
+    const double w = q[0], qx = q[1], qy = q[2], qz = q[3];
+    p.R[0] = (float)(1.0 - 2.0 * (qy * qy + qz * qz)); p.R[1] = (float)(2.0 * (qx * qy - w * qz)); p.R[2] = (float)(2.0 * (qx * qz + w * qy));
+    p.R[3] = (float)(2.0 * (qx * qy + w * qz)); p.R[4] = (float)(1.0 - 2.0 * (qx * qx + qz * qz)); p.R[5] = (float)(2.0 * (qy * qz - w * qx));
+    p.R[6] = (float)(2.0 * (qx * qz - w * qy)); p.R[7] = (float)(2.0 * (qy * qz + w * qx)); p.R[8] = (float)(1.0 - 2.0 * (qx * qx + qy * qy));
+    for (int i = 0; i < 3; ++i) p.t[i] = (float)x[i];
+    return p;
+}
+
+__device__ __forceinline__ void project_vertex(const float* v, const RenderPose& P, float fx, float fy, float cx,
+                                               float cy, float& sx, float& sy, float& z)
+{
+    const float X = ((P.R[0] * v[0] + P.R[1] * v[1]) + P.R[2] * v[2]) + P.t[0];
+    const float Y = ((P.R[3] * v[0] + P.R[4] * v[1]) + P.R[5] * v[2]) + P.t[1];
+    z = ((P.R[6] * v[0] + P.R[7] * v[1]) + P.R[8] * v[2]) + P.t[2];
+    if (z > 0.001f) {
+        sx = (fx * X) / z + cx;
+        sy = (fy * Y) / z + cy;
+    } else {
+        sx = sy = 0.0f;
+    }
+}
+
+__device__ void raster_triangle(const float* verts, const int32_t* tri, const RenderPose& P, float fx, float fy,
+                                float cx, float cy, int w, int h, uint32_t* zbuf)
+{
+    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+    project_vertex(verts + (size_t)3 * tri[0], P, fx, fy, cx, cy, x0, y0, z0);
+    project_vertex(verts + (size_t)3 * tri[1], P, fx, fy, cx, cy, x1, y1, z1);
+    project_vertex(verts + (size_t)3 * tri[2], P, fx, fy, cx, cy, x2, y2, z2);
+    if (!(z0 > 0.001f && z1 > 0.001f && z2 > 0.001f)) return;
+    const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    if (area == 0.0f || !(area == area)) return;
+    const float minx = fminf(x0, fminf(x1, x2)), maxx = fmaxf(x0, fmaxf(x1, x2));
+    const float miny = fminf(y0, fminf(y1, y2)), maxy = fmaxf(y0, fmaxf(y1, y2));
+    float fi0 = ceilf(minx - 0.5f), fi1 = floorf(maxx - 0.5f);
+    float fj0 = ceilf(miny - 0.5f), fj1 = floorf(maxy - 0.5f);
+    if (fi0 < 0.0f) fi0 = 0.0f;
+    if (fj0 < 0.0f) fj0 = 0.0f;
+    if (fi1 > (float)(w - 1)) fi1 = (float)(w - 1);
+    if (fj1 > (float)(h - 1)) fj1 = (float)(h - 1);
+    if (!(fi0 <= fi1) || !(fj0 <= fj1)) return;
+    const int ia = (int)fi0, ib = (int)fi1, ja = (int)fj0, jb = (int)fj1;
+    const float iz0 = 1.0f / z0, iz1 = 1.0f / z1, iz2 = 1.0f / z2;
+    for (int j = ja; j <= jb; ++j) {
+        const float py = (float)j + 0.5f;
+        for (int i = ia; i <= ib; ++i) {
+            const float px = (float)i + 0.5f;
+            const float w0 = (x2 - x1) * (py - y1) - (y2 - y1) * (px - x1);
+            const float w1 = (x0 - x2) * (py - y2) - (y0 - y2) * (px - x2);
+            const float w2 = (x1 - x0) * (py - y0) - (y1 - y0) * (px - x0);
+            const bool inside = (area > 0.0f) ? (w0 >= 0.0f && w1 >= 0.0f && w2 >= 0.0f)
+                                              : (w0 <= 0.0f && w1 <= 0.0f && w2 <= 0.0f);
+            if (!inside) continue;
+            const float b0 = w0 / area, b1 = w1 / area, b2 = w2 / area;
+            const float iz = (b0 * iz0 + b1 * iz1) + b2 * iz2;
+            const float z = 1.0f / iz;
+            if (!(z > 0.0f)) continue;
+            atomicMin(&zbuf[(size_t)j * w + i], __float_as_uint(z));
+        }
+    }
+}
+
+// grid: (ceil(n_tris_max/256), 2 alternatives, n_obj)
+__global__ __launch_bounds__(256) void raster_engine_kernel(EngineArrays a)
+{
+    const int obj = blockIdx.z, alt = blockIdx.y;
+    const FrameCtrl& c = a.ctrl[obj];
+    if (c.outlier_step < 0) return;
+    const ObjParams& prm = a.params[obj];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= prm.n_tris) return;
+    const PoseBelief& bl = a.state[obj].belief[alt == 0 ? B_ALT0 : B_ALT1];
+    const RenderPose P = make_pose(bl.mean + 6, bl.mean + 9);
+    const int d = a.cam.divider;
+    const float fx = (float)(a.cam.fx / d), fy = (float)(a.cam.fy / d), cx = (float)(a.cam.cx / d),
+                cy = (float)(a.cam.cy / d);
+    uint32_t* zb = a.zbuf + ((size_t)obj * 2 + alt) * a.tile_w * a.tile_h;
+    raster_triangle(prm.verts, prm.tris + (size_t)3 * t, P, fx, fy, cx, cy, a.tile_w, a.tile_h, zb);
+}
+
+// one workgroup per object: likelihood of both alternatives over the buffered features, decision,
+// and the selected belief becomes the corrected belief (ROFTFilter.cpp:581-583, 670-675)
+__global__ __launch_bounds__(256) void outlier_kernel(EngineArrays a)
+{
+    __shared__ double s_err[2][4];
+    __shared__ double s_cnt[2][4];
+    __shared__ int s_sel;
+    const int obj = blockIdx.x;
+    const FrameCtrl& c = a.ctrl[obj];
+    if (c.outlier_step < 0) return;
+    ObjState& st = a.state[obj];
+    const int W = a.cam.W, d = a.cam.divider, tw = a.tile_w;
+    const uint32_t* fpix = a.feat_pix + (size_t)obj * a.feat_cap;
+    const float* fdep = a.feat_depth + (size_t)obj * a.feat_cap;
+    const uint32_t* z0 = a.zbuf + ((size_t)obj * 2) * a.tile_w * a.tile_h;
+    const uint32_t* z1 = z0 + (size_t)a.tile_w * a.tile_h;
+    double err[2] = {0.0, 0.0}, cnt[2] = {0.0, 0.0};
+    const int n = st.n_feat;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float dep = fdep[i];
+        if (!((dep > 0) && ((double)dep < 2.0))) continue;  // hard-coded 2.0 (ROFTFilter.cpp:561)
+        const uint32_t p = fpix[i];
+        const int v = (int)(p / W), u = (int)(p % W);
+        const size_t ti = (size_t)(v / d) * tw + (u / d);
+        const uint32_t b0 = z0[ti], b1 = z1[ti];
+        if (b0 != 0x7F800000u) { err[0] += (double)fabsf(dep - __uint_as_float(b0)); cnt[0] += 1.0; }
+        if (b1 != 0x7F800000u) { err[1] += (double)fabsf(dep - __uint_as_float(b1)); cnt[1] += 1.0; }
+    }
+    for (int k = 0; k < 2; ++k) {
+        double e = err[k], n2 = cnt[k];
+        for (int off = 32; off > 0; off >>= 1) { e += __shfl_down(e, off, 64); n2 += __shfl_down(n2, off, 64); }
+        if ((threadIdx.x & 63) == 0) { s_err[k][threadIdx.x >> 6] = e; s_cnt[k][threadIdx.x >> 6] = n2; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double L[2];
+        for (int k = 0; k < 2; ++k) {
+            double e = 0.0, n2 = 0.0;
+            for (int w = 0; w < 4; ++w) { e += s_err[k][w]; n2 += s_cnt[k][w]; }
+            L[k] = (n2 == 0.0) ? 1.7976931348623157e308 : (e / n2) / 1.0;  // gain is a bool -> 1.0 (ROFTFilter.h:64)
+        }
+        const int sel = (L[0] > 2.0 * L[1]) ? 1 : 0;
+        st.outlier_selected = sel;
+        st.outlier_L[0] = L[0];
+        st.outlier_L[1] = L[1];
+        for (int k = 0; k < 2; ++k) {
+            double n2 = 0.0;
+            for (int w = 0; w < 4; ++w) n2 += s_cnt[k][w];
+            st.outlier_cnt[k] = n2;
+        }
+        s_sel = sel;
+    }
+    __syncthreads();
+    const PoseBelief& src = st.belief[s_sel ? B_ALT1 : B_ALT0];
+    PoseBelief& dst = st.belief[B_CORR];
+    for (int i = threadIdx.x; i < 144; i += blockDim.x) dst.cov[i] = src.cov[i];
+    if (threadIdx.x < 13) dst.mean[threadIdx.x] = src.mean[threadIdx.x];
+}
+
+void launch_outlier(const EngineArrays& a, hipStream_t s)
+{
+    // objects that do not test this frame return immediately
+    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.zbuf), 0x7F800000, (size_t)a.n_obj * 2 * a.tile_w * a.tile_h, s);
+    hipLaunchKernelGGL(raster_engine_kernel, dim3((a.max_tris + 255) / 256, 2, a.n_obj), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(256), 0, s, a);
+}
+
+void launch_outlier_only(const EngineArrays& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(256), 0, s, a);
+}
+
+// ---- operator level: render one pose into a float tile ------------------------------------------
+__global__ __launch_bounds__(256) void raster_single_kernel(const float* verts, const int32_t* tris, int n_tris,
+                                                            const double* xq, DevCamera cam, uint32_t* zbuf)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tris) return;
+    const RenderPose P = make_pose(xq, xq + 3);
+    const int d = cam.divider;
+    const float fx = (float)(cam.fx / d), fy = (float)(cam.fy / d), cx = (float)(cam.cx / d), cy = (float)(cam.cy / d);
+    raster_triangle(verts, tris + (size_t)3 * t, P, fx, fy, cx, cy, cam.W / d, cam.H / d, zbuf);
+}
+
+__global__ __launch_bounds__(256) void zbuf_to_tile_kernel(const uint32_t* zbuf, float* tile, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = zbuf[i];
+    tile[i] = (b == 0x7F800000u) ? 0.0f : __uint_as_float(b);
+}
+
+void launch_render(const float* verts, const int32_t* tris, int n_tris, const double* xq, DevCamera cam, uint32_t* zbuf,
+                   float* tile_out, hipStream_t s)
+{
+    const int n = (cam.W / cam.divider) * (cam.H / cam.divider);
+    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(zbuf), 0x7F800000, n, s);
+    hipLaunchKernelGGL(raster_single_kernel, dim3((n_tris + 255) / 256), dim3(256), 0, s, verts, tris, n_tris, xq, cam, zbuf);
+    hipLaunchKernelGGL(zbuf_to_tile_kernel, dim3((n + 255) / 256), dim3(256), 0, s, zbuf, tile_out, n);
+}
+
+}  // namespace roft

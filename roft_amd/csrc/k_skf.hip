@@ -1,0 +1,415 @@
+// k_skf.hip -- velocity Kalman filter: prediction + sequential correction in information form (gfx950).
+//
+// Reference:
+//   bfl::KFPrediction over SpatialVelocityModel (F = I, P += Q)   src/roft-lib/src/SpatialVelocityModel.cpp:15-27
+//   SKFCorrection::correctStep                                    src/roft-lib/src/SKFCorrection.cpp:37-153
+//   observability rule (N < 3 -> keep the belief from before the prediction)  src/roft-lib/src/ROFTFilter.cpp:294-301
+//
+// The reference applies the N two-row measurements one after the other (cpp:129-149).  All of
+// them are linearised at fixed H_j and their weights l_j are fixed before the loop, so the
+// recursion is algebraically the batch update
+//     Lambda = (P^-)^-1 + sum_j l_j H_j' R^-1 H_j,   P^+ = Lambda^-1,
+//     s^+    = s^- + P^+ sum_j l_j H_j' R^-1 (y_j - H_j s^-)
+// which is a pure reduction over the measurements: one workgroup per object, fp64 accumulators,
+// wave shuffle + LDS reduction, 6x6 Cholesky solves on one lane.  Differs from the sequential
+// form only by rounding (tolerance stated in tests/test_parity_gpu.py).
+//
+// Laplacian re-weighting, including the reference's pairing quirk: the 2N innovation vector is
+// viewed as an N x 2 COLUMN-major matrix (cpp:93), so the median / scale are fitted to
+// sqrt(e[k]^2 + e[N+k]^2) while the likelihoods use the true per-point norm (cpp:111).
+// The median is an exact order statistic found by an 8-pass radix select over the IEEE bit
+// patterns (non-negative doubles order like unsigned integers) -- no sort.
+#include "roft_device.h"
+
+namespace roft {
+
+__device__ __forceinline__ void h_rows(const FlowRec& r, const DevCamera& cam, double dt, double h[12])
+{
+    const double z = (double)r.z;
+    const double uu = (r.u - cam.cx);
+    const double vv = (r.v - cam.cy);
+    h[0] = (cam.fx / z) * dt;
+    h[1] = 0.0;
+    h[2] = (-uu / z) * dt;
+    h[3] = (-uu * vv / cam.fy) * dt;
+    h[4] = (cam.fx + uu * uu / cam.fx) * dt;
+    h[5] = (-vv * cam.fx / cam.fy) * dt;
+    h[6] = 0.0;
+    h[7] = (cam.fy / z) * dt;
+    h[8] = (-vv / z) * dt;
+    h[9] = (-(cam.fy + vv * vv / cam.fy)) * dt;
+    h[10] = (vv * uu / cam.fx) * dt;
+    h[11] = (uu * cam.fy / cam.fx) * dt;
+}
+
+// Measurement accessors: the engine feeds compact flow records (H rows rebuilt on the fly, no
+// 96-byte-per-point matrix in HBM); the operator-level entry point feeds explicit (y, H) arrays.
+struct RecAccessor {
+    const FlowRec* recs;
+    DevCamera cam;
+    double dt;
+    __device__ __forceinline__ void get(int j, double h[12], double y[2]) const
+    {
+        const FlowRec r = recs[j];
+        h_rows(r, cam, dt, h);
+        y[0] = (double)r.dx;
+        y[1] = (double)r.dy;
+    }
+};
+
+struct ArrayAccessor {
+    const double* y;
+    const double* H;
+    __device__ __forceinline__ void get(int j, double h[12], double yy[2]) const
+    {
+        for (int i = 0; i < 12; ++i) h[i] = H[(size_t)12 * j + i];
+        yy[0] = y[2 * j];
+        yy[1] = y[2 * j + 1];
+    }
+};
+
+// innovation component k (flat index into the 2N vector) at the predicted mean
+template <class Acc>
+__device__ __forceinline__ double innov_at(const Acc& acc, int k, const double* x)
+{
+    double h[12], y[2];
+    acc.get(k >> 1, h, y);
+    const double* hr = h + 6 * (k & 1);
+    double pred = 0.0;
+    for (int i = 0; i < 6; ++i) pred += hr[i] * x[i];
+    return -(pred - y[k & 1]);
+}
+
+constexpr int kSkfThreads = 256;
+
+__device__ double block_sum(double v, double* s_red)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_red[w];
+    return t;
+}
+
+__device__ double block_max(double v, double* s_red)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = s_red[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, s_red[w]);
+    return t;
+}
+
+// exact order statistic `rank` (0-based) of N non-negative doubles
+__device__ unsigned long long radix_select(const double* vals, int N, int rank, int* s_hist, int* s_sel)
+{
+    unsigned long long prefix = 0, mask = 0;
+    for (int pass = 7; pass >= 0; --pass) {
+        const int shift = pass * 8;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) s_hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += blockDim.x) {
+            const unsigned long long k = (unsigned long long)__double_as_longlong(vals[i]);
+            if ((k & mask) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & 255ull)], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            const int h0 = s_hist[4 * l], h1 = s_hist[4 * l + 1], h2 = s_hist[4 * l + 2], h3 = s_hist[4 * l + 3];
+            const int loc = h0 + h1 + h2 + h3;
+            int inc = loc;
+            for (int off = 1; off < 64; off <<= 1) {
+                int t = __shfl_up(inc, off, 64);
+                if (l >= off) inc += t;
+            }
+            const int exc = inc - loc;
+            // the lane whose [exc, inc) interval contains rank
+            if (rank >= exc && rank < inc) {
+                int r = rank - exc, b = 4 * l;
+                if (r >= h0) { r -= h0; ++b; if (r >= h1) { r -= h1; ++b; if (r >= h2) { r -= h2; ++b; } } }
+                s_sel[0] = b;
+                s_sel[1] = r;
+            }
+        }
+        __syncthreads();
+        prefix |= ((unsigned long long)s_sel[0]) << shift;
+        mask |= 255ull << shift;
+        rank = s_sel[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// A (6x6 SPD, row-major) -> A^-1 via Cholesky; returns false if not positive definite
+__device__ bool spd_inverse6(const double* A, double* Ainv)
+{
+    double L[36];
+    for (int i = 0; i < 36; ++i) L[i] = 0.0;
+    for (int j = 0; j < 6; ++j) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) d -= L[j * 6 + k] * L[j * 6 + k];
+        if (!(d > 0.0)) return false;
+        const double ljj = sqrt(d);
+        L[j * 6 + j] = ljj;
+        for (int i = j + 1; i < 6; ++i) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
+            L[i * 6 + j] = s / ljj;
+        }
+    }
+    double Li[36];  // inverse of lower-triangular L
+    for (int i = 0; i < 36; ++i) Li[i] = 0.0;
+    for (int j = 0; j < 6; ++j) {
+        Li[j * 6 + j] = 1.0 / L[j * 6 + j];
+        for (int i = j + 1; i < 6; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s -= L[i * 6 + k] * Li[k * 6 + j];
+            Li[i * 6 + j] = s / L[i * 6 + i];
+        }
+    }
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) {
+            double s = 0.0;
+            for (int k = j; k < 6; ++k) s += Li[k * 6 + i] * Li[k * 6 + j];
+            Ainv[i * 6 + j] = s;
+            Ainv[j * 6 + i] = s;
+        }
+    return true;
+}
+
+struct SkfShared {
+    double red[kSkfThreads / 64];
+    double acc[27][kSkfThreads / 64];
+    int hist[256];
+    int sel[2];
+};
+
+// Correction of (x, P_pred) with N measurements; thread 0 returns the result in x_out / P_out.
+// Returns (to every thread) 0 = corrected, 3 = numerically singular.
+template <class Acc>
+__device__ int skf_core(const Acc& acc_in, int N, const double x[6], const double* P_pred, const double r_flow[2],
+                        int reweight, double* qn, SkfShared& S, double x_out[6], double* P_out)
+{
+    double mi = 0.0, b = 0.0, lmax = 1.0;
+    bool weighted = false;
+    if (reweight) {
+        for (int k = threadIdx.x; k < N; k += blockDim.x) {
+            const double e0 = innov_at(acc_in, k, x);
+            const double e1 = innov_at(acc_in, N + k, x);
+            qn[k] = sqrt(e0 * e0 + e1 * e1);
+        }
+        __syncthreads();  // qn is written and read by this workgroup only
+        const unsigned long long ka = radix_select(qn, N, (N % 2 == 0) ? N / 2 - 1 : N / 2, S.hist, S.sel);
+        const double va = __longlong_as_double((long long)ka);
+        mi = va;
+        if (N % 2 == 0) {
+            // element of rank N/2: va again if duplicates reach that rank, else the smallest value > va
+            double cnt_le = 0.0, min_gt = INFINITY;
+            for (int k = threadIdx.x; k < N; k += blockDim.x) {
+                const double v = qn[k];
+                if (v <= va) cnt_le += 1.0; else min_gt = fmin(min_gt, v);
+            }
+            cnt_le = block_sum(cnt_le, S.red);
+            min_gt = -block_max(-min_gt, S.red);
+            const double vb = (cnt_le > (double)(N / 2)) ? va : min_gt;
+            mi = 0.5 * (va + vb);
+        }
+        double sabs = 0.0;
+        for (int k = threadIdx.x; k < N; k += blockDim.x) sabs += fabs(qn[k] - mi);
+        b = block_sum(sabs, S.red) / N;
+        if (b > 1e-4) {
+            weighted = true;
+            double m = 0.0;
+            for (int j = threadIdx.x; j < N; j += blockDim.x) {
+                const double e0 = innov_at(acc_in, 2 * j, x), e1 = innov_at(acc_in, 2 * j + 1, x);
+                const double nj = sqrt(e0 * e0 + e1 * e1);
+                double l = 1.0 / (2 * b) * exp(-fabs(nj - mi) / b);
+                if (l < 1e-6) l = 1e-6;
+                m = fmax(m, l);
+            }
+            lmax = block_max(m, S.red);
+        }
+    }
+
+    // information accumulation: 21 unique entries of sum l H'R^-1 H and 6 of sum l H'R^-1 e
+    double acc[27];
+    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    const double ir0 = 1.0 / r_flow[0], ir1 = 1.0 / r_flow[1];
+    for (int j = threadIdx.x; j < N; j += blockDim.x) {
+        double h[12], y[2];
+        acc_in.get(j, h, y);
+        double p0 = 0.0, p1 = 0.0;
+        for (int i = 0; i < 6; ++i) { p0 += h[i] * x[i]; p1 += h[6 + i] * x[i]; }
+        const double e0 = -(p0 - y[0]), e1 = -(p1 - y[1]);
+        double l = 1.0;
+        if (weighted) {
+            const double nj = sqrt(e0 * e0 + e1 * e1);
+            l = 1.0 / (2 * b) * exp(-fabs(nj - mi) / b);
+            if (l < 1e-6) l = 1e-6;
+            l /= lmax;
+        }
+        const double w0 = l * ir0, w1 = l * ir1;
+        int t = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int k = i; k < 6; ++k) acc[t++] += w0 * h[i] * h[k] + w1 * h[6 + i] * h[6 + k];
+        for (int i = 0; i < 6; ++i) acc[21 + i] += w0 * h[i] * e0 + w1 * h[6 + i] * e1;
+    }
+    __syncthreads();
+    for (int i = 0; i < 27; ++i) {
+        double v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) S.acc[i][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+
+    if (threadIdx.x == 0) {
+        double Lm[36], eta[6];
+        int t = 0;
+        for (int i = 0; i < 6; ++i)
+            for (int k = i; k < 6; ++k) {
+                double v = 0.0;
+                for (int w = 0; w < kSkfThreads / 64; ++w) v += S.acc[t][w];
+                Lm[i * 6 + k] = v;
+                Lm[k * 6 + i] = v;
+                ++t;
+            }
+        for (int i = 0; i < 6; ++i) {
+            double v = 0.0;
+            for (int w = 0; w < kSkfThreads / 64; ++w) v += S.acc[21 + i][w];
+            eta[i] = v;
+        }
+        double Ppi[36], Pn[36];
+        bool ok = spd_inverse6(P_pred, Ppi);
+        if (ok) {
+            for (int i = 0; i < 36; ++i) Lm[i] += Ppi[i];
+            ok = spd_inverse6(Lm, Pn);
+        }
+        if (ok) {
+            for (int i = 0; i < 6; ++i) {
+                double s = 0.0;
+                for (int k = 0; k < 6; ++k) s += Pn[i * 6 + k] * eta[k];
+                x_out[i] = x[i] + s;
+            }
+            for (int i = 0; i < 36; ++i) P_out[i] = Pn[i];
+        }
+        S.sel[0] = ok ? 0 : 3;
+    }
+    __syncthreads();
+    return S.sel[0];
+}
+
+__global__ __launch_bounds__(kSkfThreads) void skf_kernel(EngineArrays a, int reweight)
+{
+    __shared__ SkfShared S;
+    __shared__ double s_x[6];
+    __shared__ double s_P[36];
+
+    const int obj = blockIdx.x;
+    const FrameCtrl& c = a.ctrl[obj];
+    ObjState& st = a.state[obj];
+    const ObjParams& prm = a.params[obj];
+    const int N = c.vel_stage ? st.n_flow_points : -1;
+
+    // unobservable / no data: the belief is left exactly as it was (ROFTFilter.cpp:291-301)
+    if (N < 3) {
+        if (threadIdx.x < 6) st.twist_hist[c.twist_slot][threadIdx.x] = st.v_mean[threadIdx.x];
+        if (threadIdx.x == 0) st.skf_status = (N <= 0) ? 1 : 2;
+        return;
+    }
+    if (threadIdx.x < 6) s_x[threadIdx.x] = st.v_mean[threadIdx.x];  // s^- = s (F = I)
+    if (threadIdx.x < 36) {
+        const int i = threadIdx.x;
+        s_P[i] = st.v_cov[i] + ((i / 6 == i % 6) ? prm.v_q[i / 6] : 0.0);  // P^- = P + Q
+    }
+    __syncthreads();
+    double x[6];
+    for (int i = 0; i < 6; ++i) x[i] = s_x[i];
+
+    RecAccessor acc{a.recs + (size_t)obj * a.cand_cap, a.cam, c.dt};
+    double xo[6], Po[36];
+    const int rc = skf_core(acc, N, x, s_P, prm.r_flow, reweight, a.norms + (size_t)obj * a.cand_cap, S, xo, Po);
+    if (threadIdx.x == 0) {
+        if (rc == 0) {
+            for (int i = 0; i < 6; ++i) st.v_mean[i] = xo[i];
+            for (int i = 0; i < 36; ++i) st.v_cov[i] = Po[i];
+        }
+        st.skf_status = rc;  // 3: numerically singular, belief left unchanged
+        for (int i = 0; i < 6; ++i) st.twist_hist[c.twist_slot][i] = st.v_mean[i];
+    }
+}
+
+void launch_skf(const EngineArrays& a, int reweight, hipStream_t s)
+{
+    hipLaunchKernelGGL(skf_kernel, dim3(a.n_obj), dim3(kSkfThreads), 0, s, a, reweight);
+}
+
+// ---- operator level ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kSkfThreads) void skf_arrays_kernel(const double* x_pred, const double* P_pred, int N,
+                                                                 const double* y, const double* H, const double* Rdiag,
+                                                                 int reweight, double* norms, double* x_out,
+                                                                 double* P_out, int* status)
+{
+    __shared__ SkfShared S;
+    if (N <= 0) {  // SKFCorrection.cpp:61-69
+        if (threadIdx.x < 6) x_out[threadIdx.x] = x_pred[threadIdx.x];
+        if (threadIdx.x < 36) P_out[threadIdx.x] = P_pred[threadIdx.x];
+        if (threadIdx.x == 0) *status = 1;
+        return;
+    }
+    double x[6], r[2] = {Rdiag[0], Rdiag[1]};
+    for (int i = 0; i < 6; ++i) x[i] = x_pred[i];
+    ArrayAccessor acc{y, H};
+    double xo[6], Po[36];
+    const int rc = skf_core(acc, N, x, P_pred, r, reweight, norms, S, xo, Po);
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < 6; ++i) x_out[i] = (rc == 0) ? xo[i] : x_pred[i];
+        for (int i = 0; i < 36; ++i) P_out[i] = (rc == 0) ? Po[i] : P_pred[i];
+        *status = rc;
+    }
+}
+
+void launch_skf_arrays(const double* x_pred, const double* P_pred, int N, const double* y, const double* H,
+                       const double* Rdiag, int reweight, double* norms, double* x_out, double* P_out, int* status,
+                       hipStream_t s)
+{
+    hipLaunchKernelGGL(skf_arrays_kernel, dim3(1), dim3(kSkfThreads), 0, s, x_pred, P_pred, N, y, H, Rdiag, reweight,
+                       norms, x_out, P_out, status);
+}
+
+__global__ void kf_predict_kernel(const double* x, const double* P, const double* qdiag, double* xo, double* Po)
+{
+    const int i = threadIdx.x;
+    if (i < 6) xo[i] = x[i];
+    if (i < 36) Po[i] = P[i] + ((i / 6 == i % 6) ? qdiag[i / 6] : 0.0);
+}
+
+void launch_kf_predict(const double* x, const double* P, const double* qdiag, double* xo, double* Po, hipStream_t s)
+{
+    hipLaunchKernelGGL(kf_predict_kernel, dim3(1), dim3(64), 0, s, x, P, qdiag, xo, Po);
+}
+
+// per-frame compact outputs (what ROFTFilter logs, ROFTFilter.cpp:386-394,448-451)
+__global__ void collect_outputs_kernel(EngineArrays a, int frame_idx)
+{
+    const int obj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (obj >= a.n_obj || !a.out_log) return;
+    const ObjState& st = a.state[obj];
+    roft_object_output& o = a.out_log[(size_t)(frame_idx % a.log_cap) * a.n_obj + obj];
+    for (int i = 0; i < 13; ++i) o.pose[i] = st.belief[B_CORR].mean[i];
+    for (int i = 0; i < 6; ++i) o.twist[i] = st.v_mean[i];
+    o.n_flow_points = st.n_flow_points;
+    o.outlier_selected = st.outlier_selected;
+    o.outlier_L[0] = st.outlier_L[0];
+    o.outlier_L[1] = st.outlier_L[1];
+}
+
+void launch_collect_outputs(const EngineArrays& a, int frame_idx, hipStream_t s)
+{
+    hipLaunchKernelGGL(collect_outputs_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frame_idx);
+}
+
+}  // namespace roft

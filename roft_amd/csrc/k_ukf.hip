@@ -1,0 +1,585 @@
+// k_ukf.hip -- pose UKF: sigma-point fan-out, prediction and correction, one wavefront per object
+// (gfx950).
+//
+// Reference:
+//   bfl::UKFPrediction (generic state model) over CartesianQuaternionModel::motion / Q(T)
+//                                              src/roft-lib/src/CartesianQuaternionModel.cpp:86-141
+//   ROFT::UKFCorrection::correctStep           src/roft-lib/src/UKFCorrection.cpp:54-133
+//   CartesianQuaternionMeasurement::{predictedMeasure, innovation}
+//                                              src/roft-lib/src/CartesianQuaternionMeasurement.cpp:357-487
+//   bfl sigma_point / unscented_transform / UTWeight / quaternion utils: third party
+//   (robotology/bayes-filters-lib, un-pinned); algorithm as restated in oracle/ro_ukf.c.
+//
+// MI355X design.  The whole step for one object (12-dof covariance, <= 49 sigma points) fits one
+// 64-lane wavefront with its matrices in LDS: lane = sigma point for the fan-out and the model
+// evaluations, lane = matrix entry for the weighted outer products.  The matrix square root is
+// U sqrt(S) from a Jacobi eigen-decomposition with the round-robin parallel ordering (n/2 disjoint
+// rotations per round, so a 12x12 sweep is 11 rounds instead of 66 sequential rotations).
+// The augmented covariance is block diagonal -- blkdiag(P, Q) or blkdiag(P, R) with R diagonal --
+// so only the 12x12 state block (and the 9x9 process-noise block) is ever decomposed, and when an
+// outlier-rejection step needs two corrections of the same prediction they share one
+// decomposition.  Products this small (12x12x49) do not fill an MFMA tile batch; plain fp64 FMA.
+#include "roft_device.h"
+
+namespace roft {
+
+// ---- quaternion helpers (same conventions as oracle/ro_la.c) -----------------------------------
+__device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4])
+{
+    const double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    const double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    const double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    const double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    o[0] = w; o[1] = x; o[2] = y; o[3] = z;
+}
+
+__device__ __forceinline__ void quat_boxplus(const double q[4], const double r[3], double o[4])
+{
+    const double n = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    double qr[4] = {1.0, 0.0, 0.0, 0.0};
+    if (n > 0.0) {
+        const double s = sin(n / 2.0) / n;
+        qr[0] = cos(n / 2.0);
+        qr[1] = s * r[0]; qr[2] = s * r[1]; qr[3] = s * r[2];
+    }
+    quat_mul(qr, q, o);
+}
+
+__device__ __forceinline__ void quat_diff(const double a[4], const double b[4], double o[3])
+{
+    const double bc[4] = {b[0], -b[1], -b[2], -b[3]};
+    double p[4];
+    quat_mul(a, bc, p);
+    const double n = sqrt(p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
+    if (n == 0.0) { o[0] = o[1] = o[2] = 0.0; return; }
+    const double angle = 2.0 * atan2(n, fabs(p[0]));
+    const double sgn = (p[0] < 0.0) ? -1.0 : 1.0;
+    const double k = sgn * angle / n;
+    o[0] = k * p[1]; o[1] = k * p[2]; o[2] = k * p[3];
+}
+
+// ---- LDS layout -----------------------------------------------------------------------------------
+constexpr int kCols = 50;  // >= 2 * 24 + 1
+
+struct UkfLds {
+    double P[144];       // matrix being decomposed (destroyed)
+    double V[144];       // its eigenvectors (columns)
+    double wP[12];       // its eigenvalues
+    double Q[100];       // process noise block padded to 10 x 10
+    double VQ[100];
+    double wQ[10];
+    double rc[12], rs[12];
+    int rp[12], rq[12];
+    double mean[13];     // mean the sigma points are drawn around
+    double cov[144];     // ... and its covariance (kept: P is destroyed)
+    double Y[13 * kCols];
+    double D[12 * kCols];
+    double X[12 * kCols];
+    double ymean[13];
+    double M4[16], V4[16], w4[4];
+    double Py[144], Pxy[144], K[144], KPy[144];
+    double aug[12 * 24];
+    double innov[12], Kin[12];
+    double noise_diag[12];
+    double red[4];
+    int flag;
+};
+
+// Symmetric Jacobi eigen-decomposition in LDS, n even (<= 12), executed by one wave.
+// On return diag(A) = eigenvalues, columns of V = eigenvectors.
+__device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
+{
+    const int lane = threadIdx.x;
+    for (int i = lane; i < n * n; i += 64) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
+    __syncthreads();
+    const int half = n / 2;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = lane; i < n * n; i += 64) {
+            const int r = i / n, cidx = i % n;
+            const double v = A[i];
+            if (r == cidx) dg += v * v; else if (r < cidx) off += v * v;
+        }
+        for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
+        if (off <= 1e-32 * dg || off == 0.0) break;
+
+        for (int round = 0; round < n - 1; ++round) {
+            if (lane < half) {
+                int p, q;
+                if (lane == 0) { p = n - 1; q = round; }
+                else { p = (round + lane) % (n - 1); q = (round - lane + (n - 1)) % (n - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                const double apq = A[p * n + q];
+                double c = 1.0, s = 0.0;
+                if (apq != 0.0) {
+                    const double app = A[p * n + p], aqq = A[q * n + q];
+                    const double tau = (aqq - app) / (2.0 * apq);
+                    const double t = (tau >= 0.0) ? 1.0 / (tau + sqrt(1.0 + tau * tau))
+                                                  : -1.0 / (-tau + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + t * t);
+                    s = t * c;
+                }
+                L.rc[lane] = c; L.rs[lane] = s; L.rp[lane] = p; L.rq[lane] = q;
+            }
+            __syncthreads();
+            for (int it = lane; it < half * n; it += 64) {  // columns p, q of A and V
+                const int i = it / n, k = it % n;
+                const int p = L.rp[i], q = L.rq[i];
+                const double c = L.rc[i], s = L.rs[i];
+                const double akp = A[k * n + p], akq = A[k * n + q];
+                A[k * n + p] = c * akp - s * akq;
+                A[k * n + q] = s * akp + c * akq;
+                const double vkp = V[k * n + p], vkq = V[k * n + q];
+                V[k * n + p] = c * vkp - s * vkq;
+                V[k * n + q] = s * vkp + c * vkq;
+            }
+            __syncthreads();
+            for (int it = lane; it < half * n; it += 64) {  // rows p, q of A
+                const int i = it / n, k = it % n;
+                const int p = L.rp[i], q = L.rq[i];
+                const double c = L.rc[i], s = L.rs[i];
+                const double apk = A[p * n + k], aqk = A[q * n + k];
+                A[p * n + k] = c * apk - s * aqk;
+                A[q * n + k] = s * apk + c * aqk;
+            }
+            __syncthreads();
+            if (lane < half && L.rs[lane] != 0.0) {
+                A[L.rp[lane] * n + L.rq[lane]] = 0.0;
+                A[L.rq[lane] * n + L.rp[lane]] = 0.0;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+}
+
+// dominant eigenvector of sum_c wm_c q_c q_c' (rows qrow..qrow+3 of Y), sign aligned with column 0
+__device__ void quaternion_mean(const double* Y, int qrow, int ncols, double wm0, double wmi, double out[4],
+                                UkfLds& L)
+{
+    const int lane = threadIdx.x;
+    if (lane < 16) {
+        const int i = lane / 4, j = lane % 4;
+        double s = 0.0;
+        for (int c = 0; c < ncols; ++c) s += (c == 0 ? wm0 : wmi) * Y[(qrow + i) * kCols + c] * Y[(qrow + j) * kCols + c];
+        L.M4[lane] = s;
+    }
+    __syncthreads();
+    jacobi_lds(L.M4, L.V4, 4, L);
+    if (lane == 0) {
+        int best = 0;
+        for (int i = 1; i < 4; ++i)
+            if (L.M4[i * 4 + i] > L.M4[best * 4 + best]) best = i;
+        double dot = 0.0;
+        for (int i = 0; i < 4; ++i) dot += L.V4[i * 4 + best] * Y[(qrow + i) * kCols + 0];
+        const double sg = (dot < 0.0) ? -1.0 : 1.0;
+        for (int i = 0; i < 4; ++i) L.w4[i] = sg * L.V4[i * 4 + best];
+    }
+    __syncthreads();
+    for (int i = 0; i < 4; ++i) out[i] = L.w4[i];
+}
+
+// C (ra x rb, leading dim ldc) = A diag(w) B'
+__device__ void weighted_outer(const double* A, int ra, const double* B, int rb, int ncols, double wc0, double wci,
+                               double* C, int ldc)
+{
+    for (int e = threadIdx.x; e < ra * rb; e += 64) {
+        const int i = e / rb, j = e % rb;
+        double s = 0.0;
+        for (int c = 0; c < ncols; ++c) s += A[i * kCols + c] * (c == 0 ? wc0 : wci) * B[j * kCols + c];
+        C[i * ldc + j] = s;
+    }
+}
+
+// Gauss-Jordan inverse with partial pivoting of the m x m matrix A (ld m) -> Ainv; one wave.
+__device__ bool inverse_lds(const double* A, int m, double* Ainv, UkfLds& L)
+{
+    const int lane = threadIdx.x;
+    double* M = L.aug;  // m x 2m
+    const int ld = 2 * m;
+    for (int e = lane; e < m * ld; e += 64) {
+        const int i = e / ld, j = e % ld;
+        M[e] = (j < m) ? A[i * m + j] : ((j - m) == i ? 1.0 : 0.0);
+    }
+    if (lane == 0) L.flag = 1;
+    __syncthreads();
+    for (int c = 0; c < m; ++c) {
+        if (lane == 0) {
+            int piv = c;
+            double best = fabs(M[c * ld + c]);
+            for (int r = c + 1; r < m; ++r) {
+                const double v = fabs(M[r * ld + c]);
+                if (v > best) { best = v; piv = r; }
+            }
+            L.rp[0] = piv;
+            if (best == 0.0 || !(best == best)) L.flag = 0;
+        }
+        __syncthreads();
+        if (!L.flag) return false;
+        const int piv = L.rp[0];
+        if (piv != c)
+            for (int j = lane; j < ld; j += 64) {
+                const double t = M[c * ld + j];
+                M[c * ld + j] = M[piv * ld + j];
+                M[piv * ld + j] = t;
+            }
+        __syncthreads();
+        const double d = 1.0 / M[c * ld + c];
+        __syncthreads();
+        for (int j = lane; j < ld; j += 64) M[c * ld + j] *= d;
+        __syncthreads();
+        // eliminate column c from every other row; factors are read before any row is modified
+        double f[5];
+        int cnt = 0;
+        for (int e = lane; e < m * ld; e += 64) f[cnt++] = M[(e / ld) * ld + c];
+        __syncthreads();
+        cnt = 0;
+        for (int e = lane; e < m * ld; e += 64) {
+            const int r = e / ld, j = e % ld;
+            const double fr = f[cnt++];
+            if (r != c && fr != 0.0) M[e] -= fr * M[c * ld + j];
+        }
+        __syncthreads();
+    }
+    for (int e = lane; e < m * m; e += 64) Ainv[e] = M[(e / m) * ld + m + (e % m)];
+    __syncthreads();
+    return true;
+}
+
+struct UtW {
+    double c, wm0, wc0, wi;
+    int ncols;
+};
+
+__device__ __forceinline__ UtW ut_weights(int n, const roft_ut_params& ut)
+{
+    UtW w;
+    const double lambda = ut.alpha * ut.alpha * (n + ut.kappa) - n;
+    w.c = n + lambda;
+    w.ncols = 2 * n + 1;
+    w.wm0 = lambda / (n + lambda);
+    w.wc0 = lambda / (n + lambda) + (1.0 - ut.alpha * ut.alpha + ut.beta);
+    w.wi = 1.0 / (2.0 * (n + lambda));
+    return w;
+}
+
+// perturbation of sigma column `col`: state part d[12] (from the decomposition of L.P, already done)
+// and noise part dn[r].  noise_eig: use (L.VQ, L.wQ) (process noise) else diagonal L.noise_diag.
+__device__ void sigma_perturbation(int col, int r, double sc, bool noise_eig, const UkfLds& L, double d[12],
+                                   double dn[12])
+{
+    const int n = 12 + r;
+    for (int i = 0; i < 12; ++i) { d[i] = 0.0; dn[i] = 0.0; }
+    if (col == 0) return;
+    const int k = (col - 1) % n;
+    const double sgn = (col <= n) ? 1.0 : -1.0;
+    if (k < 12) {
+        const double s = sqrt(fabs(L.wP[k]));
+        for (int i = 0; i < 12; ++i) d[i] = sgn * sc * L.V[i * 12 + k] * s;
+    } else {
+        const int kk = k - 12;
+        if (noise_eig) {
+            const double s = sqrt(fabs(L.wQ[kk]));
+            for (int i = 0; i < r; ++i) dn[i] = sgn * sc * L.VQ[i * 10 + kk] * s;
+        } else {
+            dn[kk] = sgn * sc * 1.0 * sqrt(fabs(L.noise_diag[kk]));
+        }
+    }
+}
+
+// Decompose L.cov (copy in L.P): eigenvalues -> L.wP, eigenvectors -> L.V
+__device__ void decompose_state_cov(UkfLds& L)
+{
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 144; i += 64) L.P[i] = L.cov[i];
+    __syncthreads();
+    jacobi_lds(L.P, L.V, 12, L);
+    if (lane < 12) L.wP[lane] = L.P[lane * 13];
+    __syncthreads();
+}
+
+// ---- prediction: (L.mean, L.cov) -> (L.mean, L.cov) ------------------------------------------------
+__device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const roft_ut_params& ut)
+{
+    const int lane = threadIdx.x;
+    const int r = 9, n = 21;
+    const UtW w = ut_weights(n, ut);
+    const double sc = sqrt(w.c);
+
+    // process noise block Q(T) (CartesianQuaternionModel.cpp:127-141), padded to 10 x 10
+    for (int i = lane; i < 100; i += 64) L.Q[i] = 0.0;
+    __syncthreads();
+    if (prm.q_override) {
+        for (int i = lane; i < 81; i += 64) L.Q[(i / 9) * 10 + (i % 9)] = prm.q_override[i];
+    } else if (lane < 3) {
+        const int i = lane;
+        L.Q[i * 10 + i] = prm.psd_lin_acc[i] * T;
+        L.Q[(3 + i) * 10 + (3 + i)] = prm.sigma_ang_vel[i];
+        L.Q[(6 + i) * 10 + (6 + i)] = prm.psd_lin_acc[i] * (pow(T, 3.0) / 3.0);
+        L.Q[i * 10 + (6 + i)] = prm.psd_lin_acc[i] * (pow(T, 2.0) / 2.0);
+        L.Q[(6 + i) * 10 + i] = prm.psd_lin_acc[i] * (pow(T, 2.0) / 2.0);
+    }
+    __syncthreads();
+    jacobi_lds(L.Q, L.VQ, 10, L);
+    if (lane < 10) L.wQ[lane] = L.Q[lane * 11];
+    __syncthreads();
+    decompose_state_cov(L);
+
+    // fan-out + motion model, lane = sigma point
+    if (lane < w.ncols) {
+        double d[12], dn[12];
+        sigma_perturbation(lane, r, sc, true, L, d, dn);
+        double v[3], wv[3], x[3], q[4];
+        for (int i = 0; i < 3; ++i) {
+            v[i] = L.mean[i] + d[i];
+            wv[i] = L.mean[3 + i] + d[3 + i];
+            x[i] = L.mean[6 + i] + d[6 + i];
+        }
+        quat_boxplus(L.mean + 9, d + 9, q);
+        for (int i = 0; i < 3; ++i) {
+            L.Y[i * kCols + lane] = v[i] + dn[i];
+            L.Y[(3 + i) * kCols + lane] = wv[i] + dn[3 + i];
+            L.Y[(6 + i) * kCols + lane] = (x[i] + dn[6 + i]) + v[i] * T;  // v without noise (cpp:94-97)
+        }
+        const double norm_w = sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]) + 2.220446049250313e-16;
+        const double c = cos(norm_w * T / 2.0);
+        const double s = sin(norm_w * T / 2.0) / norm_w;
+        L.Y[9 * kCols + lane] = c * q[0] + s * (-wv[0] * q[1] - wv[1] * q[2] - wv[2] * q[3]);
+        L.Y[10 * kCols + lane] = c * q[1] + s * (wv[0] * q[0] - wv[2] * q[2] + wv[1] * q[3]);
+        L.Y[11 * kCols + lane] = c * q[2] + s * (wv[1] * q[0] + wv[2] * q[1] - wv[0] * q[3]);
+        L.Y[12 * kCols + lane] = c * q[3] + s * (wv[2] * q[0] - wv[1] * q[1] + wv[0] * q[2]);
+    }
+    __syncthreads();
+
+    // mean
+    if (lane < 9) {
+        double s = 0.0;
+        for (int c = 0; c < w.ncols; ++c) s += L.Y[lane * kCols + c] * (c == 0 ? w.wm0 : w.wi);
+        L.ymean[lane] = s;
+    }
+    double qm[4];
+    quaternion_mean(L.Y, 9, w.ncols, w.wm0, w.wi, qm, L);
+    if (lane == 0)
+        for (int i = 0; i < 4; ++i) L.ymean[9 + i] = qm[i];
+    __syncthreads();
+    // deviations
+    if (lane < w.ncols) {
+        for (int i = 0; i < 9; ++i) L.D[i * kCols + lane] = L.Y[i * kCols + lane] - L.ymean[i];
+        const double q[4] = {L.Y[9 * kCols + lane], L.Y[10 * kCols + lane], L.Y[11 * kCols + lane],
+                             L.Y[12 * kCols + lane]};
+        double dq[3];
+        quat_diff(q, L.ymean + 9, dq);
+        for (int i = 0; i < 3; ++i) L.D[(9 + i) * kCols + lane] = dq[i];
+    }
+    __syncthreads();
+    weighted_outer(L.D, 12, L.D, 12, w.ncols, w.wc0, w.wi, L.cov, 12);
+    if (lane < 13) L.mean[lane] = L.ymean[lane];
+    __syncthreads();
+}
+
+// ---- correction of (L.mean, L.cov) [decomposition already in L.V / L.wP] -> out ------------------------
+// returns status: 0 corrected, 1 no measurement, 2 singular Py
+__device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const double* twist, const double* pose_x,
+                           const double* pose_q, const roft_ut_params& ut, PoseBelief* out)
+{
+    const int lane = threadIdx.x;
+    if (type == ROFT_MEAS_NONE) {
+        for (int i = lane; i < 144; i += 64) out->cov[i] = L.cov[i];
+        if (lane < 13) out->mean[lane] = L.mean[lane];
+        return 1;
+    }
+    const bool has_vel = (type == ROFT_MEAS_VELOCITY || type == ROFT_MEAS_POSE_VELOCITY);
+    const bool has_pose = (type == ROFT_MEAS_POSE || type == ROFT_MEAS_POSE_VELOCITY);
+    const int r = (has_vel ? 6 : 0) + (has_pose ? 6 : 0);
+    const int m = r;
+    const int mtot = (has_vel ? 6 : 0) + (has_pose ? 7 : 0);
+    const int nlin = mtot - (has_pose ? 4 : 0);
+    const int n = 12 + r;
+    const UtW w = ut_weights(n, ut);
+    const double sc = sqrt(w.c);
+
+    // measurement vector and noise diagonal in measurement order (velocity first)
+    double meas[13];
+    {
+        int k = 0;
+        if (has_vel) { for (int i = 0; i < 6; ++i) meas[k++] = twist[i]; }
+        if (has_pose) { for (int i = 0; i < 3; ++i) meas[k++] = pose_x[i]; for (int i = 0; i < 4; ++i) meas[k++] = pose_q[i]; }
+    }
+    if (lane == 0) {
+        int k = 0;
+        if (has_vel) { for (int i = 0; i < 3; ++i) L.noise_diag[k++] = prm.R_v[i]; for (int i = 0; i < 3; ++i) L.noise_diag[k++] = prm.R_w[i]; }
+        if (has_pose) { for (int i = 0; i < 3; ++i) L.noise_diag[k++] = prm.R_x[i]; for (int i = 0; i < 3; ++i) L.noise_diag[k++] = prm.R_q[i]; }
+    }
+    __syncthreads();
+
+    if (lane < w.ncols) {
+        double d[12], dn[12];
+        sigma_perturbation(lane, r, sc, false, L, d, dn);
+        double v[3], wv[3], x[3], q[4];
+        for (int i = 0; i < 3; ++i) {
+            v[i] = L.mean[i] + d[i];
+            wv[i] = L.mean[3 + i] + d[3 + i];
+            x[i] = L.mean[6 + i] + d[6 + i];
+        }
+        quat_boxplus(L.mean + 9, d + 9, q);
+        // input deviations of the state dof rows (recomputed like bfl does)
+        for (int i = 0; i < 3; ++i) {
+            L.X[i * kCols + lane] = v[i] - L.mean[i];
+            L.X[(3 + i) * kCols + lane] = wv[i] - L.mean[3 + i];
+            L.X[(6 + i) * kCols + lane] = x[i] - L.mean[6 + i];
+        }
+        double dq[3];
+        quat_diff(q, L.mean + 9, dq);
+        for (int i = 0; i < 3; ++i) L.X[(9 + i) * kCols + lane] = dq[i];
+
+        int row = 0;
+        if (has_vel) {
+            const double p[3] = {-x[0], -x[1], -x[2]};
+            const double cr[3] = {wv[1] * p[2] - wv[2] * p[1], wv[2] * p[0] - wv[0] * p[2], wv[0] * p[1] - wv[1] * p[0]};
+            for (int i = 0; i < 3; ++i) {
+                L.Y[(row + i) * kCols + lane] = (v[i] + cr[i]) + dn[i];
+                L.Y[(row + 3 + i) * kCols + lane] = wv[i] + dn[3 + i];
+            }
+            row += 6;
+        }
+        if (has_pose) {
+            const int off = has_vel ? 6 : 0;
+            for (int i = 0; i < 3; ++i) L.Y[(row + i) * kCols + lane] = x[i] + dn[off + i];
+            const double rv[3] = {dn[r - 3], dn[r - 2], dn[r - 1]};
+            double qo[4];
+            quat_boxplus(q, rv, qo);
+            for (int i = 0; i < 4; ++i) L.Y[(row + 3 + i) * kCols + lane] = qo[i];
+        }
+    }
+    __syncthreads();
+
+    if (lane < nlin) {
+        double s = 0.0;
+        for (int c = 0; c < w.ncols; ++c) s += L.Y[lane * kCols + c] * (c == 0 ? w.wm0 : w.wi);
+        L.ymean[lane] = s;
+    }
+    if (has_pose) {
+        double qm[4];
+        quaternion_mean(L.Y, nlin, w.ncols, w.wm0, w.wi, qm, L);
+        if (lane == 0)
+            for (int i = 0; i < 4; ++i) L.ymean[nlin + i] = qm[i];
+    }
+    __syncthreads();
+    if (lane < w.ncols) {
+        for (int i = 0; i < nlin; ++i) L.D[i * kCols + lane] = L.Y[i * kCols + lane] - L.ymean[i];
+        if (has_pose) {
+            const double q[4] = {L.Y[nlin * kCols + lane], L.Y[(nlin + 1) * kCols + lane],
+                                 L.Y[(nlin + 2) * kCols + lane], L.Y[(nlin + 3) * kCols + lane]};
+            double dq[3];
+            quat_diff(q, L.ymean + nlin, dq);
+            for (int i = 0; i < 3; ++i) L.D[(nlin + i) * kCols + lane] = dq[i];
+        }
+    }
+    __syncthreads();
+    weighted_outer(L.D, m, L.D, m, w.ncols, w.wc0, w.wi, L.Py, m);
+    weighted_outer(L.X, 12, L.D, m, w.ncols, w.wc0, w.wi, L.Pxy, m);
+    if (lane < nlin) L.innov[lane] = -(L.ymean[lane] - meas[lane]);
+    if (has_pose && lane == 0) {
+        double dq[3];
+        quat_diff(meas + nlin, L.ymean + nlin, dq);
+        for (int i = 0; i < 3; ++i) L.innov[nlin + i] = dq[i];
+    }
+    __syncthreads();
+
+    // K = Pxy Py^-1 ; the inverse lands in KPy (scratch), then KPy = K Py
+    if (!inverse_lds(L.Py, m, L.KPy, L)) {
+        for (int i = lane; i < 144; i += 64) out->cov[i] = L.cov[i];
+        if (lane < 13) out->mean[lane] = L.mean[lane];
+        return 2;
+    }
+    for (int e = lane; e < 12 * m; e += 64) {
+        const int i = e / m, j = e % m;
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += L.Pxy[i * m + k] * L.KPy[k * m + j];
+        L.K[i * m + j] = s;
+    }
+    __syncthreads();
+    for (int e = lane; e < 12 * m; e += 64) {
+        const int i = e / m, j = e % m;
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += L.K[i * m + k] * L.Py[k * m + j];
+        L.KPy[i * m + j] = s;
+    }
+    if (lane < 12) {
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += L.K[lane * m + k] * L.innov[k];
+        L.Kin[lane] = s;
+    }
+    __syncthreads();
+    if (lane < 9) out->mean[lane] = L.mean[lane] + L.Kin[lane];
+    if (lane == 9) {
+        double qo[4];
+        quat_boxplus(L.mean + 9, L.Kin + 9, qo);
+        for (int i = 0; i < 4; ++i) out->mean[9 + i] = qo[i];
+    }
+    for (int e = lane; e < 144; e += 64) {
+        const int i = e / 12, j = e % 12;
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += L.KPy[i * m + k] * L.K[j * m + k];
+        out->cov[e] = L.cov[e] - s;
+    }
+    __syncthreads();
+    return 0;
+}
+
+// One launch = one StepDesc per object: optional prediction, then 0, 1 or 2 corrections of it.
+__global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step, roft_ut_params ut)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    UkfLds& L = *reinterpret_cast<UkfLds*>(smem);
+    const int obj = blockIdx.x;
+    const FrameCtrl& c = a.ctrl[obj];
+    if (step >= c.n_steps) return;
+    const StepDesc sd = c.steps[step];
+    if (!sd.op) return;
+    ObjState& st = a.state[obj];
+    const ObjParams& prm = a.params[obj];
+    const int lane = threadIdx.x;
+
+    const PoseBelief& src = st.belief[sd.src];
+    for (int i = lane; i < 144; i += 64) L.cov[i] = src.cov[i];
+    if (lane < 13) L.mean[lane] = src.mean[lane];
+    __syncthreads();
+    if (sd.save_corr_to_buf) {
+        const PoseBelief& cr = st.belief[B_CORR];
+        PoseBelief& bf = st.belief[B_BUF];
+        for (int i = lane; i < 144; i += 64) bf.cov[i] = cr.cov[i];
+        if (lane < 13) bf.mean[lane] = cr.mean[lane];
+    }
+
+    if (sd.do_predict) {
+        ukf_predict(L, prm, c.dt, ut);
+        PoseBelief& pr = st.belief[B_PRED];
+        for (int i = lane; i < 144; i += 64) pr.cov[i] = L.cov[i];
+        if (lane < 13) pr.mean[lane] = L.mean[lane];
+    }
+    if (sd.n_corr == 0) {
+        PoseBelief& d = st.belief[sd.dst[0]];
+        for (int i = lane; i < 144; i += 64) d.cov[i] = L.cov[i];
+        if (lane < 13) d.mean[lane] = L.mean[lane];
+        return;
+    }
+    decompose_state_cov(L);  // shared by both corrections of an outlier-rejection step
+    const double* twist = st.twist_hist[sd.twist_slot];
+    int status = 0;
+    for (int k = 0; k < sd.n_corr; ++k) {
+        const int rc = ukf_correct(L, prm, sd.type[k], twist, c.pose_x, c.pose_q, ut, &st.belief[sd.dst[k]]);
+        status |= rc << (4 * k);
+        __syncthreads();
+    }
+    if (lane == 0) st.ukf_status = status;
+}
+
+static size_t ukf_lds_bytes() { return (sizeof(UkfLds) + 15) & ~(size_t)15; }
+
+void launch_ukf_step(const EngineArrays& a, int step, roft_ut_params ut, hipStream_t s)
+{
+    hipLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(64), ukf_lds_bytes(), s, a, step, ut);
+}
+
+}  // namespace roft

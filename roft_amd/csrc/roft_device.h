@@ -1,0 +1,168 @@
+// roft_device.h -- device-visible data layout of the MI355X ROFT engine (gfx950 only).
+//
+// Everything the per-frame hot path touches lives in HBM in these structures; the host only
+// uploads one small FrameCtrl block per frame and enqueues a fixed sequence of batched kernels
+// (one workgroup per object), so a frame needs no device->host round trip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/roft_engine.h"
+
+namespace roft {
+
+constexpr int kWave = 64;              // CDNA wavefront
+constexpr int kNumBelief = 6;          // pose belief slots per object
+constexpr int kTwistRing = 16;         // twist history ring (velocity deque of the measurement model)
+constexpr int kMaxFlowHist = 6;        // flows a new mask can be chased through (frames between masks)
+constexpr int kMaxSteps = 10;          // UKF launches per frame (re-sync replays <= 7)
+constexpr int kPlaneSlots = ROFT_RETAIN_FRAMES;  // mask bit-plane ring per object
+
+enum BeliefSlot { B_CORR = 0, B_PRED = 1, B_BUF = 2, B_ALT0 = 3, B_ALT1 = 4, B_SPARE = 5 };
+
+struct DevCamera {
+    int W, H;
+    int wpr;       // 32-bit words per bit-plane row
+    int divider;   // render divider (ROFTFilter.cpp:191-193)
+    double fx, fy, cx, cy;
+};
+
+struct DevFlowFmt {
+    int type;   // ROFT_FLOW_*
+    int cols, rows, grid;
+    float scale;
+};
+
+struct PoseBelief {
+    double mean[13];   // v w x q(wxyz)
+    double cov[144];   // 12 x 12 row-major
+};
+
+struct ObjParams {
+    double sigma_ang_vel[3];
+    double psd_lin_acc[3];
+    double v_q[6];
+    double R_v[3], R_w[3], R_x[3], R_q[3];
+    double r_flow[2];
+    const float* verts;
+    const int32_t* tris;
+    int n_verts, n_tris;
+    const double* q_override;  // operator level only: explicit 9x9 process noise (else Q(T) from the PSDs)
+};
+
+// compact flow measurement record (what the SKF kernel consumes)
+struct FlowRec {
+    int u, v;
+    float z, dx, dy;
+};
+
+struct ObjState {
+    double v_mean[6];
+    double v_cov[36];
+    PoseBelief belief[kNumBelief];
+    double twist_hist[kTwistRing][6];
+    int fbuf_n;            // flows buffered since the last consumed mask (OF-aided source)
+    int new_mask_count;    // non-zero pixels of the newly ingested mask
+    int mask_mode;         // decided by the scatter kernel: 0 copy, 1 propagate, 2 new mask
+    int bbox[4];           // target bounding box of the scatter: xmin, ymin, xmax, ymax
+    int n_flow_points;     // N of the velocity stage (-1: did not run)
+    int n_feat;            // buffered outlier-rejection samples (rank-even mask pixels)
+    int outlier_selected;
+    double outlier_L[2];
+    double outlier_cnt[2];
+    int skf_status;
+    int ukf_status;
+};
+
+// one UKF launch for one object
+struct StepDesc {
+    int op;          // 0 = nop
+    int src;         // belief slot read
+    int do_predict;  // run the prediction (result also stored to B_PRED)
+    int n_corr;      // 0: dst0 <- prediction; 1 or 2 corrections
+    int type[2];     // ROFT_MEAS_*
+    int dst[2];      // belief slots written
+    int twist_slot;  // twist_hist index used as the velocity measurement
+    int save_corr_to_buf;  // re-sync: after reading src, B_BUF <- B_CORR (ROFTFilter.cpp:333-340)
+};
+
+struct FrameCtrl {
+    double dt;
+    const float* depth_prev;
+    const float* depth_cur;
+    const void* flow[kMaxFlowHist];  // [0] = this frame's flow, [j] = frame k-j
+    const uint8_t* new_mask;         // raw u8 mask delivered this frame (device) or null
+    int flow_valid;                  // this frame's flow exists and it is not the first frame
+    int has_new_mask;
+    int first_mask;                  // first mask ever: initialisation, not "new" (hpp:169-178)
+    int slot_prev, slot_cur;         // bit-plane ring slots
+    int vel_stage;                   // run the velocity stage this frame
+    int twist_slot;                  // twist_hist slot written this frame
+    int buffer_features_before;      // buffer outlier features before the UKF steps (first frame)
+    int buffer_features_after;       // ... after them (pose re-sync frames, ROFTFilter.cpp:353)
+    int features_current;            // non-resync outlier rejection: features of the current frame
+    int n_steps;
+    double pose_x[3];
+    double pose_q[4];
+    StepDesc steps[kMaxSteps];
+    int outlier_step;                // index of the step followed by render + likelihood (-1 none)
+    int force_mode;                  // operator level: force the mask mode (0 = decide on device)
+};
+
+// ---- launch wrappers (defined in the k_*.hip files) -------------------------------------------
+
+struct EngineArrays {
+    int n_obj;
+    DevCamera cam;
+    DevFlowFmt ffmt;
+    ObjParams* params;       // [n_obj]
+    ObjState* state;         // [n_obj]
+    FrameCtrl* ctrl;         // [n_obj] (current frame)
+    uint32_t* planes;        // [n_obj][kPlaneSlots + 2][2][wpr*H]   (nz plane, obj plane)
+    int32_t* map;            // [n_obj][W*H] scatter map (kept all-zero between frames)
+    FlowRec* cand;           // [n_obj][cand_cap] candidate scratch
+    FlowRec* recs;           // [n_obj][cand_cap] kept flow records
+    double* norms;           // [n_obj][cand_cap] SKF scratch
+    uint32_t* feat_pix;      // [n_obj][feat_cap] buffered feature pixel (linear index)
+    float* feat_depth;       // [n_obj][feat_cap]
+    uint32_t* zbuf;          // [n_obj][2][tile_h*tile_w] float bits, +inf = empty
+    int cand_cap, feat_cap;
+    size_t plane_words;      // wpr*H
+    int tile_w, tile_h;
+    int max_tris;            // largest mesh among the objects
+    roft_object_output* out_log;  // [log_cap][n_obj] per-frame outputs, or null
+    int log_cap;
+};
+
+constexpr int kSlotNew = kPlaneSlots;       // plane slot receiving an ingested mask
+constexpr int kSlotFeat = kPlaneSlots + 1;  // plane slot holding the buffered features' mask
+
+__host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, int slot, int which)
+{
+    return (((size_t)obj * (kPlaneSlots + 2) + slot) * 2 + which) * a.plane_words;
+}
+
+void launch_mask_ingest(const EngineArrays& a, hipStream_t s);
+void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s);
+void launch_planes_to_mask(const uint32_t* nz, const uint32_t* ob, int npix, uint8_t* mask, hipStream_t s);
+void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, hipStream_t s);
+void launch_skf(const EngineArrays& a, int reweight, hipStream_t s);
+// operator level: explicit (y, H) arrays, x_pred/P_pred in, x/P out (all device pointers)
+void launch_skf_arrays(const double* x_pred, const double* P_pred, int N, const double* y, const double* H,
+                       const double* Rdiag, int reweight, double* norms, double* x_out, double* P_out, int* status,
+                       hipStream_t s);
+void launch_kf_predict(const double* x, const double* P, const double* qdiag, double* xo, double* Po, hipStream_t s);
+void launch_collect_outputs(const EngineArrays& a, int frame_idx, hipStream_t s);
+void launch_ukf_step(const EngineArrays& a, int step, roft_ut_params ut, hipStream_t s);
+void launch_features(const EngineArrays& a, int phase, hipStream_t s);
+void launch_outlier(const EngineArrays& a, hipStream_t s);       // z-buffer clear + render + likelihood + decision
+void launch_outlier_only(const EngineArrays& a, hipStream_t s);  // likelihood + decision on filled z-buffers
+
+// operator-level helpers on raw device buffers (used by the C ABI operator entry points)
+void launch_expand_yh(const FlowRec* recs, const int* n, DevCamera cam, double dt, int32_t* uv, double* y,
+                      double* H, int cap, hipStream_t s);
+void launch_render(const float* verts, const int32_t* tris, int n_tris, const double* xq /*7*/, DevCamera cam,
+                   uint32_t* zbuf, float* tile_out, hipStream_t s);
+
+}  // namespace roft

@@ -1,0 +1,143 @@
+"""Batched ROFT filtering engine: host-side mirror of ROFT::ROFTFilter for many objects at once.
+
+Thin wrapper over the C ABI (include/roft_engine.h): `ROFTFilterBatch` plays the role the
+reference's `ROFTFilter` plays for one object (src/roft-lib/include/ROFT/ROFTFilter.h:38-194) --
+construct with the same parameters, feed one frame at a time -- but every object of the batch
+advances in the same kernel launches and all filter state stays in HBM.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def default_config(width, height, flow_type=L.FLOW_F32C2, max_objects=64, device=0):
+    cfg = L.Config()
+    L.check(L.lib().roft_default_config(C.byref(cfg), width, height, flow_type))
+    cfg.max_objects = max_objects
+    cfg.device = device
+    return cfg
+
+
+def default_object():
+    o = L.ObjectDesc()
+    L.check(L.lib().roft_default_object(C.byref(o)))
+    return o
+
+
+class ROFTFilterBatch:
+    def __init__(self, cfg):
+        L.require_device()
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        L.check(L.lib().roft_engine_create(C.byref(cfg), C.byref(self._h)))
+        self.n_objects = 0
+        self._keep = []
+        self._inputs = None
+        self.W, self.H = cfg.cam.width, cfg.cam.height
+
+    def add_object(self, desc, verts, tris):
+        verts = np.ascontiguousarray(verts, np.float32)
+        tris = np.ascontiguousarray(tris, np.int32)
+        desc.mesh = L.Mesh(verts.ctypes.data, verts.shape[0], tris.ctypes.data, tris.shape[0])
+        oid = C.c_int(-1)
+        L.check(L.lib().roft_object_add(self._h, C.byref(desc), C.byref(oid)))
+        self.n_objects += 1
+        self._inputs = (L.FrameInput * self.n_objects)()
+        return oid.value
+
+    def submit(self, frames):
+        """frames: one dict per object with keys depth, flow, mask, pose (None or (x, q)), dt,
+        mem_kind; depth/flow/mask are numpy arrays (HOST) or integer device addresses (DEVICE)."""
+        assert len(frames) == self.n_objects
+        keep = []
+        for i, f in enumerate(frames):
+            fi = self._inputs[i]
+            kind = f.get("mem_kind", L.MEM_HOST)
+            fi.mem_kind = kind
+            fi.dt = f.get("dt", 0.0)
+            for key in ("depth", "flow", "mask"):
+                v = f.get(key)
+                if v is None:
+                    setattr(fi, key, None)
+                elif kind == L.MEM_DEVICE:
+                    setattr(fi, key, int(v))
+                else:
+                    v = np.ascontiguousarray(v)
+                    keep.append(v)
+                    setattr(fi, key, v.ctypes.data)
+            pose = f.get("pose")
+            if pose is not None:
+                fi.pose_valid = 1
+                fi.pose_x = (C.c_double * 3)(*pose[0])
+                fi.pose_q = (C.c_double * 4)(*pose[1])
+            else:
+                fi.pose_valid = 0
+        self._keep = keep
+        L.check(L.lib().roft_frame_submit(self._h, self._inputs, self.n_objects))
+
+    def step(self):
+        L.check(L.lib().roft_step(self._h))
+
+    def sync(self):
+        L.check(L.lib().roft_sync(self._h))
+
+    def state(self, obj):
+        pose, P, tw, Pv = np.zeros(13), np.zeros((12, 12)), np.zeros(6), np.zeros((6, 6))
+        L.check(L.lib().roft_get_state(self._h, obj, pose.ctypes.data, P.ctypes.data, tw.ctypes.data, Pv.ctypes.data))
+        return pose, P, tw, Pv
+
+    def outputs(self):
+        outs = (L.ObjectOutput * self.n_objects)()
+        L.check(L.lib().roft_get_outputs(self._h, outs, self.n_objects))
+        return outs
+
+    def mask(self, obj):
+        m = np.zeros((self.H, self.W), np.uint8)
+        L.check(L.lib().roft_get_mask(self._h, obj, m.ctypes.data))
+        return m
+
+    def enable_log(self, n_frames):
+        L.check(L.lib().roft_engine_enable_log(self._h, n_frames))
+
+    def get_log(self, first, n):
+        outs = (L.ObjectOutput * (n * self.n_objects))()
+        L.check(L.lib().roft_engine_get_log(self._h, first, n, outs))
+        pose = np.zeros((n, self.n_objects, 13))
+        twist = np.zeros((n, self.n_objects, 6))
+        npts = np.zeros((n, self.n_objects), np.int64)
+        sel = np.zeros((n, self.n_objects), np.int64)
+        for f in range(n):
+            for o in range(self.n_objects):
+                r = outs[f * self.n_objects + o]
+                pose[f, o] = r.pose[:]
+                twist[f, o] = r.twist[:]
+                npts[f, o] = r.n_flow_points
+                sel[f, o] = r.outlier_selected
+        return pose, twist, npts, sel
+
+    def stream(self):
+        return L.lib().roft_engine_stream(self._h)
+
+    def enable_timing(self, on=True):
+        L.check(L.lib().roft_engine_enable_timing(self._h, int(on)))
+
+    def timing(self):
+        n = C.c_int(0)
+        names = C.POINTER(C.c_char_p)()
+        ms = C.POINTER(C.c_float)()
+        launches = C.POINTER(C.c_int)()
+        L.check(L.lib().roft_engine_get_timing(self._h, C.byref(n), C.byref(names), C.byref(ms), C.byref(launches)))
+        return {names[i].decode(): (ms[i], launches[i]) for i in range(n.value)}
+
+    def close(self):
+        if self._h:
+            L.lib().roft_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,131 @@
+"""Operator-level host API over the C ABI: one function per reference operator, numpy in / out.
+
+Names follow the reference's classes (hsp-iit/roft `src/roft-lib`):
+  flow_measurement  <- ImageOpticalFlowMeasurement<T>::freeze
+  kf_predict        <- bfl::KFPrediction(SpatialVelocityModel)
+  skf_correct       <- SKFCorrection::correctStep
+  mask_propagate    <- ImageSegmentationOFAidedSource<T>::map + cv::remap
+  ukf_predict       <- bfl::UKFPrediction(CartesianQuaternionModel)
+  ukf_correct       <- ROFT::UKFCorrection::correctStep(CartesianQuaternionMeasurement)
+  render_depth      <- SICAD::superimpose(..., depth)
+  depth_likelihood  <- ROFTFilter::pick_best_alternative (inner loop)
+All of them run on the GPU; none has a CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def make_flow(arr, width):
+    assert arr.flags["C_CONTIGUOUS"] and arr.ndim == 3 and arr.shape[2] == 2
+    if arr.dtype == np.int16:
+        typ, scale = L.FLOW_S16C2, 32.0
+    elif arr.dtype == np.float32:
+        typ, scale = L.FLOW_F32C2, 1.0
+    else:
+        raise TypeError("flow must be int16 (CV_16SC2) or float32 (CV_32FC2)")
+    rows, cols = arr.shape[:2]
+    return L.Flow(arr.ctypes.data, typ, cols, rows, width // cols, scale, 1)
+
+
+def flow_measurement(cam, prev_mask, prev_depth, flow_arr, dt, radius=35.0, depth_max=2.0):
+    H, W = prev_mask.shape
+    cap = H * W // max(int(radius), 1) + 16
+    uv = np.zeros((cap, 2), np.int32)
+    y = np.zeros(2 * cap)
+    Hm = np.zeros((2 * cap, 6))
+    n = C.c_int(0)
+    fl = make_flow(flow_arr, W)
+    prev_mask = np.ascontiguousarray(prev_mask, np.uint8)
+    prev_depth = np.ascontiguousarray(prev_depth, np.float32)
+    L.check(L.lib().roft_flow_measurement(C.byref(cam), _p(prev_mask), _p(prev_depth), C.byref(fl), dt,
+                                          np.float32(radius), depth_max, cap, _p(uv), _p(y), _p(Hm), C.byref(n)))
+    n = n.value
+    return n, uv[:n].copy(), y[:2 * n].copy(), Hm[:2 * n].copy()
+
+
+def kf_predict(x, P, qdiag):
+    x, P, qdiag = _f64(x), _f64(P), _f64(qdiag)
+    xo, Po = np.zeros(6), np.zeros((6, 6))
+    L.check(L.lib().roft_kf_predict(_p(x), _p(P), _p(qdiag), _p(xo), _p(Po)))
+    return xo, Po
+
+
+def skf_correct(x, P, y, Hm, rdiag=(1.0, 1.0), reweight=True):
+    x, P, y, Hm, rd = _f64(x), _f64(P), _f64(y), _f64(Hm), _f64(rdiag)
+    n = y.size // 2
+    xo, Po = np.zeros(6), np.zeros((6, 6))
+    st = C.c_int(0)
+    L.check(L.lib().roft_skf_correct(_p(x), _p(P), n, _p(y), _p(Hm), _p(rd), int(reweight), _p(xo), _p(Po),
+                                     C.byref(st)))
+    return st.value, xo, Po
+
+
+def mask_propagate(mask, flow_arrs, frames_between=6):
+    mask = np.ascontiguousarray(mask, np.uint8).copy()
+    H, W = mask.shape
+    arr = (L.Flow * max(1, len(flow_arrs)))()
+    for i, f in enumerate(flow_arrs):
+        arr[i] = make_flow(f, W)
+    L.check(L.lib().roft_mask_propagate(_p(mask), W, H, arr, len(flow_arrs), frames_between))
+    return mask
+
+
+def process_noise(psd, sig_w, T):
+    Q = np.zeros((9, 9))
+    L.check(L.lib().roft_pose_process_noise(_p(_f64(psd)), _p(_f64(sig_w)), T, _p(Q)))
+    return Q
+
+
+def ukf_predict(mean, P, Q, T, ut=(1.0, 2.0, 0.0)):
+    mean, P, Q = _f64(mean), _f64(P), _f64(Q)
+    mo, Po = np.zeros(13), np.zeros((12, 12))
+    u = L.UT(*ut)
+    L.check(L.lib().roft_ukf_predict(_p(mean), _p(P), _p(Q), T, C.byref(u), _p(mo), _p(Po)))
+    return mo, Po
+
+
+def ukf_correct(mean, P, mtype, meas, rdiag, ut=(1.0, 2.0, 0.0)):
+    mean, P, meas, rdiag = _f64(mean), _f64(P), _f64(meas), _f64(rdiag)
+    mo, Po = np.zeros(13), np.zeros((12, 12))
+    u = L.UT(*ut)
+    st = C.c_int(0)
+    L.check(L.lib().roft_ukf_correct(_p(mean), _p(P), mtype, _p(meas), _p(rdiag), C.byref(u), _p(mo), _p(Po),
+                                     C.byref(st)))
+    return st.value, mo, Po
+
+
+def make_mesh(verts, tris):
+    verts = np.ascontiguousarray(verts, np.float32)
+    tris = np.ascontiguousarray(tris, np.int32)
+    m = L.Mesh(verts.ctypes.data, verts.shape[0], tris.ctypes.data, tris.shape[0])
+    m._keep = (verts, tris)
+    return m
+
+
+def render_depth(mesh, x, q, cam, divider):
+    x, q = _f64(x), _f64(q)
+    tile = np.zeros((cam.height // divider, cam.width // divider), np.float32)
+    L.check(L.lib().roft_render_depth(C.byref(mesh), _p(x), _p(q), C.byref(cam), divider, _p(tile)))
+    return tile
+
+
+def depth_likelihood(cam, depth, mask, tile, divider):
+    depth = np.ascontiguousarray(depth, np.float32)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    tile = np.ascontiguousarray(tile, np.float32)
+    Lv = C.c_double(0.0)
+    ns = C.c_long(0)
+    L.check(L.lib().roft_depth_likelihood(C.byref(cam), _p(depth), _p(mask), _p(tile), divider, C.byref(Lv),
+                                          C.byref(ns)))
+    return Lv.value, ns.value

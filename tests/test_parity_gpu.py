@@ -1,0 +1,292 @@
+"""GPU parity tests: every HIP operator, called through the C ABI, against the CPU oracle on the
+same seeded inputs.  Bars (see DESIGN.md "Parity"):
+  * integer / index / byte work (flow point selection, mask propagation, render coverage): bit exact;
+  * the float rasteriser and the double H-matrix assembly: bit exact (same operation order,
+    -ffp-contract=off on both sides);
+  * filter algebra whose summation order differs from the sequential CPU form (SKF information
+    form, UKF, likelihood tree reduction): stated tolerances below.
+"""
+import numpy as np
+import pytest
+
+from roft_amd import _lib as L
+from roft_amd import ops, synth
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+# stated tolerances
+SKF_RTOL = 1e-8        # information form vs the sequential 2-row recursion
+UKF_ATOL = 1e-9        # block-wise parallel Jacobi vs cyclic Jacobi of the augmented covariance
+LIK_RTOL = 1e-12       # tree reduction vs sequential double accumulation of float terms
+
+
+def _cam(st):
+    c = st.camera
+    return L.Camera(c.width, c.height, c.fx, c.fy, c.cx, c.cy)
+
+
+# ---------------------------------------------------------------------------------------------
+# velocity stage
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("flow_type,scale,shape", [
+    (synth.FLOW_F32C2, 2, "A"), (synth.FLOW_S16C2, 2, "A"), (synth.FLOW_F32C2, 1, "A"), (synth.FLOW_S16C2, 2, "B")])
+def test_flow_measurement_bit_exact(oracle, flow_type, scale, shape):
+    st = util.stream(11, 4, scale=scale, flow_type=flow_type, shape=shape)
+    ocam = util.oracle_camera(oracle, st.camera)
+    for k in (1, 3):
+        mask = st.mask_gt[k - 1].numpy()
+        depth = st.depth[k - 1].numpy()
+        flow = st.flow[k].numpy()
+        n0, uv0, y0, H0 = oracle.flow_measurement(ocam, mask, depth, flow, st.dt)
+        n1, uv1, y1, H1 = ops.flow_measurement(_cam(st), mask, depth, flow, st.dt)
+        assert n0 > 10
+        assert n1 == n0
+        assert np.array_equal(uv0, uv1)
+        assert np.array_equal(y0, y1)
+        assert np.array_equal(H0, H1)
+
+
+def test_flow_measurement_edge_cases(oracle):
+    st = util.stream(12, 2, scale=2)
+    ocam = util.oracle_camera(oracle, st.camera)
+    cam = _cam(st)
+    H, W = st.camera.height, st.camera.width
+    depth = st.depth[0].numpy()
+    flow = st.flow[1].numpy()
+    rng = np.random.default_rng(0)
+    cases = {
+        "empty": np.zeros((H, W), np.uint8),
+        "full": np.full((H, W), 255, np.uint8),
+        "single": np.pad(np.array([[255]], np.uint8), ((H // 2, H - H // 2 - 1), (W // 2, W - W // 2 - 1))),
+        "random": (rng.random((H, W)) < 0.3).astype(np.uint8) * 255,
+        "last_pixel": np.pad(np.array([[255]], np.uint8), ((H - 1, 0), (W - 1, 0))),
+    }
+    for name, mask in cases.items():
+        for radius in (35.0, 1.0, 7.0):
+            if name == "full" and radius == 1.0:
+                continue
+            n0, uv0, y0, H0 = oracle.flow_measurement(ocam, mask, depth, flow, st.dt, radius=radius)
+            n1, uv1, y1, H1 = ops.flow_measurement(cam, mask, depth, flow, st.dt, radius=radius)
+            assert n1 == n0, (name, radius)
+            assert np.array_equal(uv0, uv1) and np.array_equal(y0, y1) and np.array_equal(H0, H1), (name, radius)
+    # all depth invalid / beyond the gate -> nothing kept
+    for bad in (np.zeros_like(depth), np.full_like(depth, 2.5), np.full_like(depth, np.nan)):
+        n1, *_ = ops.flow_measurement(cam, st.mask_gt[0].numpy(), bad, flow, st.dt)
+        assert n1 == 0
+    # all flow invalid
+    n1, *_ = ops.flow_measurement(cam, st.mask_gt[0].numpy(), depth, np.full_like(flow, np.nan), st.dt)
+    assert n1 == 0
+    n1, *_ = ops.flow_measurement(cam, st.mask_gt[0].numpy(), depth, np.full_like(flow, 1e10), st.dt)
+    assert n1 == 0
+
+
+def test_kf_predict(oracle):
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=6)
+    A = rng.normal(size=(6, 6))
+    P = A @ A.T
+    q = rng.random(6)
+    x0, P0 = oracle.kf_predict(x, P, q)
+    x1, P1 = ops.kf_predict(x, P, q)
+    assert np.array_equal(x0, x1) and np.array_equal(P0, P1)
+
+
+@pytest.mark.parametrize("reweight", [True, False])
+def test_skf_correct_parity(oracle, reweight):
+    st = util.stream(13, 6, scale=1)
+    ocam = util.oracle_camera(oracle, st.camera)
+    x = np.zeros(6)
+    P = np.eye(6) * 1e-3
+    worst = 0.0
+    for k in range(1, 6):
+        n, uv, y, Hm = oracle.flow_measurement(ocam, st.mask_gt[k - 1].numpy(), st.depth[k - 1].numpy(),
+                                               st.flow[k].numpy(), st.dt)
+        xp, Pp = oracle.kf_predict(x, P, np.full(6, 0.1))
+        for nn in (n, n - 1):   # even and odd measurement counts (median of two / middle element)
+            rc0, x0, P0 = oracle.skf_correct(xp, Pp, y[:2 * nn], Hm[:2 * nn], reweight=reweight)
+            rc1, x1, P1 = ops.skf_correct(xp, Pp, y[:2 * nn], Hm[:2 * nn], reweight=reweight)
+            assert rc0 == 0 and rc1 == 0
+            sx = np.sqrt(np.diag(P0))
+            worst = max(worst, np.max(np.abs(x1 - x0) / sx))
+            np.testing.assert_allclose(x1, x0, rtol=SKF_RTOL, atol=SKF_RTOL * np.max(np.abs(x0)))
+            np.testing.assert_allclose(P1, P0, rtol=SKF_RTOL, atol=SKF_RTOL * np.max(np.abs(P0)))
+        x, P = x0, P0
+    assert worst < 1e-6  # mean differs by far less than its own standard deviation
+
+
+def test_skf_correct_small_and_empty(oracle):
+    rng = np.random.default_rng(5)
+    xp = rng.normal(size=6) * 0.1
+    Pp = np.eye(6) * 0.1
+    Hm = rng.normal(size=(6, 6)) * 10
+    y = rng.normal(size=6)
+    for n in (0, 1, 2, 3):
+        rc0, x0, P0 = oracle.skf_correct(xp, Pp, y[:2 * n], Hm[:2 * n])
+        rc1, x1, P1 = ops.skf_correct(xp, Pp, y[:2 * n], Hm[:2 * n])
+        assert rc0 == rc1
+        np.testing.assert_allclose(x1, x0, rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(P1, P0, rtol=1e-9, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# mask stage
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("flow_type,scale", [(synth.FLOW_F32C2, 2), (synth.FLOW_S16C2, 2), (synth.FLOW_F32C2, 1)])
+def test_mask_propagate_bit_exact(oracle, flow_type, scale):
+    st = util.stream(14, 8, scale=scale, flow_type=flow_type)
+    flows = [st.flow[k].numpy() for k in range(1, 8)]
+    m = st.mask_gt[0].numpy()
+    for nfl in (0, 1, 3, 6):
+        a = oracle.mask_propagate(m, flows[:nfl])
+        b = ops.mask_propagate(m, flows[:nfl])
+        assert np.array_equal(a, b), nfl
+        assert a.any()
+    # 7 flows given, only the last 6 are used (hpp:239-245)
+    a = oracle.mask_propagate(m, flows[:7], 6)
+    assert np.array_equal(a, ops.mask_propagate(m, flows[:7], 6))
+    assert np.array_equal(a, ops.mask_propagate(m, flows[1:7], 6))
+    # chained single-flow propagation, the every-frame path (hpp:221-226)
+    a = b = m
+    for k in range(1, 6):
+        a2 = a.copy(); a2[0, 0] = 0
+        b2 = b.copy(); b2[0, 0] = 0
+        a = oracle.mask_propagate(a2, [flows[k - 1]])
+        b = ops.mask_propagate(b2, [flows[k - 1]])
+        assert np.array_equal(a, b), k
+
+
+def test_mask_propagate_edge_cases(oracle):
+    st = util.stream(15, 3, scale=2)
+    H, W = st.camera.height, st.camera.width
+    rng = np.random.default_rng(1)
+    flow = (rng.normal(size=(H, W, 2)) * 4).astype(np.float32)
+    flow[rng.random((H, W)) < 0.02] = np.nan
+    flow[rng.random((H, W)) < 0.02] = 1e10
+    flow[rng.random((H, W)) < 0.02] = -1e10
+    flow2 = (rng.normal(size=(H, W, 2)) * 30).astype(np.float32)   # many targets leave the image
+    masks = {
+        "empty": np.zeros((H, W), np.uint8),
+        "full": np.full((H, W), 255, np.uint8),
+        "values_0_1_255": rng.choice(np.array([0, 1, 255], np.uint8), size=(H, W)),
+        "corner_set": np.pad(np.full((8, 8), 255, np.uint8), ((0, H - 8), (0, W - 8))),  # mask(0,0) != 0
+        "blob": st.mask_gt[0].numpy(),
+    }
+    for name, m in masks.items():
+        for fl in ([flow], [flow2], [flow, flow2], [flow2, flow, flow2]):
+            a = oracle.mask_propagate(m, fl)
+            b = ops.mask_propagate(m, fl)
+            assert np.array_equal(a, b), name
+
+
+# ---------------------------------------------------------------------------------------------
+# pose stage
+# ---------------------------------------------------------------------------------------------
+def _random_belief(rng, scale=1e-3):
+    mean = np.zeros(13)
+    mean[:9] = rng.normal(size=9) * np.array([.1, .1, .1, .5, .5, .5, .1, .1, .1]) + np.array([0] * 6 + [0, 0, .7])
+    q = rng.normal(size=4)
+    mean[9:] = q / np.linalg.norm(q)
+    A = rng.normal(size=(12, 12))
+    P = A @ A.T * scale + np.eye(12) * scale
+    return mean, P
+
+
+def test_ukf_predict_parity(oracle):
+    rng = np.random.default_rng(21)
+    for i in range(6):
+        mean, P = _random_belief(rng)
+        if i == 0:
+            P = np.eye(12) * 1e-3            # degenerate spectrum (the initial condition)
+        T = 1.0 / 30.0 if i < 4 else 0.05
+        Q = oracle.process_noise([1.0, 1.0, 1.0], [1.0, 1.0, 1.0], T)
+        m0, P0 = oracle.ukf_predict(mean, P, Q, T)
+        m1, P1 = ops.ukf_predict(mean, P, Q, T)
+        np.testing.assert_allclose(m1, m0, rtol=0, atol=UKF_ATOL)
+        np.testing.assert_allclose(P1, P0, rtol=0, atol=UKF_ATOL)
+        assert np.array_equal(ops.process_noise([1.0, 1.0, 1.0], [1.0, 1.0, 1.0], T), Q)
+
+
+@pytest.mark.parametrize("mtype", [L.MEAS_VELOCITY, L.MEAS_POSE_VELOCITY, L.MEAS_POSE])
+def test_ukf_correct_parity(oracle, mtype):
+    rng = np.random.default_rng(22 + mtype)
+    rv = [0.1] * 3 + [1e-4] * 3
+    rp = [1e-3] * 3 + [1e-4] * 3
+    for i in range(6):
+        mean, P = _random_belief(rng)
+        if i == 0:
+            P = np.eye(12) * 1e-3
+        vel = rng.normal(size=6) * 0.3
+        q = mean[9:] + rng.normal(size=4) * 0.05
+        if i == 3:
+            q = -q                           # double cover: -q is the same rotation
+        pose = np.concatenate([mean[6:9] + rng.normal(size=3) * 0.01, q / np.linalg.norm(q)])
+        if mtype == L.MEAS_VELOCITY:
+            meas, rd = vel, rv
+        elif mtype == L.MEAS_POSE:
+            meas, rd = pose, rp
+        else:
+            meas, rd = np.concatenate([vel, pose]), rv + rp
+        rc0, m0, P0 = oracle.ukf_correct(mean, P, mtype, meas, rd)
+        rc1, m1, P1 = ops.ukf_correct(mean, P, mtype, meas, rd)
+        assert rc0 == 0 and rc1 == 0
+        np.testing.assert_allclose(m1, m0, rtol=0, atol=UKF_ATOL)
+        np.testing.assert_allclose(P1, P0, rtol=0, atol=UKF_ATOL)
+
+
+def test_ukf_correct_no_measurement(oracle):
+    rng = np.random.default_rng(2)
+    mean, P = _random_belief(rng)
+    rc, m1, P1 = ops.ukf_correct(mean, P, L.MEAS_NONE, np.zeros(6), np.ones(6))
+    assert rc == 1
+    assert np.array_equal(m1, mean) and np.array_equal(P1, P)
+
+
+# ---------------------------------------------------------------------------------------------
+# outlier rejection
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scale,mesh_n", [(2, 12), (1, 36)])
+def test_render_depth_bit_exact(oracle, scale, mesh_n):
+    st = util.stream(16, 2, scale=scale, mesh_n=mesh_n)
+    verts, tris = st.mesh
+    ocam = util.oracle_camera(oracle, st.camera)
+    omesh = oracle.make_mesh(verts, tris)
+    mesh = ops.make_mesh(verts, tris)
+    div = 2 if st.camera.width == 640 else 4
+    for k in range(2):
+        x, q = st.gt.x[k], st.gt.q[k]
+        t0 = oracle.render_depth(omesh, x, q, ocam, div)
+        t1 = ops.render_depth(mesh, x, q, _cam(st), div)
+        assert (t0 > 0).sum() > 50
+        assert np.array_equal(t0, t1)
+    # object behind the camera / off screen -> empty tile
+    t1 = ops.render_depth(mesh, [0, 0, -1.0], [1, 0, 0, 0], _cam(st), div)
+    assert not t1.any()
+    t1 = ops.render_depth(mesh, [50.0, 0, 1.0], [1, 0, 0, 0], _cam(st), div)
+    assert not t1.any()
+
+
+def test_depth_likelihood_parity(oracle):
+    st = util.stream(17, 2, scale=1, mesh_n=24)
+    verts, tris = st.mesh
+    ocam = util.oracle_camera(oracle, st.camera)
+    omesh = oracle.make_mesh(verts, tris)
+    div = 2
+    depth = st.depth[0].numpy()
+    mask = st.mask_gt[0].numpy()
+    for dx in (0.0, 0.02, 0.3):
+        x = st.gt.x[0] + np.array([dx, 0, dx])
+        tile = oracle.render_depth(omesh, x, st.gt.q[0], ocam, div)
+        L0, n0 = oracle.depth_likelihood(ocam, depth, mask, tile, div)
+        L1, n1 = ops.depth_likelihood(_cam(st), depth, mask, tile, div)
+        assert n0 == n1
+        if n0 == 0:
+            assert L0 == L1 == np.finfo(np.float64).max
+        else:
+            assert abs(L1 - L0) <= LIK_RTOL * abs(L0)
+    # no samples: empty mask, empty render
+    L1, n1 = ops.depth_likelihood(_cam(st), depth, np.zeros_like(mask), tile, div)
+    assert n1 == 0 and L1 == np.finfo(np.float64).max
+    L1, n1 = ops.depth_likelihood(_cam(st), depth, mask, np.zeros_like(tile), div)
+    assert n1 == 0 and L1 == np.finfo(np.float64).max

@@ -1,0 +1,56 @@
+"""Shared helpers for the tests: cached synthetic streams and oracle/engine drivers."""
+import functools
+
+import numpy as np
+
+from roft_amd import synth
+
+
+@functools.lru_cache(maxsize=16)
+def stream(seed, n_frames, scale=2, flow_type=synth.FLOW_F32C2, shape="A", **kw):
+    cam = synth.Camera.shape_a() if shape == "A" else synth.Camera.shape_b()
+    if scale > 1:
+        cam = cam.scaled(scale)
+    return synth.make_stream(seed, n_frames, cam, flow_type=flow_type, mesh_n=kw.pop("mesh_n", 12), **kw)
+
+
+def oracle_camera(ob, cam):
+    return ob.camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy)
+
+
+def frame_inputs(st, k):
+    """What the Dataset* sources would hand to the tracker at frame k."""
+    mask = st.mask_gt[st.mask_delivery[k]].cpu().numpy() if st.mask_delivery[k] >= 0 else None
+    pose = (st.pose_meas[k, :3].copy(), st.pose_meas[k, 3:].copy()) if st.pose_valid[k] else None
+    flow = st.flow[k].cpu().numpy() if st.flow_valid[k] else None
+    depth = st.depth[k].cpu().numpy()
+    return depth, flow, mask, pose
+
+
+def oracle_config(ob, st, **over):
+    cam = st.camera
+    cfg = ob.default_config(640 if cam.width in (640, 320, 160) else 1280, cam.height)
+    cfg.cam.width, cfg.cam.height = cam.width, cam.height
+    cfg.cam.fx, cfg.cam.fy, cfg.cam.cx, cfg.cam.cy = cam.fx, cam.fy, cam.cx, cam.cy
+    m0 = synth.initial_pose_from_stream(st)
+    for i in range(13):
+        cfg.p_mean0[i] = m0[i]
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def run_oracle_tracker(ob, st, n_frames=None, **over):
+    cfg = oracle_config(ob, st, **over)
+    verts, tris = st.mesh
+    trk = ob.Tracker(cfg, verts, tris)
+    # the oracle picks the render divider from width == 640 like the reference; scaled test
+    # cameras use the same rule (ROFTFilter.cpp:191-193)
+    out = []
+    for k in range(n_frames or st.n_frames):
+        depth, flow, mask, pose = frame_inputs(st, k)
+        r = trk.step(st.dt, depth, flow, mask, pose)
+        out.append(dict(pose=np.array(r.pose), twist=np.array(r.twist), n=r.n_flow_points,
+                        sel=r.outlier_selected, L=np.array(r.outlier_L), mask=trk.mask()))
+    trk.close()
+    return out
