@@ -556,24 +556,26 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
     return ROFT_OK;
 }
 
+// Timing marks accumulate over any number of steps until roft_engine_get_timing() collects them:
+// mark i closes the interval (event i-1, event i] and attributes it to kernel id tmark[i]
+// (-1 = step start, attributes nothing).
 static void tmark(roft_engine* e, const char* name)
 {
     if (!e->timing) return;
-    // one event after each (group of) launch(es); names resolved in roft_engine_get_timing
-    size_t idx = e->tmark.size();
-    if (e->tev.size() <= idx + 1) {
-        while (e->tev.size() <= idx + 1) {
-            hipEvent_t ev;
-            (void)hipEventCreate(&ev);
-            e->tev.push_back(ev);
-        }
+    const size_t idx = e->tmark.size();
+    while (e->tev.size() <= idx) {
+        hipEvent_t ev;
+        (void)hipEventCreate(&ev);
+        e->tev.push_back(ev);
     }
     int id = -1;
-    for (size_t i = 0; i < e->tnames_s.size(); ++i)
-        if (e->tnames_s[i] == name) id = (int)i;
-    if (id < 0) { e->tnames_s.push_back(name); id = (int)e->tnames_s.size() - 1; }
+    if (name) {
+        for (size_t i = 0; i < e->tnames_s.size(); ++i)
+            if (e->tnames_s[i] == name) id = (int)i;
+        if (id < 0) { e->tnames_s.push_back(name); id = (int)e->tnames_s.size() - 1; }
+    }
     e->tmark.push_back(id);
-    (void)hipEventRecord(e->tev[idx + 1], e->stream);
+    (void)hipEventRecord(e->tev[idx], e->stream);
 }
 
 int roft_step(roft_engine* e)
@@ -588,11 +590,7 @@ int roft_step(roft_engine* e)
     HIP_TRY(hipEventRecord(e->stage_ev[si], s));
     e->stage_idx = (si + 1) % roft_engine::kStage;
 
-    if (e->timing) {
-        e->tmark.clear();
-        if (e->tev.empty()) { hipEvent_t ev; (void)hipEventCreate(&ev); e->tev.push_back(ev); }
-        (void)hipEventRecord(e->tev[0], s);
-    }
+    tmark(e, nullptr);
     const int radius = (int)(size_t)e->cfg.subsampling_radius;
     if (e->any_new_mask) { launch_mask_ingest(a, s); tmark(e, "mask_ingest"); }
     launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, s);
@@ -715,12 +713,14 @@ int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, 
     const size_t nk = e->tnames_s.size();
     e->tms.assign(nk, 0.f);
     e->tlaunches.assign(nk, 0);
-    for (size_t i = 0; i < e->tmark.size(); ++i) {
+    for (size_t i = 1; i < e->tmark.size(); ++i) {
+        if (e->tmark[i] < 0) continue;
         float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e->tev[i], e->tev[i + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms, e->tev[i - 1], e->tev[i]));
         e->tms[e->tmark[i]] += ms;
         e->tlaunches[e->tmark[i]] += 1;
     }
+    e->tmark.clear();
     e->tnames.clear();
     for (auto& s : e->tnames_s) e->tnames.push_back(s.c_str());
     *n_out = (int)nk;

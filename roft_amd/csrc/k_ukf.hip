@@ -87,12 +87,22 @@ struct UkfLds {
 
 // Symmetric Jacobi eigen-decomposition in LDS, n even (<= 12), executed by one wave.
 // On return diag(A) = eigenvalues, columns of V = eigenvectors.
+//
+// Round-robin parallel ordering: each round rotates n/2 disjoint index pairs (p_i, q_i).  With
+// all pairs fixed, A' = J'AJ decomposes into (n/2)^2 independent 2x2 blocks,
+//   block(a, b) = rows {p_a, q_a} x cols {p_b, q_b}   ->   R_a' * block * R_b,
+// so lane (a, b) owns one block of A and one of V for the round: it reads 4 + 4 values from LDS,
+// gets the two rotations by wave shuffle from the lanes owning the diagonal blocks (a, a), (b, b)
+// -- which computed them from their own registers -- and writes 4 + 4 values back.  One LDS round
+// trip and one barrier per round; no rotation parameters ever go through memory.
 __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
 {
     const int lane = threadIdx.x;
     for (int i = lane; i < n * n; i += 64) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
     __syncthreads();
     const int half = n / 2;
+    const bool active = lane < half * half;
+    const int ba = active ? lane / half : 0, bb = active ? lane % half : 0;
     for (int sweep = 0; sweep < 40; ++sweep) {
         double off = 0.0, dg = 0.0;
         for (int i = lane; i < n * n; i += 64) {
@@ -104,48 +114,41 @@ __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
         if (off <= 1e-32 * dg || off == 0.0) break;
 
         for (int round = 0; round < n - 1; ++round) {
-            if (lane < half) {
-                int p, q;
-                if (lane == 0) { p = n - 1; q = round; }
-                else { p = (round + lane) % (n - 1); q = (round - lane + (n - 1)) % (n - 1); }
+            // pair i of this round
+            auto pair_of = [&](int i, int& p, int& q) {
+                if (i == 0) { p = n - 1; q = round; }
+                else { p = (round + i) % (n - 1); q = (round - i + (n - 1)) % (n - 1); }
                 if (p > q) { const int t = p; p = q; q = t; }
-                const double apq = A[p * n + q];
-                double c = 1.0, s = 0.0;
-                if (apq != 0.0) {
-                    const double app = A[p * n + p], aqq = A[q * n + q];
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    const double t = (tau >= 0.0) ? 1.0 / (tau + sqrt(1.0 + tau * tau))
-                                                  : -1.0 / (-tau + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + t * t);
-                    s = t * c;
-                }
-                L.rc[lane] = c; L.rs[lane] = s; L.rp[lane] = p; L.rq[lane] = q;
+            };
+            int pa, qa, pb, qb;
+            pair_of(ba, pa, qa);
+            pair_of(bb, pb, qb);
+            double a00 = 0, a01 = 0, a10 = 0, a11 = 0, v00 = 0, v01 = 0, v10 = 0, v11 = 0;
+            if (active) {
+                a00 = A[pa * n + pb]; a01 = A[pa * n + qb]; a10 = A[qa * n + pb]; a11 = A[qa * n + qb];
+                v00 = V[pa * n + pb]; v01 = V[pa * n + qb]; v10 = V[qa * n + pb]; v11 = V[qa * n + qb];
             }
-            __syncthreads();
-            for (int it = lane; it < half * n; it += 64) {  // columns p, q of A and V
-                const int i = it / n, k = it % n;
-                const int p = L.rp[i], q = L.rq[i];
-                const double c = L.rc[i], s = L.rs[i];
-                const double akp = A[k * n + p], akq = A[k * n + q];
-                A[k * n + p] = c * akp - s * akq;
-                A[k * n + q] = s * akp + c * akq;
-                const double vkp = V[k * n + p], vkq = V[k * n + q];
-                V[k * n + p] = c * vkp - s * vkq;
-                V[k * n + q] = s * vkp + c * vkq;
+            double c = 1.0, s = 0.0;
+            if (active && ba == bb && a01 != 0.0) {  // diagonal block: (app, apq; apq, aqq)
+                const double tau = (a11 - a00) / (2.0 * a01);
+                const double t = (tau >= 0.0) ? 1.0 / (tau + sqrt(1.0 + tau * tau))
+                                              : -1.0 / (-tau + sqrt(1.0 + tau * tau));
+                c = 1.0 / sqrt(1.0 + t * t);
+                s = t * c;
             }
-            __syncthreads();
-            for (int it = lane; it < half * n; it += 64) {  // rows p, q of A
-                const int i = it / n, k = it % n;
-                const int p = L.rp[i], q = L.rq[i];
-                const double c = L.rc[i], s = L.rs[i];
-                const double apk = A[p * n + k], aqk = A[q * n + k];
-                A[p * n + k] = c * apk - s * aqk;
-                A[q * n + k] = s * apk + c * aqk;
-            }
-            __syncthreads();
-            if (lane < half && L.rs[lane] != 0.0) {
-                A[L.rp[lane] * n + L.rq[lane]] = 0.0;
-                A[L.rq[lane] * n + L.rp[lane]] = 0.0;
+            const double ca = __shfl(c, ba * half + ba, 64), sa = __shfl(s, ba * half + ba, 64);
+            const double cb = __shfl(c, bb * half + bb, 64), sb = __shfl(s, bb * half + bb, 64);
+            if (active) {
+                // columns (p_b, q_b): x_p' = c x_p - s x_q, x_q' = s x_p + c x_q
+                double b00 = cb * a00 - sb * a01, b01 = sb * a00 + cb * a01;
+                double b10 = cb * a10 - sb * a11, b11 = sb * a10 + cb * a11;
+                // rows (p_a, q_a)
+                double c00 = ca * b00 - sa * b10, c10 = sa * b00 + ca * b10;
+                double c01 = ca * b01 - sa * b11, c11 = sa * b01 + ca * b11;
+                if (ba == bb && s != 0.0) { c01 = 0.0; c10 = 0.0; }
+                A[pa * n + pb] = c00; A[pa * n + qb] = c01; A[qa * n + pb] = c10; A[qa * n + qb] = c11;
+                V[pa * n + pb] = cb * v00 - sb * v01; V[pa * n + qb] = sb * v00 + cb * v01;
+                V[qa * n + pb] = cb * v10 - sb * v11; V[qa * n + qb] = sb * v10 + cb * v11;
             }
             __syncthreads();
         }
@@ -307,21 +310,36 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
     const double sc = sqrt(w.c);
 
     // process noise block Q(T) (CartesianQuaternionModel.cpp:127-141), padded to 10 x 10
-    for (int i = lane; i < 100; i += 64) L.Q[i] = 0.0;
+    for (int i = lane; i < 100; i += 64) { L.Q[i] = 0.0; L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0; }
     __syncthreads();
     if (prm.q_override) {
         for (int i = lane; i < 81; i += 64) L.Q[(i / 9) * 10 + (i % 9)] = prm.q_override[i];
+        __syncthreads();
+        jacobi_lds(L.Q, L.VQ, 10, L);
+        if (lane < 10) L.wQ[lane] = L.Q[lane * 11];
     } else if (lane < 3) {
+        // Q(T) couples only (v_i, x_i): three independent symmetric 2x2 blocks, each diagonalised
+        // exactly by ONE Jacobi rotation (the same rotation the generic sweep would apply first).
         const int i = lane;
-        L.Q[i * 10 + i] = prm.psd_lin_acc[i] * T;
-        L.Q[(3 + i) * 10 + (3 + i)] = prm.sigma_ang_vel[i];
-        L.Q[(6 + i) * 10 + (6 + i)] = prm.psd_lin_acc[i] * (pow(T, 3.0) / 3.0);
-        L.Q[i * 10 + (6 + i)] = prm.psd_lin_acc[i] * (pow(T, 2.0) / 2.0);
-        L.Q[(6 + i) * 10 + i] = prm.psd_lin_acc[i] * (pow(T, 2.0) / 2.0);
+        const double app = prm.psd_lin_acc[i] * T;
+        const double aqq = prm.psd_lin_acc[i] * (pow(T, 3.0) / 3.0);
+        const double apq = prm.psd_lin_acc[i] * (pow(T, 2.0) / 2.0);
+        double c = 1.0, s = 0.0;
+        if (apq != 0.0) {
+            const double tau = (aqq - app) / (2.0 * apq);
+            const double t = (tau >= 0.0) ? 1.0 / (tau + sqrt(1.0 + tau * tau)) : -1.0 / (-tau + sqrt(1.0 + tau * tau));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = t * c;
+        }
+        // columns then rows, like the generic update
+        const double b00 = c * app - s * apq, b01 = s * app + c * apq;
+        const double b10 = c * apq - s * aqq, b11 = s * apq + c * aqq;
+        L.wQ[i] = c * b00 - s * b10;
+        L.wQ[6 + i] = s * b01 + c * b11;
+        L.wQ[3 + i] = prm.sigma_ang_vel[i];
+        L.VQ[i * 10 + i] = c;       L.VQ[i * 10 + (6 + i)] = s;
+        L.VQ[(6 + i) * 10 + i] = -s; L.VQ[(6 + i) * 10 + (6 + i)] = c;
     }
-    __syncthreads();
-    jacobi_lds(L.Q, L.VQ, 10, L);
-    if (lane < 10) L.wQ[lane] = L.Q[lane * 11];
     __syncthreads();
     decompose_state_cov(L);
 

@@ -50,6 +50,10 @@ class ROFTFilterBatch:
     def submit(self, frames):
         """frames: one dict per object with keys depth, flow, mask, pose (None or (x, q)), dt,
         mem_kind; depth/flow/mask are numpy arrays (HOST) or integer device addresses (DEVICE)."""
+        self._fill(frames)
+        L.check(L.lib().roft_frame_submit(self._h, self._inputs, self.n_objects))
+
+    def _fill(self, frames):
         assert len(frames) == self.n_objects
         keep = []
         for i, f in enumerate(frames):
@@ -75,7 +79,18 @@ class ROFTFilterBatch:
             else:
                 fi.pose_valid = 0
         self._keep = keep
-        L.check(L.lib().roft_frame_submit(self._h, self._inputs, self.n_objects))
+
+    def build_inputs(self, frames):
+        """Pre-build the ctypes input array of one frame (see submit) for submit_raw."""
+        saved = self._inputs
+        self._inputs = (L.FrameInput * self.n_objects)()
+        self._fill(frames)
+        arr, keep = self._inputs, self._keep
+        self._inputs = saved
+        return arr, keep
+
+    def submit_raw(self, inputs):
+        L.check(L.lib().roft_frame_submit(self._h, inputs, self.n_objects))
 
     def step(self):
         L.check(L.lib().roft_step(self._h))

@@ -149,17 +149,20 @@ class Stream:
 
 
 def _render_box(cam, half, x, R, device):
-    """Ray/box slab intersection.  Returns depth Z of the box surface [H, W] (inf = miss)."""
+    """Ray/box slab intersection for a batch of poses.  x: [F,3], R: [F,3,3] (numpy).
+    Returns depth Z of the box surface [F, H, W] (inf = miss)."""
     u = torch.arange(cam.width, device=device, dtype=torch.float64)
     v = torch.arange(cam.height, device=device, dtype=torch.float64)
     dx = ((u - cam.cx) / cam.fx)[None, :].expand(cam.height, cam.width)
     dy = ((v - cam.cy) / cam.fy)[:, None].expand(cam.height, cam.width)
-    d = torch.stack([dx, dy, torch.ones_like(dx)], -1)           # camera-frame ray, d.z = 1
-    Rt = torch.as_tensor(R.T, device=device, dtype=torch.float64)
-    o = -(Rt @ torch.as_tensor(x, device=device, dtype=torch.float64))
-    dl = d @ Rt.T                                                 # R^T d
+    d = torch.stack([dx, dy, torch.ones_like(dx)], -1)            # [H,W,3] camera-frame ray, d.z = 1
+    Rt = torch.as_tensor(np.ascontiguousarray(np.swapaxes(R, 1, 2)), device=device, dtype=torch.float64)  # R^T
+    xt = torch.as_tensor(x, device=device, dtype=torch.float64)
+    o = -torch.einsum("fij,fj->fi", Rt, xt)                        # [F,3]
+    dl = torch.einsum("hwj,fij->fhwi", d, Rt)                      # R^T d
     h = torch.as_tensor(half, device=device, dtype=torch.float64)
     inv = 1.0 / torch.where(dl.abs() < 1e-12, torch.full_like(dl, 1e-12), dl)
+    o = o[:, None, None, :]
     t1 = (-h - o) * inv
     t2 = (h - o) * inv
     tn = torch.minimum(t1, t2).amax(-1)
@@ -171,62 +174,67 @@ def _render_box(cam, half, x, R, device):
 def make_stream(seed, n_frames, camera=None, flow_type=FLOW_F32C2, half_extents=CRACKER_BOX_HALF_EXTENTS,
                 device="cpu", background_z=1.5, mask_period=6, pose_period=6, depth_noise=1e-3,
                 depth_dropout=0.02, flow_invalid=0.005, pose_noise_x=0.005, pose_noise_rot=math.radians(2.0),
-                pose_outlier_prob=0.10, pose_drop_prob=0.03, mask_dilate=1, speed=1.0, mesh_n=36):
+                pose_outlier_prob=0.10, pose_drop_prob=0.03, mask_dilate=1, speed=1.0, mesh_n=36, chunk=8):
     cam = camera or Camera.shape_a()
     dt = 1.0 / 30.0
     gt = make_trajectory(seed, n_frames, dt, speed)
     rng = np.random.default_rng(seed + 7919)
-    g = torch.Generator(device="cpu").manual_seed(seed)
+    device = torch.device(device)
+    g = torch.Generator(device=device).manual_seed(seed)   # seeded per (seed, device type)
     H, W = cam.height, cam.width
     grid = 4 if flow_type == FLOW_S16C2 else 1
     scale = 32.0 if flow_type == FLOW_S16C2 else 1.0
+    Rall = np.stack([quat_to_rot(q) for q in gt.q])
 
-    depths, masks, flows = [], [], []
-    z_prev = None
-    for k in range(n_frames):
-        R = quat_to_rot(gt.q[k])
-        zb = _render_box(cam, half_extents, gt.x[k], R, device)
+    depth = torch.empty(n_frames, H, W, device=device, dtype=torch.float32)
+    mask_gt = torch.empty(n_frames, H, W, device=device, dtype=torch.uint8)
+    flow = torch.zeros(n_frames, H // grid, W // grid, 2, device=device,
+                       dtype=torch.int16 if flow_type == FLOW_S16C2 else torch.float32)
+    u = torch.arange(W, device=device, dtype=torch.float64)[None, None, :]
+    v = torch.arange(H, device=device, dtype=torch.float64)[None, :, None]
+    for k0 in range(0, n_frames, chunk):
+        k1 = min(n_frames, k0 + chunk)
+        f = k1 - k0
+        zb = _render_box(cam, half_extents, gt.x[k0:k1], Rall[k0:k1], device)
         hit = torch.isfinite(zb)
         z_clean = torch.where(hit, zb, torch.full_like(zb, background_z))
-        masks.append((hit.to(torch.uint8) * 255))
-        noise = torch.randn(H, W, generator=g, dtype=torch.float32).to(device) * depth_noise
-        drop = (torch.rand(H, W, generator=g) < depth_dropout).to(device)
-        depths.append(torch.where(drop, torch.zeros((), device=device), z_clean.float() + noise))
+        mask_gt[k0:k1] = hit.to(torch.uint8) * 255
+        noise = torch.randn(f, H, W, generator=g, dtype=torch.float32, device=device) * depth_noise
+        drop = torch.rand(f, H, W, generator=g, device=device) < depth_dropout
+        depth[k0:k1] = torch.where(drop, torch.zeros((), device=device), z_clean.float() + noise)
 
-        if k == 0:
-            flows.append(torch.zeros(H // grid, W // grid, 2, device=device,
-                                     dtype=torch.int16 if flow_type == FLOW_S16C2 else torch.float32))
-        else:
-            # forward flow of frame k-1 pixels: back-project with the clean depth of frame k-1,
-            # move object points rigidly with the GT motion, re-project.
-            zp, hp = z_prev
-            u = torch.arange(W, device=device, dtype=torch.float64)[None, :].expand(H, W)
-            v = torch.arange(H, device=device, dtype=torch.float64)[:, None].expand(H, W)
-            P = torch.stack([(u - cam.cx) / cam.fx * zp, (v - cam.cy) / cam.fy * zp, zp], -1)
-            Rp = torch.as_tensor(quat_to_rot(gt.q[k - 1]), device=device)
-            Rk = torch.as_tensor(R, device=device)
-            xp = torch.as_tensor(gt.x[k - 1], device=device)
-            xk = torch.as_tensor(gt.x[k], device=device)
-            Pn = (P - xp) @ Rp @ Rk.T + xk           # R_k R_{k-1}^T (P - x_{k-1}) + x_k
+        # forward flow of frame k pixels towards frame k+1 (stored as flow[k+1]): back-project with
+        # the clean depth of frame k, move object points rigidly with the GT motion, re-project.
+        kk = np.arange(k0, min(k1, n_frames - 1))
+        if len(kk):
+            zp, hp = z_clean[:len(kk)], hit[:len(kk)]
+            P = torch.stack([(u - cam.cx) / cam.fx * zp, (v - cam.cy) / cam.fy * zp, zp], -1)   # [f,H,W,3]
+            Rp = torch.as_tensor(Rall[kk], device=device)
+            Rk = torch.as_tensor(Rall[kk + 1], device=device)
+            xp = torch.as_tensor(gt.x[kk], device=device)[:, None, None, :]
+            xk = torch.as_tensor(gt.x[kk + 1], device=device)[:, None, None, :]
+            M = torch.einsum("fij,fkj->fik", Rk, Rp)                 # R_{k+1} R_k^T
+            Pn = torch.einsum("fhwj,fij->fhwi", P - xp, M) + xk
             un = cam.fx * Pn[..., 0] / Pn[..., 2] + cam.cx
             vn = cam.fy * Pn[..., 1] / Pn[..., 2] + cam.cy
-            fl = torch.stack([torch.where(hp, un - u, torch.zeros_like(u)),
-                              torch.where(hp, vn - v, torch.zeros_like(v))], -1).float()
+            fl = torch.stack([torch.where(hp, un - u, torch.zeros_like(un)),
+                              torch.where(hp, vn - v, torch.zeros_like(vn))], -1).float()
             if flow_type == FLOW_S16C2:
-                fl = fl[grid // 2::grid, grid // 2::grid]
+                fl = fl[:, grid // 2::grid, grid // 2::grid]
                 fl = torch.clamp(torch.round(fl * scale), -32768, 32767).to(torch.int16)
             else:
-                bad = torch.rand(H, W, generator=g).to(device)
+                bad = torch.rand(len(kk), H, W, generator=g, device=device)
                 fl = torch.where((bad < flow_invalid / 2)[..., None], torch.full_like(fl, float("nan")), fl)
                 fl = torch.where(((bad >= flow_invalid / 2) & (bad < flow_invalid))[..., None],
                                  torch.full_like(fl, 1e10), fl)
-            flows.append(fl.contiguous())
-        z_prev = (z_clean, hit)
+            flow[kk + 1] = fl
+        del zb, hit, z_clean
 
-    mask_gt = torch.stack(masks)
     if mask_dilate > 0:  # crude segmentation noise: the network mask is a bit fatter than GT
         k = 2 * mask_dilate + 1
-        mask_gt = torch.nn.functional.max_pool2d(mask_gt[:, None].float(), k, 1, mask_dilate)[:, 0].to(torch.uint8)
+        for k0 in range(0, n_frames, 32):
+            m = mask_gt[k0:k0 + 32]
+            mask_gt[k0:k0 + 32] = torch.nn.functional.max_pool2d(m[:, None].float(), k, 1, mask_dilate)[:, 0].to(torch.uint8)
 
     # delivery schedules: frame h delivers the content of frame max(h - D, 0) iff (h - D) % D == 0
     mask_delivery = np.full(n_frames, -1, np.int64)
@@ -251,8 +259,7 @@ def make_stream(seed, n_frames, camera=None, flow_type=FLOW_F32C2, half_extents=
 
     flow_valid = np.ones(n_frames, bool)
     flow_valid[0] = False
-    return Stream(cam, flow_type, grid, scale, tuple(half_extents), torch.stack(depths).contiguous(),
-                  torch.stack(flows).contiguous(), flow_valid, mask_gt.contiguous(), mask_delivery,
+    return Stream(cam, flow_type, grid, scale, tuple(half_extents), depth, flow, flow_valid, mask_gt, mask_delivery,
                   pose_valid, pose_meas, gt, dt, box_mesh(half_extents, mesh_n))
 
 
