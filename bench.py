@@ -44,19 +44,15 @@ def parse():
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
     from roft_amd import _lib as L
     from roft_amd import engine as E
-    from roft_amd import metrics, synth
+    from roft_amd import metrics, parallel, synth
+    import torch.distributed as dist
+
+    rank, local_rank, world = parallel.env_rank()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    parallel.init("nccl")   # RCCL; only the barrier / max-over-ranks timing uses it
 
     n_obj = args.objects_per_gpu
     n_frames = args.warmup + args.steps
@@ -66,8 +62,8 @@ def main():
     # ---- synthetic streams, generated on the GPU and left resident in HBM
     t_gen = time.time()
     streams = []
-    for o in range(n_obj):
-        seed = 4000 + rank * 1000 + o  # stream seed = 1000 * config + object index
+    for o, gid in enumerate(parallel.weak_objects(n_obj, rank)):
+        seed = 4000 + gid  # stream seed = 1000 * config + global object index
         scale = 0.8 + 0.4 * ((o * 7) % 10) / 9.0
         half = tuple(h * scale for h in synth.CRACKER_BOX_HALF_EXTENTS)
         streams.append(synth.make_stream(seed, n_frames, cam, flow_type=ftype, half_extents=half, device=dev))
@@ -97,9 +93,7 @@ def main():
                                pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE))
         inputs.append(eng.build_inputs(frames))
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = parallel.barrier
 
     for k in range(args.warmup):
         eng.submit_raw(inputs[k][0])
@@ -118,10 +112,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(elapsed, dev)
 
     kernels = {}
     if not args.no_kernel_timing:

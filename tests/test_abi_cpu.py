@@ -1,0 +1,85 @@
+"""The C-ABI shared library: loads, exports every symbol include/roft_engine.h declares, and has no
+CPU fallback (compute entry points fail loudly without a HIP device)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from roft_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "roft_engine.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(roft_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    L.build()
+    lib = L.lib()
+    decl = declared_symbols()
+    assert len(decl) >= 25
+    for name in decl:
+        assert hasattr(lib, name), "libroft_hip.so does not export %s" % name
+    assert sorted(L.ABI_SYMBOLS) == decl
+
+
+def test_struct_layouts_match_header_sizes():
+    # sizes the C compiler gives the ABI structs (guards the ctypes mirrors)
+    import subprocess
+    import tempfile
+    src = '#include <stdio.h>\n#include "roft_engine.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(roft_camera), sizeof(roft_flow), sizeof(roft_config), sizeof(roft_object_desc), sizeof(roft_frame_input), sizeof(roft_object_output));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "s.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
+        sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
+    assert sizes == [C.sizeof(L.Camera), C.sizeof(L.Flow), C.sizeof(L.Config), C.sizeof(L.ObjectDesc),
+                     C.sizeof(L.FrameInput), C.sizeof(L.ObjectOutput)]
+
+
+def test_defaults_follow_the_reference_config():
+    """config/config_fast_ycb.cfg + test/test.sh:70-71 defaults."""
+    lib = L.lib()
+    cfg = L.Config()
+    assert lib.roft_default_config(C.byref(cfg), 1280, 720, L.FLOW_S16C2) == 0
+    assert (cfg.flow_grid, cfg.flow_scale) == (4, 32.0)
+    assert abs(cfg.cam.fx - 1229.4285612615463) < 1e-9 and cfg.cam.cx == 640.0 and cfg.cam.cy == 360.0
+    assert abs(cfg.sample_time - 1 / 30) < 1e-12 and (cfg.ut.alpha, cfg.ut.beta, cfg.ut.kappa) == (1.0, 2.0, 0.0)
+    assert cfg.depth_maximum == 2.0 and cfg.subsampling_radius == 35.0 and cfg.flow_weighting == 1
+    assert (cfg.use_pose, cfg.use_pose_resync, cfg.use_velocity, cfg.outlier_rejection, cfg.flow_aided_segmentation) == (1,) * 5
+    assert cfg.mask_frames_between == 6 and cfg.pose_frames_between == 6
+    o = L.ObjectDesc()
+    assert lib.roft_default_object(C.byref(o)) == 0
+    assert list(o.p_cov0_diag) == [1e-3] * 12 and list(o.v_q_diag) == [0.1] * 6
+    assert list(o.p_meas_cov_v) == [0.1] * 3 and list(o.p_meas_cov_w) == [1e-4] * 3
+    assert list(o.p_meas_cov_x) == [1e-3] * 3 and list(o.p_meas_cov_q) == [1e-4] * 3
+    assert list(o.v_meas_cov_flow) == [1.0, 1.0] and o.p_mean0[9] == 1.0
+
+
+def test_no_cpu_fallback():
+    lib = L.lib()
+    if lib.roft_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    from roft_amd import ops
+    with pytest.raises(L.RoftError):
+        ops.kf_predict(np.zeros(6), np.eye(6), np.ones(6))
+    with pytest.raises(L.RoftError):
+        ops.mask_propagate(np.zeros((64, 64), np.uint8), [])
+    from roft_amd import engine as E
+    with pytest.raises(L.RoftError):
+        E.ROFTFilterBatch(E.default_config(640, 480))
+    assert b"no HIP device" in lib.roft_last_error_string() or b"CPU" in lib.roft_last_error_string()
+
+
+def test_argument_validation_without_device():
+    lib = L.lib()
+    assert lib.roft_default_config(None, 640, 480, L.FLOW_F32C2) == -1
+    assert lib.roft_pose_process_noise(None, None, 0.1, None) == -1
+    Q = np.zeros((9, 9))
+    a = np.ones(3)
+    assert lib.roft_pose_process_noise(a.ctypes.data, a.ctypes.data, 0.5, Q.ctypes.data) == 0
+    assert Q[0, 0] == 0.5 and Q[3, 3] == 1.0 and Q[0, 6] == 0.125

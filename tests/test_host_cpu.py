@@ -1,0 +1,101 @@
+"""Host-side logic on CPU: synthetic stream generator, delivery schedules, object sharding over ranks
+(world_size 2, gloo)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from roft_amd import parallel, synth
+
+import util
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_stream_shapes_and_schedule():
+    st = util.stream(51, 14, scale=4)
+    cam = st.camera
+    assert st.depth.shape == (14, cam.height, cam.width) and st.depth.dtype.is_floating_point
+    assert st.flow.shape == (14, cam.height, cam.width, 2)
+    assert set(np.unique(st.mask_gt.numpy())) <= {0, 255}
+    # DatasetImageSegmentationDelayed.cpp:42-63: frame h delivers frame max(h-6, 0) iff (h-6) % 6 == 0
+    assert list(st.mask_delivery) == [0, -1, -1, -1, -1, -1, 0, -1, -1, -1, -1, -1, 6, -1]
+    assert st.pose_valid[0] and not st.pose_valid[1:6].any()
+    assert not st.flow_valid[0] and st.flow_valid[1:].all()
+    bad = ~np.isfinite(st.flow[1:].numpy()) | (np.abs(st.flow[1:].numpy()) > 1e9)
+    assert 0 < bad.mean() < 0.02                      # a few invalid flow entries (NaN / 1e10)
+    assert 0.005 < (st.depth.numpy() == 0).mean() < 0.05
+
+
+def test_stream_is_deterministic_and_s16_quantised():
+    a = synth.make_stream(52, 3, synth.Camera.shape_a().scaled(4))
+    b = synth.make_stream(52, 3, synth.Camera.shape_a().scaled(4))
+    assert np.array_equal(a.depth.numpy(), b.depth.numpy()) and np.array_equal(a.pose_meas, b.pose_meas)
+    s = synth.make_stream(52, 3, synth.Camera.shape_a().scaled(4), flow_type=synth.FLOW_S16C2)
+    assert s.flow.dtype.is_floating_point is False and s.flow.shape[1:3] == (s.camera.height // 4, s.camera.width // 4)
+    f32 = a.flow[1].numpy()[2::4, 2::4]
+    ok = np.isfinite(f32).all(-1) & (np.abs(f32) < 1e9).all(-1)
+    assert np.abs(s.flow[1].numpy()[ok] / 32.0 - f32[ok]).max() <= 1 / 64 + 1e-6
+
+
+def test_flow_moves_mask_onto_next_mask():
+    """Sanity of the generator itself: GT flow carries frame k-1's silhouette onto frame k's."""
+    st = synth.make_stream(53, 3, synth.Camera.shape_a().scaled(2), flow_invalid=0.0, mask_dilate=0)
+    m0, m1 = st.mask_gt[0].numpy() > 0, st.mask_gt[1].numpy() > 0
+    fl = st.flow[1].numpy()
+    vs, us = np.nonzero(m0)
+    tx = np.round(us + fl[vs, us, 0]).astype(int).clip(0, m1.shape[1] - 1)
+    ty = np.round(vs + fl[vs, us, 1]).astype(int).clip(0, m1.shape[0] - 1)
+    assert m1[ty, tx].mean() > 0.97
+
+
+def test_box_mesh_is_closed_and_sized_like_ycb():
+    v, t = synth.box_mesh(synth.CRACKER_BOX_HALF_EXTENTS, 36)
+    assert v.shape == (8214, 3) and t.shape == (15552, 3)
+    assert np.allclose(np.abs(v).max(0), synth.CRACKER_BOX_HALF_EXTENTS)
+
+
+def test_shard_objects_partitions():
+    for n, g in ((64, 8), (64, 1), (5, 2), (3, 4), (16, 3)):
+        parts = [parallel.shard_objects(n, r, g) for r in range(g)]
+        flat = [i for p in parts for i in p]
+        assert flat == list(range(n))
+        assert max(len(p) for p in parts) == -(-n // g)
+    assert parallel.weak_objects(4, 2) == [8, 9, 10, 11]
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch
+from roft_amd import parallel
+rank, local, world = parallel.init("gloo")
+mine = parallel.shard_objects(5, rank, world)
+assert parallel.weak_objects(3, rank) == [3 * rank + i for i in range(3)]
+parallel.barrier()
+t = parallel.max_over_ranks(1.0 + rank)
+assert t == float(world), t
+rec = torch.full((3, 19), float(rank))
+allrec = parallel.gather_records(rec)
+assert allrec.shape == (3 * world, 19) and float(allrec[:, 0].sum()) == 3.0 * sum(range(world))
+# every object is owned by exactly one rank
+own = torch.zeros(5)
+own[mine] = 1
+import torch.distributed as dist
+dist.all_reduce(own)
+assert bool((own == 1).all())
+print("rank", rank, "ok", mine)
+'''
+
+
+def test_two_rank_gloo_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "rank 0 ok [0, 1, 2]" in outs[0] and "rank 1 ok [3, 4]" in outs[1]
