@@ -1144,3 +1144,16 @@ int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint
 }
 
 }  // extern "C"
+
+// debugging aid (not part of the public ABI): phase cycle counters of the last ukf_step launch of one
+// object; only filled by builds with -DROFT_UKF_PROFILE
+extern "C" int roft_debug_get_dbg(roft_engine* e, int id, long long out[32])
+{
+    if (!e || id < 0 || id >= (int)e->objs.size()) return ROFT_ERR_INVALID;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return ROFT_ERR_DEVICE;
+    ObjState* st = new ObjState();
+    hipError_t err = hipMemcpy(st, e->arr.state.p + id, sizeof(ObjState), hipMemcpyDeviceToHost);
+    if (err == hipSuccess) std::memcpy(out, st->dbg, sizeof(long long) * 32);
+    delete st;
+    return err == hipSuccess ? ROFT_OK : ROFT_ERR_DEVICE;
+}

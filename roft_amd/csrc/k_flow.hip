@@ -11,7 +11,7 @@
 // candidate c is located by a binary search over the row prefix and a word walk -- no full-image
 // pass over depth or flow: only the ~N_mask/R candidate pixels are gathered from HBM.
 // Output order equals the reference's (candidates in rank order, invalid ones dropped).
-#include "roft_device.h"
+#include "plane_rank.h"
 
 namespace roft {
 
@@ -35,29 +35,6 @@ __device__ __forceinline__ bool is_flow_valid(float fx, float fy)
     return !isnan(fx) && !isnan(fy) && fabs((double)fx) < 1e9 && fabs((double)fy) < 1e9;
 }
 
-// block-wide exclusive scan of one int per thread (blockDim.x multiple of 64, <= 1024)
-__device__ int block_exclusive_scan(int v, int* s_wave /*>= 17 ints*/, int* total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int w = 0; w < nw; ++w) { int t = s_wave[w]; s_wave[w] = run; run += t; }
-        s_wave[16] = run;
-    }
-    __syncthreads();
-    const int res = s_wave[wave] + inc - v;
-    *total = s_wave[16];
-    __syncthreads();
-    return res;
-}
-
 constexpr int kFlowThreads = 512;
 
 // dynamic LDS: plane words [wpr*H] | rowpref [H+1]
@@ -76,29 +53,9 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays
     uint32_t* s_plane = reinterpret_cast<uint32_t*>(smem);
     int* s_rowpref = reinterpret_cast<int*>(smem + ((a.plane_words * 4 + 15) & ~(size_t)15));
 
-    // 1. stage the previous frame's obj plane in LDS (16-byte coalesced loads)
-    const uint32_t* plane = a.planes + plane_offset(a, obj, c.slot_prev, 1);
-    const size_t n4 = a.plane_words / 4;
-    for (size_t i = threadIdx.x; i < n4; i += blockDim.x)
-        reinterpret_cast<uint4*>(s_plane)[i] = reinterpret_cast<const uint4*>(plane)[i];
-    for (size_t i = n4 * 4 + threadIdx.x; i < a.plane_words; i += blockDim.x) s_plane[i] = plane[i];
-    __syncthreads();
-
-    // 2. row popcounts -> exclusive row prefix
-    int carry = 0;
-    for (int r0 = 0; r0 < H; r0 += blockDim.x) {
-        const int r = r0 + threadIdx.x;
-        int cnt = 0;
-        if (r < H)
-            for (int w = 0; w < wpr; ++w) cnt += __popc(s_plane[(size_t)r * wpr + w]);
-        int total;
-        const int ex = block_exclusive_scan(cnt, s_wave, &total);
-        if (r < H) s_rowpref[r] = carry + ex;
-        carry += total;
-    }
-    if (threadIdx.x == 0) s_rowpref[H] = carry;
-    __syncthreads();
-    const int M = s_rowpref[H];
+    // 1+2. stage the previous frame's obj plane in LDS, row popcounts -> exclusive row prefix
+    const int M = stage_plane(a.planes + plane_offset(a, obj, c.slot_prev, 1), a.plane_words, H, wpr, s_plane, s_rowpref,
+                              s_wave);
     const int C = (M + radius - 1) / radius;
 
     // 3. candidates, blocked assignment so that the compaction keeps rank order
@@ -108,19 +65,8 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays
     const float* depth = c.depth_prev;
     int n_valid = 0;
     for (int ci = c_begin; ci < c_end; ++ci) {
-        const int rank = ci * radius;
-        int lo = 0, hi = H;  // largest row with rowpref[row] <= rank
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_rowpref[mid] <= rank) lo = mid; else hi = mid;
-        }
-        int k = rank - s_rowpref[lo];
-        int w = 0;
-        uint32_t bits = s_plane[(size_t)lo * wpr];
-        int pc = __popc(bits);
-        while (k >= pc) { k -= pc; ++w; bits = s_plane[(size_t)lo * wpr + w]; pc = __popc(bits); }
-        for (int i = 0; i < k; ++i) bits &= bits - 1;
-        const int u = w * 32 + __builtin_ctz(bits), v = lo;
+        int u, v;
+        select_rank(s_plane, s_rowpref, H, wpr, ci * radius, u, v);
 
         const float z = depth[(size_t)v * W + u];
         float dx, dy;
@@ -143,7 +89,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays
 
 void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, hipStream_t s)
 {
-    const size_t lds = ((a.plane_words * 4 + 15) & ~(size_t)15) + (size_t)(a.cam.H + 1) * 4;
+    const size_t lds = plane_lds_bytes(a.plane_words, a.cam.H);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_measure_kernel),

@@ -92,7 +92,9 @@ __device__ __forceinline__ int decide_mode(const FrameCtrl& c, const ObjState& s
     return c.flow_valid ? 1 : 0;
 }
 
-// grid: (ceil(words/256), n_obj); thread = one 32-pixel word of the source nz plane
+// grid: (ceil(W*H/1024), n_obj), block 256 = 4 waves; a wave owns 64 consecutive pixels per iteration
+// (4 iterations per wave) and its lanes chase their pixel through the flows in parallel: the flow reads
+// of a wave are row-contiguous (64 x 8 B), the map atomics land on neighbouring addresses.
 __global__ __launch_bounds__(256) void mask_scatter_kernel(EngineArrays a, int frames_between)
 {
     const int obj = blockIdx.y;
@@ -108,38 +110,46 @@ __global__ __launch_bounds__(256) void mask_scatter_kernel(EngineArrays a, int f
     __syncthreads();
 
     const int W = a.cam.W, H = a.cam.H;
-    const size_t widx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t npix = (size_t)W * H;
+    const int lane = threadIdx.x & 63;
+    const uint2* plane2 = reinterpret_cast<const uint2*>(a.planes + plane_offset(a, obj, src_slot, 0));
+    int32_t* map = a.map + (size_t)obj * npix;
     int bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = -1, by1 = -1;
-    if (widx < a.plane_words) {
-        uint32_t bits = a.planes[plane_offset(a, obj, src_slot, 0) + widx];
-        if (mode == 1 && widx == 0) bits &= ~1u;  // mask_.at<uchar>(0,0) = 0
-        const int py = (int)(widx / a.cam.wpr);
-        const int px0 = (int)(widx % a.cam.wpr) * 32;
-        int32_t* map = a.map + (size_t)obj * W * H;
-        while (bits) {
-            const int b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            const int px = px0 + b;
-            float t_x = (float)px, t_y = (float)py;
-            bool error = false;
-            // flows in chronological order: oldest buffered first (c.flow[n_flows-1]) ... current
-            for (int j = n_flows - 1; j >= 0; --j) {
-                const int ix = trunc_int_x86(t_x), iy = trunc_int_x86(t_y);
-                if (ix < 0 || ix >= W || iy < 0 || iy >= H) { error = true; break; }
-                float dx, dy;
-                flow_at(c.flow[j], a.ffmt, trunc_int_x86(t_y / (float)a.ffmt.grid),
-                        trunc_int_x86(t_x / (float)a.ffmt.grid), dx, dy);
-                t_x += dx;
-                t_y += dy;
-            }
+    const size_t wave0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;  // first 64-pixel group of this wave
+    for (int it = 0; it < 4; ++it) {
+        const size_t grp = wave0 + it;
+        if (grp * 64 >= npix) break;
+        const uint2 w2 = plane2[grp];                                   // wave-uniform load
+        unsigned long long bits = ((unsigned long long)w2.y << 32) | w2.x;
+        if (mode == 1 && grp == 0) bits &= ~1ull;                         // mask_.at<uchar>(0,0) = 0
+        if (bits == 0) continue;
+        if (!((bits >> lane) & 1ull)) continue;
+        const size_t p = grp * 64 + lane;
+        const int py = (int)(p / W), px = (int)(p % W);
+        float t_x = (float)px, t_y = (float)py;
+        bool error = false;
+        // flows in chronological order: oldest buffered first (c.flow[n_flows-1]) ... current
+        for (int j = n_flows - 1; j >= 0; --j) {
             const int ix = trunc_int_x86(t_x), iy = trunc_int_x86(t_y);
-            if (error || ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
-            atomicMax(&map[(size_t)iy * W + ix], py * W + px);
-            bx0 = min(bx0, ix); bx1 = max(bx1, ix);
-            by0 = min(by0, iy); by1 = max(by1, iy);
+            if (ix < 0 || ix >= W || iy < 0 || iy >= H) { error = true; break; }
+            float dx, dy;
+            flow_at(c.flow[j], a.ffmt, trunc_int_x86(t_y / (float)a.ffmt.grid), trunc_int_x86(t_x / (float)a.ffmt.grid),
+                    dx, dy);
+            t_x += dx;
+            t_y += dy;
         }
+        const int ix = trunc_int_x86(t_x), iy = trunc_int_x86(t_y);
+        if (error || ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
+        atomicMax(&map[(size_t)iy * W + ix], (int)p);
+        bx0 = min(bx0, ix); bx1 = max(bx1, ix);
+        by0 = min(by0, iy); by1 = max(by1, iy);
     }
-    if (bx1 >= 0) {
+    // bounding box of the targets: wave shuffle -> LDS -> one set of global atomics per block
+    for (int off = 32; off > 0; off >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, off, 64)); by0 = min(by0, __shfl_xor(by0, off, 64));
+        bx1 = max(bx1, __shfl_xor(bx1, off, 64)); by1 = max(by1, __shfl_xor(by1, off, 64));
+    }
+    if (lane == 0 && bx1 >= 0) {
         atomicMin(&s_bbox[0], bx0); atomicMin(&s_bbox[1], by0);
         atomicMax(&s_bbox[2], bx1); atomicMax(&s_bbox[3], by1);
     }
@@ -184,10 +194,21 @@ __global__ __launch_bounds__(256) void mask_gather_kernel(EngineArrays a, int fr
             }
             continue;
         }
+        // the 64 pixels of a wave lie in one row when W % 64 == 0 -> wave-uniform fast path
+        if ((W & 63) == 0) {
+            const int yw = (int)(base / W), xw = (int)(base % W);
+            if (yw < by0 || yw > by1 || xw > bx1 || xw + 63 < bx0) {
+                if (lane == 0) {
+                    const uint32_t f1 = bg_nz ? 0xFFFFFFFFu : 0u, f2 = bg_ob ? 0xFFFFFFFFu : 0u;
+                    reinterpret_cast<uint2*>(dnz)[word2] = make_uint2(f1, f1);
+                    reinterpret_cast<uint2*>(dob)[word2] = make_uint2(f2, f2);
+                }
+                continue;
+            }
+        }
         const size_t p = base + lane;
         const int y = (int)(p / W), x = (int)(p % W);
         bool nzb = bg_nz, obb = bg_ob;
-        // the 64 pixels of a wave lie in one row (W % 64 == 0) -> wave-uniform row test
         if (y >= by0 && y <= by1 && x >= bx0 && x <= bx1) {
             const int m = map[p];
             if (m != 0) {
@@ -250,8 +271,8 @@ void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_a
         hipLaunchKernelGGL(mask_finish_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frames_between);
         return;
     }
-    hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)((a.plane_words + 255) / 256), a.n_obj), dim3(256), 0, s, a,
-                       frames_between);
+    hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)(((size_t)a.cam.W * a.cam.H + 1023) / 1024), a.n_obj), dim3(256),
+                       0, s, a, frames_between);
     const size_t waves = ((size_t)a.cam.W * a.cam.H + 63) / 64;
     int gx = (int)((waves + 3) / 4);
     if (gx > 128) gx = 128;

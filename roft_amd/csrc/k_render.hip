@@ -16,85 +16,53 @@
 //    frames later (findNonZero, every second pixel).  Here the "features" are extracted once into
 //    a compact (pixel, depth) list indexed by rank/2, so the likelihood is a dense reduction over
 //    ~N_mask/2 samples and the frame itself need not be retained.
-#include "roft_device.h"
+#include "plane_rank.h"
 
 namespace roft {
 
-constexpr int kFeatThreads = 512;
-
-__device__ int block_exclusive_scan_r(int v, int* s_wave, int* total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int w = 0; w < nw; ++w) { int t = s_wave[w]; s_wave[w] = run; run += t; }
-        s_wave[16] = run;
-    }
-    __syncthreads();
-    const int res = s_wave[wave] + inc - v;
-    *total = s_wave[16];
-    __syncthreads();
-    return res;
-}
+constexpr int kFeatThreads = 1024;
 
 // phase 0: before the UKF steps (first frame / non-resync outlier rejection uses the current frame)
 // phase 1: after them (re-buffer at pose re-sync frames, ROFTFilter.cpp:353)
+// Feature slot s holds the pixel of row-major rank 2s of the current obj plane (`k += 2` over the
+// findNonZero list, ROFTFilter.cpp:556) and its depth; slots are independent, so the work is
+// spread evenly over the workgroup whatever the mask shape.
 __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a, int phase)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_wave[17];
-    __shared__ int s_carry;
     const int obj = blockIdx.x;
     const FrameCtrl& c = a.ctrl[obj];
     const bool run = (phase == 0) ? (c.buffer_features_before || c.features_current) : c.buffer_features_after;
     if (!run) return;
     const int W = a.cam.W, H = a.cam.H, wpr = a.cam.wpr;
-    const uint32_t* plane = a.planes + plane_offset(a, obj, c.slot_cur, 1);
+    uint32_t* s_plane = reinterpret_cast<uint32_t*>(smem);
+    int* s_rowpref = reinterpret_cast<int*>(smem + ((a.plane_words * 4 + 15) & ~(size_t)15));
+    const int M = stage_plane(a.planes + plane_offset(a, obj, c.slot_cur, 1), a.plane_words, H, wpr, s_plane, s_rowpref,
+                              s_wave);
     const float* depth = c.depth_cur;
     uint32_t* fpix = a.feat_pix + (size_t)obj * a.feat_cap;
     float* fdep = a.feat_depth + (size_t)obj * a.feat_cap;
-
-    int carry = 0;
-    for (int r0 = 0; r0 < H; r0 += blockDim.x) {
-        const int r = r0 + threadIdx.x;
-        int cnt = 0;
-        if (r < H)
-            for (int w = 0; w < wpr; ++w) cnt += __popc(plane[(size_t)r * wpr + w]);
-        int total;
-        int rank = carry + block_exclusive_scan_r(cnt, s_wave, &total);
-        carry += total;
-        if (r < H && cnt) {
-            for (int w = 0; w < wpr; ++w) {
-                uint32_t bits = plane[(size_t)r * wpr + w];
-                while (bits) {
-                    const int b = __builtin_ctz(bits);
-                    bits &= bits - 1;
-                    if ((rank & 1) == 0) {   // `k += 2` over findNonZero order (ROFTFilter.cpp:556)
-                        const int u = w * 32 + b;
-                        const int slot = rank >> 1;
-                        if (slot < a.feat_cap) {
-                            fpix[slot] = (uint32_t)(r * W + u);
-                            fdep[slot] = depth[(size_t)r * W + u];
-                        }
-                    }
-                    ++rank;
-                }
-            }
-        }
+    const int n = min((M + 1) / 2, a.feat_cap);
+    for (int s = threadIdx.x; s < n; s += blockDim.x) {
+        int u, v;
+        select_rank(s_plane, s_rowpref, H, wpr, 2 * s, u, v);
+        fpix[s] = (uint32_t)(v * W + u);
+        fdep[s] = depth[(size_t)v * W + u];
     }
-    if (threadIdx.x == 0) a.state[obj].n_feat = min((carry + 1) / 2, a.feat_cap);
-    (void)s_carry;
+    if (threadIdx.x == 0) a.state[obj].n_feat = n;
 }
 
 void launch_features(const EngineArrays& a, int phase, hipStream_t s)
 {
-    hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), 0, s, a, phase);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 256);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), plane_lds_bytes(a.plane_words, a.cam.H), s, a,
+                       phase);
 }
 
 // ---- rasteriser ---------------------------------------------------------------------------------
@@ -188,10 +156,12 @@ __global__ __launch_bounds__(256) void raster_engine_kernel(EngineArrays a)
 
 // one workgroup per object: likelihood of both alternatives over the buffered features, decision,
 // and the selected belief becomes the corrected belief (ROFTFilter.cpp:581-583, 670-675)
-__global__ __launch_bounds__(256) void outlier_kernel(EngineArrays a)
+constexpr int kOutlierThreads = 1024;
+
+__global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a)
 {
-    __shared__ double s_err[2][4];
-    __shared__ double s_cnt[2][4];
+    __shared__ double s_err[2][kOutlierThreads / 64];
+    __shared__ double s_cnt[2][kOutlierThreads / 64];
     __shared__ int s_sel;
     const int obj = blockIdx.x;
     const FrameCtrl& c = a.ctrl[obj];
@@ -224,7 +194,7 @@ __global__ __launch_bounds__(256) void outlier_kernel(EngineArrays a)
         double L[2];
         for (int k = 0; k < 2; ++k) {
             double e = 0.0, n2 = 0.0;
-            for (int w = 0; w < 4; ++w) { e += s_err[k][w]; n2 += s_cnt[k][w]; }
+            for (int w = 0; w < kOutlierThreads / 64; ++w) { e += s_err[k][w]; n2 += s_cnt[k][w]; }
             L[k] = (n2 == 0.0) ? 1.7976931348623157e308 : (e / n2) / 1.0;  // gain is a bool -> 1.0 (ROFTFilter.h:64)
         }
         const int sel = (L[0] > 2.0 * L[1]) ? 1 : 0;
@@ -233,7 +203,7 @@ __global__ __launch_bounds__(256) void outlier_kernel(EngineArrays a)
         st.outlier_L[1] = L[1];
         for (int k = 0; k < 2; ++k) {
             double n2 = 0.0;
-            for (int w = 0; w < 4; ++w) n2 += s_cnt[k][w];
+            for (int w = 0; w < kOutlierThreads / 64; ++w) n2 += s_cnt[k][w];
             st.outlier_cnt[k] = n2;
         }
         s_sel = sel;
@@ -250,12 +220,12 @@ void launch_outlier(const EngineArrays& a, hipStream_t s)
     // objects that do not test this frame return immediately
     (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.zbuf), 0x7F800000, (size_t)a.n_obj * 2 * a.tile_w * a.tile_h, s);
     hipLaunchKernelGGL(raster_engine_kernel, dim3((a.max_tris + 255) / 256, 2, a.n_obj), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(kOutlierThreads), 0, s, a);
 }
 
 void launch_outlier_only(const EngineArrays& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(kOutlierThreads), 0, s, a);
 }
 
 // ---- operator level: render one pose into a float tile ------------------------------------------

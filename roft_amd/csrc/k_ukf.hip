@@ -23,6 +23,14 @@
 
 namespace roft {
 
+// phase cycle counters (build with -DROFT_UKF_PROFILE): TICK(L, i) adds the shader cycles since the
+// previous tick to slot i
+#ifdef ROFT_UKF_PROFILE
+#define TICK(L, i) do { __syncthreads(); if (threadIdx.x == 0) { long long _t = clock64(); (L).dbg[i] += _t - (L).t0; (L).t0 = _t; } } while (0)
+#else
+#define TICK(L, i) do {} while (0)
+#endif
+
 // ---- quaternion helpers (same conventions as oracle/ro_la.c) -----------------------------------
 __device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4])
 {
@@ -83,7 +91,43 @@ struct UkfLds {
     double noise_diag[12];
     double red[4];
     int flag;
+    long long t0;
+    long long dbg[32];
 };
+
+// 1/x and 1/sqrt(x) from the hardware seeds (v_rcp_f64 / v_rsq_f64, ~24 good bits) plus two Newton
+// steps: full double accuracy in ~10 FMAs instead of the ~40-instruction IEEE division / square root
+// sequences, which otherwise dominate the serial rotation set-up of every Jacobi round.
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return x;
+}
+
+__device__ __forceinline__ double fast_rsqrt(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    const double h = 0.5 * d;
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    y = fma(y, fma(-h * y, y, 0.5), y);
+    return y;
+}
+
+// Symmetric Schur rotation annihilating apq (apq != 0):
+//   tau = (aqq - app) / (2 apq),  t = sgn(tau) / (|tau| + sqrt(1 + tau^2)),  c = 1/sqrt(1 + t^2),  s = t c
+// evaluated division-free as t = sgn * |b| / (|a| + sqrt(a^2 + b^2)) with a = aqq - app, b = 2 apq.
+__device__ __forceinline__ void schur_rotation(double app, double aqq, double apq, double& c, double& s)
+{
+    const double a = aqq - app, b = 2.0 * apq;
+    const double h2 = a * a + b * b;
+    const double hyp = h2 * fast_rsqrt(h2);
+    const double sgn = ((a >= 0.0) == (b >= 0.0) || a == 0.0) ? 1.0 : -1.0;
+    const double t = sgn * fabs(b) * fast_rcp(fabs(a) + hyp);
+    c = fast_rsqrt(1.0 + t * t);
+    s = t * c;
+}
 
 // Symmetric Jacobi eigen-decomposition in LDS, n even (<= 12), executed by one wave.
 // On return diag(A) = eigenvalues, columns of V = eigenvectors.
@@ -111,13 +155,20 @@ __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
             if (r == cidx) dg += v * v; else if (r < cidx) off += v * v;
         }
         for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
-        if (off <= 1e-32 * dg || off == 0.0) break;
+        // off/diag <= 1e-14 in norm: two orders below the 1e-12 relative accuracy the sigma points need
+        if (off <= 1e-28 * dg || off == 0.0) break;
+#ifdef ROFT_UKF_PROFILE
+        if (lane == 0) L.dbg[16 + (n == 12 ? 0 : (n == 4 ? 1 : 2))] += 1;
+#endif
 
         for (int round = 0; round < n - 1; ++round) {
             // pair i of this round
             auto pair_of = [&](int i, int& p, int& q) {
                 if (i == 0) { p = n - 1; q = round; }
-                else { p = (round + i) % (n - 1); q = (round - i + (n - 1)) % (n - 1); }
+                else {
+                    p = round + i; if (p >= n - 1) p -= n - 1;
+                    q = round - i; if (q < 0) q += n - 1;
+                }
                 if (p > q) { const int t = p; p = q; q = t; }
             };
             int pa, qa, pb, qb;
@@ -129,13 +180,8 @@ __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
                 v00 = V[pa * n + pb]; v01 = V[pa * n + qb]; v10 = V[qa * n + pb]; v11 = V[qa * n + qb];
             }
             double c = 1.0, s = 0.0;
-            if (active && ba == bb && a01 != 0.0) {  // diagonal block: (app, apq; apq, aqq)
-                const double tau = (a11 - a00) / (2.0 * a01);
-                const double t = (tau >= 0.0) ? 1.0 / (tau + sqrt(1.0 + tau * tau))
-                                              : -1.0 / (-tau + sqrt(1.0 + tau * tau));
-                c = 1.0 / sqrt(1.0 + t * t);
-                s = t * c;
-            }
+            if (active && ba == bb && a01 != 0.0)  // diagonal block: (app, apq; apq, aqq)
+                schur_rotation(a00, a11, a01, c, s);
             const double ca = __shfl(c, ba * half + ba, 64), sa = __shfl(s, ba * half + ba, 64);
             const double cb = __shfl(c, bb * half + bb, 64), sb = __shfl(s, bb * half + bb, 64);
             if (active) {
@@ -290,19 +336,63 @@ __device__ void sigma_perturbation(int col, int r, double sc, bool noise_eig, co
     }
 }
 
-// Decompose L.cov (copy in L.P): eigenvalues -> L.wP, eigenvectors -> L.V
-__device__ void decompose_state_cov(UkfLds& L)
+// Decompose L.cov: eigenvalues -> L.wP, eigenvectors -> L.V.
+// Warm start: consecutive frames have nearly the same covariance, so the previous eigenvector basis
+// V0 almost diagonalises it; Jacobi on B = V0' P V0 then needs 1-2 sweeps instead of ~8, and
+// V = V0 VB.  Any orthogonal V0 is valid (B is similar to P), so this changes the result only by
+// rounding.  A cold start every kWarmRefresh uses stops the orthogonality error of the running
+// product from accumulating.
+__device__ void decompose_state_cov(UkfLds& L, double* warm, int* warm_age)
 {
     const int lane = threadIdx.x;
-    for (int i = lane; i < 144; i += 64) L.P[i] = L.cov[i];
-    __syncthreads();
-    jacobi_lds(L.P, L.V, 12, L);
+    const int age = warm ? *warm_age : 0;
+    const bool use = warm && age > 0 && age < kWarmRefresh;
+    if (use) {
+        double* V0 = L.K;      // scratch: K / KPy are free until the correction computes them
+        double* T = L.KPy;
+        for (int i = lane; i < 144; i += 64) V0[i] = warm[i];
+        __syncthreads();
+        for (int e = lane; e < 144; e += 64) {
+            const int i = e / 12, j = e % 12;
+            double s = 0.0;
+            for (int k = 0; k < 12; ++k) s += L.cov[i * 12 + k] * V0[k * 12 + j];
+            T[e] = s;
+        }
+        __syncthreads();
+        for (int e = lane; e < 144; e += 64) {
+            const int r = e / 12, c = e % 12;
+            const int i = r < c ? r : c, j = r < c ? c : r;   // both triangles evaluate the same sum
+            double s = 0.0;
+            for (int k = 0; k < 12; ++k) s += V0[k * 12 + i] * T[k * 12 + j];
+            L.P[e] = s;
+        }
+        __syncthreads();
+        jacobi_lds(L.P, L.V, 12, L);   // L.V = VB
+        for (int e = lane; e < 144; e += 64) {
+            const int i = e / 12, j = e % 12;
+            double s = 0.0;
+            for (int k = 0; k < 12; ++k) s += V0[i * 12 + k] * L.V[k * 12 + j];
+            T[e] = s;
+        }
+        __syncthreads();
+        for (int i = lane; i < 144; i += 64) L.V[i] = T[i];
+    } else {
+        for (int i = lane; i < 144; i += 64) L.P[i] = L.cov[i];
+        __syncthreads();
+        jacobi_lds(L.P, L.V, 12, L);
+    }
     if (lane < 12) L.wP[lane] = L.P[lane * 13];
+    __syncthreads();
+    if (warm) {
+        for (int i = lane; i < 144; i += 64) warm[i] = L.V[i];
+        if (lane == 0) *warm_age = use ? age + 1 : 1;
+    }
     __syncthreads();
 }
 
 // ---- prediction: (L.mean, L.cov) -> (L.mean, L.cov) ------------------------------------------------
-__device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const roft_ut_params& ut)
+__device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const roft_ut_params& ut, double* warm,
+                            int* warm_age)
 {
     const int lane = threadIdx.x;
     const int r = 9, n = 21;
@@ -341,7 +431,9 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
         L.VQ[(6 + i) * 10 + i] = -s; L.VQ[(6 + i) * 10 + (6 + i)] = c;
     }
     __syncthreads();
-    decompose_state_cov(L);
+    TICK(L, 1);
+    decompose_state_cov(L, warm, warm_age);
+    TICK(L, 2);
 
     // fan-out + motion model, lane = sigma point
     if (lane < w.ncols) {
@@ -369,6 +461,7 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
     }
     __syncthreads();
 
+    TICK(L, 3);
     // mean
     if (lane < 9) {
         double s = 0.0;
@@ -377,6 +470,7 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
     }
     double qm[4];
     quaternion_mean(L.Y, 9, w.ncols, w.wm0, w.wi, qm, L);
+    TICK(L, 4);
     if (lane == 0)
         for (int i = 0; i < 4; ++i) L.ymean[9 + i] = qm[i];
     __syncthreads();
@@ -393,6 +487,7 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
     weighted_outer(L.D, 12, L.D, 12, w.ncols, w.wc0, w.wi, L.cov, 12);
     if (lane < 13) L.mean[lane] = L.ymean[lane];
     __syncthreads();
+    TICK(L, 5);
 }
 
 // ---- correction of (L.mean, L.cov) [decomposition already in L.V / L.wP] -> out ------------------------
@@ -471,6 +566,7 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
     }
     __syncthreads();
 
+    TICK(L, 8);
     if (lane < nlin) {
         double s = 0.0;
         for (int c = 0; c < w.ncols; ++c) s += L.Y[lane * kCols + c] * (c == 0 ? w.wm0 : w.wi);
@@ -494,6 +590,7 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
         }
     }
     __syncthreads();
+    TICK(L, 9);
     weighted_outer(L.D, m, L.D, m, w.ncols, w.wc0, w.wi, L.Py, m);
     weighted_outer(L.X, 12, L.D, m, w.ncols, w.wc0, w.wi, L.Pxy, m);
     if (lane < nlin) L.innov[lane] = -(L.ymean[lane] - meas[lane]);
@@ -504,12 +601,14 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
     }
     __syncthreads();
 
+    TICK(L, 10);
     // K = Pxy Py^-1 ; the inverse lands in KPy (scratch), then KPy = K Py
     if (!inverse_lds(L.Py, m, L.KPy, L)) {
         for (int i = lane; i < 144; i += 64) out->cov[i] = L.cov[i];
         if (lane < 13) out->mean[lane] = L.mean[lane];
         return 2;
     }
+    TICK(L, 11);
     for (int e = lane; e < 12 * m; e += 64) {
         const int i = e / m, j = e % m;
         double s = 0.0;
@@ -542,6 +641,7 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
         out->cov[e] = L.cov[e] - s;
     }
     __syncthreads();
+    TICK(L, 12);
     return 0;
 }
 
@@ -559,6 +659,11 @@ __global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step, 
     const ObjParams& prm = a.params[obj];
     const int lane = threadIdx.x;
 
+#ifdef ROFT_UKF_PROFILE
+    if (lane < 32) L.dbg[lane] = 0;
+    if (lane == 0) L.t0 = clock64();
+    __syncthreads();
+#endif
     const PoseBelief& src = st.belief[sd.src];
     for (int i = lane; i < 144; i += 64) L.cov[i] = src.cov[i];
     if (lane < 13) L.mean[lane] = src.mean[lane];
@@ -570,8 +675,9 @@ __global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step, 
         if (lane < 13) bf.mean[lane] = cr.mean[lane];
     }
 
+    TICK(L, 0);
     if (sd.do_predict) {
-        ukf_predict(L, prm, c.dt, ut);
+        ukf_predict(L, prm, c.dt, ut, st.warm_V[0], &st.warm_age[0]);
         PoseBelief& pr = st.belief[B_PRED];
         for (int i = lane; i < 144; i += 64) pr.cov[i] = L.cov[i];
         if (lane < 13) pr.mean[lane] = L.mean[lane];
@@ -582,7 +688,9 @@ __global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step, 
         if (lane < 13) d.mean[lane] = L.mean[lane];
         return;
     }
-    decompose_state_cov(L);  // shared by both corrections of an outlier-rejection step
+    TICK(L, 6);
+    decompose_state_cov(L, st.warm_V[1], &st.warm_age[1]);  // shared by both corrections of an outlier-rejection step
+    TICK(L, 7);
     const double* twist = st.twist_hist[sd.twist_slot];
     int status = 0;
     for (int k = 0; k < sd.n_corr; ++k) {
@@ -591,6 +699,10 @@ __global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step, 
         __syncthreads();
     }
     if (lane == 0) st.ukf_status = status;
+#ifdef ROFT_UKF_PROFILE
+    __syncthreads();
+    if (lane < 32) st.dbg[lane] = L.dbg[lane];
+#endif
 }
 
 static size_t ukf_lds_bytes() { return (sizeof(UkfLds) + 15) & ~(size_t)15; }

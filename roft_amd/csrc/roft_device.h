@@ -73,7 +73,13 @@ struct ObjState {
     double outlier_cnt[2];
     int skf_status;
     int ukf_status;
+    // warm start of the covariance eigen-decomposition: [0] prediction input, [1] correction input
+    double warm_V[2][144];
+    int warm_age[2];       // 0 = no basis yet; a cold start is forced every kWarmRefresh uses
+    long long dbg[32];     // phase cycle counters of the last ukf_step (ROFT_UKF_PROFILE builds only)
 };
+
+constexpr int kWarmRefresh = 32;
 
 // one UKF launch for one object
 struct StepDesc {

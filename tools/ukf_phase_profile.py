@@ -1,0 +1,15 @@
+import sys, ctypes as C
+sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+import numpy as np, util
+from roft_amd import engine as E, synth, _lib as L
+import test_engine_gpu as T
+streams=[util.stream(100,14,scale=2)]
+eng=T.make_engine(streams)
+for k in range(14):
+    depth,flow,mask,pose=util.frame_inputs(streams[0],k)
+    eng.submit([dict(depth=depth,flow=flow,mask=mask,pose=pose,dt=streams[0].dt)]); eng.step(); eng.sync()
+    if k in (4,5,11,13):
+        # read ObjState.dbg: find offset via struct size: use hipMemcpy through roft_get_state? not exposed -> use debug export
+        buf=(C.c_longlong*32)()
+        L.lib().roft_debug_get_dbg(eng._h,0,buf)
+        print(k,[int(x) for x in buf][:13], 'sweeps n12/n4/n10:', [int(x) for x in buf][16:19])
