@@ -1,0 +1,68 @@
+"""C++ facade (include/ROFT/Filters.h): compiles against the C ABI, fails loudly without a device,
+and on the GPU returns what the operator-level ABI returns."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "roft_amd", "csrc")
+
+
+def build_exe(tmp_path):
+    from roft_amd import _lib
+    _lib.build()
+    exe = str(tmp_path / "facade_check")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "facade_check.cpp"), "-o", exe, "-L", CSRC, "-lroft_hip",
+                           "-Wl,-rpath," + CSRC, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def problem(tmp_path):
+    rng = np.random.default_rng(9)
+    n = 40
+    x = rng.normal(size=6) * 0.05
+    P = np.eye(6) * 1e-3
+    q = np.full(6, 0.1)
+    H = rng.normal(size=(2 * n, 6)) * 20
+    y = H @ (x + rng.normal(size=6) * 0.02) + rng.normal(size=2 * n)
+    pm = np.zeros(13)
+    pm[6:9] = [0.0, 0.1, 0.7]
+    pm[9] = 1.0
+    pm[3:6] = [0.2, -0.1, 0.3]
+    pP = np.eye(12) * 1e-3
+    path = str(tmp_path / "in.bin")
+    with open(path, "wb") as f:
+        f.write(struct.pack("i", n))
+        for a in (x, P, q, y, H, pm, pP):
+            f.write(np.ascontiguousarray(a, np.float64).tobytes())
+    return path, (x, P, q, y, H, pm, pP)
+
+
+def test_facade_compiles_and_fails_loudly_without_device(tmp_path):
+    from roft_amd import _lib
+    exe = build_exe(tmp_path)
+    if _lib.lib().roft_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    inp, _ = problem(tmp_path)
+    r = subprocess.run([exe, inp, str(tmp_path / "out.bin")], capture_output=True, text=True)
+    assert r.returncode == 3 and "runtime_error" in r.stdout
+
+
+@pytest.mark.gpu
+def test_facade_matches_operator_abi(tmp_path):
+    from roft_amd import ops
+    exe = build_exe(tmp_path)
+    inp, (x, P, q, y, H, pm, pP) = problem(tmp_path)
+    out = str(tmp_path / "out.bin")
+    subprocess.check_call([exe, inp, out])
+    got = np.fromfile(out, np.float64)
+    xp, Pp = ops.kf_predict(x, P, q)
+    rc, xc, Pc = ops.skf_correct(xp, Pp, y, H, (1.0, 1.0), True)
+    Q = ops.process_noise([1.0] * 3, [1.0] * 3, 1.0 / 30.0)
+    m1, P1 = ops.ukf_predict(pm, pP, Q, 1.0 / 30.0)
+    assert np.array_equal(got[:6], xc) and np.array_equal(got[6:42].reshape(6, 6), Pc)
+    assert np.array_equal(got[42:55], m1) and np.array_equal(got[55:].reshape(12, 12), P1)
