@@ -15,6 +15,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -125,7 +126,7 @@ struct Arrays {
         HIP_TRY(map.ensure((size_t)n_obj * npix, true));
         HIP_TRY(cand.ensure((size_t)n_obj * a.cand_cap));
         HIP_TRY(recs.ensure((size_t)n_obj * a.cand_cap));
-        HIP_TRY(norms.ensure((size_t)n_obj * a.cand_cap));
+        HIP_TRY(norms.ensure((size_t)n_obj * 3 * a.cand_cap));
         HIP_TRY(feat_pix.ensure((size_t)n_obj * a.feat_cap));
         HIP_TRY(feat_depth.ensure((size_t)n_obj * a.feat_cap));
         HIP_TRY(zbuf.ensure((size_t)n_obj * 2 * a.tile_w * a.tile_h));
@@ -181,7 +182,13 @@ struct HostObject {
 struct roft_engine {
     roft_config cfg{};
     Arrays arr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // image chain: uploads, mask stage, flow measurement, velocity filter
+    hipStream_t pose_stream = nullptr;  // pose chain: features, UKF steps, outlier rejection
+    static constexpr int kCtrlRing = 4; // device FrameCtrl blocks in flight (image chain leads by <= 2 frames)
+    DevBuf<FrameCtrl> dctrl[kCtrlRing];
+    hipEvent_t ev_img[kCtrlRing] = {};
+    hipEvent_t ev_pose[kCtrlRing] = {};
+    bool two_streams = true;
     std::vector<HostObject*> objs;
     std::vector<ObjParams> h_params;
     // pinned staging ring for FrameCtrl blocks
@@ -201,7 +208,8 @@ struct roft_engine {
     std::vector<const char*> tnames;
     std::vector<float> tms;
     std::vector<int> tlaunches;
-    std::vector<int> tmark;  // kernel id per event interval
+    std::vector<int> tmark;    // kernel id per event interval (-1 = chain start)
+    std::vector<int> tstream;  // stream of each mark (0 image chain, 1 pose chain)
 };
 
 extern "C" {
@@ -281,6 +289,20 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
     roft_engine* e = new roft_engine();
     e->cfg = *cfg;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    // The image chain of frame k+1 does not depend on the pose chain of frame k (only the other way round,
+    // through the twist ring and the mask planes), so the two CAN run on separate HIP streams
+    // (ROFT_TWO_STREAMS=1).  Measured on MI355X / ROCm 7.2 (profiles/README.md): the two cross-queue event
+    // waits per frame cost more than the overlap wins at 64 objects (0.64 vs 0.40 ms per frame), so one
+    // stream is the default.
+    const char* two = getenv("ROFT_TWO_STREAMS");
+    e->two_streams = (two && two[0] == '1');
+    if (e->two_streams) HIP_TRY(hipStreamCreateWithFlags(&e->pose_stream, hipStreamNonBlocking));
+    else e->pose_stream = e->stream;
+    for (int i = 0; i < roft_engine::kCtrlRing; ++i) {
+        HIP_TRY(e->dctrl[i].ensure(cfg->max_objects, true));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_img[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_pose[i], hipEventDisableTiming));
+    }
     DevFlowFmt ff;
     ff.type = cfg->flow_type;
     ff.grid = cfg->flow_grid;
@@ -305,6 +327,12 @@ int roft_engine_destroy(roft_engine* e)
     if (!e) return ROFT_OK;
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->pose_stream) (void)hipStreamSynchronize(e->pose_stream);
+    for (int i = 0; i < roft_engine::kCtrlRing; ++i) {
+        if (e->ev_img[i]) (void)hipEventDestroy(e->ev_img[i]);
+        if (e->ev_pose[i]) (void)hipEventDestroy(e->ev_pose[i]);
+    }
+    if (e->two_streams && e->pose_stream) (void)hipStreamDestroy(e->pose_stream);
     for (auto* o : e->objs) delete o;
     for (int i = 0; i < roft_engine::kStage; ++i) {
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
@@ -544,6 +572,7 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
             c.buffer_features_before = 1;
             o.features_initialized = true;
         }
+        c.frame_idx = e->frame_counter;
         build_pose_program(e, o, in, c);
         e->max_steps = std::max(e->max_steps, c.n_steps);
         if (c.outlier_step >= 0) e->any_outlier = true;
@@ -559,7 +588,7 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
 // Timing marks accumulate over any number of steps until roft_engine_get_timing() collects them:
 // mark i closes the interval (event i-1, event i] and attributes it to kernel id tmark[i]
 // (-1 = step start, attributes nothing).
-static void tmark(roft_engine* e, const char* name)
+static void tmark(roft_engine* e, const char* name, int which = 0)
 {
     if (!e->timing) return;
     const size_t idx = e->tmark.size();
@@ -575,7 +604,8 @@ static void tmark(roft_engine* e, const char* name)
         if (id < 0) { e->tnames_s.push_back(name); id = (int)e->tnames_s.size() - 1; }
     }
     e->tmark.push_back(id);
-    (void)hipEventRecord(e->tev[idx], e->stream);
+    e->tstream.push_back(which);
+    (void)hipEventRecord(e->tev[idx], which ? e->pose_stream : e->stream);
 }
 
 int roft_step(roft_engine* e)
@@ -583,30 +613,43 @@ int roft_step(roft_engine* e)
     if (!e) return fail(ROFT_ERR_INVALID, "null engine");
     if (!e->submitted) return fail(ROFT_ERR_STATE, "roft_frame_submit must precede roft_step");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    const EngineArrays& a = e->arr.a;
-    hipStream_t s = e->stream;
+    EngineArrays a = e->arr.a;
+    hipStream_t s = e->stream, sp = e->pose_stream;
     const int si = e->stage_idx;
+    const int ci = e->frame_counter % roft_engine::kCtrlRing;
+    // throttle: the image chain may lead the pose chain by at most two frames (bit-plane ring, depth ring,
+    // twist ring and this FrameCtrl ring are sized for that)
+    if (e->two_streams && e->frame_counter >= 2)
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_pose[(e->frame_counter - 2) % roft_engine::kCtrlRing], 0));
+    a.ctrl = e->dctrl[ci].p;
     HIP_TRY(hipMemcpyAsync(a.ctrl, e->cur, sizeof(FrameCtrl) * a.n_obj, hipMemcpyHostToDevice, s));
     HIP_TRY(hipEventRecord(e->stage_ev[si], s));
     e->stage_idx = (si + 1) % roft_engine::kStage;
 
-    tmark(e, nullptr);
+    // ---- image chain
+    tmark(e, nullptr, 0);
     const int radius = (int)(size_t)e->cfg.subsampling_radius;
-    if (e->any_new_mask) { launch_mask_ingest(a, s); tmark(e, "mask_ingest"); }
-    launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, s);
-    tmark(e, "mask_propagate");
-    launch_flow_measure(a, e->cfg.depth_maximum, radius, s);
-    tmark(e, "flow_measure");
+    if (e->any_new_mask) { launch_mask_ingest(a, s); tmark(e, "mask_ingest", 0); }
+    launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, false, s);
+    tmark(e, "mask_propagate", 0);
+    launch_flow_measure(a, e->cfg.depth_maximum, radius, true, s);
+    tmark(e, "flow_measure", 0);
     launch_skf(a, e->cfg.flow_weighting, s);
-    tmark(e, "skf");
-    if (e->any_feat0) { launch_features(a, 0, s); tmark(e, "features"); }
-    for (int k = 0; k < e->max_steps; ++k) {
-        launch_ukf_step(a, k, e->cfg.ut, s);
-        tmark(e, "ukf_step");
-        if (k == 0 && e->any_outlier) { launch_outlier(a, s); tmark(e, "outlier_render_likelihood"); }
+    tmark(e, "skf", 0);
+    // ---- pose chain (needs this frame's twist and mask planes; the next frame's image chain does not wait for it)
+    if (e->two_streams) {
+        HIP_TRY(hipEventRecord(e->ev_img[ci], s));
+        HIP_TRY(hipStreamWaitEvent(sp, e->ev_img[ci], 0));
     }
-    if (e->any_feat1) { launch_features(a, 1, s); tmark(e, "features"); }
-    if (a.out_log) { launch_collect_outputs(a, e->frame_counter, s); tmark(e, "collect_outputs"); }
+    tmark(e, nullptr, 1);
+    if (e->any_feat0) { launch_features(a, 0, sp); tmark(e, "features", 1); }
+    for (int k = 0; k < e->max_steps; ++k) {
+        launch_ukf_step(a, k, e->cfg.ut, sp);
+        tmark(e, "ukf_step", 1);
+        if (k == 0 && e->any_outlier) { launch_outlier(a, sp); tmark(e, "outlier_render_likelihood", 1); }
+    }
+    if (e->any_feat1) { launch_features(a, 1, sp); tmark(e, "features", 1); }
+    if (e->two_streams) HIP_TRY(hipEventRecord(e->ev_pose[ci], sp));
     HIP_TRY(hipGetLastError());
     e->frame_counter++;
     e->submitted = false;
@@ -618,6 +661,7 @@ int roft_sync(roft_engine* e)
     if (!e) return fail(ROFT_ERR_INVALID, "null engine");
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->two_streams) HIP_TRY(hipStreamSynchronize(e->pose_stream));
     return ROFT_OK;
 }
 
@@ -658,8 +702,7 @@ int roft_get_outputs(roft_engine* e, roft_object_output* outs, int n_outs)
 int roft_engine_enable_log(roft_engine* e, int n_frames)
 {
     if (!e || n_frames <= 0) return fail(ROFT_ERR_INVALID, "bad arguments");
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (int rc = roft_sync(e)) return rc;
     HIP_TRY(e->arr.log.ensure((size_t)n_frames * e->cfg.max_objects, true));
     e->arr.a.out_log = e->arr.log.p;
     e->arr.a.log_cap = n_frames;
@@ -684,7 +727,7 @@ int roft_get_mask(roft_engine* e, int id, uint8_t* mask_out)
     if (!e || !mask_out || id < 0 || id >= (int)e->objs.size()) return fail(ROFT_ERR_INVALID, "bad arguments");
     HostObject& o = *e->objs[id];
     if (o.frame_idx == 0) return fail(ROFT_ERR_STATE, "no frame processed yet");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (int rc = roft_sync(e)) return rc;
     const EngineArrays& a = e->arr.a;
     const int slot = (o.frame_idx - 1) % kPlaneSlots;
     const size_t npix = (size_t)a.cam.W * a.cam.H;
@@ -713,14 +756,19 @@ int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, 
     const size_t nk = e->tnames_s.size();
     e->tms.assign(nk, 0.f);
     e->tlaunches.assign(nk, 0);
-    for (size_t i = 1; i < e->tmark.size(); ++i) {
-        if (e->tmark[i] < 0) continue;
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e->tev[i - 1], e->tev[i]));
-        e->tms[e->tmark[i]] += ms;
-        e->tlaunches[e->tmark[i]] += 1;
+    long prev[2] = {-1, -1};
+    for (size_t i = 0; i < e->tmark.size(); ++i) {
+        const int w = e->tstream[i];
+        if (e->tmark[i] >= 0 && prev[w] >= 0) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, e->tev[prev[w]], e->tev[i]));
+            e->tms[e->tmark[i]] += ms;
+            e->tlaunches[e->tmark[i]] += 1;
+        }
+        prev[w] = (long)i;
     }
     e->tmark.clear();
+    e->tstream.clear();
     e->tnames.clear();
     for (auto& s : e->tnames_s) e->tnames.push_back(s.c_str());
     *n_out = (int)nk;
@@ -824,7 +872,7 @@ int roft_flow_measurement(const roft_camera* cam, const uint8_t* prev_mask, cons
     fc.vel_stage = 1;
     if (int rc = upload_ctrl(c, fc)) return rc;
     launch_mask_ingest(c.arr.a, c.stream);
-    launch_flow_measure(c.arr.a, depth_max, r, c.stream);
+    launch_flow_measure(c.arr.a, depth_max, r, false, c.stream);
     int n = 0;
     HIP_TRY(hipMemcpyAsync(&n, &c.arr.state.p->n_flow_points, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
@@ -895,7 +943,7 @@ int roft_skf_correct(const double x_pred[6], const double P_pred[36], int N, con
     const int n = std::max(N, 0);
     if (int rc = to_dev(c.b1, y, (size_t)2 * n, c.stream)) return rc;
     if (int rc = to_dev(c.b2, H, (size_t)12 * n, c.stream)) return rc;
-    HIP_TRY(c.b3.ensure(sizeof(double) * std::max(n, 1)));
+    HIP_TRY(c.b3.ensure(sizeof(double) * 3 * std::max(n, 1)));
     HIP_TRY(c.b4.ensure(sizeof(double) * 44));
     double* d = reinterpret_cast<double*>(c.b0.p);
     double* o = reinterpret_cast<double*>(c.b4.p);
@@ -949,7 +997,7 @@ int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int
     HIP_TRY(hipMemcpyAsync(c.arr.state.p, &st, sizeof(st), hipMemcpyHostToDevice, c.stream));
     if (int rc = upload_ctrl(c, fc)) return rc;
     launch_mask_ingest(c.arr.a, c.stream);
-    launch_mask_propagate(c.arr.a, frames_between, 1, c.stream);
+    launch_mask_propagate(c.arr.a, frames_between, 1, true, c.stream);
     HIP_TRY(c.b2.ensure(npix));
     launch_planes_to_mask(c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 0), c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 1),
                           (int)npix, c.b2.p, c.stream);
@@ -1150,7 +1198,7 @@ int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint
 extern "C" int roft_debug_get_dbg(roft_engine* e, int id, long long out[32])
 {
     if (!e || id < 0 || id >= (int)e->objs.size()) return ROFT_ERR_INVALID;
-    if (hipStreamSynchronize(e->stream) != hipSuccess) return ROFT_ERR_DEVICE;
+    if (roft_sync(e) != ROFT_OK) return ROFT_ERR_DEVICE;
     ObjState* st = new ObjState();
     hipError_t err = hipMemcpy(st, e->arr.state.p + id, sizeof(ObjState), hipMemcpyDeviceToHost);
     if (err == hipSuccess) std::memcpy(out, st->dbg, sizeof(long long) * 32);

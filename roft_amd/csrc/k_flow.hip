@@ -38,13 +38,17 @@ __device__ __forceinline__ bool is_flow_valid(float fx, float fy)
 constexpr int kFlowThreads = 512;
 
 // dynamic LDS: plane words [wpr*H] | rowpref [H+1]
-__global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays a, double depth_max, int radius)
+__global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays a, double depth_max, int radius,
+                                                                   int mask_finish)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_wave[17];
     const int obj = blockIdx.x;
     const FrameCtrl& c = a.ctrl[obj];
     ObjState& st = a.state[obj];
+    // the mask stage's per-object bookkeeping rides along (saves a launch per frame); this kernel reads
+    // none of the fields it touches
+    if (mask_finish && threadIdx.x == 0) mask_bookkeeping(c, st);
     if (!c.vel_stage) {
         if (threadIdx.x == 0) st.n_flow_points = -1;
         return;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays
     if (threadIdx.x == 0) st.n_flow_points = total;
 }
 
-void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, hipStream_t s)
+void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bool mask_finish, hipStream_t s)
 {
     const size_t lds = plane_lds_bytes(a.plane_words, a.cam.H);
     static bool attr_set = false;
@@ -96,7 +100,8 @@ void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, hi
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
         attr_set = true;
     }
-    hipLaunchKernelGGL(flow_measure_kernel, dim3(a.n_obj), dim3(kFlowThreads), lds, s, a, depth_max, radius);
+    hipLaunchKernelGGL(flow_measure_kernel, dim3(a.n_obj), dim3(kFlowThreads), lds, s, a, depth_max, radius,
+                       mask_finish ? 1 : 0);
 }
 
 // ---- records -> (uv, y, H) exactly as the reference assembles them (hpp:258-283) -------------

@@ -71,30 +71,13 @@ __global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a)
     if (lane == 0 && count) atomicAdd(&a.state[obj].new_mask_count, count);
 }
 
-// ---- mode decision + scatter ----------------------------------------------------------------
-// mode 0: copy (no flow, no usable new mask); 1: propagate last mask through this frame's flow,
-// mask(0,0) forced to 0 (hpp:221-226); 2: new mask chased through the buffered flows (hpp:211-219)
-__device__ __forceinline__ int decide_mode(const FrameCtrl& c, const ObjState& st, int& src_slot, int& n_flows)
-{
-    const int n_avail = st.fbuf_n + (c.flow_valid ? 1 : 0);
-    if (c.force_mode == 3) {  // operator level: map() + remap() of the given mask through n flows
-        src_slot = kSlotNew;
-        n_flows = n_avail < kMaxFlowHist ? n_avail : kMaxFlowHist;
-        return 2;
-    }
-    if (c.has_new_mask && !c.first_mask && st.new_mask_count > 0) {
-        src_slot = kSlotNew;
-        n_flows = n_avail < kMaxFlowHist ? n_avail : kMaxFlowHist;
-        return 2;
-    }
-    src_slot = (c.has_new_mask && c.first_mask) ? kSlotNew : c.slot_prev;
-    n_flows = 1;
-    return c.flow_valid ? 1 : 0;
-}
+constexpr int kScatterBlocks = 48;  // per object; x 4 waves x ~25 groups each at 640x480
 
-// grid: (ceil(W*H/1024), n_obj), block 256 = 4 waves; a wave owns 64 consecutive pixels per iteration
-// (4 iterations per wave) and its lanes chase their pixel through the flows in parallel: the flow reads
-// of a wave are row-contiguous (64 x 8 B), the map atomics land on neighbouring addresses.
+// ---- scatter (mode decision: decide_mode() in roft_device.h) --------------------------------------
+// grid: (kScatterBlocks, n_obj), block 256 = 4 waves; a wave owns 64 consecutive pixels per iteration and
+// strides over the image (interleaved, so the object's rows spread over all waves); its lanes chase their
+// pixel through the flows in parallel: the flow reads of a wave are row-contiguous (64 x 8 B), the map
+// atomics land on neighbouring addresses.  Empty 64-pixel groups cost one wave-uniform 8-byte load.
 __global__ __launch_bounds__(256) void mask_scatter_kernel(EngineArrays a, int frames_between)
 {
     const int obj = blockIdx.y;
@@ -115,10 +98,8 @@ __global__ __launch_bounds__(256) void mask_scatter_kernel(EngineArrays a, int f
     const uint2* plane2 = reinterpret_cast<const uint2*>(a.planes + plane_offset(a, obj, src_slot, 0));
     int32_t* map = a.map + (size_t)obj * npix;
     int bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = -1, by1 = -1;
-    const size_t wave0 = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;  // first 64-pixel group of this wave
-    for (int it = 0; it < 4; ++it) {
-        const size_t grp = wave0 + it;
-        if (grp * 64 >= npix) break;
+    const size_t n_grp = npix / 64, wave_stride = (size_t)gridDim.x * 4;
+    for (size_t grp = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < n_grp; grp += wave_stride) {
         const uint2 w2 = plane2[grp];                                   // wave-uniform load
         unsigned long long bits = ((unsigned long long)w2.y << 32) | w2.x;
         if (mode == 1 && grp == 0) bits &= ~1ull;                         // mask_.at<uchar>(0,0) = 0
@@ -231,17 +212,7 @@ __global__ void mask_finish_kernel(EngineArrays a, int frames_between)
 {
     const int obj = blockIdx.x * blockDim.x + threadIdx.x;
     if (obj >= a.n_obj) return;
-    const FrameCtrl& c = a.ctrl[obj];
-    ObjState& st = a.state[obj];
-    int src_slot, n_flows;
-    const int mode = decide_mode(c, st, src_slot, n_flows);
-    int n_avail = st.fbuf_n + (c.flow_valid ? 1 : 0);
-    if (n_avail > kMaxFlowHist) n_avail = kMaxFlowHist;
-    st.fbuf_n = (mode == 2) ? 0 : n_avail;
-    st.mask_mode = mode;
-    st.new_mask_count = 0;
-    st.outlier_selected = -1;
-    st.bbox[0] = INT32_MAX; st.bbox[1] = INT32_MAX; st.bbox[2] = -1; st.bbox[3] = -1;
+    mask_bookkeeping(a.ctrl[obj], a.state[obj]);
 }
 
 // no flow-aided segmentation: the delivered mask is used as is, otherwise the last one persists
@@ -264,20 +235,19 @@ void launch_mask_ingest(const EngineArrays& a, hipStream_t s)
     hipLaunchKernelGGL(mask_ingest_kernel, dim3(gx, a.n_obj), dim3(256), 0, s, a);
 }
 
-void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s)
+void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_aided, bool finish, hipStream_t s)
 {
     if (!flow_aided) {
         hipLaunchKernelGGL(mask_plain_kernel, dim3((unsigned)((a.plane_words + 255) / 256), a.n_obj), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(mask_finish_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frames_between);
+        if (finish) hipLaunchKernelGGL(mask_finish_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frames_between);
         return;
     }
-    hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)(((size_t)a.cam.W * a.cam.H + 1023) / 1024), a.n_obj), dim3(256),
-                       0, s, a, frames_between);
+    hipLaunchKernelGGL(mask_scatter_kernel, dim3(kScatterBlocks, a.n_obj), dim3(256), 0, s, a, frames_between);
     const size_t waves = ((size_t)a.cam.W * a.cam.H + 63) / 64;
     int gx = (int)((waves + 3) / 4);
     if (gx > 128) gx = 128;
     hipLaunchKernelGGL(mask_gather_kernel, dim3(gx, a.n_obj), dim3(256), 0, s, a, frames_between);
-    hipLaunchKernelGGL(mask_finish_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frames_between);
+    if (finish) hipLaunchKernelGGL(mask_finish_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frames_between);
 }
 
 // ---- plane -> u8 mask (operator-level output / roft_get_mask) --------------------------------

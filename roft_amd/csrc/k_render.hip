@@ -213,6 +213,14 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
     PoseBelief& dst = st.belief[B_CORR];
     for (int i = threadIdx.x; i < 144; i += blockDim.x) dst.cov[i] = src.cov[i];
     if (threadIdx.x < 13) dst.mean[threadIdx.x] = src.mean[threadIdx.x];
+    if (roft_object_output* row = log_row(a, obj)) {
+        if (threadIdx.x < 13) row->pose[threadIdx.x] = src.mean[threadIdx.x];
+        if (threadIdx.x == 0) {
+            row->outlier_selected = s_sel;
+            row->outlier_L[0] = st.outlier_L[0];
+            row->outlier_L[1] = st.outlier_L[1];
+        }
+    }
 }
 
 void launch_outlier(const EngineArrays& a, hipStream_t s)

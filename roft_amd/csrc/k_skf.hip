@@ -48,10 +48,25 @@ struct RecAccessor {
     const FlowRec* recs;
     DevCamera cam;
     double dt;
+    // H rows with reciprocal multiplies instead of the ten IEEE divisions of the literal expression
+    // (hpp:279-280): agrees with h_rows() to an ulp or two; the bit-exact assembly is expand_yh_kernel.
     __device__ __forceinline__ void get(int j, double h[12], double y[2]) const
     {
         const FlowRec r = recs[j];
-        h_rows(r, cam, dt, h);
+        const double iz = 1.0 / (double)r.z, ifx = 1.0 / cam.fx, ify = 1.0 / cam.fy;
+        const double uu = (r.u - cam.cx), vv = (r.v - cam.cy);
+        h[0] = (cam.fx * iz) * dt;
+        h[1] = 0.0;
+        h[2] = (-uu * iz) * dt;
+        h[3] = (-uu * vv * ify) * dt;
+        h[4] = (cam.fx + uu * uu * ifx) * dt;
+        h[5] = (-vv * cam.fx * ify) * dt;
+        h[6] = 0.0;
+        h[7] = (cam.fy * iz) * dt;
+        h[8] = (-vv * iz) * dt;
+        h[9] = (-(cam.fy + vv * vv * ify)) * dt;
+        h[10] = (vv * uu * ifx) * dt;
+        h[11] = (uu * cam.fy * ifx) * dt;
         y[0] = (double)r.dx;
         y[1] = (double)r.dy;
     }
@@ -181,43 +196,151 @@ __device__ bool spd_inverse6(const double* A, double* Ainv)
     return true;
 }
 
+constexpr int kSkfLdsN = 1024;  // measurement counts up to this keep innovations + norms in LDS
+constexpr int kBins = 1024;
+constexpr int kBucketCap = 256;
+static_assert(kBins == 4 * 256, "bucket_select2 scans 4 bins per thread of a 256-thread block");
+
 struct SkfShared {
     double red[kSkfThreads / 64];
     double acc[27][kSkfThreads / 64];
-    int hist[256];
+    int hist[kBins];
     int sel[2];
+    int wave[17];
+    int bin[2], base[2], cnt[2];
+    double list[2][kBucketCap];
+    double med[2];
+    double ein[2 * kSkfLdsN];
+    double qn[kSkfLdsN];
 };
+
+__device__ int skf_block_scan(int v, int* s_wave, int* total)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int w = 0; w < nw; ++w) { int t = s_wave[w]; s_wave[w] = run; run += t; }
+        s_wave[16] = run;
+    }
+    __syncthreads();
+    const int res = s_wave[wave] + inc - v;
+    *total = s_wave[16];
+    __syncthreads();
+    return res;
+}
+
+// Exact order statistics of ranks ra <= rb (rb - ra <= 1) of N non-negative doubles in ~5 barrier phases:
+// a monotone 1024-bin histogram over [min, max] locates the bucket of each rank, the (few) members of that
+// bucket are collected and ranked by counting.  Returns false if a bucket holds more than kBucketCap values.
+__device__ bool bucket_select2(const double* vals, int N, int ra, int rb, SkfShared& S, double& va, double& vb)
+{
+    double lo = INFINITY, hi = 0.0;
+    for (int k = threadIdx.x; k < N; k += blockDim.x) { const double v = vals[k]; lo = fmin(lo, v); hi = fmax(hi, v); }
+    lo = -block_max(-lo, S.red);
+    hi = block_max(hi, S.red);
+    if (!(hi > lo)) { va = vb = lo; return true; }
+    const double scale = (double)(kBins - 1) / (hi - lo);
+    for (int i = threadIdx.x; i < kBins; i += blockDim.x) S.hist[i] = 0;
+    if (threadIdx.x < 2) S.cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+        int b = (int)((vals[k] - lo) * scale);   // monotone in vals[k]
+        b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+        atomicAdd(&S.hist[b], 1);
+    }
+    __syncthreads();
+    {   // exclusive prefix over the bins, 4 bins per thread
+        const int t = threadIdx.x;
+        const int h0 = S.hist[4 * t], h1 = S.hist[4 * t + 1], h2 = S.hist[4 * t + 2], h3 = S.hist[4 * t + 3];
+        int total;
+        const int ex = skf_block_scan(h0 + h1 + h2 + h3, S.wave, &total);
+        const int pre[5] = {ex, ex + h0, ex + h0 + h1, ex + h0 + h1 + h2, ex + h0 + h1 + h2 + h3};
+        for (int q = 0; q < 2; ++q) {
+            const int r = q ? rb : ra;
+            for (int i = 0; i < 4; ++i)
+                if (r >= pre[i] && r < pre[i + 1]) { S.bin[q] = 4 * t + i; S.base[q] = pre[i]; }
+        }
+    }
+    __syncthreads();
+    const int binA = S.bin[0], binB = S.bin[1];
+    for (int k = threadIdx.x; k < N; k += blockDim.x) {
+        const double v = vals[k];
+        int b = (int)((v - lo) * scale);
+        b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+        if (b == binA) { const int p = atomicAdd(&S.cnt[0], 1); if (p < kBucketCap) S.list[0][p] = v; }
+        if (b == binB) { const int p = atomicAdd(&S.cnt[1], 1); if (p < kBucketCap) S.list[1][p] = v; }
+    }
+    __syncthreads();
+    if (S.cnt[0] > kBucketCap || S.cnt[1] > kBucketCap) return false;
+    for (int q = 0; q < 2; ++q) {
+        const int m = S.cnt[q], r = (q ? rb : ra) - S.base[q];
+        if ((int)threadIdx.x < m) {
+            const double v = S.list[q][threadIdx.x];
+            int less = 0, eq = 0;
+            for (int j = 0; j < m; ++j) { const double u = S.list[q][j]; less += (u < v) ? 1 : 0; eq += (u == v) ? 1 : 0; }
+            if (r >= less && r < less + eq) S.med[q] = v;   // all writers hold the same value
+        }
+    }
+    __syncthreads();
+    va = S.med[0];
+    vb = S.med[1];
+    __syncthreads();
+    return true;
+}
 
 // Correction of (x, P_pred) with N measurements; thread 0 returns the result in x_out / P_out.
 // Returns (to every thread) 0 = corrected, 3 = numerically singular.
+// scratch: 3 * N doubles of global memory, used only when N > kSkfLdsN.
 template <class Acc>
 __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const double* P_pred, const double r_flow[2],
-                        int reweight, double* qn, SkfShared& S, double x_out[6], double* P_out)
+                        int reweight, double* scratch, SkfShared& S, double x_out[6], double* P_out)
 {
     double mi = 0.0, b = 0.0, lmax = 1.0;
     bool weighted = false;
+    const bool in_lds = N <= kSkfLdsN;
+    double* ein = in_lds ? S.ein : scratch;            // 2N innovations at the predicted mean
+    double* qn = in_lds ? S.qn : scratch + 2 * (size_t)N;
     if (reweight) {
+        for (int j = threadIdx.x; j < N; j += blockDim.x) {
+            double h[12], y[2];
+            acc_in.get(j, h, y);
+            double p0 = 0.0, p1 = 0.0;
+            for (int i = 0; i < 6; ++i) { p0 += h[i] * x[i]; p1 += h[6 + i] * x[i]; }
+            ein[2 * j] = -(p0 - y[0]);
+            ein[2 * j + 1] = -(p1 - y[1]);
+        }
+        __syncthreads();  // (scratch is written and read by this workgroup only)
         for (int k = threadIdx.x; k < N; k += blockDim.x) {
-            const double e0 = innov_at(acc_in, k, x);
-            const double e1 = innov_at(acc_in, N + k, x);
+            const double e0 = ein[k], e1 = ein[N + k];   // column-major pairing of the reference (cpp:93)
             qn[k] = sqrt(e0 * e0 + e1 * e1);
         }
-        __syncthreads();  // qn is written and read by this workgroup only
-        const unsigned long long ka = radix_select(qn, N, (N % 2 == 0) ? N / 2 - 1 : N / 2, S.hist, S.sel);
-        const double va = __longlong_as_double((long long)ka);
-        mi = va;
-        if (N % 2 == 0) {
-            // element of rank N/2: va again if duplicates reach that rank, else the smallest value > va
-            double cnt_le = 0.0, min_gt = INFINITY;
-            for (int k = threadIdx.x; k < N; k += blockDim.x) {
-                const double v = qn[k];
-                if (v <= va) cnt_le += 1.0; else min_gt = fmin(min_gt, v);
+        __syncthreads();
+        const int ra = (N % 2 == 0) ? N / 2 - 1 : N / 2, rb = N / 2;
+        double va, vb;
+        if (!bucket_select2(qn, N, ra, rb, S, va, vb)) {
+            // a bucket overflowed (heavily clustered values): exact 8-pass radix select instead
+            va = __longlong_as_double((long long)radix_select(qn, N, ra, S.hist, S.sel));
+            vb = va;
+            if (rb != ra) {
+                // element of rank N/2: va again if duplicates reach that rank, else the smallest value > va
+                double cnt_le = 0.0, min_gt = INFINITY;
+                for (int k = threadIdx.x; k < N; k += blockDim.x) {
+                    const double vq = qn[k];
+                    if (vq <= va) cnt_le += 1.0; else min_gt = fmin(min_gt, vq);
+                }
+                cnt_le = block_sum(cnt_le, S.red);
+                min_gt = -block_max(-min_gt, S.red);
+                vb = (cnt_le > (double)(N / 2)) ? va : min_gt;
             }
-            cnt_le = block_sum(cnt_le, S.red);
-            min_gt = -block_max(-min_gt, S.red);
-            const double vb = (cnt_le > (double)(N / 2)) ? va : min_gt;
-            mi = 0.5 * (va + vb);
         }
+        mi = (N % 2 == 0) ? 0.5 * (va + vb) : vb;
         double sabs = 0.0;
         for (int k = threadIdx.x; k < N; k += blockDim.x) sabs += fabs(qn[k] - mi);
         b = block_sum(sabs, S.red) / N;
@@ -225,7 +348,7 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
             weighted = true;
             double m = 0.0;
             for (int j = threadIdx.x; j < N; j += blockDim.x) {
-                const double e0 = innov_at(acc_in, 2 * j, x), e1 = innov_at(acc_in, 2 * j + 1, x);
+                const double e0 = ein[2 * j], e1 = ein[2 * j + 1];
                 const double nj = sqrt(e0 * e0 + e1 * e1);
                 double l = 1.0 / (2 * b) * exp(-fabs(nj - mi) / b);
                 if (l < 1e-6) l = 1e-6;
@@ -317,7 +440,14 @@ __global__ __launch_bounds__(kSkfThreads) void skf_kernel(EngineArrays a, int re
     // unobservable / no data: the belief is left exactly as it was (ROFTFilter.cpp:291-301)
     if (N < 3) {
         if (threadIdx.x < 6) st.twist_hist[c.twist_slot][threadIdx.x] = st.v_mean[threadIdx.x];
-        if (threadIdx.x == 0) st.skf_status = (N <= 0) ? 1 : 2;
+        if (threadIdx.x == 0) {
+            st.skf_status = (N <= 0) ? 1 : 2;
+            if (roft_object_output* row = log_row(a, obj)) {
+                for (int i = 0; i < 6; ++i) row->twist[i] = st.v_mean[i];
+                row->n_flow_points = st.n_flow_points;
+                row->outlier_selected = -1;
+            }
+        }
         return;
     }
     if (threadIdx.x < 6) s_x[threadIdx.x] = st.v_mean[threadIdx.x];  // s^- = s (F = I)
@@ -331,7 +461,7 @@ __global__ __launch_bounds__(kSkfThreads) void skf_kernel(EngineArrays a, int re
 
     RecAccessor acc{a.recs + (size_t)obj * a.cand_cap, a.cam, c.dt};
     double xo[6], Po[36];
-    const int rc = skf_core(acc, N, x, s_P, prm.r_flow, reweight, a.norms + (size_t)obj * a.cand_cap, S, xo, Po);
+    const int rc = skf_core(acc, N, x, s_P, prm.r_flow, reweight, a.norms + (size_t)obj * 3 * a.cand_cap, S, xo, Po);
     if (threadIdx.x == 0) {
         if (rc == 0) {
             for (int i = 0; i < 6; ++i) st.v_mean[i] = xo[i];
@@ -339,6 +469,11 @@ __global__ __launch_bounds__(kSkfThreads) void skf_kernel(EngineArrays a, int re
         }
         st.skf_status = rc;  // 3: numerically singular, belief left unchanged
         for (int i = 0; i < 6; ++i) st.twist_hist[c.twist_slot][i] = st.v_mean[i];
+        if (roft_object_output* row = log_row(a, obj)) {
+            for (int i = 0; i < 6; ++i) row->twist[i] = st.v_mean[i];
+            row->n_flow_points = st.n_flow_points;
+            row->outlier_selected = -1;
+        }
     }
 }
 
@@ -390,26 +525,6 @@ __global__ void kf_predict_kernel(const double* x, const double* P, const double
 void launch_kf_predict(const double* x, const double* P, const double* qdiag, double* xo, double* Po, hipStream_t s)
 {
     hipLaunchKernelGGL(kf_predict_kernel, dim3(1), dim3(64), 0, s, x, P, qdiag, xo, Po);
-}
-
-// per-frame compact outputs (what ROFTFilter logs, ROFTFilter.cpp:386-394,448-451)
-__global__ void collect_outputs_kernel(EngineArrays a, int frame_idx)
-{
-    const int obj = blockIdx.x * blockDim.x + threadIdx.x;
-    if (obj >= a.n_obj || !a.out_log) return;
-    const ObjState& st = a.state[obj];
-    roft_object_output& o = a.out_log[(size_t)(frame_idx % a.log_cap) * a.n_obj + obj];
-    for (int i = 0; i < 13; ++i) o.pose[i] = st.belief[B_CORR].mean[i];
-    for (int i = 0; i < 6; ++i) o.twist[i] = st.v_mean[i];
-    o.n_flow_points = st.n_flow_points;
-    o.outlier_selected = st.outlier_selected;
-    o.outlier_L[0] = st.outlier_L[0];
-    o.outlier_L[1] = st.outlier_L[1];
-}
-
-void launch_collect_outputs(const EngineArrays& a, int frame_idx, hipStream_t s)
-{
-    hipLaunchKernelGGL(collect_outputs_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frame_idx);
 }
 
 }  // namespace roft

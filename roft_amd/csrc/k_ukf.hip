@@ -202,7 +202,12 @@ __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
     __syncthreads();
 }
 
-// dominant eigenvector of sum_c wm_c q_c q_c' (rows qrow..qrow+3 of Y), sign aligned with column 0
+// dominant eigenvector of M = sum_c wm_c q_c q_c' (rows qrow..qrow+3 of Y), sign aligned with column 0.
+// The sigma quaternions are a tight cluster, so M is a rank-one matrix plus a perturbation of the size of
+// the rotational covariance: eigenvalue gap ratio r = lambda_2 / lambda_1 << 1.  Power iteration on
+// M^16 (four squarings, 16 lanes, renormalised) converges like r^16 per step from the central sigma point;
+// iterate to a fixed point in double.  Same vector as a 4x4 eigen-solver returns, at a tenth of the cost of
+// a Jacobi sweep sequence.
 __device__ void quaternion_mean(const double* Y, int qrow, int ncols, double wm0, double wmi, double out[4],
                                 UkfLds& L)
 {
@@ -214,28 +219,47 @@ __device__ void quaternion_mean(const double* Y, int qrow, int ncols, double wm0
         L.M4[lane] = s;
     }
     __syncthreads();
-    jacobi_lds(L.M4, L.V4, 4, L);
+    for (int it = 0; it < 4; ++it) {  // M <- M^2 / trace-normalised, ping-pong M4 <-> V4
+        double* src = (it & 1) ? L.V4 : L.M4;
+        double* dst = (it & 1) ? L.M4 : L.V4;
+        if (lane < 16) {
+            const int i = lane / 4, j = lane % 4;
+            double s = 0.0;
+            for (int k = 0; k < 4; ++k) s += src[i * 4 + k] * src[k * 4 + j];
+            const double tr = src[0] * src[0] + src[5] * src[5] + src[10] * src[10] + src[15] * src[15];
+            dst[lane] = s / tr;   // keeps the entries O(1); any positive scale is fine
+        }
+        __syncthreads();
+    }
     if (lane == 0) {
-        int best = 0;
-        for (int i = 1; i < 4; ++i)
-            if (L.M4[i * 4 + i] > L.M4[best * 4 + best]) best = i;
-        double dot = 0.0;
-        for (int i = 0; i < 4; ++i) dot += L.V4[i * 4 + best] * Y[(qrow + i) * kCols + 0];
-        const double sg = (dot < 0.0) ? -1.0 : 1.0;
-        for (int i = 0; i < 4; ++i) L.w4[i] = sg * L.V4[i * 4 + best];
+        const double* M16 = L.M4;  // after 4 ping-pongs the result is back in M4
+        double v[4];
+        for (int i = 0; i < 4; ++i) v[i] = Y[(qrow + i) * kCols + 0];
+        for (int it = 0; it < 32; ++it) {
+            double w[4];
+            for (int i = 0; i < 4; ++i) w[i] = M16[i * 4] * v[0] + M16[i * 4 + 1] * v[1] + M16[i * 4 + 2] * v[2] + M16[i * 4 + 3] * v[3];
+            const double inv = 1.0 / sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3]);
+            double diff = 0.0;
+            for (int i = 0; i < 4; ++i) { w[i] *= inv; diff = fmax(diff, fabs(w[i] - v[i])); v[i] = w[i]; }
+            if (diff < 4e-16) break;
+        }
+        for (int i = 0; i < 4; ++i) L.w4[i] = v[i];
     }
     __syncthreads();
     for (int i = 0; i < 4; ++i) out[i] = L.w4[i];
 }
 
-// C (ra x rb, leading dim ldc) = A diag(w) B'
+// C (ra x rb, leading dim ldc) = A diag(w) B'   (column 0 carries wc0, the rest the common weight)
 __device__ void weighted_outer(const double* A, int ra, const double* B, int rb, int ncols, double wc0, double wci,
                                double* C, int ldc)
 {
     for (int e = threadIdx.x; e < ra * rb; e += 64) {
         const int i = e / rb, j = e % rb;
-        double s = 0.0;
-        for (int c = 0; c < ncols; ++c) s += A[i * kCols + c] * (c == 0 ? wc0 : wci) * B[j * kCols + c];
+        const double* ar = A + i * kCols;
+        const double* br = B + j * kCols;
+        double s = ar[0] * wc0 * br[0];
+#pragma unroll 8
+        for (int c = 1; c < ncols; ++c) s += ar[c] * wci * br[c];
         C[i * ldc + j] = s;
     }
 }
@@ -293,6 +317,55 @@ __device__ bool inverse_lds(const double* A, int m, double* Ainv, UkfLds& L)
     for (int e = lane; e < m * m; e += 64) Ainv[e] = M[(e / m) * ld + m + (e % m)];
     __syncthreads();
     return true;
+}
+
+// Cholesky factor of the SPD m x m matrix A (ld m) into Lc (lower, ld m) + reciprocal diagonal; lanes =
+// rows, one column per step.  Returns false if A is not positive definite.
+__device__ bool cholesky_lds(const double* A, int m, double* Lc, double* inv_diag, UkfLds& L)
+{
+    const int lane = threadIdx.x;
+    if (lane == 0) L.flag = 1;
+    __syncthreads();
+    for (int j = 0; j < m; ++j) {
+        double s = 0.0;
+        if (lane >= j && lane < m) {
+            s = A[lane * m + j];
+            for (int k = 0; k < j; ++k) s -= Lc[lane * m + k] * Lc[j * m + k];
+        }
+        const double d = __shfl(s, j, 64);
+        if (!(d > 0.0)) { if (lane == 0) L.flag = 0; break; }
+        const double r = fast_rsqrt(d);
+        if (lane == j) { Lc[j * m + j] = d * r; inv_diag[j] = r; }
+        else if (lane > j && lane < m) Lc[lane * m + j] = s * r;
+        __syncthreads();
+    }
+    __syncthreads();
+    return L.flag != 0;
+}
+
+// K (12 x M) = Pxy (12 x M) * inv(Lc Lc'), one lane per row of K: two triangular solves in registers
+template <int M>
+__device__ void chol_solve_rows(const double* Lc, const double* inv_diag, const double* Pxy, double* K)
+{
+    const int lane = threadIdx.x;
+    if (lane >= 12) return;
+    double w[M];
+#pragma unroll
+    for (int r = 0; r < M; ++r) {
+        double s = Pxy[lane * M + r];
+#pragma unroll
+        for (int k = 0; k < r; ++k) s -= Lc[r * M + k] * w[k];
+        w[r] = s * inv_diag[r];
+    }
+#pragma unroll
+    for (int r = M - 1; r >= 0; --r) {
+        double s = w[r];
+#pragma unroll
+        for (int k = r + 1; k < M; ++k) s -= Lc[k * M + r] * w[k];
+        w[r] = s * inv_diag[r];
+    }
+#pragma unroll
+    for (int r = 0; r < M; ++r) K[lane * M + r] = w[r];
 }
 
 struct UtW {
@@ -602,19 +675,16 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
     __syncthreads();
 
     TICK(L, 10);
-    // K = Pxy Py^-1 ; the inverse lands in KPy (scratch), then KPy = K Py
-    if (!inverse_lds(L.Py, m, L.KPy, L)) {
+    // K = Pxy Py^-1 through the Cholesky factor of the SPD innovation covariance (the reference inverts
+    // Py by LU, UKFCorrection.cpp:118; same K up to rounding), then KPy = K Py
+    if (!cholesky_lds(L.Py, m, L.aug, L.rc, L)) {
         for (int i = lane; i < 144; i += 64) out->cov[i] = L.cov[i];
         if (lane < 13) out->mean[lane] = L.mean[lane];
         return 2;
     }
     TICK(L, 11);
-    for (int e = lane; e < 12 * m; e += 64) {
-        const int i = e / m, j = e % m;
-        double s = 0.0;
-        for (int k = 0; k < m; ++k) s += L.Pxy[i * m + k] * L.KPy[k * m + j];
-        L.K[i * m + j] = s;
-    }
+    if (m == 6) chol_solve_rows<6>(L.aug, L.rc, L.Pxy, L.K);
+    else chol_solve_rows<12>(L.aug, L.rc, L.Pxy, L.K);
     __syncthreads();
     for (int e = lane; e < 12 * m; e += 64) {
         const int i = e / m, j = e % m;
@@ -652,10 +722,11 @@ __global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step, 
     UkfLds& L = *reinterpret_cast<UkfLds*>(smem);
     const int obj = blockIdx.x;
     const FrameCtrl& c = a.ctrl[obj];
+    ObjState& st = a.state[obj];
+    if (step == 0 && threadIdx.x == 0) st.outlier_selected = -1;  // set again by outlier_kernel if it runs
     if (step >= c.n_steps) return;
     const StepDesc sd = c.steps[step];
     if (!sd.op) return;
-    ObjState& st = a.state[obj];
     const ObjParams& prm = a.params[obj];
     const int lane = threadIdx.x;
 
@@ -686,6 +757,8 @@ __global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step, 
         PoseBelief& d = st.belief[sd.dst[0]];
         for (int i = lane; i < 144; i += 64) d.cov[i] = L.cov[i];
         if (lane < 13) d.mean[lane] = L.mean[lane];
+        if (roft_object_output* row = log_row(a, obj))
+            if (lane < 13 && sd.dst[0] == B_CORR) row->pose[lane] = L.mean[lane];
         return;
     }
     TICK(L, 6);
@@ -699,6 +772,11 @@ __global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step, 
         __syncthreads();
     }
     if (lane == 0) st.ukf_status = status;
+    // output log: the corrected belief after this frame's last step is what ROFTFilter logs
+    if (roft_object_output* row = log_row(a, obj)) {
+        __syncthreads();
+        if (lane < 13) row->pose[lane] = st.belief[B_CORR].mean[lane];
+    }
 #ifdef ROFT_UKF_PROFILE
     __syncthreads();
     if (lane < 32) st.dbg[lane] = L.dbg[lane];

@@ -114,6 +114,7 @@ struct FrameCtrl {
     StepDesc steps[kMaxSteps];
     int outlier_step;                // index of the step followed by render + likelihood (-1 none)
     int force_mode;                  // operator level: force the mask mode (0 = decide on device)
+    int frame_idx;                   // engine frame counter (row of the output log)
 };
 
 // ---- launch wrappers (defined in the k_*.hip files) -------------------------------------------
@@ -129,7 +130,7 @@ struct EngineArrays {
     int32_t* map;            // [n_obj][W*H] scatter map (kept all-zero between frames)
     FlowRec* cand;           // [n_obj][cand_cap] candidate scratch
     FlowRec* recs;           // [n_obj][cand_cap] kept flow records
-    double* norms;           // [n_obj][cand_cap] SKF scratch
+    double* norms;           // [n_obj][3 * cand_cap] SKF scratch (innovations + norms when N > LDS capacity)
     uint32_t* feat_pix;      // [n_obj][feat_cap] buffered feature pixel (linear index)
     float* feat_depth;       // [n_obj][feat_cap]
     uint32_t* zbuf;          // [n_obj][2][tile_h*tile_w] float bits, +inf = empty
@@ -141,8 +142,50 @@ struct EngineArrays {
     int log_cap;
 };
 
+// row of the device-side output log this frame writes (null when logging is off)
+__device__ inline roft_object_output* log_row(const EngineArrays& a, int obj)
+{
+    if (!a.out_log) return nullptr;
+    return a.out_log + (size_t)(a.ctrl[obj].frame_idx % a.log_cap) * a.n_obj + obj;
+}
+
 constexpr int kSlotNew = kPlaneSlots;       // plane slot receiving an ingested mask
 constexpr int kSlotFeat = kPlaneSlots + 1;  // plane slot holding the buffered features' mask
+
+// Mask mode of this frame (ImageSegmentationOFAidedSource::step_frame, hpp:169-226), decided on the device
+// because it depends on whether the newly delivered mask is empty:
+// 0 copy (no flow, no usable new mask); 1 propagate the last mask through this frame's flow with
+// mask(0,0) forced to 0 (hpp:221-226); 2 new mask chased through the buffered flows (hpp:211-219)
+__device__ inline int decide_mode(const FrameCtrl& c, const ObjState& st, int& src_slot, int& n_flows)
+{
+    const int n_avail = st.fbuf_n + (c.flow_valid ? 1 : 0);
+    if (c.force_mode == 3) {  // operator level: map() + remap() of the given mask through n flows
+        src_slot = kSlotNew;
+        n_flows = n_avail < kMaxFlowHist ? n_avail : kMaxFlowHist;
+        return 2;
+    }
+    if (c.has_new_mask && !c.first_mask && st.new_mask_count > 0) {
+        src_slot = kSlotNew;
+        n_flows = n_avail < kMaxFlowHist ? n_avail : kMaxFlowHist;
+        return 2;
+    }
+    src_slot = (c.has_new_mask && c.first_mask) ? kSlotNew : c.slot_prev;
+    n_flows = 1;
+    return c.flow_valid ? 1 : 0;
+}
+
+// bookkeeping after the gather (one thread per object): flow buffer count, per-frame scratch reset
+__device__ inline void mask_bookkeeping(const FrameCtrl& c, ObjState& st)
+{
+    int src_slot, n_flows;
+    const int mode = decide_mode(c, st, src_slot, n_flows);
+    int n_avail = st.fbuf_n + (c.flow_valid ? 1 : 0);
+    if (n_avail > kMaxFlowHist) n_avail = kMaxFlowHist;
+    st.fbuf_n = (mode == 2) ? 0 : n_avail;
+    st.mask_mode = mode;
+    st.new_mask_count = 0;
+    st.bbox[0] = INT32_MAX; st.bbox[1] = INT32_MAX; st.bbox[2] = -1; st.bbox[3] = -1;
+}
 
 __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, int slot, int which)
 {
@@ -150,16 +193,16 @@ __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, i
 }
 
 void launch_mask_ingest(const EngineArrays& a, hipStream_t s);
-void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s);
+// finish = false: the caller guarantees that flow_measure_kernel (which then does the bookkeeping) follows
+void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_aided, bool finish, hipStream_t s);
 void launch_planes_to_mask(const uint32_t* nz, const uint32_t* ob, int npix, uint8_t* mask, hipStream_t s);
-void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, hipStream_t s);
+void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bool mask_finish, hipStream_t s);
 void launch_skf(const EngineArrays& a, int reweight, hipStream_t s);
 // operator level: explicit (y, H) arrays, x_pred/P_pred in, x/P out (all device pointers)
 void launch_skf_arrays(const double* x_pred, const double* P_pred, int N, const double* y, const double* H,
                        const double* Rdiag, int reweight, double* norms, double* x_out, double* P_out, int* status,
                        hipStream_t s);
 void launch_kf_predict(const double* x, const double* P, const double* qdiag, double* xo, double* Po, hipStream_t s);
-void launch_collect_outputs(const EngineArrays& a, int frame_idx, hipStream_t s);
 void launch_ukf_step(const EngineArrays& a, int step, roft_ut_params ut, hipStream_t s);
 void launch_features(const EngineArrays& a, int phase, hipStream_t s);
 void launch_outlier(const EngineArrays& a, hipStream_t s);       // z-buffer clear + render + likelihood + decision

@@ -116,6 +116,22 @@ def test_skf_correct_parity(oracle, reweight):
     assert worst < 1e-6  # mean differs by far less than its own standard deviation
 
 
+def test_skf_correct_large_n_uses_radix_select(oracle):
+    """N > 1024 leaves the LDS counting-rank path and takes the radix-select median."""
+    st = util.stream(13, 3, scale=1)
+    ocam = util.oracle_camera(oracle, st.camera)
+    n, uv, y, Hm = oracle.flow_measurement(ocam, st.mask_gt[1].numpy(), st.depth[1].numpy(), st.flow[2].numpy(), st.dt,
+                                           radius=7.0)
+    assert n > 2500
+    xp, Pp = oracle.kf_predict(np.zeros(6), np.eye(6) * 1e-3, np.full(6, 0.1))
+    for nn in (n, n - 1, 1025, 1024):
+        rc0, x0, P0 = oracle.skf_correct(xp, Pp, y[:2 * nn], Hm[:2 * nn], reweight=True)
+        rc1, x1, P1 = ops.skf_correct(xp, Pp, y[:2 * nn], Hm[:2 * nn], reweight=True)
+        assert rc0 == 0 and rc1 == 0
+        np.testing.assert_allclose(x1, x0, rtol=SKF_RTOL, atol=SKF_RTOL * np.max(np.abs(x0)))
+        np.testing.assert_allclose(P1, P0, rtol=SKF_RTOL, atol=SKF_RTOL * np.max(np.abs(P0)))
+
+
 def test_skf_correct_small_and_empty(oracle):
     rng = np.random.default_rng(5)
     xp = rng.normal(size=6) * 0.1
