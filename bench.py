@@ -50,9 +50,19 @@ def main():
     import torch.distributed as dist
 
     rank, local_rank, world = parallel.env_rank()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    parallel.init("nccl")   # RCCL; only the barrier / max-over-ranks timing uses it
+    # ROFT_BENCH_DEVICE / ROFT_BENCH_BACKEND exist only to exercise the N > 1 code path on a one-GPU box
+    # (several ranks on cuda:0 over gloo); the driver's multi-GPU runs use LOCAL_RANK and RCCL.
+    dev_index = int(os.environ.get("ROFT_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("ROFT_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if backend == "nccl":
+        parallel.init("nccl")   # RCCL; only the barrier / max-over-ranks timing uses it
+        red_dev = dev
+    else:
+        parallel.init(backend)
+        red_dev = "cpu"
+    local_rank = dev_index
 
     n_obj = args.objects_per_gpu
     n_frames = args.warmup + args.steps
@@ -112,7 +122,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(elapsed, dev)
+    elapsed = parallel.max_over_ranks(elapsed, red_dev)
 
     kernels = {}
     if not args.no_kernel_timing:

@@ -160,6 +160,14 @@ void clear_ctrl(FrameCtrl& c)
 // batched engine
 // =================================================================================================
 
+// FrameCtrl upload without the copy engine: a kernel reads the pinned (device-visible) staging block and
+// writes the device copy, so the per-frame control block travels in-order on the compute queue instead of
+// through an SDMA copy with its cross-engine signalling.
+__global__ void ctrl_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
 struct HostObject {
     // schedule-driven mirrors of the reference's source / measurement-model state machines
     int frame_idx = 0;
@@ -188,7 +196,8 @@ struct roft_engine {
     DevBuf<FrameCtrl> dctrl[kCtrlRing];
     hipEvent_t ev_img[kCtrlRing] = {};
     hipEvent_t ev_pose[kCtrlRing] = {};
-    bool two_streams = true;
+    bool two_streams = false;
+    bool kernel_upload = true;
     std::vector<HostObject*> objs;
     std::vector<ObjParams> h_params;
     // pinned staging ring for FrameCtrl blocks
@@ -294,6 +303,8 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
     // (ROFT_TWO_STREAMS=1).  Measured on MI355X / ROCm 7.2 (profiles/README.md): the two cross-queue event
     // waits per frame cost more than the overlap wins at 64 objects (0.64 vs 0.40 ms per frame), so one
     // stream is the default.
+    const char* ku = getenv("ROFT_MEMCPY_UPLOAD");
+    e->kernel_upload = !(ku && ku[0] == '1');
     const char* two = getenv("ROFT_TWO_STREAMS");
     e->two_streams = (two && two[0] == '1');
     if (e->two_streams) HIP_TRY(hipStreamCreateWithFlags(&e->pose_stream, hipStreamNonBlocking));
@@ -622,7 +633,14 @@ int roft_step(roft_engine* e)
     if (e->two_streams && e->frame_counter >= 2)
         HIP_TRY(hipStreamWaitEvent(s, e->ev_pose[(e->frame_counter - 2) % roft_engine::kCtrlRing], 0));
     a.ctrl = e->dctrl[ci].p;
-    HIP_TRY(hipMemcpyAsync(a.ctrl, e->cur, sizeof(FrameCtrl) * a.n_obj, hipMemcpyHostToDevice, s));
+    static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
+    if (e->kernel_upload) {
+        const size_t n16 = sizeof(FrameCtrl) * a.n_obj / 16;
+        hipLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
+                           reinterpret_cast<const uint4*>(e->cur), reinterpret_cast<uint4*>(a.ctrl), n16);
+    } else {
+        HIP_TRY(hipMemcpyAsync(a.ctrl, e->cur, sizeof(FrameCtrl) * a.n_obj, hipMemcpyHostToDevice, s));
+    }
     HIP_TRY(hipEventRecord(e->stage_ev[si], s));
     e->stage_idx = (si + 1) % roft_engine::kStage;
 

@@ -93,20 +93,26 @@ __global__ __launch_bounds__(256) void mask_scatter_kernel(EngineArrays a, int f
     __syncthreads();
 
     const int W = a.cam.W, H = a.cam.H;
-    const size_t npix = (size_t)W * H;
+    const int npix = W * H;
     const int lane = threadIdx.x & 63;
     const uint2* plane2 = reinterpret_cast<const uint2*>(a.planes + plane_offset(a, obj, src_slot, 0));
     int32_t* map = a.map + (size_t)obj * npix;
     int bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = -1, by1 = -1;
-    const size_t n_grp = npix / 64, wave_stride = (size_t)gridDim.x * 4;
-    for (size_t grp = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); grp < n_grp; grp += wave_stride) {
-        const uint2 w2 = plane2[grp];                                   // wave-uniform load
-        unsigned long long bits = ((unsigned long long)w2.y << 32) | w2.x;
+    const int n_grp = npix / 64, wave_stride = gridDim.x * 4;
+    const int wave_first = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // lane i prefetches the plane words of this wave's i-th group: one load instead of a chain of
+    // dependent wave-uniform loads (needs <= 64 groups per wave)
+    const int my_grp = wave_first + lane * wave_stride;
+    uint2 mine = make_uint2(0u, 0u);
+    if (my_grp < n_grp) mine = plane2[my_grp];
+    for (int it = 0, grp = wave_first; grp < n_grp; ++it, grp += wave_stride) {
+        unsigned long long bits = ((unsigned long long)(uint32_t)__shfl((int)mine.y, it, 64) << 32) |
+                                  (uint32_t)__shfl((int)mine.x, it, 64);
         if (mode == 1 && grp == 0) bits &= ~1ull;                         // mask_.at<uchar>(0,0) = 0
         if (bits == 0) continue;
         if (!((bits >> lane) & 1ull)) continue;
-        const size_t p = grp * 64 + lane;
-        const int py = (int)(p / W), px = (int)(p % W);
+        const int p = grp * 64 + lane;
+        const int py = p / W, px = p - py * W;
         float t_x = (float)px, t_y = (float)py;
         bool error = false;
         // flows in chronological order: oldest buffered first (c.flow[n_flows-1]) ... current
@@ -121,7 +127,7 @@ __global__ __launch_bounds__(256) void mask_scatter_kernel(EngineArrays a, int f
         }
         const int ix = trunc_int_x86(t_x), iy = trunc_int_x86(t_y);
         if (error || ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
-        atomicMax(&map[(size_t)iy * W + ix], (int)p);
+        atomicMax(&map[iy * W + ix], p);
         bx0 = min(bx0, ix); bx1 = max(bx1, ix);
         by0 = min(by0, iy); by1 = max(by1, iy);
     }
@@ -155,10 +161,10 @@ __global__ __launch_bounds__(256) void mask_gather_kernel(EngineArrays a, int fr
     uint32_t* dnz = a.planes + plane_offset(a, obj, c.slot_cur, 0);
     uint32_t* dob = a.planes + plane_offset(a, obj, c.slot_cur, 1);
     const int W = a.cam.W;
-    const size_t npix = (size_t)W * a.cam.H;
+    const int npix = W * a.cam.H;
     const int lane = threadIdx.x & 63;
-    const size_t wave_global = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const size_t nwaves = (size_t)gridDim.x * 4;
+    const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
 
     // background = mask(0,0) of the source: forced to 0 in mode 1
     bool bg_nz = false, bg_ob = false;
@@ -166,8 +172,8 @@ __global__ __launch_bounds__(256) void mask_gather_kernel(EngineArrays a, int fr
     const int bx0 = st.bbox[0], by0 = st.bbox[1], bx1 = st.bbox[2], by1 = st.bbox[3];
     int32_t* map = a.map + (size_t)obj * npix;
 
-    for (size_t base = wave_global * 64; base < npix; base += nwaves * 64) {
-        const size_t word2 = base >> 6;
+    for (int base = wave_global * 64; base < npix; base += nwaves * 64) {
+        const int word2 = base >> 6;
         if (mode == 0) {
             if (lane == 0) {
                 reinterpret_cast<uint2*>(dnz)[word2] = reinterpret_cast<const uint2*>(snz)[word2];
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void mask_gather_kernel(EngineArrays a, int fr
         }
         // the 64 pixels of a wave lie in one row when W % 64 == 0 -> wave-uniform fast path
         if ((W & 63) == 0) {
-            const int yw = (int)(base / W), xw = (int)(base % W);
+            const int yw = base / W, xw = base - yw * W;
             if (yw < by0 || yw > by1 || xw > bx1 || xw + 63 < bx0) {
                 if (lane == 0) {
                     const uint32_t f1 = bg_nz ? 0xFFFFFFFFu : 0u, f2 = bg_ob ? 0xFFFFFFFFu : 0u;
@@ -187,8 +193,8 @@ __global__ __launch_bounds__(256) void mask_gather_kernel(EngineArrays a, int fr
                 continue;
             }
         }
-        const size_t p = base + lane;
-        const int y = (int)(p / W), x = (int)(p % W);
+        const int p = base + lane;
+        const int y = p / W, x = p - y * W;
         bool nzb = bg_nz, obb = bg_ob;
         if (y >= by0 && y <= by1 && x >= bx0 && x <= bx1) {
             const int m = map[p];
@@ -242,7 +248,10 @@ void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_a
         if (finish) hipLaunchKernelGGL(mask_finish_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frames_between);
         return;
     }
-    hipLaunchKernelGGL(mask_scatter_kernel, dim3(kScatterBlocks, a.n_obj), dim3(256), 0, s, a, frames_between);
+    const int n_grp = a.cam.W * a.cam.H / 64;
+    int sblocks = kScatterBlocks;
+    while (sblocks * 4 * 64 < n_grp) sblocks *= 2;   // each wave prefetches at most 64 groups
+    hipLaunchKernelGGL(mask_scatter_kernel, dim3(sblocks, a.n_obj), dim3(256), 0, s, a, frames_between);
     const size_t waves = ((size_t)a.cam.W * a.cam.H + 63) / 64;
     int gx = (int)((waves + 3) / 4);
     if (gx > 128) gx = 128;

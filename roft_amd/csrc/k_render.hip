@@ -25,44 +25,54 @@ constexpr int kFeatThreads = 1024;
 // phase 0: before the UKF steps (first frame / non-resync outlier rejection uses the current frame)
 // phase 1: after them (re-buffer at pose re-sync frames, ROFTFilter.cpp:353)
 // Feature slot s holds the pixel of row-major rank 2s of the current obj plane (`k += 2` over the
-// findNonZero list, ROFTFilter.cpp:556) and its depth; slots are independent, so the work is
-// spread evenly over the workgroup whatever the mask shape.
+// findNonZero list, ROFTFilter.cpp:556) and its depth.  Plane words are in row-major order, so one block
+// scan over the word popcounts gives every word its starting rank; each thread then expands its own
+// contiguous chunk of words, issuing its depth gathers back to back.
 __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a, int phase)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_wave[17];
     const int obj = blockIdx.x;
     const FrameCtrl& c = a.ctrl[obj];
     const bool run = (phase == 0) ? (c.buffer_features_before || c.features_current) : c.buffer_features_after;
     if (!run) return;
-    const int W = a.cam.W, H = a.cam.H, wpr = a.cam.wpr;
-    uint32_t* s_plane = reinterpret_cast<uint32_t*>(smem);
-    int* s_rowpref = reinterpret_cast<int*>(smem + ((a.plane_words * 4 + 15) & ~(size_t)15));
-    const int M = stage_plane(a.planes + plane_offset(a, obj, c.slot_cur, 1), a.plane_words, H, wpr, s_plane, s_rowpref,
-                              s_wave);
+    const int W = a.cam.W, wpr = a.cam.wpr;
+    const uint32_t* plane = a.planes + plane_offset(a, obj, c.slot_cur, 1);
     const float* depth = c.depth_cur;
     uint32_t* fpix = a.feat_pix + (size_t)obj * a.feat_cap;
     float* fdep = a.feat_depth + (size_t)obj * a.feat_cap;
-    const int n = min((M + 1) / 2, a.feat_cap);
-    for (int s = threadIdx.x; s < n; s += blockDim.x) {
-        int u, v;
-        select_rank(s_plane, s_rowpref, H, wpr, 2 * s, u, v);
-        fpix[s] = (uint32_t)(v * W + u);
-        fdep[s] = depth[(size_t)v * W + u];
+    const int n_words = (int)a.plane_words;
+    const int per = (n_words + blockDim.x - 1) / blockDim.x;
+    const int w0 = min(n_words, (int)threadIdx.x * per), w1 = min(n_words, w0 + per);
+    int cnt = 0;
+    for (int w = w0; w < w1; ++w) cnt += __popc(plane[w]);
+    int total;
+    int rank = block_exclusive_scan(cnt, s_wave, &total);
+    if (cnt) {
+        for (int w = w0; w < w1; ++w) {
+            uint32_t bits = plane[w];
+            const int row = w / wpr, col0 = (w - row * wpr) * 32;
+            // keep the bits whose rank is even: parity alternates along the set bits of the word
+            while (bits) {
+                const int bpos = __builtin_ctz(bits);
+                bits &= bits - 1;
+                if ((rank & 1) == 0) {
+                    const int slot = rank >> 1;
+                    if (slot < a.feat_cap) fpix[slot] = (uint32_t)(row * W + col0 + bpos);
+                }
+                ++rank;
+            }
+        }
     }
-    if (threadIdx.x == 0) a.state[obj].n_feat = n;
+    __syncthreads();  // fpix is written and read by this workgroup only
+    // depth gathers: independent per slot, spread over the whole workgroup
+    const int n = min((total + 1) / 2, a.feat_cap);
+    for (int s = threadIdx.x; s < n; s += blockDim.x) fdep[s] = depth[fpix[s]];
+    if (threadIdx.x == 0) a.state[obj].n_feat = min((total + 1) / 2, a.feat_cap);
 }
 
 void launch_features(const EngineArrays& a, int phase, hipStream_t s)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - 256);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), plane_lds_bytes(a.plane_words, a.cam.H), s, a,
-                       phase);
+    hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), 0, s, a, phase);
 }
 
 // ---- rasteriser ---------------------------------------------------------------------------------
@@ -174,15 +184,30 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
     const uint32_t* z1 = z0 + (size_t)a.tile_w * a.tile_h;
     double err[2] = {0.0, 0.0}, cnt[2] = {0.0, 0.0};
     const int n = st.n_feat;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const float dep = fdep[i];
-        if (!((dep > 0) && ((double)dep < 2.0))) continue;  // hard-coded 2.0 (ROFTFilter.cpp:561)
-        const uint32_t p = fpix[i];
-        const int v = (int)(p / W), u = (int)(p % W);
-        const size_t ti = (size_t)(v / d) * tw + (u / d);
-        const uint32_t b0 = z0[ti], b1 = z1[ti];
-        if (b0 != 0x7F800000u) { err[0] += (double)fabsf(dep - __uint_as_float(b0)); cnt[0] += 1.0; }
-        if (b1 != 0x7F800000u) { err[1] += (double)fabsf(dep - __uint_as_float(b1)); cnt[1] += 1.0; }
+    // four feature slots per iteration: their 4 + 4 + 8 loads are independent and go out together
+    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+        float dep[4];
+        uint32_t pix[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * blockDim.x;
+            dep[k] = (i < n) ? fdep[i] : 0.0f;
+            pix[k] = (i < n) ? fpix[i] : 0u;
+        }
+        uint32_t b0[4], b1[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int v = (int)(pix[k] / W), u = (int)(pix[k] - v * W);
+            const size_t ti = (size_t)(v / d) * tw + (u / d);
+            b0[k] = z0[ti];
+            b1[k] = z1[ti];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!((dep[k] > 0) && ((double)dep[k] < 2.0))) continue;  // hard-coded 2.0 (ROFTFilter.cpp:561)
+            if (b0[k] != 0x7F800000u) { err[0] += (double)fabsf(dep[k] - __uint_as_float(b0[k])); cnt[0] += 1.0; }
+            if (b1[k] != 0x7F800000u) { err[1] += (double)fabsf(dep[k] - __uint_as_float(b1[k])); cnt[1] += 1.0; }
+        }
     }
     for (int k = 0; k < 2; ++k) {
         double e = err[k], n2 = cnt[k];

@@ -93,7 +93,7 @@ struct StepDesc {
     int save_corr_to_buf;  // re-sync: after reading src, B_BUF <- B_CORR (ROFTFilter.cpp:333-340)
 };
 
-struct FrameCtrl {
+struct alignas(16) FrameCtrl {
     double dt;
     const float* depth_prev;
     const float* depth_cur;

@@ -23,7 +23,7 @@ def init(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {}
         if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", local_rank)
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
