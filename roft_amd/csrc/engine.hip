@@ -530,6 +530,9 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
             d_depth = in.depth;
             d_flow = in.flow;
             d_mask = in.mask;
+            if ((reinterpret_cast<uintptr_t>(d_mask) & 15) || (reinterpret_cast<uintptr_t>(d_flow) & 7) ||
+                (reinterpret_cast<uintptr_t>(d_depth) & 3))
+                return fail(ROFT_ERR_INVALID, "device buffers must be aligned: mask 16 B, flow 8 B, depth 4 B");
         } else {
             HIP_TRY(o.depth_ring[rs].ensure(npix));
             HIP_TRY(hipMemcpyAsync(o.depth_ring[rs].p, in.depth, npix * sizeof(float), hipMemcpyHostToDevice, e->stream));

@@ -41,37 +41,48 @@ __device__ __forceinline__ void flow_at(const void* data, const DevFlowFmt& f, i
 }
 
 // ---- ingest: raw u8 mask -> (nz, obj) bit planes + non-zero count -------------------------------
-// grid: (ceil(W*H/64/4), n_obj), block 256 = 4 waves; each wave converts 64 consecutive pixels per
-// iteration (coalesced byte loads, one ballot per plane).
+// One thread converts 64 consecutive pixels: four 16-byte loads, two 64-bit masks built in registers,
+// two coalesced 8-byte stores.  grid: (ceil(W*H/64/256), n_obj).
+__device__ __forceinline__ void bytes_to_bits(uint32_t w, int shift, unsigned long long& nz, unsigned long long& ob)
+{
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t v = (w >> (8 * k)) & 0xFFu;
+        nz |= (unsigned long long)(v != 0u) << (shift + k);
+        ob |= (unsigned long long)(v > 1u) << (shift + k);
+    }
+}
+
 __global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a)
 {
     const int obj = blockIdx.y;
     const FrameCtrl& c = a.ctrl[obj];
     if (!c.has_new_mask) return;
-    const uint8_t* src = c.new_mask;
-    uint32_t* nz = a.planes + plane_offset(a, obj, kSlotNew, 0);
-    uint32_t* ob = a.planes + plane_offset(a, obj, kSlotNew, 1);
-    const int lane = threadIdx.x & 63;
-    const size_t npix = (size_t)a.cam.W * a.cam.H;
-    const size_t wave_global = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const size_t nwaves = (size_t)gridDim.x * 4;
+    const uint4* src = reinterpret_cast<const uint4*>(c.new_mask);
+    uint2* nz = reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, kSlotNew, 0));
+    uint2* ob = reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, kSlotNew, 1));
+    const int n_grp = (a.cam.W * a.cam.H) >> 6;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
     int count = 0;
-    for (size_t base = wave_global * 64; base < npix; base += nwaves * 64) {
-        const size_t p = base + lane;
-        uint8_t v = (p < npix) ? src[p] : 0;
-        unsigned long long bnz = __ballot(v != 0);
-        unsigned long long bob = __ballot(v > 1);
-        if (lane == 0) {
-            // W % 32 == 0, so linear pixel index / 32 is the plane word index
-            reinterpret_cast<uint2*>(nz)[base >> 6] = make_uint2((uint32_t)bnz, (uint32_t)(bnz >> 32));
-            reinterpret_cast<uint2*>(ob)[base >> 6] = make_uint2((uint32_t)bob, (uint32_t)(bob >> 32));
-            count += __popcll(bnz);
+    if (g < n_grp) {
+        unsigned long long bnz = 0, bob = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 v = src[(size_t)g * 4 + q];
+            bytes_to_bits(v.x, 16 * q, bnz, bob);
+            bytes_to_bits(v.y, 16 * q + 4, bnz, bob);
+            bytes_to_bits(v.z, 16 * q + 8, bnz, bob);
+            bytes_to_bits(v.w, 16 * q + 12, bnz, bob);
         }
+        nz[g] = make_uint2((uint32_t)bnz, (uint32_t)(bnz >> 32));
+        ob[g] = make_uint2((uint32_t)bob, (uint32_t)(bob >> 32));
+        count = __popcll(bnz);
     }
-    if (lane == 0 && count) atomicAdd(&a.state[obj].new_mask_count, count);
+    for (int off = 32; off > 0; off >>= 1) count += __shfl_xor(count, off, 64);
+    if ((threadIdx.x & 63) == 0 && count) atomicAdd(&a.state[obj].new_mask_count, count);
 }
 
-constexpr int kScatterBlocks = 48;  // per object; x 4 waves x ~25 groups each at 640x480
+constexpr int kScatterBlocks = 96;  // per object; x 4 waves x ~25 groups each at 640x480
 
 // ---- scatter (mode decision: decide_mode() in roft_device.h) --------------------------------------
 // grid: (kScatterBlocks, n_obj), block 256 = 4 waves; a wave owns 64 consecutive pixels per iteration and
@@ -172,27 +183,77 @@ __global__ __launch_bounds__(256) void mask_gather_kernel(EngineArrays a, int fr
     const int bx0 = st.bbox[0], by0 = st.bbox[1], bx1 = st.bbox[2], by1 = st.bbox[3];
     int32_t* map = a.map + (size_t)obj * npix;
 
-    for (int base = wave_global * 64; base < npix; base += nwaves * 64) {
-        const int word2 = base >> 6;
-        if (mode == 0) {
-            if (lane == 0) {
-                reinterpret_cast<uint2*>(dnz)[word2] = reinterpret_cast<const uint2*>(snz)[word2];
-                reinterpret_cast<uint2*>(dob)[word2] = reinterpret_cast<const uint2*>(sob)[word2];
-            }
-            continue;
-        }
-        // the 64 pixels of a wave lie in one row when W % 64 == 0 -> wave-uniform fast path
-        if ((W & 63) == 0) {
-            const int yw = base / W, xw = base - yw * W;
-            if (yw < by0 || yw > by1 || xw > bx1 || xw + 63 < bx0) {
-                if (lane == 0) {
-                    const uint32_t f1 = bg_nz ? 0xFFFFFFFFu : 0u, f2 = bg_ob ? 0xFFFFFFFFu : 0u;
-                    reinterpret_cast<uint2*>(dnz)[word2] = make_uint2(f1, f1);
-                    reinterpret_cast<uint2*>(dob)[word2] = make_uint2(f2, f2);
-                }
+    const uint32_t f1 = bg_nz ? 0xFFFFFFFFu : 0u, f2 = bg_ob ? 0xFFFFFFFFu : 0u;
+    if (mode == 0 || (W & 63) == 0) {
+        // ---- phase A: copy (mode 0) or constant fill of every 64-pixel group outside the target bounding
+        // box; no map traffic.  Groups inside the box are left to phase B.
+        // (one 64-pixel group per LANE: the 8-byte words of a wave's 64 groups are stored coalesced)
+        const int n_grp = npix >> 6;
+        const uint2* snz2 = reinterpret_cast<const uint2*>(snz);
+        const uint2* sob2 = reinterpret_cast<const uint2*>(sob);
+        uint2* dnz2 = reinterpret_cast<uint2*>(dnz);
+        uint2* dob2 = reinterpret_cast<uint2*>(dob);
+        for (int g = wave_global * 64 + lane; g < n_grp; g += nwaves * 64) {
+            if (mode == 0) {
+                dnz2[g] = snz2[g];
+                dob2[g] = sob2[g];
                 continue;
             }
+            const int base = g << 6;
+            const int yw = base / W, xw = base - yw * W;
+            if (yw < by0 || yw > by1 || xw > bx1 || xw + 63 < bx0) {
+                dnz2[g] = make_uint2(f1, f1);
+                dob2[g] = make_uint2(f2, f2);
+            }
         }
+        if (mode == 0 || bx1 < 0) return;
+        // ---- phase B: the groups inside the box, spread evenly over all waves and processed four at a
+        // time so that the map loads (and then the source-plane loads) of a batch are in flight together
+        const int gx0 = bx0 >> 6, cols = (bx1 >> 6) - gx0 + 1, count = (by1 - by0 + 1) * cols;
+        for (int q0 = wave_global * 4; q0 < count; q0 += nwaves * 4) {
+            int pp[4], mm[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = q0 + k;
+                pp[k] = -1;
+                mm[k] = 0;
+                if (q < count) {
+                    const int r = q / cols;
+                    const int p = (by0 + r) * W + (gx0 + (q - r * cols)) * 64 + lane;
+                    pp[k] = p;
+                    const int x = p - (by0 + r) * W;
+                    if (x >= bx0 && x <= bx1) mm[k] = map[p];
+                }
+            }
+            uint32_t wn[4], wo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                wn[k] = 0; wo[k] = 0;
+                if (mm[k] != 0) {
+                    map[pp[k]] = 0;
+                    wn[k] = snz[mm[k] >> 5];
+                    wo[k] = sob[mm[k] >> 5];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (pp[k] < 0) continue;   // wave-uniform
+                const bool nzb = mm[k] ? ((wn[k] >> (mm[k] & 31)) & 1u) : bg_nz;
+                const bool obb = mm[k] ? ((wo[k] >> (mm[k] & 31)) & 1u) : bg_ob;
+                const unsigned long long b1 = __ballot(nzb);
+                const unsigned long long b2 = __ballot(obb);
+                if (lane == 0) {
+                    const int word2 = pp[k] >> 6;
+                    reinterpret_cast<uint2*>(dnz)[word2] = make_uint2((uint32_t)b1, (uint32_t)(b1 >> 32));
+                    reinterpret_cast<uint2*>(dob)[word2] = make_uint2((uint32_t)b2, (uint32_t)(b2 >> 32));
+                }
+            }
+        }
+        return;
+    }
+    // ---- generic path (W not a multiple of 64: a group may straddle rows)
+    for (int base = wave_global * 64; base < npix; base += nwaves * 64) {
+        const int word2 = base >> 6;
         const int p = base + lane;
         const int y = p / W, x = p - y * W;
         bool nzb = bg_nz, obb = bg_ob;
@@ -235,10 +296,8 @@ __global__ __launch_bounds__(256) void mask_plain_kernel(EngineArrays a)
 
 void launch_mask_ingest(const EngineArrays& a, hipStream_t s)
 {
-    const size_t waves = ((size_t)a.cam.W * a.cam.H + 63) / 64;
-    int gx = (int)((waves + 3) / 4);
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(mask_ingest_kernel, dim3(gx, a.n_obj), dim3(256), 0, s, a);
+    const int n_grp = a.cam.W * a.cam.H / 64;
+    hipLaunchKernelGGL(mask_ingest_kernel, dim3((n_grp + 255) / 256, a.n_obj), dim3(256), 0, s, a);
 }
 
 void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_aided, bool finish, hipStream_t s)
@@ -254,7 +313,7 @@ void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_a
     hipLaunchKernelGGL(mask_scatter_kernel, dim3(sblocks, a.n_obj), dim3(256), 0, s, a, frames_between);
     const size_t waves = ((size_t)a.cam.W * a.cam.H + 63) / 64;
     int gx = (int)((waves + 3) / 4);
-    if (gx > 128) gx = 128;
+    if (gx > 64) gx = 64;
     hipLaunchKernelGGL(mask_gather_kernel, dim3(gx, a.n_obj), dim3(256), 0, s, a, frames_between);
     if (finish) hipLaunchKernelGGL(mask_finish_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a, frames_between);
 }
