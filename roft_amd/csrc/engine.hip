@@ -566,7 +566,6 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
         }
         c.flow_valid = valid_flow ? 1 : 0;
         for (int j = 0; j < kMaxFlowHist; ++j) c.flow[j] = j < (int)o.flow_hist.size() ? o.flow_hist[j] : nullptr;
-        if (!valid_flow) c.flow[0] = d_flow;  // (unused by the mask stage then)
         if (c.has_new_mask) e->any_new_mask = true;
 
         // ---- ImageOpticalFlowMeasurement::freeze state machine (hpp:217-229)
@@ -578,7 +577,7 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
         c.vel_stage = data_in ? 1 : 0;
         c.depth_prev = o.depth_prev;
         c.depth_cur = d_depth;
-        if (data_in) c.flow[0] = d_flow;
+        // (data_in implies valid_flow, so c.flow[0] is this frame's flow whenever the velocity stage runs)
         o.depth_prev = d_depth;
 
         // ---- outlier-rejection features on the first frame (ROFTFilter.cpp:313-322)

@@ -1,0 +1,85 @@
+"""GPU parity of the batched engine on the awkward paths of ROFTFilter::filtering_step: dropped and
+irregular pose deliveries (velocity deque of varying length), empty delivered masks, missing flow frames,
+unobservable velocity steps (N < 3), the 1280x720 / CV_16SC2 shape, and a longer many-object run."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from roft_amd import synth
+
+import util
+from test_engine_gpu import compare
+
+pytestmark = pytest.mark.gpu
+
+
+def clone(st):
+    c = copy.copy(st)
+    c.depth, c.flow, c.mask_gt = st.depth.clone(), st.flow.clone(), st.mask_gt.clone()
+    c.mask_delivery, c.pose_valid, c.pose_meas, c.flow_valid = (st.mask_delivery.copy(), st.pose_valid.copy(),
+                                                                st.pose_meas.copy(), st.flow_valid.copy())
+    return c
+
+
+def test_dropped_and_irregular_poses():
+    """40 % of the pose deliveries are dropped: the re-sync replays deques of 7, 13, 19 ... velocities
+    trimmed to the last D + 1 (CartesianQuaternionMeasurement.cpp:100-104)."""
+    streams = [util.stream(500 + i, 44, scale=2, pose_drop_prob=0.4, device="cuda") for i in range(3)]
+    assert any((~st.pose_valid[::6]).any() for st in streams)
+    compare(streams, 44)
+
+
+def test_pose_on_every_frame_and_never():
+    st = clone(util.stream(510, 20, scale=2, device="cuda"))
+    # a pose measurement on every frame (un-delayed source): re-sync with a one-element deque
+    every = clone(st)
+    every.pose_valid[:] = True
+    for k in range(20):
+        every.pose_meas[k, :3] = st.gt.x[k] + 0.002
+        every.pose_meas[k, 3:] = st.gt.q[k]
+    compare([every], 20)
+    never = clone(st)
+    never.pose_valid[1:] = False
+    compare([never], 20)
+
+
+def test_empty_delivered_mask_is_ignored():
+    """A delivered but empty mask must not replace the propagated one (hpp:186-198)."""
+    st = clone(util.stream(520, 20, scale=2, device="cuda"))
+    st.mask_gt[6] = 0            # delivered at frame 12
+    assert st.mask_delivery[12] == 6
+    compare([st], 20)
+
+
+def test_missing_flow_frames():
+    """Flow absent on some frames: no velocity stage, no mask propagation, depth/mask still latched
+    (hpp:217-229); the flow buffer simply skips those frames."""
+    st = clone(util.stream(530, 24, scale=2, device="cuda"))
+    st.flow_valid[[5, 6, 13]] = False
+    compare([st], 24)
+
+
+def test_unobservable_velocity_step():
+    """A mask of one or two pixels gives N < 3: the twist belief is restored (ROFTFilter.cpp:294-301)."""
+    st = clone(util.stream(540, 14, scale=2, device="cuda"))
+    tiny = torch.zeros_like(st.mask_gt[0])
+    vs, us = np.nonzero(st.mask_gt[0].numpy())
+    tiny[vs[len(vs) // 2], us[len(us) // 2]] = 255
+    st.mask_gt[0] = tiny          # delivered at frames 0 and 6
+    compare([st], 14)
+
+
+def test_engine_shape_b_s16():
+    """1280x720, CV_16SC2 grid 4 (config_fast_ycb.cfg + nvof_1_slow): render divider 4."""
+    streams = [util.stream(550 + i, 9, scale=1, shape="B", flow_type=synth.FLOW_S16C2, mesh_n=24, device="cuda")
+               for i in range(2)]
+    compare(streams, 9)
+
+
+def test_long_many_object_run():
+    """BASELINE config #5 in small: 16 objects, re-sync + outlier rejection on, 90 frames."""
+    streams = [util.stream(600 + i, 90, scale=2, device="cuda") for i in range(16)]
+    n_tests = compare(streams, 90, check_masks=False)
+    assert n_tests >= 16 * 10

@@ -7,11 +7,16 @@ from roft_amd import synth
 
 
 @functools.lru_cache(maxsize=16)
-def stream(seed, n_frames, scale=2, flow_type=synth.FLOW_F32C2, shape="A", **kw):
+def stream(seed, n_frames, scale=2, flow_type=synth.FLOW_F32C2, shape="A", device="cpu", **kw):
+    """Seeded synthetic stream.  device="cuda" generates on the GPU (fast) and moves the tensors to the
+    host so that the oracle and the engine see the same bytes."""
     cam = synth.Camera.shape_a() if shape == "A" else synth.Camera.shape_b()
     if scale > 1:
         cam = cam.scaled(scale)
-    return synth.make_stream(seed, n_frames, cam, flow_type=flow_type, mesh_n=kw.pop("mesh_n", 12), **kw)
+    st = synth.make_stream(seed, n_frames, cam, flow_type=flow_type, mesh_n=kw.pop("mesh_n", 12), device=device, **kw)
+    if device != "cpu":
+        st.depth, st.flow, st.mask_gt = st.depth.cpu(), st.flow.cpu(), st.mask_gt.cpu()
+    return st
 
 
 def oracle_camera(ob, cam):
