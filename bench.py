@@ -37,6 +37,8 @@ def parse():
     p.add_argument("--flow", default="f32", choices=["f32", "s16"])
     p.add_argument("--cpu-sample-objects", type=int, default=8)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--host-inputs", action="store_true",
+                   help="hand the engine HOST buffers (PCIe-inclusive rate; never the headline value)")
     p.add_argument("--no-kernel-timing", action="store_true",
                    help="do not record HIP events between launches in the timed region")
     return p.parse_args()
@@ -92,15 +94,20 @@ def main():
     eng.enable_log(n_frames)
 
     inputs = []
+    host = None
+    if args.host_inputs:   # pinned host copies of the streams: the boundary then pays the PCIe transfer
+        host = [dict(depth=st.depth.cpu().pin_memory(), flow=st.flow.cpu().pin_memory(), mask=st.mask_gt.cpu().pin_memory())
+                for st in streams]
     for k in range(n_frames):
         frames = []
-        for st in streams:
+        for o, st in enumerate(streams):
             mi = st.mask_delivery[k]
             pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
-            frames.append(dict(depth=st.depth[k].data_ptr(),
-                               flow=st.flow[k].data_ptr() if st.flow_valid[k] else None,
-                               mask=st.mask_gt[mi].data_ptr() if mi >= 0 else None,
-                               pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE))
+            src = host[o] if host else dict(depth=st.depth, flow=st.flow, mask=st.mask_gt)
+            frames.append(dict(depth=src["depth"][k].data_ptr(),
+                               flow=src["flow"][k].data_ptr() if st.flow_valid[k] else None,
+                               mask=src["mask"][mi].data_ptr() if mi >= 0 else None,
+                               pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE if not host else L.MEM_HOST))
         inputs.append(eng.build_inputs(frames))
 
     barrier = parallel.barrier
@@ -215,8 +222,17 @@ def main():
         dur_s = kernels["flow_measure"]["avg_us"] * 1e-6
         achieved = bytes_per_obj * n_obj / dur_s / 1e9
         dense = (cam.width * cam.height * 5 + (cam.width // g) * (cam.height // g) * e) * n_obj / dur_s / 1e9
+        # HBM traffic of this kernel from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE on this
+        # same command, KB per dispatch; see profiles/README.md for the gfx950 caveats) -- only for the default workload
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_fetch.csv")
+        if os.path.exists(pmc_path) and (n_obj, args.shape, args.flow) == (64, "A", "f32"):
+            for line in open(pmc_path):
+                f = line.strip().split(",")
+                if f[0] == "roft::flow_measure_kernel" and f[1] == "FETCH_SIZE":
+                    traffic = float(f[3]) * 1024.0
         roofline = dict(kernel="flow_measure_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None,
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic,
                         algorithmic_bytes_per_launch=bytes_per_obj * n_obj, avg_launch_us=kernels["flow_measure"]["avg_us"],
                         dense_equivalent_GBs=dense,
                         note="culled bytes: mask bit plane + sampled depth/flow + records; dense_equivalent = the "
@@ -236,6 +252,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
+        "inputs": "host (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
         "config": {"workload": "BASELINE config #4 at one GPU: %dx%d, %s flow grid %d, %d objects per GPU "
                                "(sharded by object, no data-path collective), masks+poses at 5 fps with 6-frame "
                                "delay, flow-aided masks, re-sync and outlier rejection on" %

@@ -65,8 +65,8 @@ class ROFTFilterBatch:
                 v = f.get(key)
                 if v is None:
                     setattr(fi, key, None)
-                elif kind == L.MEM_DEVICE:
-                    setattr(fi, key, int(v))
+                elif kind == L.MEM_DEVICE or isinstance(v, int):
+                    setattr(fi, key, int(v))   # raw address (device pointer, or a host pointer kept alive by the caller)
                 else:
                     v = np.ascontiguousarray(v)
                     keep.append(v)

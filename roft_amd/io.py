@@ -1,0 +1,286 @@
+"""On-disk formats either side of the filtering path.
+
+These are the files the reference's Dataset* sources read and its logger writes, so that the engine can
+be fed from -- and its output compared with -- a Fast-YCB / HO-3D style directory:
+
+  optical_flow/<set>/<index>.float   OpticalFlowUtils::read_flow / save_flow
+                                      (src/roft-lib/src/OpticalFlowUtilities.cpp:26-136)
+  depth/<index>.float                 tools/dataset/conversion/ho3d_utils.py:65-79
+  masks/<set>/<object>_<index>.png    DatasetImageSegmentation::read_file (src/roft-lib/src/DatasetImageSegmentation.cpp:128-147)
+  <set>/poses.txt                     x y z ax ay az angle per frame, all-zero row = invalid
+                                      (tools/dataset/conversion/utils.py:150-163, tools/dataset/dope_pose_finder/pose_finder.py:23-27)
+  data.txt                            stamp_rgb stamp_depth cam_x cam_y cam_z ax ay az angle
+                                      (tools/dataset/data_txt_generation/generate_data_txt.py:20-24)
+  <name>.obj                          Wavefront mesh: `v x y z [r g b]`, `vn`, `f a//a b//b c//c`
+                                      (src/roft-lib/meshes/DOPE/*.obj, src/roft-lib/src/SICADModel.cpp:99-110)
+  pose_estimate / velocity_estimate   ROFTFilter's log rows (src/roft-lib/src/ROFTFilter.cpp:386-394,448-451)
+
+Pure numpy / stdlib (zlib for PNG); no OpenCV.
+"""
+import os
+import struct
+import zlib
+
+import numpy as np
+
+CV_16SC2 = 11
+CV_32FC2 = 13
+
+
+# ---- optical flow .float ------------------------------------------------------------------------------
+def save_flow(flow, path):
+    """flow: [rows, cols, 2] int16 (S10.5 fixed point) or float32."""
+    flow = np.ascontiguousarray(flow)
+    if flow.ndim != 3 or flow.shape[2] != 2 or flow.dtype not in (np.int16, np.float32):
+        raise ValueError("only CV_32FC2 or CV_16SC2 frames are supported")
+    typ = CV_16SC2 if flow.dtype == np.int16 else CV_32FC2
+    with open(path, "wb") as f:
+        f.write(struct.pack("=i", typ))                                  # int frame_type
+        f.write(struct.pack("=QQ", flow.shape[1], flow.shape[0]))        # size_t {cols, rows}
+        f.write(flow.tobytes())
+
+
+def read_flow(path):
+    """Returns (valid, flow) like OpticalFlowUtils::read_flow; never raises on a missing / short file."""
+    try:
+        with open(path, "rb") as f:
+            head = f.read(4 + 16)
+            if len(head) != 20:
+                return False, None
+            typ, = struct.unpack("=i", head[:4])
+            cols, rows = struct.unpack("=QQ", head[4:])
+            if typ not in (CV_16SC2, CV_32FC2):
+                return False, None
+            dt = np.int16 if typ == CV_16SC2 else np.float32
+            n = cols * rows * 2
+            data = np.frombuffer(f.read(n * np.dtype(dt).itemsize), dtype=dt)
+            if data.size != n:
+                return False, None
+            return True, data.reshape(rows, cols, 2).copy()
+    except (OSError, ValueError):
+        return False, None
+
+
+def flow_format(flow, image_width):
+    """(type, grid, scale) as DatasetImageOpticalFlow derives them (DatasetImageOpticalFlow.cpp:46-50)."""
+    typ = CV_16SC2 if flow.dtype == np.int16 else CV_32FC2
+    return typ, image_width // flow.shape[1], (32.0 if typ == CV_16SC2 else 1.0)
+
+
+# ---- depth .float -----------------------------------------------------------------------------------------
+def write_depth(path, depth):
+    depth = np.ascontiguousarray(depth, np.float32)
+    with open(path, "wb") as f:
+        f.write(struct.pack("=Q", depth.shape[1]))
+        f.write(struct.pack("=Q", depth.shape[0]))
+        f.write(depth.tobytes())
+
+
+def read_depth(path):
+    with open(path, "rb") as f:
+        w, h = struct.unpack("=QQ", f.read(16))
+        d = np.frombuffer(f.read(w * h * 4), np.float32)
+    if d.size != w * h:
+        raise ValueError("truncated depth frame " + path)
+    return d.reshape(h, w).copy()
+
+
+# ---- poses.txt / data.txt ---------------------------------------------------------------------------------
+def axis_angle_to_quat(axis, angle):
+    axis = np.asarray(axis, float)
+    n = np.linalg.norm(axis)
+    if n == 0.0:
+        return np.array([1.0, 0.0, 0.0, 0.0])
+    s = np.sin(angle / 2.0)
+    return np.concatenate([[np.cos(angle / 2.0)], s * axis / n])
+
+
+def quat_to_axis_angle(q):
+    """Eigen::AngleAxisd(Quaterniond): angle in [0, pi], axis (1,0,0) for the identity."""
+    q = np.asarray(q, float)
+    n = np.linalg.norm(q[1:])
+    if n == 0.0:
+        return np.array([1.0, 0.0, 0.0]), 0.0
+    angle = 2.0 * np.arctan2(n, abs(q[0]))
+    return q[1:] / (n if q[0] >= 0 else -n), angle
+
+
+def read_poses(path, skip_rows=0, skip_cols=0):
+    """Rows `[skip_cols values] x y z ax ay az angle`; returns (pose [F,7] = x + quaternion wxyz, valid [F]).
+    An all-zero pose row is an invalid detection."""
+    rows = []
+    with open(path) as f:
+        for i, line in enumerate(f):
+            if i < skip_rows:
+                continue
+            vals = [float(v) if v.lower() != "nan" else np.nan for v in line.split()]
+            if len(vals) >= skip_cols + 7:
+                rows.append(vals[skip_cols:skip_cols + 7])
+    a = np.array(rows, float).reshape(-1, 7)
+    valid = np.any(a != 0.0, axis=1)
+    pose = np.zeros((len(a), 7))
+    pose[:, 3] = 1.0
+    for k in np.nonzero(valid)[0]:
+        pose[k, :3] = a[k, :3]
+        pose[k, 3:] = axis_angle_to_quat(a[k, 3:6], a[k, 6])
+    return pose, valid
+
+
+def read_data_txt(path):
+    """Returns (stamp_rgb [F], stamp_depth [F], camera_pose [F,7 axis-angle form])."""
+    a = np.loadtxt(path, ndmin=2)
+    return a[:, 0], a[:, 1], a[:, 2:9]
+
+
+def write_estimate_logs(prefix, pose13, twist6):
+    """ROFTFilter's `pose_estimate` (v w x axis angle, 13 columns) and `velocity_estimate` (6 columns)."""
+    pose13 = np.atleast_2d(pose13)
+    twist6 = np.atleast_2d(twist6)
+    with open(prefix + "pose_estimate", "w") as fp:
+        for r in pose13:
+            axis, angle = quat_to_axis_angle(r[9:13])
+            fp.write(" ".join("%.12g" % v for v in list(r[:9]) + list(axis) + [angle]) + "\n")
+    with open(prefix + "velocity_estimate", "w") as fv:
+        for r in twist6:
+            fv.write(" ".join("%.12g" % v for v in r) + "\n")
+
+
+def delivery_schedule(n_frames, original_fps=30.0, desired_fps=5.0, head_0=0, simulate_inference_time=True):
+    """Frame index delivered at each frame by DatasetImageSegmentationDelayed / DatasetTransformDelayed, -1 = none
+    (src/roft-lib/src/DatasetImageSegmentationDelayed.cpp:42-63)."""
+    delay = int(original_fps / desired_fps)
+    out = np.full(n_frames, -1, np.int64)
+    for h in range(n_frames):
+        head = head_0 + h
+        index = head - delay if simulate_inference_time else head
+        if abs(index - head_0) % delay != 0:   # C's % keeps the sign; only "== 0" matters
+            continue
+        if index < 0:
+            index = head_0
+        out[h] = index
+    return out
+
+
+# ---- Wavefront OBJ --------------------------------------------------------------------------------------
+def load_obj(path):
+    """Vertices (float32 [V,3]) and triangles (int32 [T,3], 0-based).  Faces with more than three corners
+    are fanned; `v//vn`, `v/vt/vn`, `v/vt` and bare `v` corner forms are accepted; negative indices are
+    relative to the end."""
+    verts, tris = [], []
+    with open(path) as f:
+        for line in f:
+            if line.startswith("v "):
+                p = line.split()
+                verts.append((float(p[1]), float(p[2]), float(p[3])))
+            elif line.startswith("f "):
+                idx = []
+                for c in line.split()[1:]:
+                    i = int(c.split("/")[0])
+                    idx.append(i - 1 if i > 0 else len(verts) + i)
+                for k in range(1, len(idx) - 1):
+                    tris.append((idx[0], idx[k], idx[k + 1]))
+    return np.array(verts, np.float32).reshape(-1, 3), np.array(tris, np.int32).reshape(-1, 3)
+
+
+# ---- PNG (8-bit, non-interlaced; gray, gray+alpha, RGB, RGBA, palette) ------------------------------------
+def read_png(path):
+    """Decodes to uint8 [H, W] (gray / palette index) or [H, W, C]."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG file: " + path)
+    pos, idat, hdr = 8, [], None
+    while pos < len(data):
+        length, = struct.unpack(">I", data[pos:pos + 4])
+        ctype = data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + length]
+        pos += 12 + length
+        if ctype == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif ctype == b"IDAT":
+            idat.append(body)
+        elif ctype == b"IEND":
+            break
+    w, h, depth, ctype, _, _, interlace = hdr
+    if depth != 8 or interlace != 0:
+        raise ValueError("only 8-bit non-interlaced PNGs are supported")
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), np.uint8)
+    stride = w * ch
+    raw = raw.reshape(h, stride + 1)
+    out = np.zeros((h, stride), np.uint8)
+    prev = np.zeros(stride, np.int32)
+    for y in range(h):
+        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:
+            cur = np.zeros(stride, np.int32)
+            for x in range(stride):
+                a = cur[x - ch] if x >= ch else 0
+                b = prev[x]
+                c = prev[x - ch] if x >= ch else 0
+                if ft == 1:
+                    pr = a
+                elif ft == 3:
+                    pr = (a + b) >> 1
+                elif ft == 4:
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                else:
+                    raise ValueError("bad PNG filter")
+                cur[x] = (line[x] + pr) & 255
+        out[y] = cur
+        prev = cur
+    return out.reshape(h, w) if ch == 1 else out.reshape(h, w, ch)
+
+
+def read_mask_png(path):
+    """Mask as ImageSegmentationMeasurement sees it before thresholding: colour images are converted to gray
+    (BGR2GRAY weights), src/roft-lib/src/ImageSegmentationMeasurement.cpp:62-63."""
+    img = read_png(path)
+    if img.ndim == 3:
+        rgb = img[..., :3].astype(np.float64)
+        img = np.clip(np.rint(0.299 * rgb[..., 0] + 0.587 * rgb[..., 1] + 0.114 * rgb[..., 2]), 0, 255).astype(np.uint8)
+    return img
+
+
+# ---- a Fast-YCB style sequence --------------------------------------------------------------------------
+class Sequence:
+    """Iterates the per-frame inputs of one object of a Fast-YCB / HO-3D style directory in the form
+    `roft_amd.engine.ROFTFilterBatch.submit` takes (HOST buffers), applying the reference's 5 fps / delayed
+    delivery schedule to masks and poses."""
+
+    def __init__(self, root, object_name, flow_set="nvof_1_slow", mask_set="mrcnn_ycbv_bop_pbr", pose_set="dope",
+                 width=1280, height=720, original_fps=30.0, desired_fps=5.0, delayed=True):
+        self.root, self.obj = root, object_name
+        self.flow_dir = os.path.join(root, "optical_flow", flow_set)
+        self.mask_dir = os.path.join(root, "masks", mask_set)
+        self.depth_dir = os.path.join(root, "depth")
+        self.stamp, _, _ = read_data_txt(os.path.join(root, "data.txt"))
+        self.poses, self.pose_ok = read_poses(os.path.join(root, pose_set, "poses.txt"))
+        self.n = len(self.stamp)
+        self.size = (width, height)
+        sched = delivery_schedule(self.n, original_fps, desired_fps) if delayed else np.arange(self.n)
+        self.mask_src = sched
+        self.pose_src = sched
+
+    def __len__(self):
+        return self.n
+
+    def frame(self, k):
+        ok, flow = read_flow(os.path.join(self.flow_dir, "%d.float" % k))
+        mi, pi = self.mask_src[k], self.pose_src[k]
+        mask = None
+        if mi >= 0:
+            p = os.path.join(self.mask_dir, "%s_%d.png" % (self.obj, mi))
+            mask = read_mask_png(p) if os.path.exists(p) else None
+        pose = None
+        if pi >= 0 and self.pose_ok[pi]:
+            pose = (self.poses[pi, :3], self.poses[pi, 3:])
+        dt = float(self.stamp[k] - self.stamp[k - 1]) if k > 0 else 0.0
+        return dict(depth=read_depth(os.path.join(self.depth_dir, "%d.float" % k)), flow=flow if ok else None,
+                    mask=mask, pose=pose, dt=dt)

@@ -1,0 +1,171 @@
+"""File formats either side of the path (roft_amd/io.py): byte-level known answers written from the reference's
+reader/writer code, round trips, and -- in the dev container only -- the reference's own mesh file."""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from roft_amd import io, synth
+
+
+def test_flow_float_byte_layout_and_roundtrip(tmp_path):
+    # OpticalFlowUtilities.cpp:99-119: int type | size_t cols | size_t rows | interleaved elements
+    f32 = np.arange(2 * 3 * 2, dtype=np.float32).reshape(2, 3, 2) * 0.5
+    p = str(tmp_path / "7.float")
+    io.save_flow(f32, p)
+    raw = open(p, "rb").read()
+    assert raw[:4] == struct.pack("=i", 13) and raw[4:20] == struct.pack("=QQ", 3, 2)
+    assert raw[20:] == f32.tobytes() and len(raw) == 20 + 48
+    ok, back = io.read_flow(p)
+    assert ok and back.dtype == np.float32 and np.array_equal(back, f32)
+    s16 = (np.arange(4 * 5 * 2, dtype=np.int16).reshape(4, 5, 2) - 17)
+    io.save_flow(s16, p)
+    assert open(p, "rb").read()[:4] == struct.pack("=i", 11)
+    ok, back = io.read_flow(p)
+    assert ok and back.dtype == np.int16 and np.array_equal(back, s16)
+    assert io.flow_format(s16, 20) == (11, 4, 32.0) and io.flow_format(f32, 3) == (13, 1, 1.0)
+    # missing / truncated files are "not available", not errors (read_flow returns (false, Mat()))
+    assert io.read_flow(str(tmp_path / "nope.float"))[0] is False
+    open(p, "wb").write(raw[:30])
+    assert io.read_flow(p)[0] is False
+    with pytest.raises(ValueError):
+        io.save_flow(np.zeros((2, 2, 2), np.float64), p)
+
+
+def test_depth_float(tmp_path):
+    d = np.random.default_rng(0).random((5, 7)).astype(np.float32)
+    p = str(tmp_path / "0.float")
+    io.write_depth(p, d)
+    raw = open(p, "rb").read()
+    assert raw[:16] == struct.pack("=QQ", 7, 5) and raw[16:] == d.tobytes()      # ho3d_utils.py:74-79
+    assert np.array_equal(io.read_depth(p), d)
+
+
+def test_poses_txt_and_logs(tmp_path):
+    p = str(tmp_path / "poses.txt")
+    open(p, "w").write("0.1 0.2 0.7 0 0 1 1.5707963267948966\n0 0 0 0 0 0 0\n")
+    pose, valid = io.read_poses(p)
+    assert list(valid) == [True, False] and len(pose) == 2
+    assert np.allclose(pose[0], [0.1, 0.2, 0.7, np.cos(np.pi / 4), 0, 0, np.sin(np.pi / 4)])
+    open(p, "w").write("header\nNaN NaN NaN NaN NaN NaN 0.3 -0.1 0.9 1 0 0 0.2\n")
+    pose, valid = io.read_poses(p, skip_rows=1, skip_cols=6)  # prediction rows carry 6 velocity columns first
+    assert valid[0] and np.allclose(pose[0, :3], [0.3, -0.1, 0.9]) and np.allclose(pose[0, 3:], [np.cos(0.1), np.sin(0.1), 0, 0])
+    # log rows: v w x axis angle
+    q = io.axis_angle_to_quat([0, 1, 0], 0.4)
+    io.write_estimate_logs(str(tmp_path) + "/", np.concatenate([np.zeros(6), [1, 2, 3], q])[None], np.arange(6.0)[None])
+    row = np.loadtxt(str(tmp_path / "pose_estimate"))
+    assert np.allclose(row, [0] * 6 + [1, 2, 3, 0, 1, 0, 0.4])
+    assert np.allclose(np.loadtxt(str(tmp_path / "velocity_estimate")), np.arange(6.0))
+    axis, angle = io.quat_to_axis_angle(-q)                    # w < 0: Eigen flips the axis, angle stays in [0, pi]
+    assert np.allclose(axis, [0, 1, 0]) and abs(angle - 0.4) < 1e-12
+    assert io.quat_to_axis_angle([1, 0, 0, 0])[0].tolist() == [1.0, 0.0, 0.0]
+
+
+def test_delivery_schedule_matches_generator():
+    st = synth.make_stream(3, 20, synth.Camera.shape_a().scaled(8))
+    assert list(io.delivery_schedule(20)) == list(st.mask_delivery)
+    assert list(io.delivery_schedule(8, 30.0, 10.0)) == [0, -1, -1, 0, -1, -1, 3, -1]
+    assert list(io.delivery_schedule(4, simulate_inference_time=False, desired_fps=15.0)) == [0, -1, 2, -1]
+
+
+def test_obj_loader(tmp_path):
+    p = str(tmp_path / "m.obj")
+    open(p, "w").write("# mesh\nv 0 0 0 0.5 0.5 0.5\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvn 0 0 1\nf 1//1 2//1 3//1\nf 1/1/1 3/2/1 4/3/1\nf 1 2 3 4\nf -4 -3 -2\n")
+    v, t = io.load_obj(p)
+    assert v.shape == (4, 3) and v.dtype == np.float32
+    assert t.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 2], [0, 2, 3], [0, 1, 2]]
+
+
+def test_obj_loader_on_the_reference_mesh():
+    ref = "/root/reference/src/roft-lib/meshes/DOPE/003_cracker_box.obj"
+    if not os.path.exists(ref):
+        pytest.skip("reference checkout not present (GPU box)")
+    v, t = io.load_obj(ref)
+    assert 7000 < len(v) < 9000 and 15000 < len(t) < 17000
+    assert np.allclose(v.min(0), [-0.080, -0.102, -0.036], atol=2e-3) and np.allclose(v.max(0), [0.084, 0.112, 0.035], atol=2e-3)
+    assert t.min() == 0 and t.max() == len(v) - 1
+
+
+def _png(img, filters):
+    h = img.shape[0]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    rows = img.reshape(h, -1).astype(np.int32)
+    out = bytearray()
+    prev = np.zeros(rows.shape[1], np.int32)
+    for y in range(h):
+        ft = filters[y % len(filters)]
+        cur = rows[y]
+        a = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        c = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        if ft == 0:
+            pr = 0
+        elif ft == 1:
+            pr = a
+        elif ft == 2:
+            pr = prev
+        elif ft == 3:
+            pr = (a + prev) >> 1
+        else:
+            p = a + prev - c
+            pa, pb, pc = abs(p - a), abs(p - prev), abs(p - c)
+            pr = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        out.append(ft)
+        out += bytes(((cur - pr) & 255).astype(np.uint8))
+        prev = cur
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b))
+
+    comp = zlib.compress(bytes(out))
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", img.shape[1], h, 8, ctype, 0, 0, 0)) +
+            chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b""))
+
+
+def test_png_decoder_all_filters(tmp_path):
+    rng = np.random.default_rng(2)
+    gray = (rng.random((13, 17)) < 0.4).astype(np.uint8) * 255
+    rgb = rng.integers(0, 256, size=(9, 11, 3), dtype=np.uint8)
+    for img in (gray, rgb, rng.integers(0, 256, size=(6, 5, 4), dtype=np.uint8)):
+        for filters in ([0], [1], [2], [3], [4], [0, 1, 2, 3, 4]):
+            p = str(tmp_path / "m.png")
+            open(p, "wb").write(_png(img, filters))
+            assert np.array_equal(io.read_png(p), img), filters
+    p = str(tmp_path / "c.png")
+    open(p, "wb").write(_png(rgb, [4]))
+    m = io.read_mask_png(p)
+    assert m.shape == rgb.shape[:2] and m.dtype == np.uint8
+    with pytest.raises(ValueError):
+        open(p, "wb").write(b"not a png")
+        io.read_png(p)
+
+
+def test_sequence_reader_feeds_the_engine_format(tmp_path):
+    """Write a tiny Fast-YCB style directory from a synthetic stream and read it back frame by frame."""
+    st = synth.make_stream(5, 8, synth.Camera.shape_a().scaled(8), flow_invalid=0.0)
+    root = tmp_path
+    for d in ("optical_flow/nvof", "masks/gt", "depth", "dope"):
+        os.makedirs(root / d)
+    with open(root / "data.txt", "w") as f:
+        for k in range(8):
+            f.write("%f %f 0 0 0 1 0 0 0\n" % (k / 30.0, k / 30.0))
+    with open(root / "dope" / "poses.txt", "w") as f:
+        for k in range(8):
+            axis, angle = io.quat_to_axis_angle(st.gt.q[k])
+            f.write(" ".join("%.17g" % v for v in list(st.gt.x[k]) + list(axis) + [angle]) + "\n")
+    for k in range(8):
+        io.write_depth(str(root / "depth" / ("%d.float" % k)), st.depth[k].numpy())
+        if k > 0:
+            io.save_flow(st.flow[k].numpy(), str(root / "optical_flow" / "nvof" / ("%d.float" % k)))
+        open(root / "masks" / "gt" / ("obj_%d.png" % k), "wb").write(_png(st.mask_gt[k].numpy(), [0, 2]))
+    seq = io.Sequence(str(root), "obj", flow_set="nvof", mask_set="gt", pose_set="dope", width=st.camera.width,
+                      height=st.camera.height)
+    assert len(seq) == 8
+    f0, f3, f6 = seq.frame(0), seq.frame(3), seq.frame(6)
+    assert f0["flow"] is None and f0["mask"] is not None and f0["pose"] is not None    # frame 0: no flow file
+    assert f3["mask"] is None and f3["pose"] is None and np.array_equal(f3["flow"], st.flow[3].numpy())
+    assert np.array_equal(f6["mask"], st.mask_gt[0].numpy()) and np.array_equal(f6["depth"], st.depth[6].numpy())
+    assert np.allclose(f6["pose"][0], st.gt.x[0]) and abs(abs(np.dot(f6["pose"][1], st.gt.q[0])) - 1) < 1e-12
+    assert abs(f6["dt"] - 1 / 30.0) < 1e-6
