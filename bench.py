@@ -167,6 +167,18 @@ def main():
         gt = np.concatenate([st.gt.x, st.gt.q], 1)
         adds_gt.append(metrics.trajectory_adds(est[args.warmup:], gt[args.warmup:n_frames], model_points(st)))
     adds_gt = np.concatenate(adds_gt)
+    # RMSE metrics of evaluation/metrics.py on the same sample (position cm, orientation deg, velocities with the
+    # pole moved to the object, evaluate.py:514-521)
+    sl = slice(args.warmup, n_frames)
+    est_x = np.concatenate([pose_log[sl, o, 6:9] for o in range(n_sample)])
+    est_q = np.concatenate([pose_log[sl, o, 9:13] for o in range(n_sample)])
+    gt_x = np.concatenate([streams[o].gt.x[sl] for o in range(n_sample)])
+    gt_q = np.concatenate([streams[o].gt.q[sl] for o in range(n_sample)])
+    est_tw = metrics.object_velocity_from_twist(np.concatenate([twist_log[sl, o] for o in range(n_sample)]), gt_x)
+    gt_tw = metrics.object_velocity_from_twist(np.concatenate([streams[o].gt.twist[sl] for o in range(n_sample)]), gt_x)
+    rmse = {"position_cm": metrics.rmse_cartesian_3d(gt_x, est_x), "orientation_deg": metrics.rmse_angular(gt_q, est_q),
+            "linear_velocity_cm_s": metrics.rmse_linear_velocity(gt_tw[:, :3], est_tw[:, :3]),
+            "angular_velocity_deg_s": metrics.rmse_angular_velocity(gt_tw[:, 3:], est_tw[:, 3:])}
 
     cpu = None
     adds_cpu = None
@@ -266,6 +278,7 @@ def main():
         "adds_vs_gt_mm": {"mean": 1e3 * float(adds_gt.mean()), "auc": metrics.auc(adds_gt)},
         "adds_vs_cpu_ref_mm": ({"mean": 1e3 * float(adds_cpu.mean()), "max": 1e3 * float(adds_cpu.max())}
                                if adds_cpu is not None else None),
+        "rmse_vs_gt": rmse,
         "kernels": kernels,
         "dominant_kernel": dominant,
         "stream_generation_s": t_gen,

@@ -53,3 +53,49 @@ def trajectory_adds(pose_est, pose_ref, pts):
     for k in range(len(pose_est)):
         out[k] = adds(quat_to_rot(pose_est[k, 3:]), pose_est[k, :3], quat_to_rot(pose_ref[k, 3:]), pose_ref[k, :3], pts)
     return out
+
+
+# ---- RMSE metrics of evaluation/metrics.py (the step right after the filtering path) -----------------------
+def _rot_angle_deg(q_ref, q_sig):
+    """Geodesic angle of R_ref R_sig^T in degrees (metrics.py:114-144)."""
+    d = abs(float(np.dot(q_ref, q_sig))) / (np.linalg.norm(q_ref) * np.linalg.norm(q_sig))
+    return np.degrees(2.0 * np.arccos(min(1.0, d)))
+
+
+def rmse_cartesian_3d(ref_x, sig_x):
+    """RMSE of the 3D position error in centimetres (metrics.py:102-111, 217-222)."""
+    err = np.linalg.norm((np.asarray(ref_x) - np.asarray(sig_x)) * 100.0, axis=1)
+    return float(np.linalg.norm(err) / np.sqrt(len(err)))
+
+
+def rmse_angular(ref_q, sig_q):
+    """RMSE of the orientation error in degrees (metrics.py:114-144, 243-248); quaternions (w,x,y,z)."""
+    err = np.array([_rot_angle_deg(a, b) for a, b in zip(ref_q, sig_q)])
+    return float(np.linalg.norm(err) / np.sqrt(len(err)))
+
+
+def object_velocity_from_twist(twist, position):
+    """The filter's linear velocity is that of the object point at the camera origin; the evaluation
+    moves the pole to the object position before comparing: v = v_O + w x r (evaluate.py:514-521)."""
+    twist = np.asarray(twist, float)
+    out = twist.copy()
+    out[:, :3] = twist[:, :3] + np.cross(twist[:, 3:], np.asarray(position, float))
+    return out
+
+
+def rmse_linear_velocity(ref_v, sig_v):
+    """cm/s (metrics.py:165-174, 251-256)."""
+    err = np.linalg.norm((np.asarray(ref_v) - np.asarray(sig_v)) * 100.0, axis=1)
+    return float(np.linalg.norm(err) / np.sqrt(len(err)))
+
+
+def rmse_angular_velocity(ref_w, sig_w):
+    """deg/s (metrics.py:177-186, 259-264)."""
+    err = np.linalg.norm(np.degrees(np.asarray(ref_w) - np.asarray(sig_w)), axis=1)
+    return float(np.linalg.norm(err) / np.sqrt(len(err)))
+
+
+def time_metrics(exec_ms):
+    """Mean execution time and the number of frames above the 33 ms real-time budget (metrics.py:347-369)."""
+    t = np.asarray(exec_ms, float)
+    return float(t.mean()), int((t > 33.0).sum())

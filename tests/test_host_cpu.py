@@ -99,3 +99,29 @@ def test_two_rank_gloo_sharding(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "rank 0 ok [0, 1, 2]" in outs[0] and "rank 1 ok [3, 4]" in outs[1]
+
+
+def test_rmse_metrics():
+    from scipy.spatial.transform import Rotation
+    from roft_amd import metrics
+    rng = np.random.default_rng(8)
+    n = 30
+    x = rng.normal(size=(n, 3))
+    assert abs(metrics.rmse_cartesian_3d(x, x + [0.03, 0.0, 0.04]) - 5.0) < 1e-12        # 5 cm
+    q = Rotation.random(n, random_state=1)
+    d = Rotation.from_rotvec(np.tile([0.0, np.radians(10.0), 0.0], (n, 1)))
+    qa = q.as_quat()[:, [3, 0, 1, 2]]
+    qb = (d * q).as_quat()[:, [3, 0, 1, 2]]
+    assert abs(metrics.rmse_angular(qa, qb) - 10.0) < 1e-9
+    assert abs(metrics.rmse_angular(qa, -qb) - 10.0) < 1e-9                              # double cover
+    tw = rng.normal(size=(n, 6))
+    v = metrics.object_velocity_from_twist(tw, x)
+    assert np.allclose(v[:, :3], tw[:, :3] + np.cross(tw[:, 3:], x)) and np.array_equal(v[:, 3:], tw[:, 3:])
+    assert abs(metrics.rmse_linear_velocity(tw[:, :3], tw[:, :3] + [0.01, 0, 0]) - 1.0) < 1e-12
+    assert abs(metrics.rmse_angular_velocity(tw[:, 3:], tw[:, 3:] + [0, np.radians(2.0), 0]) - 2.0) < 1e-12
+    assert metrics.time_metrics([10, 20, 40, 33, 34]) == (27.4, 2)
+    # the synthetic ground-truth twist is the origin-form twist: moving the pole recovers the body velocity
+    st = util.stream(60, 12, scale=8)
+    body = metrics.object_velocity_from_twist(st.gt.twist, st.gt.x)
+    fd = np.gradient(st.gt.x, st.dt, axis=0)
+    assert np.abs(body[2:-2, :3] - fd[2:-2]).max() < 0.02
