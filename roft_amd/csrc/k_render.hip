@@ -30,13 +30,22 @@ constexpr int kFeatThreads = 1024;
 // contiguous chunk of words, issuing its depth gathers back to back.
 __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a, int phase)
 {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_wave[17];
     const int obj = blockIdx.x;
     const FrameCtrl& c = a.ctrl[obj];
     const bool run = (phase == 0) ? (c.buffer_features_before || c.features_current) : c.buffer_features_after;
     if (!run) return;
     const int W = a.cam.W, wpr = a.cam.wpr;
-    const uint32_t* plane = a.planes + plane_offset(a, obj, c.slot_cur, 1);
+    uint32_t* plane = reinterpret_cast<uint32_t*>(smem);   // staged with coalesced 16-byte loads
+    {
+        const uint32_t* gplane = a.planes + plane_offset(a, obj, c.slot_cur, 1);
+        const size_t n4 = a.plane_words / 4;
+        for (size_t i = threadIdx.x; i < n4; i += blockDim.x)
+            reinterpret_cast<uint4*>(plane)[i] = reinterpret_cast<const uint4*>(gplane)[i];
+        for (size_t i = n4 * 4 + threadIdx.x; i < a.plane_words; i += blockDim.x) plane[i] = gplane[i];
+        __syncthreads();
+    }
     const float* depth = c.depth_cur;
     uint32_t* fpix = a.feat_pix + (size_t)obj * a.feat_cap;
     float* fdep = a.feat_depth + (size_t)obj * a.feat_cap;
@@ -72,7 +81,13 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a, 
 
 void launch_features(const EngineArrays& a, int phase, hipStream_t s)
 {
-    hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), 0, s, a, phase);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 256);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), (a.plane_words * 4 + 15) & ~(size_t)15, s, a, phase);
 }
 
 // ---- rasteriser ---------------------------------------------------------------------------------
