@@ -1225,3 +1225,35 @@ extern "C" int roft_debug_get_dbg(roft_engine* e, int id, long long out[32])
     delete st;
     return err == hipSuccess ? ROFT_OK : ROFT_ERR_DEVICE;
 }
+
+// Host-logic check without a device (not part of the public ABI): runs the per-frame program builder -- the
+// mirror of the Standard / PopBufferedMeasurement / RepeatOnlyVelocity state machine of
+// CartesianQuaternionMeasurement::freeze and of the re-sync loop of ROFTFilter::filtering_step -- over a
+// sequence of pose-validity flags and reports, per frame, the number of UKF launches, the number of
+// corrections, whether the outlier test runs, and the twist-ring slots replayed.
+extern "C" int roft_debug_plan(const roft_config* cfg, const int* pose_valid, int n_frames, int* n_steps, int* n_corrections,
+                               int* outlier, int* slots /* n_frames x kMaxSteps, -1 padded */)
+{
+    if (!cfg || !pose_valid || n_frames < 0) return ROFT_ERR_INVALID;
+    roft_engine e;
+    e.cfg = *cfg;
+    HostObject o;
+    roft_frame_input in{};
+    for (int k = 0; k < n_frames; ++k) {
+        FrameCtrl c;
+        clear_ctrl(c);
+        in.pose_valid = pose_valid[k];
+        build_pose_program(&e, o, in, c);
+        o.frame_idx++;
+        if (n_steps) n_steps[k] = c.n_steps;
+        int nc = 0;
+        for (int s = 0; s < c.n_steps; ++s) {
+            nc += c.steps[s].n_corr;
+            if (slots) slots[k * kMaxSteps + s] = c.steps[s].twist_slot;
+        }
+        if (slots) for (int s = c.n_steps; s < kMaxSteps; ++s) slots[k * kMaxSteps + s] = -1;
+        if (n_corrections) n_corrections[k] = nc;
+        if (outlier) outlier[k] = c.outlier_step;
+    }
+    return ROFT_OK;
+}

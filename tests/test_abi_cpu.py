@@ -83,3 +83,50 @@ def test_argument_validation_without_device():
     a = np.ones(3)
     assert lib.roft_pose_process_noise(a.ctypes.data, a.ctypes.data, 0.5, Q.ctypes.data) == 0
     assert Q[0, 0] == 0.5 and Q[3, 3] == 1.0 and Q[0, 6] == 0.125
+
+
+def _plan(cfg, pose_valid):
+    lib = L.lib()
+    n = len(pose_valid)
+    pv = (C.c_int * n)(*[int(v) for v in pose_valid])
+    ns, nc, out = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+    slots = (C.c_int * (n * 10))()
+    lib.roft_debug_plan.argtypes = [C.POINTER(L.Config), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.roft_debug_plan(C.byref(cfg), pv, n, ns, nc, out, slots) == 0
+    return list(ns), list(nc), list(out), np.array(list(slots)).reshape(n, 10)
+
+
+def test_frame_program_matches_the_oracle_state_machine(oracle):
+    """Host logic, no GPU: the per-frame UKF program (re-sync replays, outlier step, velocity deque) built by
+    the engine has exactly as many corrections per frame as the oracle's ROFTFilter restatement performs."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    for seed, drop in ((71, 0.0), (72, 0.5)):
+        st = util.stream(seed, 40, scale=8, pose_drop_prob=drop)
+        for over in (dict(), dict(use_pose_resync=0), dict(outlier_rejection=0), dict(use_pose=0, use_pose_resync=0, outlier_rejection=0)):
+            ref = util.run_oracle_tracker(oracle, st, **over)
+            cfg = L.Config()
+            L.lib().roft_default_config(C.byref(cfg), 640, 480, L.FLOW_F32C2)
+            for k, v in over.items():
+                setattr(cfg, k, v)
+            ns, nc, out, slots = _plan(cfg, st.pose_valid)
+            from oracle import binding as ob
+            cfg_o = util.oracle_config(ob, st, **over)
+            trk = ob.Tracker(cfg_o, *st.mesh)
+            want = []
+            for k in range(40):
+                depth, flow, mask, pose = util.frame_inputs(st, k)
+                want.append(trk.step(st.dt, depth, flow, mask, pose).n_ukf_corrections)
+            trk.close()
+            assert nc == want, (seed, over)
+            tested = [k for k in range(40) if out[k] >= 0]
+            assert tested == [k for k, r in enumerate(ref) if r["sel"] >= 0]
+    # steady state with re-sync: a pose frame replays the D + 1 = 7 buffered twists, oldest first
+    cfg = L.Config()
+    L.lib().roft_default_config(C.byref(cfg), 640, 480, L.FLOW_F32C2)
+    pv = [k % 6 == 0 for k in range(20)]
+    ns, nc, out, slots = _plan(cfg, pv)
+    assert ns[12] == 7 and nc[12] == 8 and out[12] == 0
+    assert list(slots[12][:7]) == [6, 7, 8, 9, 10, 11, 12]
+    assert ns[13] == 1 and nc[13] == 1 and out[13] == -1 and slots[13][0] == 13
