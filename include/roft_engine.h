@@ -218,8 +218,10 @@ int roft_engine_get_log(roft_engine* e, int first_frame, int n_frames, roft_obje
 /* HIP stream the engine enqueues on (as void*), for timing with hipEvents */
 void* roft_engine_stream(roft_engine* e);
 
-/* Per-kernel timing of the last roft_step, measured with HIP events on the engine's stream when
- * enabled (adds event records between launches).  names/ms arrays are owned by the engine. */
+/* Kernel timing with HIP events on the engine's stream, accumulated over the steps since the last
+ * roft_engine_get_timing.  enable: 0 off, 1 only flow_measure_kernel (two event records per frame, what
+ * bench.py keeps on inside its timed region), 2 every launch group (adds ~10 event records per frame).
+ * names/ms arrays are owned by the engine. */
 int roft_engine_enable_timing(roft_engine* e, int enable);
 int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, const float** ms_out,
                            const int** launches_out);

@@ -212,6 +212,7 @@ struct roft_engine {
     int frame_counter = 0;
     // timing
     bool timing = false;
+    int timing_level = 2;   // 1: only flow_measure_kernel (two events per frame), 2: every launch group
     std::vector<hipEvent_t> tev;
     std::vector<std::string> tnames_s;
     std::vector<const char*> tnames;
@@ -604,6 +605,13 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
 static void tmark(roft_engine* e, const char* name, int which = 0)
 {
     if (!e->timing) return;
+    if (e->timing_level == 1) {
+        // only the roofline kernel: the mark before it opens the interval, its own mark closes it
+        if (!name) return;
+        const bool opens = std::strcmp(name, "mask_propagate") == 0, closes = std::strcmp(name, "flow_measure") == 0;
+        if (!opens && !closes) return;
+        if (opens) name = nullptr;
+    }
     const size_t idx = e->tmark.size();
     while (e->tev.size() <= idx) {
         hipEvent_t ev;
@@ -765,6 +773,7 @@ int roft_engine_enable_timing(roft_engine* e, int enable)
 {
     if (!e) return fail(ROFT_ERR_INVALID, "null engine");
     e->timing = enable != 0;
+    e->timing_level = (enable == 1) ? 1 : 2;
     return ROFT_OK;
 }
 

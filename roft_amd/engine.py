@@ -135,8 +135,9 @@ class ROFTFilterBatch:
     def stream(self):
         return L.lib().roft_engine_stream(self._h)
 
-    def enable_timing(self, on=True):
-        L.check(L.lib().roft_engine_enable_timing(self._h, int(on)))
+    def enable_timing(self, level=2):
+        """0 off, 1 only the flow measurement kernel, 2 every launch group."""
+        L.check(L.lib().roft_engine_enable_timing(self._h, int(level)))
 
     def timing(self):
         n = C.c_int(0)
