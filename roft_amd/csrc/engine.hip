@@ -671,10 +671,15 @@ int roft_step(roft_engine* e)
     }
     tmark(e, nullptr, 1);
     if (e->any_feat0) { launch_features(a, 0, sp); tmark(e, "features", 1); }
-    for (int k = 0; k < e->max_steps; ++k) {
-        launch_ukf_step(a, k, e->cfg.ut, sp);
+    // step 0 (possibly followed by the outlier render + test), then all remaining steps in one launch
+    if (e->max_steps > 0) {
+        launch_ukf_step(a, 0, 1, e->cfg.ut, sp);
         tmark(e, "ukf_step", 1);
-        if (k == 0 && e->any_outlier) { launch_outlier(a, sp); tmark(e, "outlier_render_likelihood", 1); }
+        if (e->any_outlier) { launch_outlier(a, sp); tmark(e, "outlier_render_likelihood", 1); }
+        if (e->max_steps > 1) {
+            launch_ukf_step(a, 1, e->max_steps, e->cfg.ut, sp);
+            tmark(e, "ukf_replay_steps", 1);
+        }
     }
     if (e->any_feat1) { launch_features(a, 1, sp); tmark(e, "features", 1); }
     if (e->two_streams) HIP_TRY(hipEventRecord(e->ev_pose[ci], sp));
@@ -1106,7 +1111,7 @@ static int op_ukf(const double mean[13], const double P[144], const double* Q81,
     if (err != hipSuccess) { delete st; HIP_TRY(err); }
     c.arr.a.n_obj = 1;
     if (int rc = upload_ctrl(c, fc)) { delete st; return rc; }
-    launch_ukf_step(c.arr.a, 0, *ut, c.stream);
+    launch_ukf_step(c.arr.a, 0, 1, *ut, c.stream);
     err = hipMemcpyAsync(st, c.arr.state.p, sizeof(ObjState), hipMemcpyDeviceToHost, c.stream);
     if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
     if (err == hipSuccess) err = hipGetLastError();

@@ -718,11 +718,8 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
 }
 
 // One launch = one StepDesc per object: optional prediction, then 0, 1 or 2 corrections of it.
-__global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step, roft_ut_params ut)
+__device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const roft_ut_params& ut, UkfLds& L)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    UkfLds& L = *reinterpret_cast<UkfLds*>(smem);
-    const int obj = blockIdx.x;
     const FrameCtrl& c = a.ctrl[obj];
     ObjState& st = a.state[obj];
     if (step == 0 && threadIdx.x == 0) st.outlier_selected = -1;  // set again by outlier_kernel if it runs
@@ -785,11 +782,23 @@ __global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step, 
 #endif
 }
 
+// One launch runs the StepDescs [step0, step1) of every object back to back (the velocity-only replays of a
+// pose re-sync need no other kernel in between, so they share one launch).
+__global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step0, int step1, roft_ut_params ut)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    UkfLds& L = *reinterpret_cast<UkfLds*>(smem);
+    for (int step = step0; step < step1; ++step) {
+        ukf_one_step(a, blockIdx.x, step, ut, L);
+        __syncthreads();   // beliefs written by this step are read by the next one (same workgroup)
+    }
+}
+
 static size_t ukf_lds_bytes() { return (sizeof(UkfLds) + 15) & ~(size_t)15; }
 
-void launch_ukf_step(const EngineArrays& a, int step, roft_ut_params ut, hipStream_t s)
+void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s)
 {
-    hipLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(64), ukf_lds_bytes(), s, a, step, ut);
+    hipLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(64), ukf_lds_bytes(), s, a, step0, step1, ut);
 }
 
 }  // namespace roft

@@ -203,7 +203,7 @@ void launch_skf_arrays(const double* x_pred, const double* P_pred, int N, const 
                        const double* Rdiag, int reweight, double* norms, double* x_out, double* P_out, int* status,
                        hipStream_t s);
 void launch_kf_predict(const double* x, const double* P, const double* qdiag, double* xo, double* Po, hipStream_t s);
-void launch_ukf_step(const EngineArrays& a, int step, roft_ut_params ut, hipStream_t s);
+void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s);  // steps [step0, step1)
 void launch_features(const EngineArrays& a, int phase, hipStream_t s);
 void launch_outlier(const EngineArrays& a, hipStream_t s);       // z-buffer clear + render + likelihood + decision
 void launch_outlier_only(const EngineArrays& a, hipStream_t s);  // likelihood + decision on filled z-buffers
