@@ -226,6 +226,37 @@ int roft_engine_enable_timing(roft_engine* e, int enable);
 int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, const float** ms_out,
                            const int** launches_out);
 
+/* ---- (3) optical-flow producer (replaces the reference's NVIDIA-hardware flow source) ---------------- *
+ * ROFT consumes pre-computed flow frames produced by cv::cuda::NvidiaOpticalFlow_{1_0,2_0}
+ * (src/roft-lib/src/ImageOpticalFlowNVOF.cpp:100-159, tools/nvof/dumper/src/main.cpp:40-146).  MI355X has no
+ * fixed-function flow unit: this is a dense pyramidal Lucas-Kanade on the CUs producing the same two products,
+ * CV_32FC2 at grid 1 (NVOF 2.0 shape) or CV_16SC2 S10.5 at grid 4 (NVOF 1.0 shape), forward flow of the PREVIOUS
+ * frame's pixels. */
+typedef struct {
+    int levels;      /* pyramid levels (1..6); width and height must be multiples of 2^(levels-1) */
+    int radius;      /* window half size: (2r+1)^2 taps */
+    int iterations;  /* Gauss-Newton iterations per level */
+    float det_min;   /* pixels whose structure tensor determinant is below this keep the coarser estimate */
+} roft_of_params;
+
+int roft_default_of_params(roft_of_params* p);
+
+/* host buffers: prev/cur gray u8 (H x W).  out_type ROFT_FLOW_F32C2 -> float[H][W][2];
+ * ROFT_FLOW_S16C2 -> int16[H/4][W/4][2]. */
+int roft_optical_flow(const uint8_t* prev_gray, const uint8_t* cur_gray, int W, int H, const roft_of_params* p,
+                      int out_type, void* flow_out);
+
+/* batched, device-resident producer: n image pairs per call, asynchronous on its own stream */
+typedef struct roft_flow_producer roft_flow_producer;
+int roft_flow_producer_create(int W, int H, int max_pairs, const roft_of_params* p, int out_type, int device,
+                              roft_flow_producer** out);
+int roft_flow_producer_destroy(roft_flow_producer* fp);
+/* prev/cur/out: host arrays of n DEVICE pointers (u8 images in, flow frames out) */
+int roft_flow_producer_run(roft_flow_producer* fp, const uint8_t* const* prev, const uint8_t* const* cur,
+                           void* const* out, int n_pairs);
+int roft_flow_producer_sync(roft_flow_producer* fp);
+void* roft_flow_producer_stream(roft_flow_producer* fp);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,9 @@ def lib():
             f.argtypes = [C.c_void_p] * 5 + [C.c_int]
         L.ro_auc.restype = C.c_double
         L.ro_auc.argtypes = [C.c_void_p, C.c_int]
+        L.ro_optical_flow.restype = C.c_int
+        L.ro_optical_flow.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]
+        L.ro_flow_to_s16_grid4.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.ro_jacobi_eig.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ro_inverse.restype = C.c_int
         L.ro_inverse.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
@@ -307,3 +310,21 @@ def adds(R_est, t_est, R_gt, t_gt, pts):
 def auc(distances):
     d = _f64(distances)
     return lib().ro_auc(_p(d), d.size)
+
+
+def optical_flow(prev, cur, levels=3, radius=3, iterations=3, det_min=100.0):
+    prev = np.ascontiguousarray(prev, np.uint8)
+    cur = np.ascontiguousarray(cur, np.uint8)
+    H, W = prev.shape
+    flow = np.zeros((H, W, 2), np.float32)
+    rc = lib().ro_optical_flow(_p(prev), _p(cur), W, H, levels, radius, iterations, np.float32(det_min), _p(flow))
+    assert rc == 0
+    return flow
+
+
+def flow_to_s16_grid4(flow):
+    flow = np.ascontiguousarray(flow, np.float32)
+    H, W = flow.shape[:2]
+    out = np.zeros((H // 4, W // 4, 2), np.int16)
+    lib().ro_flow_to_s16_grid4(_p(flow), W, H, _p(out))
+    return out

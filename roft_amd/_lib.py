@@ -37,6 +37,10 @@ class UT(C.Structure):
     _fields_ = [("alpha", C.c_double), ("beta", C.c_double), ("kappa", C.c_double)]
 
 
+class OFParams(C.Structure):
+    _fields_ = [("levels", C.c_int), ("radius", C.c_int), ("iterations", C.c_int), ("det_min", C.c_float)]
+
+
 class Mesh(C.Structure):
     _fields_ = [("verts", C.c_void_p), ("n_verts", C.c_int), ("tris", C.c_void_p), ("n_tris", C.c_int)]
 
@@ -78,7 +82,8 @@ ABI_SYMBOLS = [
     "roft_default_object", "roft_engine_create", "roft_engine_destroy", "roft_object_add",
     "roft_frame_submit", "roft_step", "roft_sync", "roft_get_state", "roft_get_outputs", "roft_get_mask",
     "roft_engine_enable_log", "roft_engine_get_log", "roft_engine_stream", "roft_engine_enable_timing",
-    "roft_engine_get_timing",
+    "roft_engine_get_timing", "roft_default_of_params", "roft_optical_flow", "roft_flow_producer_create",
+    "roft_flow_producer_destroy", "roft_flow_producer_run", "roft_flow_producer_sync", "roft_flow_producer_stream",
 ]
 
 
@@ -136,9 +141,17 @@ def lib():
     L.roft_engine_enable_timing.argtypes = [vp, C.c_int]
     L.roft_engine_get_timing.argtypes = [vp, ip, C.POINTER(C.POINTER(C.c_char_p)), C.POINTER(C.POINTER(C.c_float)),
                                          C.POINTER(ip)]
+    L.roft_default_of_params.argtypes = [C.POINTER(OFParams)]
+    L.roft_optical_flow.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(OFParams), C.c_int, vp]
+    L.roft_flow_producer_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(OFParams), C.c_int, C.c_int, C.POINTER(vp)]
+    L.roft_flow_producer_destroy.argtypes = [vp]
+    L.roft_flow_producer_run.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int]
+    L.roft_flow_producer_sync.argtypes = [vp]
+    L.roft_flow_producer_stream.restype = vp
+    L.roft_flow_producer_stream.argtypes = [vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
-        if name not in ("roft_last_error_string", "roft_engine_stream"):
+        if name not in ("roft_last_error_string", "roft_engine_stream", "roft_flow_producer_stream"):
             f.restype = C.c_int
     _lib = L
     return L

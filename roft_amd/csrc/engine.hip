@@ -36,6 +36,15 @@ int fail(int code, const std::string& msg)
     return code;
 }
 
+}  // namespace
+
+namespace roft {
+// shared with flow_producer.hip
+int set_last_error(int code, const std::string& msg) { return fail(code, msg); }
+}  // namespace roft
+
+namespace {
+
 #define HIP_TRY(expr)                                                                                      \
     do {                                                                                                   \
         hipError_t _e = (expr);                                                                            \

@@ -9,6 +9,7 @@ Names follow the reference's classes (hsp-iit/roft `src/roft-lib`):
   ukf_correct       <- ROFT::UKFCorrection::correctStep(CartesianQuaternionMeasurement)
   render_depth      <- SICAD::superimpose(..., depth)
   depth_likelihood  <- ROFTFilter::pick_best_alternative (inner loop)
+  optical_flow      <- ImageOpticalFlowNVOF::step_frame (the product contract; the algorithm is this project's own)
 All of them run on the GPU; none has a CPU fallback.
 """
 import ctypes as C
@@ -129,3 +130,57 @@ def depth_likelihood(cam, depth, mask, tile, divider):
     L.check(L.lib().roft_depth_likelihood(C.byref(cam), _p(depth), _p(mask), _p(tile), divider, C.byref(Lv),
                                           C.byref(ns)))
     return Lv.value, ns.value
+
+
+def of_params(levels=3, radius=3, iterations=3, det_min=100.0):
+    p = L.OFParams()
+    L.check(L.lib().roft_default_of_params(C.byref(p)))
+    p.levels, p.radius, p.iterations, p.det_min = levels, radius, iterations, det_min
+    return p
+
+
+def optical_flow(prev_gray, cur_gray, flow_type=L.FLOW_F32C2, **kw):
+    """Forward flow of `prev_gray` pixels towards `cur_gray` (u8, H x W).  CV_32FC2: float (H, W, 2); CV_16SC2: int16
+    (H/4, W/4, 2) S10.5 -- the two products of ImageOpticalFlowNVOF.cpp:19-80."""
+    prev = np.ascontiguousarray(prev_gray, np.uint8)
+    cur = np.ascontiguousarray(cur_gray, np.uint8)
+    if prev.shape != cur.shape or prev.ndim != 2:
+        raise ValueError("two gray images of the same shape expected")
+    H, W = prev.shape
+    out = np.zeros((H, W, 2), np.float32) if flow_type == L.FLOW_F32C2 else np.zeros((H // 4, W // 4, 2), np.int16)
+    p = of_params(**kw)
+    L.check(L.lib().roft_optical_flow(_p(prev), _p(cur), W, H, C.byref(p), flow_type, _p(out)))
+    return out
+
+
+class FlowProducer:
+    """Batched device-resident producer (roft_flow_producer_*): `run` takes lists of device pointers."""
+
+    def __init__(self, width, height, max_pairs, flow_type=L.FLOW_F32C2, device=0, **kw):
+        self._h = C.c_void_p()
+        self.width, self.height, self.max_pairs, self.flow_type = width, height, max_pairs, flow_type
+        p = of_params(**kw)
+        L.check(L.lib().roft_flow_producer_create(width, height, max_pairs, C.byref(p), flow_type, device, C.byref(self._h)))
+
+    def run(self, prev_ptrs, cur_ptrs, out_ptrs):
+        n = len(prev_ptrs)
+        arr = C.c_void_p * n
+        L.check(L.lib().roft_flow_producer_run(self._h, arr(*prev_ptrs), arr(*cur_ptrs), arr(*out_ptrs), n))
+
+    def sync(self):
+        L.check(L.lib().roft_flow_producer_sync(self._h))
+
+    @property
+    def stream(self):
+        return L.lib().roft_flow_producer_stream(self._h)
+
+    def close(self):
+        if self._h:
+            L.lib().roft_flow_producer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

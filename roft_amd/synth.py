@@ -142,6 +142,7 @@ class Stream:
     gt: Trajectory = None
     dt: float = 1.0 / 30.0
     mesh: tuple = field(default=None, repr=False)
+    gray: torch.Tensor = None  # [F, H, W] u8 textured intensity image (only with with_gray=True)
 
     @property
     def n_frames(self):
@@ -171,10 +172,22 @@ def _render_box(cam, half, x, R, device):
     return torch.where(hit, tn, torch.full_like(tn, float("inf")))
 
 
+def _texture(P, scale):
+    """Smooth procedural texture attached to 3-D surface points P [..., 3] (metres): a few sinusoids of
+    wavelength ~scale, so that brightness is constant along the motion of a surface point."""
+    k = 2.0 * math.pi / scale
+    t = (torch.sin(k * (1.00 * P[..., 0] + 0.37 * P[..., 1] + 0.21 * P[..., 2])) +
+         torch.sin(k * (-0.43 * P[..., 0] + 0.91 * P[..., 1] + 0.55 * P[..., 2]) * 1.31 + 1.0) +
+         torch.sin(k * (0.29 * P[..., 0] - 0.47 * P[..., 1] + 1.07 * P[..., 2]) * 0.77 + 2.0) +
+         0.6 * torch.sin(k * (0.83 * P[..., 0] + 0.59 * P[..., 1] - 0.35 * P[..., 2]) * 2.3 + 0.5))
+    return 128.0 + 30.0 * t
+
+
 def make_stream(seed, n_frames, camera=None, flow_type=FLOW_F32C2, half_extents=CRACKER_BOX_HALF_EXTENTS,
                 device="cpu", background_z=1.5, mask_period=6, pose_period=6, depth_noise=1e-3,
                 depth_dropout=0.02, flow_invalid=0.005, pose_noise_x=0.005, pose_noise_rot=math.radians(2.0),
-                pose_outlier_prob=0.10, pose_drop_prob=0.03, mask_dilate=1, speed=1.0, mesh_n=36, chunk=8):
+                pose_outlier_prob=0.10, pose_drop_prob=0.03, mask_dilate=1, speed=1.0, mesh_n=36, chunk=8,
+                with_gray=False):
     cam = camera or Camera.shape_a()
     dt = 1.0 / 30.0
     gt = make_trajectory(seed, n_frames, dt, speed)
@@ -192,6 +205,7 @@ def make_stream(seed, n_frames, camera=None, flow_type=FLOW_F32C2, half_extents=
                        dtype=torch.int16 if flow_type == FLOW_S16C2 else torch.float32)
     u = torch.arange(W, device=device, dtype=torch.float64)[None, None, :]
     v = torch.arange(H, device=device, dtype=torch.float64)[None, :, None]
+    gray = torch.empty(n_frames, H, W, device=device, dtype=torch.uint8) if with_gray else None
     for k0 in range(0, n_frames, chunk):
         k1 = min(n_frames, k0 + chunk)
         f = k1 - k0
@@ -202,6 +216,13 @@ def make_stream(seed, n_frames, camera=None, flow_type=FLOW_F32C2, half_extents=
         noise = torch.randn(f, H, W, generator=g, dtype=torch.float32, device=device) * depth_noise
         drop = torch.rand(f, H, W, generator=g, device=device) < depth_dropout
         depth[k0:k1] = torch.where(drop, torch.zeros((), device=device), z_clean.float() + noise)
+        if with_gray:
+            Pc = torch.stack([(u - cam.cx) / cam.fx * z_clean, (v - cam.cy) / cam.fy * z_clean, z_clean], -1)
+            Rf = torch.as_tensor(Rall[k0:k1], device=device)
+            xf = torch.as_tensor(gt.x[k0:k1], device=device)[:, None, None, :]
+            Pobj = torch.einsum("fhwj,fji->fhwi", Pc - xf, Rf)            # R^T (P - x)
+            tex = torch.where(hit, _texture(Pobj, 0.035), _texture(Pc, 0.12))
+            gray[k0:k1] = tex.clamp(0, 255).round().to(torch.uint8)
 
         # forward flow of frame k pixels towards frame k+1 (stored as flow[k+1]): back-project with
         # the clean depth of frame k, move object points rigidly with the GT motion, re-project.
@@ -260,7 +281,7 @@ def make_stream(seed, n_frames, camera=None, flow_type=FLOW_F32C2, half_extents=
     flow_valid = np.ones(n_frames, bool)
     flow_valid[0] = False
     return Stream(cam, flow_type, grid, scale, tuple(half_extents), depth, flow, flow_valid, mask_gt, mask_delivery,
-                  pose_valid, pose_meas, gt, dt, box_mesh(half_extents, mesh_n))
+                  pose_valid, pose_meas, gt, dt, box_mesh(half_extents, mesh_n), gray)
 
 
 def initial_pose_from_stream(stream):
