@@ -127,6 +127,7 @@ def main():
     for k in range(args.warmup, n_timed_end):
         eng.submit_raw(inputs[k][0])
         eng.step()
+    host_enqueue = time.perf_counter() - t0   # host side of the loop (frame programs + launches), GPU still running
     eng.sync()
     torch.cuda.synchronize()
     barrier()
@@ -273,6 +274,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
+        "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,

@@ -166,11 +166,13 @@ typedef struct {
 } roft_object_desc;
 
 /* One object's inputs for one frame.  Image pointers are HOST or DEVICE memory according to
- * mem_kind.  DEVICE buffers are used in place (zero copy) and must stay valid and unmodified for
- * the next ROFT_RETAIN_FRAMES steps (previous depth, buffered flows and the outlier-rejection
- * features of ROFTFilter.cpp:624-646 are references into them).  HOST buffers are copied into the
+ * mem_kind.  DEVICE buffers are used in place (zero copy): previous depth, the buffered flows a new mask is
+ * chased through and the outlier-rejection features of ROFTFilter.cpp:624-646 are references into them, and
+ * the engine keeps several frames in flight.  A DEVICE buffer handed over for frame k must therefore stay
+ * valid and unmodified until roft_frame_submit() for frame k + ROFT_RETAIN_FRAMES has returned (that call
+ * blocks until every frame that can still read it has finished on the GPU).  HOST buffers are copied into the
  * engine's own ring before roft_frame_submit returns. */
-#define ROFT_RETAIN_FRAMES 8
+#define ROFT_RETAIN_FRAMES 16
 typedef struct {
     double dt;            /* RGB stamp delta; <= 0 means cfg.sample_time */
     const float* depth;   /* H x W metres, 0 = invalid; required */

@@ -16,7 +16,7 @@ FLOW_S16C2 = 11
 FLOW_F32C2 = 13
 MEAS_NONE, MEAS_VELOCITY, MEAS_POSE, MEAS_POSE_VELOCITY = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
-RETAIN_FRAMES = 8
+RETAIN_FRAMES = 16
 
 
 class RoftError(RuntimeError):

@@ -201,7 +201,18 @@ struct roft_engine {
     Arrays arr;
     hipStream_t stream = nullptr;       // image chain: uploads, mask stage, flow measurement, velocity filter
     hipStream_t pose_stream = nullptr;  // pose chain: features, UKF steps, outlier rejection
-    static constexpr int kCtrlRing = 4; // device FrameCtrl blocks in flight (image chain leads by <= 2 frames)
+    // Frames in flight.  The image chain of frame k+1 does not depend on the pose chain of frame k, so it runs
+    // ahead of it by up to kLead frames (a pose re-sync frame costs the pose chain ~5 ordinary frames; the lead
+    // absorbs it).  The host may be kMaxInFlight frames ahead of the slowest chain; rings are sized for that:
+    //   device FrameCtrl ring / events kCtrlRing > kMaxInFlight;  plane ring kPlaneSlots > kLead + 1;
+    //   twist ring kTwistRing > kLead + pose_frames_between + 2;
+    //   caller buffers: frame m is read until frame m + kMaxFlowHist - 1 ends, and roft_frame_submit(j) returns
+    //   only when frame j - kMaxInFlight has ended  =>  ROFT_RETAIN_FRAMES >= kMaxInFlight + kMaxFlowHist.
+    static constexpr int kLead = 6;
+    static constexpr int kMaxInFlight = 10;
+    static constexpr int kCtrlRing = 16;
+    static_assert(kMaxInFlight + kMaxFlowHist <= ROFT_RETAIN_FRAMES, "caller buffer retention");
+    static_assert(kLead + 1 < kPlaneSlots && kMaxInFlight < kCtrlRing, "ring sizes");
     DevBuf<FrameCtrl> dctrl[kCtrlRing];
     hipEvent_t ev_img[kCtrlRing] = {};
     hipEvent_t ev_pose[kCtrlRing] = {};
@@ -210,7 +221,7 @@ struct roft_engine {
     std::vector<HostObject*> objs;
     std::vector<ObjParams> h_params;
     // pinned staging ring for FrameCtrl blocks
-    static constexpr int kStage = 8;
+    static constexpr int kStage = 16;
     FrameCtrl* stage[kStage] = {};
     hipEvent_t stage_ev[kStage] = {};
     int stage_idx = 0;
@@ -309,14 +320,12 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
     e->cfg = *cfg;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     // The image chain of frame k+1 does not depend on the pose chain of frame k (only the other way round,
-    // through the twist ring and the mask planes), so the two CAN run on separate HIP streams
-    // (ROFT_TWO_STREAMS=1).  Measured on MI355X / ROCm 7.2 (profiles/README.md): the two cross-queue event
-    // waits per frame cost more than the overlap wins at 64 objects (0.64 vs 0.40 ms per frame), so one
-    // stream is the default.
+    // through the twist ring and the mask planes), so the two run on separate HIP streams, ordered by one
+    // event per frame in each direction.  ROFT_ONE_STREAM=1 serialises everything on one stream (debugging).
     const char* ku = getenv("ROFT_MEMCPY_UPLOAD");
     e->kernel_upload = !(ku && ku[0] == '1');
-    const char* two = getenv("ROFT_TWO_STREAMS");
-    e->two_streams = (two && two[0] == '1');
+    const char* one = getenv("ROFT_ONE_STREAM");
+    e->two_streams = !(one && one[0] == '1');
     if (e->two_streams) HIP_TRY(hipStreamCreateWithFlags(&e->pose_stream, hipStreamNonBlocking));
     else e->pose_stream = e->stream;
     for (int i = 0; i < roft_engine::kCtrlRing; ++i) {
@@ -519,6 +528,9 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
 
     const int si = e->stage_idx;
     HIP_TRY(hipEventSynchronize(e->stage_ev[si]));  // staging block free again?
+    // bound the frames in flight (see roft_engine::kMaxInFlight): frame j - kMaxInFlight must have ended
+    if (e->frame_counter >= roft_engine::kMaxInFlight)
+        HIP_TRY(hipEventSynchronize(e->ev_pose[(e->frame_counter - roft_engine::kMaxInFlight) % roft_engine::kCtrlRing]));
     FrameCtrl* blk = e->stage[si];
     e->max_steps = 0;
     e->any_new_mask = e->any_outlier = e->any_feat0 = e->any_feat1 = false;
@@ -647,10 +659,9 @@ int roft_step(roft_engine* e)
     hipStream_t s = e->stream, sp = e->pose_stream;
     const int si = e->stage_idx;
     const int ci = e->frame_counter % roft_engine::kCtrlRing;
-    // throttle: the image chain may lead the pose chain by at most two frames (bit-plane ring, depth ring,
-    // twist ring and this FrameCtrl ring are sized for that)
-    if (e->two_streams && e->frame_counter >= 2)
-        HIP_TRY(hipStreamWaitEvent(s, e->ev_pose[(e->frame_counter - 2) % roft_engine::kCtrlRing], 0));
+    // throttle: the image chain leads the pose chain by at most kLead frames
+    if (e->two_streams && e->frame_counter >= roft_engine::kLead)
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_pose[(e->frame_counter - roft_engine::kLead) % roft_engine::kCtrlRing], 0));
     a.ctrl = e->dctrl[ci].p;
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
     if (e->kernel_upload) {
@@ -691,7 +702,7 @@ int roft_step(roft_engine* e)
         }
     }
     if (e->any_feat1) { launch_features(a, 1, sp); tmark(e, "features", 1); }
-    if (e->two_streams) HIP_TRY(hipEventRecord(e->ev_pose[ci], sp));
+    HIP_TRY(hipEventRecord(e->ev_pose[ci], sp));
     HIP_TRY(hipGetLastError());
     e->frame_counter++;
     e->submitted = false;

@@ -21,6 +21,10 @@
 // decomposition.  Products this small (12x12x49) do not fill an MFMA tile batch; plain fp64 FMA.
 #include "roft_device.h"
 
+// Nothing in this file is compared bit for bit with the oracle (the UKF agrees with it to rounding, not exactly),
+// so fused multiply-adds are welcome here although the build default is -ffp-contract=off.
+#pragma clang fp contract(fast)
+
 namespace roft {
 
 // phase cycle counters (build with -DROFT_UKF_PROFILE): TICK(L, i) adds the shader cycles since the
@@ -73,6 +77,7 @@ struct UkfLds {
     double P[144];       // matrix being decomposed (destroyed)
     double V[144];       // its eigenvectors (columns)
     double wP[12];       // its eigenvalues
+    double S[144];       // matrix square root the sigma points are drawn from (see decompose_state_cov)
     double Q[100];       // process noise block padded to 10 x 10
     double VQ[100];
     double wQ[10];
@@ -115,18 +120,29 @@ __device__ __forceinline__ double fast_rsqrt(double d)
     return y;
 }
 
-// Symmetric Schur rotation annihilating apq (apq != 0):
+// Symmetric Schur rotation (almost) annihilating apq (apq != 0):
 //   tau = (aqq - app) / (2 apq),  t = sgn(tau) / (|tau| + sqrt(1 + tau^2)),  c = 1/sqrt(1 + t^2),  s = t c
 // evaluated division-free as t = sgn * |b| / (|a| + sqrt(a^2 + b^2)) with a = aqq - app, b = 2 apq.
+// The angle only steers convergence, so t is computed in SINGLE precision (v_rsq_f32 / v_rcp_f32, after scaling
+// a and b by a power of two into float range); what must hold to double accuracy is c^2 + s^2 = 1, and c comes
+// from a double Newton refinement of the float seed of 1/sqrt(1 + t^2).  The caller applies the rotation to the
+// pivot block like to any other block (the off-diagonal is left at ~1e-7 |apq| instead of being forced to 0).
 __device__ __forceinline__ void schur_rotation(double app, double aqq, double apq, double& c, double& s)
 {
     const double a = aqq - app, b = 2.0 * apq;
-    const double h2 = a * a + b * b;
-    const double hyp = h2 * fast_rsqrt(h2);
-    const double sgn = ((a >= 0.0) == (b >= 0.0) || a == 0.0) ? 1.0 : -1.0;
-    const double t = sgn * fabs(b) * fast_rcp(fabs(a) + hyp);
-    c = fast_rsqrt(1.0 + t * t);
-    s = t * c;
+    const int e = __builtin_amdgcn_frexp_exp(fmax(fabs(a), fabs(b)));
+    const float af = fabsf((float)ldexp(a, -e)), bf = fabsf((float)ldexp(b, -e));   // max(af, bf) in [0.5, 1)
+    const float h2 = af * af + bf * bf;
+    const float hyp = h2 * __builtin_amdgcn_rsqf(h2);
+    const float tf = bf * __builtin_amdgcn_rcpf(af + hyp);
+    const double t = ((a >= 0.0) == (b >= 0.0) || a == 0.0) ? (double)tf : -(double)tf;
+    const double x = fma(t, t, 1.0);
+    double y = (double)__builtin_amdgcn_rsqf((float)x);
+    const double hx = 0.5 * x;
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    y = fma(y, fma(-hx * y, y, 0.5), y);
+    c = y;
+    s = t * y;
 }
 
 // Symmetric Jacobi eigen-decomposition in LDS, n even (<= 12), executed by one wave.
@@ -139,6 +155,11 @@ __device__ __forceinline__ void schur_rotation(double app, double aqq, double ap
 // gets the two rotations by wave shuffle from the lanes owning the diagonal blocks (a, a), (b, b)
 // -- which computed them from their own registers -- and writes 4 + 4 values back.  One LDS round
 // trip and one barrier per round; no rotation parameters ever go through memory.
+#ifndef ROFT_JACOBI_TOL
+#define ROFT_JACOBI_TOL 1e-6
+#endif
+constexpr double kJacobiTol = ROFT_JACOBI_TOL;
+
 __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
 {
     const int lane = threadIdx.x;
@@ -155,10 +176,9 @@ __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
             if (r == cidx) dg += v * v; else if (r < cidx) off += v * v;
         }
         for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
-        // converged when ||off-diagonal|| <= 1e-11 ||diagonal||: the sigma points (square root of P) are then
-        // accurate to ~1e-11 relative, i.e. ~1e-14 absolute on a pose covariance of 1e-3 -- far below the filter's
-        // own noise floor and the stated parity tolerance, and it saves the last, almost idle, sweep
-        if (off <= 1e-22 * dg || off == 0.0) break;
+        // stop when ||off-diagonal|| <= kJacobiTol ||diagonal||; decompose_state_cov() absorbs the remaining
+        // off-diagonal part into the square root to first order
+        if (off <= kJacobiTol * kJacobiTol * dg || off == 0.0) break;
 #ifdef ROFT_UKF_PROFILE
         if (lane == 0) L.dbg[16 + (n == 12 ? 0 : (n == 4 ? 1 : 2))] += 1;
 #endif
@@ -193,7 +213,7 @@ __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
                 // rows (p_a, q_a)
                 double c00 = ca * b00 - sa * b10, c10 = sa * b00 + ca * b10;
                 double c01 = ca * b01 - sa * b11, c11 = sa * b01 + ca * b11;
-                if (ba == bb && s != 0.0) { c01 = 0.0; c10 = 0.0; }
+                if (ba == bb) { c01 = c10 = 0.5 * (c01 + c10); }   // keep the pivot block symmetric
                 A[pa * n + pb] = c00; A[pa * n + qb] = c01; A[qa * n + pb] = c10; A[qa * n + qb] = c11;
                 V[pa * n + pb] = cb * v00 - sb * v01; V[pa * n + qb] = sb * v00 + cb * v01;
                 V[qa * n + pb] = cb * v10 - sb * v11; V[qa * n + qb] = sb * v10 + cb * v11;
@@ -398,8 +418,7 @@ __device__ void sigma_perturbation(int col, int r, double sc, bool noise_eig, co
     const int k = (col - 1) % n;
     const double sgn = (col <= n) ? 1.0 : -1.0;
     if (k < 12) {
-        const double s = sqrt(fabs(L.wP[k]));
-        for (int i = 0; i < 12; ++i) d[i] = sgn * sc * L.V[i * 12 + k] * s;
+        for (int i = 0; i < 12; ++i) d[i] = sgn * sc * L.S[i * 12 + k];
     } else {
         const int kk = k - 12;
         if (noise_eig) {
@@ -461,6 +480,32 @@ __device__ void decompose_state_cov(UkfLds& L, double* warm, int* warm_age)
     if (warm) {
         for (int i = lane; i < 144; i += 64) warm[i] = L.V[i];
         if (lane == 0) *warm_age = use ? age + 1 : 1;
+    }
+    // Square root.  The Jacobi sweeps stop at B = V' cov V = D + E with a small off-diagonal rest E
+    // (||E|| <= kJacobiTol ||D||) instead of running one more sweep to annihilate it.  The symmetric square root of
+    // B is D^1/2 + X + O(E^2) with X_ij = E_ij / (sqrt(d_i) + sqrt(d_j)) -- no eigenvalue gap in the denominator --
+    // so S = V (D^1/2 + X) satisfies S S' = cov up to O(E^2) ~ 1e-12 relative, and S equals the exact U sqrt(Lambda)
+    // times an orthogonal matrix within O(E) of the identity: the sigma set the reference draws, to rounding.
+    {
+        double* M = L.KPy;   // scratch, free until the correction computes it
+        for (int e = lane; e < 144; e += 64) {
+            const int i = e / 12, j = e % 12;
+            const double si = sqrt(fabs(L.wP[i])), sj = sqrt(fabs(L.wP[j]));
+            double m;
+            if (i == j) m = si;
+            else {
+                const double eij = 0.5 * (L.P[i * 12 + j] + L.P[j * 12 + i]);
+                m = (si + sj > 0.0) ? eij / (si + sj) : 0.0;
+            }
+            M[e] = m;
+        }
+        __syncthreads();
+        for (int e = lane; e < 144; e += 64) {
+            const int i = e / 12, j = e % 12;
+            double acc = 0.0;
+            for (int k = 0; k < 12; ++k) acc += L.V[i * 12 + k] * M[k * 12 + j];
+            L.S[e] = acc;
+        }
     }
     __syncthreads();
 }
@@ -565,7 +610,7 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
     TICK(L, 5);
 }
 
-// ---- correction of (L.mean, L.cov) [decomposition already in L.V / L.wP] -> out ------------------------
+// ---- correction of (L.mean, L.cov) [decomposition already in L.S] -> out ------------------------
 // returns status: 0 corrected, 1 no measurement, 2 singular Py
 __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const double* twist, const double* pose_x,
                            const double* pose_q, const roft_ut_params& ut, PoseBelief* out)
@@ -786,19 +831,18 @@ __device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const rof
 // pose re-sync need no other kernel in between, so they share one launch).
 __global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step0, int step1, roft_ut_params ut)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    UkfLds& L = *reinterpret_cast<UkfLds*>(smem);
+    // static LDS on purpose: with `extern __shared__` the compiler re-reads the dynamic-LDS base address from a
+    // table in global memory inside every Jacobi round (two dependent global loads per round)
+    __shared__ UkfLds L;
     for (int step = step0; step < step1; ++step) {
         ukf_one_step(a, blockIdx.x, step, ut, L);
         __syncthreads();   // beliefs written by this step are read by the next one (same workgroup)
     }
 }
 
-static size_t ukf_lds_bytes() { return (sizeof(UkfLds) + 15) & ~(size_t)15; }
-
 void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s)
 {
-    hipLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(64), ukf_lds_bytes(), s, a, step0, step1, ut);
+    hipLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(64), 0, s, a, step0, step1, ut);
 }
 
 }  // namespace roft

@@ -14,7 +14,7 @@ namespace roft {
 
 constexpr int kWave = 64;              // CDNA wavefront
 constexpr int kNumBelief = 6;          // pose belief slots per object
-constexpr int kTwistRing = 16;         // twist history ring (velocity deque of the measurement model)
+constexpr int kTwistRing = 32;         // twist history ring (velocity deque of the measurement model + frames in flight)
 constexpr int kMaxFlowHist = 6;        // flows a new mask can be chased through (frames between masks)
 constexpr int kMaxSteps = 10;          // UKF launches per frame (re-sync replays <= 7)
 constexpr int kPlaneSlots = ROFT_RETAIN_FRAMES;  // mask bit-plane ring per object

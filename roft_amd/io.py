@@ -216,6 +216,8 @@ def read_png(path):
             cur = line
         elif ft == 2:
             cur = (line + prev) & 255
+        elif ft == 1:   # Sub: running sum per channel
+            cur = (np.cumsum(line.reshape(-1, ch), axis=0) & 255).reshape(-1).astype(np.int32)
         else:
             cur = np.zeros(stride, np.int32)
             for x in range(stride):
@@ -238,14 +240,36 @@ def read_png(path):
     return out.reshape(h, w) if ch == 1 else out.reshape(h, w, ch)
 
 
+def write_png(path, img):
+    """8-bit gray [H, W] or RGB(A) [H, W, C] PNG, filter 0 (used by the synthetic dataset writer and the tests)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    ctype = {1: 0, 2: 4, 3: 2, 4: 6}[ch]
+    raw = np.zeros((h, w * ch + 1), np.uint8)
+    raw[:, 1:] = img.reshape(h, w * ch)
+
+    def chunk(t, b):
+        return struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) +
+                chunk(b"IDAT", zlib.compress(raw.tobytes(), 3)) + chunk(b"IEND", b""))
+
+
+def rgb_to_gray(img):
+    """cv::cvtColor(..., COLOR_BGR2GRAY) on 8-bit data: fixed point, (R*4899 + G*9617 + B*1868 + 2^13) >> 14.
+    `img` is [H, W, >=3] in R,G,B order (as PNG stores it); a gray image passes through."""
+    if img.ndim == 2:
+        return img
+    c = img[..., :3].astype(np.int32)
+    return ((c[..., 0] * 4899 + c[..., 1] * 9617 + c[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+
+
 def read_mask_png(path):
     """Mask as ImageSegmentationMeasurement sees it before thresholding: colour images are converted to gray
-    (BGR2GRAY weights), src/roft-lib/src/ImageSegmentationMeasurement.cpp:62-63."""
-    img = read_png(path)
-    if img.ndim == 3:
-        rgb = img[..., :3].astype(np.float64)
-        img = np.clip(np.rint(0.299 * rgb[..., 0] + 0.587 * rgb[..., 1] + 0.114 * rgb[..., 2]), 0, 255).astype(np.uint8)
-    return img
+    (cv::cvtColor BGR2GRAY), src/roft-lib/src/ImageSegmentationMeasurement.cpp:62-63."""
+    return rgb_to_gray(read_png(path))
 
 
 # ---- a Fast-YCB style sequence --------------------------------------------------------------------------

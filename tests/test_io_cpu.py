@@ -169,3 +169,33 @@ def test_sequence_reader_feeds_the_engine_format(tmp_path):
     assert np.array_equal(f6["mask"], st.mask_gt[0].numpy()) and np.array_equal(f6["depth"], st.depth[6].numpy())
     assert np.allclose(f6["pose"][0], st.gt.x[0]) and abs(abs(np.dot(f6["pose"][1], st.gt.q[0])) - 1) < 1e-12
     assert abs(f6["dt"] - 1 / 30.0) < 1e-6
+
+
+def test_png_writer_and_gray_conversion(tmp_path):
+    rng = np.random.default_rng(3)
+    for shape in ((7, 9), (5, 6, 3), (4, 4, 4)):
+        img = rng.integers(0, 256, shape, dtype=np.uint8)
+        p = str(tmp_path / "w.png")
+        io.write_png(p, img)
+        assert np.array_equal(io.read_png(p), img)
+    # cv::cvtColor BGR2GRAY fixed-point known answers
+    rgb = np.array([[[255, 255, 255], [0, 0, 0], [255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 77]]], np.uint8)
+    assert io.rgb_to_gray(rgb).tolist() == [[255, 0, 76, 150, 29, 129]]
+    g = rng.integers(0, 256, (3, 3), dtype=np.uint8)
+    assert io.rgb_to_gray(g) is g
+
+
+def test_flow_dumper_argument_errors(capsys):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("flow_dumper", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "flow_dumper.py"))
+    fd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fd)
+    assert fd.main(["x"]) == 1
+    assert "Synopsis: ROFT-of-dumper" in capsys.readouterr().err
+    base = ["x", "/nonexistent", "txt", "png", "6", "0", "640", "480"]
+    assert fd.main(base + ["nvof3", "/tmp/out"]) == 1
+    assert 'Invalid <nvof_version> "nvof3"' in capsys.readouterr().err
+    bad = list(base)
+    bad[4] = "six"
+    assert fd.main(bad + ["nvof1", "/tmp/out"]) == 1
+    assert "Invalid value six for parameter <heading_zeros>." in capsys.readouterr().err

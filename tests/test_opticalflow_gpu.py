@@ -130,3 +130,33 @@ def test_tracker_fed_by_the_produced_flow():
         eng.close()
     assert errs["produced"] < 0.02, errs
     assert errs["produced"] < errs["analytic"] + 0.01, errs
+
+
+def test_flow_dumper_writes_the_reference_file_layout(tmp_path):
+    """tools/flow_dumper.py (the ROFT-of-dumper counterpart): RGB PNG frames in, `<index>.float` files out."""
+    import importlib.util
+    import os
+
+    from roft_amd import io
+    st, gray = gray_stream(76, 5)
+    H, W = gray.shape[1:]
+    root = tmp_path / "seq"
+    (root / "rgb").mkdir(parents=True)
+    rgbs = []
+    for k in range(5):
+        rgb = np.stack([gray[k], np.roll(gray[k], 1, 0), 255 - gray[k]], -1)   # three different channels
+        rgbs.append(io.rgb_to_gray(rgb))
+        io.write_png(str(root / "rgb" / ("%06d.png" % (k + 2))), rgb)
+    np.savetxt(str(root / "data.txt"), np.zeros((5, 9)))
+    spec = importlib.util.spec_from_file_location("flow_dumper", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                              "tools", "flow_dumper.py"))
+    fd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fd)
+    for nvof, ft in (("nvof1", L.FLOW_S16C2), ("nvof2", L.FLOW_F32C2)):
+        out = tmp_path / nvof
+        assert fd.main(["x", str(root), "txt", "png", "6", "2", str(W), str(H), nvof, str(out)]) == 0
+        assert sorted(os.listdir(out)) == ["%06d.float" % i for i in range(3, 7)]
+        for k in range(1, 5):
+            ok, fl = io.read_flow(str(out / ("%06d.float" % (k + 2))))
+            assert ok and np.array_equal(fl, ops.optical_flow(rgbs[k - 1], rgbs[k], flow_type=ft))
+            assert io.flow_format(fl, W) == ((11, 4, 32.0) if nvof == "nvof1" else (13, 1, 1.0))
