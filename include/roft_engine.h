@@ -149,6 +149,19 @@ typedef struct {
     int mask_frames_between;                     /* original_fps / desired_fps of the mask source */
     int pose_frames_between;                     /* original_fps / desired_fps of the pose source */
     int max_objects;
+    /* Square root the sigma points are drawn from.  The reference (bfl) uses U sqrt(S) of the eigen-decomposition
+     * of the covariance.  Any square root reproduces the first two moments; the choice only shows in fourth-order
+     * terms: of the quaternion kinematics, ~ (var(theta) + T^2 var(omega))^2, in the prediction, and of the
+     * quaternion measurement and the bilinear term w x r of the velocity measurement, ~ var(omega) var(x), in the
+     * correction.  While these are small the engine draws the sigma points from the (much cheaper) Cholesky factor
+     * and falls back to the eigen-decomposition otherwise:
+     *   prediction:  max var(theta) + T^2 max var(omega) <= ukf_cholesky_guard
+     *   correction:  max var(theta) <= ukf_cholesky_guard  and  max var(omega) max var(x) <= ukf_cholesky_guard_bilinear
+     * Measured effect on the trajectories at the defaults (2e-4, 4e-3): <= 1e-10 (m, m/s, rad/s), DESIGN.md.
+     * ukf_cholesky_guard = 0: always the eigen-decomposition; ukf_cholesky_guard_bilinear = 0: always for the
+     * correction. */
+    double ukf_cholesky_guard;
+    double ukf_cholesky_guard_bilinear;
     int device;                                  /* HIP device ordinal */
 } roft_config;
 

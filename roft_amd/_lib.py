@@ -51,7 +51,9 @@ class Config(C.Structure):
                 ("subsampling_radius", C.c_double), ("flow_weighting", C.c_int), ("use_pose", C.c_int),
                 ("use_pose_resync", C.c_int), ("use_velocity", C.c_int), ("outlier_rejection", C.c_int),
                 ("flow_aided_segmentation", C.c_int), ("mask_frames_between", C.c_int),
-                ("pose_frames_between", C.c_int), ("max_objects", C.c_int), ("device", C.c_int)]
+                ("pose_frames_between", C.c_int), ("max_objects", C.c_int), ("ukf_cholesky_guard", C.c_double),
+                ("ukf_cholesky_guard_bilinear", C.c_double),
+                ("device", C.c_int)]
 
 
 class ObjectDesc(C.Structure):

@@ -145,6 +145,8 @@ struct Arrays {
         a.out_log = nullptr;
         a.log_cap = 0;
         a.max_tris = 0;
+        a.ukf_chol_guard = 0.0;
+        a.ukf_chol_guard_bil = 0.0;
         return ROFT_OK;
     }
 };
@@ -199,7 +201,9 @@ struct HostObject {
 struct roft_engine {
     roft_config cfg{};
     Arrays arr;
-    hipStream_t stream = nullptr;       // image chain: uploads, mask stage, flow measurement, velocity filter
+    // Three in-order chains per frame, one HIP stream each (ROFT_ONE_STREAM=1 puts them on one stream):
+    hipStream_t stream = nullptr;       // mask chain: uploads, FrameCtrl, mask ingest / scatter / gather
+    hipStream_t vel_stream = nullptr;   // velocity chain: flow measurement, velocity filter
     hipStream_t pose_stream = nullptr;  // pose chain: features, UKF steps, outlier rejection
     // Frames in flight.  The image chain of frame k+1 does not depend on the pose chain of frame k, so it runs
     // ahead of it by up to kLead frames (a pose re-sync frame costs the pose chain ~5 ordinary frames; the lead
@@ -214,8 +218,10 @@ struct roft_engine {
     static_assert(kMaxInFlight + kMaxFlowHist <= ROFT_RETAIN_FRAMES, "caller buffer retention");
     static_assert(kLead + 1 < kPlaneSlots && kMaxInFlight < kCtrlRing, "ring sizes");
     DevBuf<FrameCtrl> dctrl[kCtrlRing];
-    hipEvent_t ev_img[kCtrlRing] = {};
-    hipEvent_t ev_pose[kCtrlRing] = {};
+    hipEvent_t ev_ctrl[kCtrlRing] = {};  // FrameCtrl (and host input copies) of frame k on the device
+    hipEvent_t ev_mask[kCtrlRing] = {};  // mask planes of frame k complete
+    hipEvent_t ev_vel[kCtrlRing] = {};   // twist of frame k complete
+    hipEvent_t ev_pose[kCtrlRing] = {};  // pose chain of frame k complete
     bool two_streams = false;
     bool kernel_upload = true;
     std::vector<HostObject*> objs;
@@ -239,7 +245,7 @@ struct roft_engine {
     std::vector<float> tms;
     std::vector<int> tlaunches;
     std::vector<int> tmark;    // kernel id per event interval (-1 = chain start)
-    std::vector<int> tstream;  // stream of each mark (0 image chain, 1 pose chain)
+    std::vector<int> tstream;  // stream of each mark (0 mask chain, 1 pose chain, 2 velocity chain)
 };
 
 extern "C" {
@@ -280,6 +286,8 @@ int roft_default_config(roft_config* c, int width, int height, int flow_type)
     c->mask_frames_between = 6;
     c->pose_frames_between = 6;
     c->max_objects = 64;
+    c->ukf_cholesky_guard = 2e-4;
+    c->ukf_cholesky_guard_bilinear = 4e-3;
     c->device = 0;
     return ROFT_OK;
 }
@@ -326,11 +334,17 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
     e->kernel_upload = !(ku && ku[0] == '1');
     const char* one = getenv("ROFT_ONE_STREAM");
     e->two_streams = !(one && one[0] == '1');
-    if (e->two_streams) HIP_TRY(hipStreamCreateWithFlags(&e->pose_stream, hipStreamNonBlocking));
-    else e->pose_stream = e->stream;
+    if (e->two_streams) {
+        HIP_TRY(hipStreamCreateWithFlags(&e->pose_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&e->vel_stream, hipStreamNonBlocking));
+    } else {
+        e->pose_stream = e->vel_stream = e->stream;
+    }
     for (int i = 0; i < roft_engine::kCtrlRing; ++i) {
         HIP_TRY(e->dctrl[i].ensure(cfg->max_objects, true));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_img[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_ctrl[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_mask[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&e->ev_vel[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_pose[i], hipEventDisableTiming));
     }
     DevFlowFmt ff;
@@ -343,6 +357,8 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
     if (radius <= 0) { delete e; return fail(ROFT_ERR_INVALID, "subsampling_radius must be >= 1"); }
     if (int rc = e->arr.alloc(cfg->max_objects, make_cam(cfg->cam), ff, radius)) { delete e; return rc; }
     e->arr.a.n_obj = 0;
+    e->arr.a.ukf_chol_guard = (cfg->ukf_cholesky_guard > 0.0) ? cfg->ukf_cholesky_guard : 0.0;
+    e->arr.a.ukf_chol_guard_bil = (cfg->ukf_cholesky_guard_bilinear > 0.0) ? cfg->ukf_cholesky_guard_bilinear : 0.0;
     for (int i = 0; i < roft_engine::kStage; ++i) {
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects));
         HIP_TRY(hipEventCreateWithFlags(&e->stage_ev[i], hipEventDisableTiming));
@@ -357,12 +373,16 @@ int roft_engine_destroy(roft_engine* e)
     if (!e) return ROFT_OK;
     (void)hipSetDevice(e->cfg.device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->vel_stream) (void)hipStreamSynchronize(e->vel_stream);
     if (e->pose_stream) (void)hipStreamSynchronize(e->pose_stream);
     for (int i = 0; i < roft_engine::kCtrlRing; ++i) {
-        if (e->ev_img[i]) (void)hipEventDestroy(e->ev_img[i]);
+        if (e->ev_ctrl[i]) (void)hipEventDestroy(e->ev_ctrl[i]);
+        if (e->ev_mask[i]) (void)hipEventDestroy(e->ev_mask[i]);
+        if (e->ev_vel[i]) (void)hipEventDestroy(e->ev_vel[i]);
         if (e->ev_pose[i]) (void)hipEventDestroy(e->ev_pose[i]);
     }
     if (e->two_streams && e->pose_stream) (void)hipStreamDestroy(e->pose_stream);
+    if (e->two_streams && e->vel_stream) (void)hipStreamDestroy(e->vel_stream);
     for (auto* o : e->objs) delete o;
     for (int i = 0; i < roft_engine::kStage; ++i) {
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
@@ -626,12 +646,13 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
 static void tmark(roft_engine* e, const char* name, int which = 0)
 {
     if (!e->timing) return;
+    // "vel_chain_start" is the mark in front of flow_measure_kernel: it opens that kernel's interval
+    const bool opens = name && std::strcmp(name, "vel_chain_start") == 0;
+    if (opens) name = nullptr;
     if (e->timing_level == 1) {
         // only the roofline kernel: the mark before it opens the interval, its own mark closes it
-        if (!name) return;
-        const bool opens = std::strcmp(name, "mask_propagate") == 0, closes = std::strcmp(name, "flow_measure") == 0;
+        const bool closes = name && std::strcmp(name, "flow_measure") == 0;
         if (!opens && !closes) return;
-        if (opens) name = nullptr;
     }
     const size_t idx = e->tmark.size();
     while (e->tev.size() <= idx) {
@@ -647,7 +668,7 @@ static void tmark(roft_engine* e, const char* name, int which = 0)
     }
     e->tmark.push_back(id);
     e->tstream.push_back(which);
-    (void)hipEventRecord(e->tev[idx], which ? e->pose_stream : e->stream);
+    (void)hipEventRecord(e->tev[idx], which == 1 ? e->pose_stream : (which == 2 ? e->vel_stream : e->stream));
 }
 
 int roft_step(roft_engine* e)
@@ -656,12 +677,14 @@ int roft_step(roft_engine* e)
     if (!e->submitted) return fail(ROFT_ERR_STATE, "roft_frame_submit must precede roft_step");
     HIP_TRY(hipSetDevice(e->cfg.device));
     EngineArrays a = e->arr.a;
-    hipStream_t s = e->stream, sp = e->pose_stream;
+    hipStream_t s = e->stream, sv = e->vel_stream, sp = e->pose_stream;
     const int si = e->stage_idx;
-    const int ci = e->frame_counter % roft_engine::kCtrlRing;
-    // throttle: the image chain leads the pose chain by at most kLead frames
-    if (e->two_streams && e->frame_counter >= roft_engine::kLead)
-        HIP_TRY(hipStreamWaitEvent(s, e->ev_pose[(e->frame_counter - roft_engine::kLead) % roft_engine::kCtrlRing], 0));
+    constexpr int R = roft_engine::kCtrlRing;
+    const int ci = e->frame_counter % R;
+    const bool multi = e->two_streams;
+    // throttle: the image chains lead the pose chain by at most kLead frames
+    if (multi && e->frame_counter >= roft_engine::kLead)
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_pose[(e->frame_counter - roft_engine::kLead) % R], 0));
     a.ctrl = e->dctrl[ci].p;
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
     if (e->kernel_upload) {
@@ -672,22 +695,33 @@ int roft_step(roft_engine* e)
         HIP_TRY(hipMemcpyAsync(a.ctrl, e->cur, sizeof(FrameCtrl) * a.n_obj, hipMemcpyHostToDevice, s));
     }
     HIP_TRY(hipEventRecord(e->stage_ev[si], s));
+    if (multi) HIP_TRY(hipEventRecord(e->ev_ctrl[ci], s));
     e->stage_idx = (si + 1) % roft_engine::kStage;
 
-    // ---- image chain
-    tmark(e, nullptr, 0);
+    // ---- velocity chain: needs FrameCtrl (+ host input copies) of this frame and the mask planes of the previous one
+    if (multi) {
+        HIP_TRY(hipStreamWaitEvent(sv, e->ev_ctrl[ci], 0));
+        if (e->frame_counter > 0) HIP_TRY(hipStreamWaitEvent(sv, e->ev_mask[(e->frame_counter - 1) % R], 0));
+    }
     const int radius = (int)(size_t)e->cfg.subsampling_radius;
+    tmark(e, "vel_chain_start", 2);
+    launch_flow_measure(a, e->cfg.depth_maximum, radius, false, sv);
+    tmark(e, "flow_measure", 2);
+    launch_skf(a, e->cfg.flow_weighting, sv);
+    tmark(e, "skf", 2);
+    if (multi) HIP_TRY(hipEventRecord(e->ev_vel[ci], sv));
+
+    // ---- mask chain
+    tmark(e, nullptr, 0);
     if (e->any_new_mask) { launch_mask_ingest(a, s); tmark(e, "mask_ingest", 0); }
-    launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, false, s);
+    launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, true, s);
     tmark(e, "mask_propagate", 0);
-    launch_flow_measure(a, e->cfg.depth_maximum, radius, true, s);
-    tmark(e, "flow_measure", 0);
-    launch_skf(a, e->cfg.flow_weighting, s);
-    tmark(e, "skf", 0);
-    // ---- pose chain (needs this frame's twist and mask planes; the next frame's image chain does not wait for it)
-    if (e->two_streams) {
-        HIP_TRY(hipEventRecord(e->ev_img[ci], s));
-        HIP_TRY(hipStreamWaitEvent(sp, e->ev_img[ci], 0));
+    if (multi) HIP_TRY(hipEventRecord(e->ev_mask[ci], s));
+
+    // ---- pose chain (needs this frame's twist and mask planes; the next frames' image chains do not wait for it)
+    if (multi) {
+        HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[ci], 0));
+        HIP_TRY(hipStreamWaitEvent(sp, e->ev_mask[ci], 0));
     }
     tmark(e, nullptr, 1);
     if (e->any_feat0) { launch_features(a, 0, sp); tmark(e, "features", 1); }
@@ -714,7 +748,10 @@ int roft_sync(roft_engine* e)
     if (!e) return fail(ROFT_ERR_INVALID, "null engine");
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->two_streams) HIP_TRY(hipStreamSynchronize(e->pose_stream));
+    if (e->two_streams) {
+        HIP_TRY(hipStreamSynchronize(e->vel_stream));
+        HIP_TRY(hipStreamSynchronize(e->pose_stream));
+    }
     return ROFT_OK;
 }
 
@@ -810,7 +847,7 @@ int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, 
     const size_t nk = e->tnames_s.size();
     e->tms.assign(nk, 0.f);
     e->tlaunches.assign(nk, 0);
-    long prev[2] = {-1, -1};
+    long prev[3] = {-1, -1, -1};
     for (size_t i = 0; i < e->tmark.size(); ++i) {
         const int w = e->tstream[i];
         if (e->tmark[i] >= 0 && prev[w] >= 0) {

@@ -10,11 +10,13 @@
 //   bfl sigma_point / unscented_transform / UTWeight / quaternion utils: third party
 //   (robotology/bayes-filters-lib, un-pinned); algorithm as restated in oracle/ro_ukf.c.
 //
-// MI355X design.  The whole step for one object (12-dof covariance, <= 49 sigma points) fits one
-// 64-lane wavefront with its matrices in LDS: lane = sigma point for the fan-out and the model
-// evaluations, lane = matrix entry for the weighted outer products.  The matrix square root is
-// U sqrt(S) from a Jacobi eigen-decomposition with the round-robin parallel ordering (n/2 disjoint
-// rotations per round, so a 12x12 sweep is 11 rounds instead of 66 sequential rotations).
+// MI355X design.  One workgroup of four wavefronts per object, matrices in LDS.  A UKF step is a chain of
+// small dependent phases, so its speed is the instruction latency of the critical path, not throughput:
+// thread = matrix entry for the 12x12 products (one pass of 144 threads), thread = sigma point for the fan-out
+// and the model evaluations (<= 49 threads of wave 0), and inside the Jacobi rounds wave 0 rotates the matrix
+// while wave 1 rotates the eigenvectors.  The matrix square root is U sqrt(S) from a Jacobi
+// eigen-decomposition with the round-robin parallel ordering (n/2 disjoint rotations per round, so a 12x12
+// sweep is 11 rounds instead of 66 sequential rotations).
 // The augmented covariance is block diagonal -- blkdiag(P, Q) or blkdiag(P, R) with R diagonal --
 // so only the 12x12 state block (and the 9x9 process-noise block) is ever decomposed, and when an
 // outlier-rejection step needs two corrections of the same prediction they share one
@@ -34,6 +36,16 @@ namespace roft {
 #else
 #define TICK(L, i) do {} while (0)
 #endif
+
+constexpr int kUkfThreads = 256;   // four waves, one per SIMD of the CU
+
+// ordering point for code executed by ONE wave of the workgroup (LDS traffic between its lanes)
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ---- quaternion helpers (same conventions as oracle/ro_la.c) -----------------------------------
 __device__ __forceinline__ void quat_mul(const double a[4], const double b[4], double o[4])
@@ -78,6 +90,8 @@ struct UkfLds {
     double V[144];       // its eigenvectors (columns)
     double wP[12];       // its eigenvalues
     double S[144];       // matrix square root the sigma points are drawn from (see decompose_state_cov)
+    uint2 jtab[11 * 36]; // Jacobi 12x12: per round and 2x2 block, the four entry offsets (16 bit each)
+    double cs[2][6][2];  // rotations (c, s) of the current round, double-buffered by round parity
     double Q[100];       // process noise block padded to 10 x 10
     double VQ[100];
     double wQ[10];
@@ -93,7 +107,6 @@ struct UkfLds {
     double Py[144], Pxy[144], K[144], KPy[144];
     double aug[12 * 24];
     double innov[12], Kin[12];
-    double noise_diag[12];
     double red[4];
     int flag;
     long long t0;
@@ -145,26 +158,38 @@ __device__ __forceinline__ void schur_rotation(double app, double aqq, double ap
     s = t * y;
 }
 
-// Symmetric Jacobi eigen-decomposition in LDS, n even (<= 12), executed by one wave.
-// On return diag(A) = eigenvalues, columns of V = eigenvectors.
-//
-// Round-robin parallel ordering: each round rotates n/2 disjoint index pairs (p_i, q_i).  With
-// all pairs fixed, A' = J'AJ decomposes into (n/2)^2 independent 2x2 blocks,
-//   block(a, b) = rows {p_a, q_a} x cols {p_b, q_b}   ->   R_a' * block * R_b,
-// so lane (a, b) owns one block of A and one of V for the round: it reads 4 + 4 values from LDS,
-// gets the two rotations by wave shuffle from the lanes owning the diagonal blocks (a, a), (b, b)
-// -- which computed them from their own registers -- and writes 4 + 4 values back.  One LDS round
-// trip and one barrier per round; no rotation parameters ever go through memory.
 #ifndef ROFT_JACOBI_TOL
 #define ROFT_JACOBI_TOL 1e-6
 #endif
 constexpr double kJacobiTol = ROFT_JACOBI_TOL;
 
-__device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
+// pair i (0 <= i < n/2) of round `round` of the round-robin ordering, p < q
+__device__ __forceinline__ void jacobi_pair(int n, int round, int i, int& p, int& q)
+{
+    if (i == 0) { p = n - 1; q = round; }
+    else {
+        p = round + i; if (p >= n - 1) p -= n - 1;
+        q = round - i; if (q < 0) q += n - 1;
+    }
+    if (p > q) { const int t = p; p = q; q = t; }
+}
+
+// Symmetric Jacobi eigen-decomposition in LDS, n even (<= 12).  On return diag(A) = eigenvalues (plus an
+// off-diagonal rest below kJacobiTol), columns of V = eigenvectors.
+//
+// Round-robin parallel ordering: each round rotates n/2 disjoint index pairs (p_i, q_i).  With
+// all pairs fixed, A' = J'AJ decomposes into (n/2)^2 independent 2x2 blocks,
+//   block(a, b) = rows {p_a, q_a} x cols {p_b, q_b}   ->   R_a' * block * R_b,
+// and V' = V J into as many blocks (rows {p_a, q_a} x cols {p_b, q_b}) * R_b.
+//
+// jacobi_wave(): generic n, executed by the lanes of WAVE 0 only (the other waves must not call it); lane (a, b)
+// owns one block of A and one of V, rotations travel by wave shuffle.  Used for the 10x10 explicit process noise
+// of the operator-level entry point.
+__device__ void jacobi_wave(double* A, double* V, int n, UkfLds& L)
 {
     const int lane = threadIdx.x;
     for (int i = lane; i < n * n; i += 64) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
-    __syncthreads();
+    wave_sync();
     const int half = n / 2;
     const bool active = lane < half * half;
     const int ba = active ? lane / half : 0, bb = active ? lane % half : 0;
@@ -176,41 +201,23 @@ __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
             if (r == cidx) dg += v * v; else if (r < cidx) off += v * v;
         }
         for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
-        // stop when ||off-diagonal|| <= kJacobiTol ||diagonal||; decompose_state_cov() absorbs the remaining
-        // off-diagonal part into the square root to first order
         if (off <= kJacobiTol * kJacobiTol * dg || off == 0.0) break;
-#ifdef ROFT_UKF_PROFILE
-        if (lane == 0) L.dbg[16 + (n == 12 ? 0 : (n == 4 ? 1 : 2))] += 1;
-#endif
-
         for (int round = 0; round < n - 1; ++round) {
-            // pair i of this round
-            auto pair_of = [&](int i, int& p, int& q) {
-                if (i == 0) { p = n - 1; q = round; }
-                else {
-                    p = round + i; if (p >= n - 1) p -= n - 1;
-                    q = round - i; if (q < 0) q += n - 1;
-                }
-                if (p > q) { const int t = p; p = q; q = t; }
-            };
             int pa, qa, pb, qb;
-            pair_of(ba, pa, qa);
-            pair_of(bb, pb, qb);
+            jacobi_pair(n, round, ba, pa, qa);
+            jacobi_pair(n, round, bb, pb, qb);
             double a00 = 0, a01 = 0, a10 = 0, a11 = 0, v00 = 0, v01 = 0, v10 = 0, v11 = 0;
             if (active) {
                 a00 = A[pa * n + pb]; a01 = A[pa * n + qb]; a10 = A[qa * n + pb]; a11 = A[qa * n + qb];
                 v00 = V[pa * n + pb]; v01 = V[pa * n + qb]; v10 = V[qa * n + pb]; v11 = V[qa * n + qb];
             }
             double c = 1.0, s = 0.0;
-            if (active && ba == bb && a01 != 0.0)  // diagonal block: (app, apq; apq, aqq)
-                schur_rotation(a00, a11, a01, c, s);
+            if (active && ba == bb && a01 != 0.0) schur_rotation(a00, a11, a01, c, s);
             const double ca = __shfl(c, ba * half + ba, 64), sa = __shfl(s, ba * half + ba, 64);
             const double cb = __shfl(c, bb * half + bb, 64), sb = __shfl(s, bb * half + bb, 64);
             if (active) {
-                // columns (p_b, q_b): x_p' = c x_p - s x_q, x_q' = s x_p + c x_q
                 double b00 = cb * a00 - sb * a01, b01 = sb * a00 + cb * a01;
                 double b10 = cb * a10 - sb * a11, b11 = sb * a10 + cb * a11;
-                // rows (p_a, q_a)
                 double c00 = ca * b00 - sa * b10, c10 = sa * b00 + ca * b10;
                 double c01 = ca * b01 - sa * b11, c11 = sa * b01 + ca * b11;
                 if (ba == bb) { c01 = c10 = 0.5 * (c01 + c10); }   // keep the pivot block symmetric
@@ -218,7 +225,87 @@ __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
                 V[pa * n + pb] = cb * v00 - sb * v01; V[pa * n + qb] = sb * v00 + cb * v01;
                 V[qa * n + pb] = cb * v10 - sb * v11; V[qa * n + qb] = sb * v10 + cb * v11;
             }
+            wave_sync();
+        }
+    }
+    wave_sync();
+}
+
+// Entry offsets of the 36 blocks of the 11 rounds of a 12x12 sweep, built once per launch.
+__device__ void jacobi12_table(UkfLds& L)
+{
+    for (int i = threadIdx.x; i < 11 * 36; i += kUkfThreads) {
+        const int round = i / 36, l = i % 36;
+        int pa, qa, pb, qb;
+        jacobi_pair(12, round, l / 6, pa, qa);
+        jacobi_pair(12, round, l % 6, pb, qb);
+        L.jtab[i] = make_uint2((uint32_t)(pa * 12 + pb) | ((uint32_t)(pa * 12 + qb) << 16),
+                               (uint32_t)(qa * 12 + pb) | ((uint32_t)(qa * 12 + qb) << 16));
+    }
+}
+
+// jacobi12(): the 12x12 state covariance, called by the WHOLE workgroup.  Wave 0 owns the 36 blocks of A and
+// computes the six rotations of a round from its diagonal blocks; wave 1 owns the 36 blocks of V.  The rotations
+// cross from wave 0 to wave 1 through L.cs (double-buffered by round parity), so a round costs ONE workgroup
+// barrier and each wave issues about half of the instructions a single wave would (the rounds are bound by the
+// instruction latency of one wave, not by throughput).  Waves 2 and 3 only keep the barrier count.
+__device__ void jacobi12(double* A, double* V, UkfLds& L)
+{
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < 144; i += kUkfThreads) V[i] = ((i / 12) == (i % 12)) ? 1.0 : 0.0;
+    __syncthreads();
+    const bool act = lane < 36 && wave < 2;
+    const int ba = act ? lane / 6 : 0, bb = act ? lane % 6 : 0;
+    double* M = (wave == 0) ? A : V;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        if (wave == 0) {
+            double off = 0.0, dg = 0.0;
+            for (int i = lane; i < 144; i += 64) {
+                const int r = i / 12, cidx = i % 12;
+                const double v = A[i];
+                if (r == cidx) dg += v * v; else if (r < cidx) off += v * v;
+            }
+            for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o, 64); dg += __shfl_xor(dg, o, 64); }
+            // stop when ||off-diagonal|| <= kJacobiTol ||diagonal||; decompose_state_cov() absorbs the remaining
+            // off-diagonal part into the square root to first order
+            if (lane == 0) L.flag = (off <= kJacobiTol * kJacobiTol * dg || off == 0.0) ? 1 : 0;
+        }
+        __syncthreads();
+        if (L.flag) break;   // (rewritten only after the barriers of the next rounds)
+#ifdef ROFT_UKF_PROFILE
+        if (tid == 0) L.dbg[16] += 1;
+#endif
+        for (int round = 0; round < 11; ++round) {
+            int o00 = 0, o01 = 0, o10 = 0, o11 = 0;
+            double x00 = 0, x01 = 0, x10 = 0, x11 = 0;
+            if (act) {
+                const uint2 pk = L.jtab[round * 36 + lane];
+                o00 = pk.x & 0xFFFF; o01 = pk.x >> 16; o10 = pk.y & 0xFFFF; o11 = pk.y >> 16;
+                x00 = M[o00]; x01 = M[o01]; x10 = M[o10]; x11 = M[o11];
+                if (wave == 0 && ba == bb) {   // diagonal block: (app, apq; apq, aqq)
+                    double c = 1.0, s = 0.0;
+                    if (x01 != 0.0) schur_rotation(x00, x11, x01, c, s);
+                    L.cs[round & 1][ba][0] = c;
+                    L.cs[round & 1][ba][1] = s;
+                }
+            }
             __syncthreads();
+            if (act) {
+                const double cb = L.cs[round & 1][bb][0], sb = L.cs[round & 1][bb][1];
+                // columns (p_b, q_b): x_p' = c x_p - s x_q, x_q' = s x_p + c x_q
+                double b00 = cb * x00 - sb * x01, b01 = sb * x00 + cb * x01;
+                double b10 = cb * x10 - sb * x11, b11 = sb * x10 + cb * x11;
+                if (wave == 0) {
+                    const double ca = L.cs[round & 1][ba][0], sa = L.cs[round & 1][ba][1];
+                    // rows (p_a, q_a)
+                    const double c00 = ca * b00 - sa * b10, c10 = sa * b00 + ca * b10;
+                    const double c01 = ca * b01 - sa * b11, c11 = sa * b01 + ca * b11;
+                    b00 = c00; b11 = c11;
+                    b01 = c01; b10 = c10;
+                    if (ba == bb) { b01 = b10 = 0.5 * (c01 + c10); }   // keep the pivot block symmetric
+                }
+                M[o00] = b00; M[o01] = b01; M[o10] = b10; M[o11] = b11;
+            }
         }
     }
     __syncthreads();
@@ -230,42 +317,48 @@ __device__ void jacobi_lds(double* A, double* V, int n, UkfLds& L)
 // M^16 (four squarings, 16 lanes, renormalised) converges like r^16 per step from the central sigma point;
 // iterate to a fixed point in double.  Same vector as a 4x4 eigen-solver returns, at a tenth of the cost of
 // a Jacobi sweep sequence.
+// Called by the whole workgroup; the work is done by wave 0 (the other waves are free to do something else
+// before the closing barrier, e.g. the linear rows of the mean -- see the callers).
 __device__ void quaternion_mean(const double* Y, int qrow, int ncols, double wm0, double wmi, double out[4],
                                 UkfLds& L)
 {
     const int lane = threadIdx.x;
-    if (lane < 16) {
-        const int i = lane / 4, j = lane % 4;
-        double s = 0.0;
-        for (int c = 0; c < ncols; ++c) s += (c == 0 ? wm0 : wmi) * Y[(qrow + i) * kCols + c] * Y[(qrow + j) * kCols + c];
-        L.M4[lane] = s;
-    }
-    __syncthreads();
-    for (int it = 0; it < 4; ++it) {  // M <- M^2 / trace-normalised, ping-pong M4 <-> V4
-        double* src = (it & 1) ? L.V4 : L.M4;
-        double* dst = (it & 1) ? L.M4 : L.V4;
+    if (lane < 64) {
         if (lane < 16) {
             const int i = lane / 4, j = lane % 4;
-            double s = 0.0;
-            for (int k = 0; k < 4; ++k) s += src[i * 4 + k] * src[k * 4 + j];
-            const double tr = src[0] * src[0] + src[5] * src[5] + src[10] * src[10] + src[15] * src[15];
-            dst[lane] = s / tr;   // keeps the entries O(1); any positive scale is fine
+            const double* yi = Y + (qrow + i) * kCols;
+            const double* yj = Y + (qrow + j) * kCols;
+            double s = wm0 * yi[0] * yj[0];
+            for (int c = 1; c < ncols; ++c) s += wmi * yi[c] * yj[c];
+            L.M4[lane] = s;
         }
-        __syncthreads();
-    }
-    if (lane == 0) {
-        const double* M16 = L.M4;  // after 4 ping-pongs the result is back in M4
-        double v[4];
-        for (int i = 0; i < 4; ++i) v[i] = Y[(qrow + i) * kCols + 0];
-        for (int it = 0; it < 32; ++it) {
-            double w[4];
-            for (int i = 0; i < 4; ++i) w[i] = M16[i * 4] * v[0] + M16[i * 4 + 1] * v[1] + M16[i * 4 + 2] * v[2] + M16[i * 4 + 3] * v[3];
-            const double inv = 1.0 / sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3]);
-            double diff = 0.0;
-            for (int i = 0; i < 4; ++i) { w[i] *= inv; diff = fmax(diff, fabs(w[i] - v[i])); v[i] = w[i]; }
-            if (diff < 4e-16) break;
+        wave_sync();
+        for (int it = 0; it < 4; ++it) {  // M <- M^2 / trace-normalised, ping-pong M4 <-> V4
+            double* src = (it & 1) ? L.V4 : L.M4;
+            double* dst = (it & 1) ? L.M4 : L.V4;
+            if (lane < 16) {
+                const int i = lane / 4, j = lane % 4;
+                double s = 0.0;
+                for (int k = 0; k < 4; ++k) s += src[i * 4 + k] * src[k * 4 + j];
+                const double tr = src[0] * src[0] + src[5] * src[5] + src[10] * src[10] + src[15] * src[15];
+                dst[lane] = s * fast_rcp(tr);   // keeps the entries O(1); any positive scale is fine
+            }
+            wave_sync();
         }
-        for (int i = 0; i < 4; ++i) L.w4[i] = v[i];
+        if (lane == 0) {
+            const double* M16 = L.M4;  // after 4 ping-pongs the result is back in M4
+            double v[4];
+            for (int i = 0; i < 4; ++i) v[i] = Y[(qrow + i) * kCols + 0];
+            for (int it = 0; it < 32; ++it) {
+                double w[4];
+                for (int i = 0; i < 4; ++i) w[i] = M16[i * 4] * v[0] + M16[i * 4 + 1] * v[1] + M16[i * 4 + 2] * v[2] + M16[i * 4 + 3] * v[3];
+                const double inv = fast_rsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3]);
+                double diff = 0.0;
+                for (int i = 0; i < 4; ++i) { w[i] *= inv; diff = fmax(diff, fabs(w[i] - v[i])); v[i] = w[i]; }
+                if (diff < 4e-16) break;
+            }
+            for (int i = 0; i < 4; ++i) L.w4[i] = v[i];
+        }
     }
     __syncthreads();
     for (int i = 0; i < 4; ++i) out[i] = L.w4[i];
@@ -275,7 +368,7 @@ __device__ void quaternion_mean(const double* Y, int qrow, int ncols, double wm0
 __device__ void weighted_outer(const double* A, int ra, const double* B, int rb, int ncols, double wc0, double wci,
                                double* C, int ldc)
 {
-    for (int e = threadIdx.x; e < ra * rb; e += 64) {
+    for (int e = threadIdx.x; e < ra * rb; e += kUkfThreads) {
         const int i = e / rb, j = e % rb;
         const double* ar = A + i * kCols;
         const double* br = B + j * kCols;
@@ -286,80 +379,47 @@ __device__ void weighted_outer(const double* A, int ra, const double* B, int rb,
     }
 }
 
-// Gauss-Jordan inverse with partial pivoting of the m x m matrix A (ld m) -> Ainv; one wave.
-__device__ bool inverse_lds(const double* A, int m, double* Ainv, UkfLds& L)
+__device__ __forceinline__ double readlane_f64(double v, int src_lane)   // src_lane: compile-time constant
 {
-    const int lane = threadIdx.x;
-    double* M = L.aug;  // m x 2m
-    const int ld = 2 * m;
-    for (int e = lane; e < m * ld; e += 64) {
-        const int i = e / ld, j = e % ld;
-        M[e] = (j < m) ? A[i * m + j] : ((j - m) == i ? 1.0 : 0.0);
-    }
-    if (lane == 0) L.flag = 1;
-    __syncthreads();
-    for (int c = 0; c < m; ++c) {
-        if (lane == 0) {
-            int piv = c;
-            double best = fabs(M[c * ld + c]);
-            for (int r = c + 1; r < m; ++r) {
-                const double v = fabs(M[r * ld + c]);
-                if (v > best) { best = v; piv = r; }
-            }
-            L.rp[0] = piv;
-            if (best == 0.0 || !(best == best)) L.flag = 0;
-        }
-        __syncthreads();
-        if (!L.flag) return false;
-        const int piv = L.rp[0];
-        if (piv != c)
-            for (int j = lane; j < ld; j += 64) {
-                const double t = M[c * ld + j];
-                M[c * ld + j] = M[piv * ld + j];
-                M[piv * ld + j] = t;
-            }
-        __syncthreads();
-        const double d = 1.0 / M[c * ld + c];
-        __syncthreads();
-        for (int j = lane; j < ld; j += 64) M[c * ld + j] *= d;
-        __syncthreads();
-        // eliminate column c from every other row; factors are read before any row is modified
-        double f[5];
-        int cnt = 0;
-        for (int e = lane; e < m * ld; e += 64) f[cnt++] = M[(e / ld) * ld + c];
-        __syncthreads();
-        cnt = 0;
-        for (int e = lane; e < m * ld; e += 64) {
-            const int r = e / ld, j = e % ld;
-            const double fr = f[cnt++];
-            if (r != c && fr != 0.0) M[e] -= fr * M[c * ld + j];
-        }
-        __syncthreads();
-    }
-    for (int e = lane; e < m * m; e += 64) Ainv[e] = M[(e / m) * ld + m + (e % m)];
-    __syncthreads();
-    return true;
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
 }
 
-// Cholesky factor of the SPD m x m matrix A (ld m) into Lc (lower, ld m) + reciprocal diagonal; lanes =
-// rows, one column per step.  Returns false if A is not positive definite.
-__device__ bool cholesky_lds(const double* A, int m, double* Lc, double* inv_diag, UkfLds& L)
+// Cholesky factor of the SPD M x M matrix A (ld M) into the lower triangle of Lc (ld M; the strict upper triangle
+// is left untouched) + reciprocal diagonal.  Called by the whole workgroup; the work is done by lanes 0..M-1 of
+// wave 0, lane = row, the row lives in registers and the column being eliminated is broadcast with v_readlane
+// (no LDS round trip inside the factorisation).  Returns false if A is not positive definite.
+template <int M>
+__device__ bool cholesky_rows(const double* A, double* Lc, double* inv_diag, UkfLds& L)
 {
     const int lane = threadIdx.x;
-    if (lane == 0) L.flag = 1;
-    __syncthreads();
-    for (int j = 0; j < m; ++j) {
-        double s = 0.0;
-        if (lane >= j && lane < m) {
-            s = A[lane * m + j];
-            for (int k = 0; k < j; ++k) s -= Lc[lane * m + k] * Lc[j * m + k];
+    if (lane < 64) {
+        double a[M];
+#pragma unroll
+        for (int k = 0; k < M; ++k) a[k] = (lane < M) ? A[lane * M + k] : 0.0;
+        double rinv[M];
+        int ok = 1;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const double d = readlane_f64(a[j], j);   // A_jj - sum_k<j L_jk^2
+            if (!(d > 0.0)) ok = 0;
+            const double r = fast_rsqrt(d);
+            rinv[j] = r;
+            const double lij = (lane == j) ? d * r : a[j] * r;
+            a[j] = lij;
+#pragma unroll
+            for (int k = j + 1; k < M; ++k) a[k] = fma(-lij, readlane_f64(lij, k), a[k]);
         }
-        const double d = __shfl(s, j, 64);
-        if (!(d > 0.0)) { if (lane == 0) L.flag = 0; break; }
-        const double r = fast_rsqrt(d);
-        if (lane == j) { Lc[j * m + j] = d * r; inv_diag[j] = r; }
-        else if (lane > j && lane < m) Lc[lane * m + j] = s * r;
-        __syncthreads();
+        if (lane < M) {
+#pragma unroll
+            for (int k = 0; k < M; ++k) if (k <= lane) Lc[lane * M + k] = a[k];
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < M; ++k) inv_diag[k] = rinv[k];
+            L.flag = ok;
+        }
     }
     __syncthreads();
     return L.flag != 0;
@@ -408,9 +468,10 @@ __device__ __forceinline__ UtW ut_weights(int n, const roft_ut_params& ut)
 }
 
 // perturbation of sigma column `col`: state part d[12] (from the decomposition of L.P, already done)
-// and noise part dn[r].  noise_eig: use (L.VQ, L.wQ) (process noise) else diagonal L.noise_diag.
-__device__ void sigma_perturbation(int col, int r, double sc, bool noise_eig, const UkfLds& L, double d[12],
-                                   double dn[12])
+// and noise part dn[r].  noise_eig: use (L.VQ, L.wQ) (process noise) else a diagonal noise covariance whose
+// entry for THIS column is noise_var.
+__device__ void sigma_perturbation(int col, int r, double sc, bool noise_eig, double noise_var,
+                                   const UkfLds& L, double d[12], double dn[12])
 {
     const int n = 12 + r;
     for (int i = 0; i < 12; ++i) { d[i] = 0.0; dn[i] = 0.0; }
@@ -425,94 +486,123 @@ __device__ void sigma_perturbation(int col, int r, double sc, bool noise_eig, co
             const double s = sqrt(fabs(L.wQ[kk]));
             for (int i = 0; i < r; ++i) dn[i] = sgn * sc * L.VQ[i * 10 + kk] * s;
         } else {
-            dn[kk] = sgn * sc * 1.0 * sqrt(fabs(L.noise_diag[kk]));
+            const double v = sgn * sc * 1.0 * sqrt(fabs(noise_var));
+#pragma unroll
+            for (int i = 0; i < 12; ++i) if (i == kk) dn[i] = v;
         }
     }
 }
 
-// Decompose L.cov: eigenvalues -> L.wP, eigenvectors -> L.V.
+// Decompose L.cov and form the square root L.S the sigma points are drawn from (called by the whole workgroup).
+//
 // Warm start: consecutive frames have nearly the same covariance, so the previous eigenvector basis
 // V0 almost diagonalises it; Jacobi on B = V0' P V0 then needs 1-2 sweeps instead of ~8, and
 // V = V0 VB.  Any orthogonal V0 is valid (B is similar to P), so this changes the result only by
 // rounding.  A cold start every kWarmRefresh uses stops the orthogonality error of the running
 // product from accumulating.
+//
+// Square root: the Jacobi sweeps stop at B = V' cov V = D + E with a small off-diagonal rest E
+// (||E|| <= kJacobiTol ||D||) instead of running one more sweep to annihilate it.  The symmetric square root of
+// B is D^1/2 + X1 + X2 + O(E^3) with X1_ij = E_ij / (sqrt(d_i) + sqrt(d_j)) and X2_ij = -(X1^2)_ij / (sqrt(d_i) +
+// sqrt(d_j)) -- no eigenvalue gap in any denominator -- so S = V (D^1/2 + X1 + X2) satisfies S S' = cov up to
+// O(E^3), and S equals the exact U sqrt(Lambda) times an orthogonal matrix within O(E) of the identity: the sigma
+// set the reference draws, to rounding.
 __device__ void decompose_state_cov(UkfLds& L, double* warm, int* warm_age)
 {
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x;
     const int age = warm ? *warm_age : 0;
     const bool use = warm && age > 0 && age < kWarmRefresh;
+    double* V0 = L.K;      // scratch: K / KPy / Pxy are free until the correction computes them
+    double* T = L.KPy;
+    double* M = L.Pxy;
+    const double* Vfull = L.V;
     if (use) {
-        double* V0 = L.K;      // scratch: K / KPy are free until the correction computes them
-        double* T = L.KPy;
-        for (int i = lane; i < 144; i += 64) V0[i] = warm[i];
+        if (tid < 144) V0[tid] = warm[tid];
         __syncthreads();
-        for (int e = lane; e < 144; e += 64) {
-            const int i = e / 12, j = e % 12;
+        if (tid < 144) {
+            const int i = tid / 12, j = tid % 12;
             double s = 0.0;
             for (int k = 0; k < 12; ++k) s += L.cov[i * 12 + k] * V0[k * 12 + j];
-            T[e] = s;
+            T[tid] = s;
         }
         __syncthreads();
-        for (int e = lane; e < 144; e += 64) {
-            const int r = e / 12, c = e % 12;
+        if (tid < 144) {
+            const int r = tid / 12, c = tid % 12;
             const int i = r < c ? r : c, j = r < c ? c : r;   // both triangles evaluate the same sum
             double s = 0.0;
             for (int k = 0; k < 12; ++k) s += V0[k * 12 + i] * T[k * 12 + j];
-            L.P[e] = s;
+            L.P[tid] = s;
         }
         __syncthreads();
-        jacobi_lds(L.P, L.V, 12, L);   // L.V = VB
-        for (int e = lane; e < 144; e += 64) {
-            const int i = e / 12, j = e % 12;
+        jacobi12(L.P, L.V, L);   // L.V = VB
+        if (tid < 144) {
+            const int i = tid / 12, j = tid % 12;
             double s = 0.0;
             for (int k = 0; k < 12; ++k) s += V0[i * 12 + k] * L.V[k * 12 + j];
-            T[e] = s;
+            T[tid] = s;          // V = V0 VB
         }
-        __syncthreads();
-        for (int i = lane; i < 144; i += 64) L.V[i] = T[i];
+        Vfull = T;
     } else {
-        for (int i = lane; i < 144; i += 64) L.P[i] = L.cov[i];
+        if (tid < 144) L.P[tid] = L.cov[tid];
         __syncthreads();
-        jacobi_lds(L.P, L.V, 12, L);
+        jacobi12(L.P, L.V, L);
     }
-    if (lane < 12) L.wP[lane] = L.P[lane * 13];
+    double inv_ss = 0.0, m1 = 0.0;
+    if (tid < 144) {
+        const int i = tid / 12, j = tid % 12;
+        const double si = sqrt(fabs(L.P[i * 13])), sj = sqrt(fabs(L.P[j * 13]));
+        inv_ss = (si + sj > 0.0) ? fast_rcp(si + sj) : 0.0;
+        if (i == j) m1 = si;
+        else m1 = 0.5 * (L.P[i * 12 + j] + L.P[j * 12 + i]) * inv_ss;
+        M[tid] = (i == j) ? 0.0 : m1;      // X1 (zero diagonal)
+    }
     __syncthreads();
-    if (warm) {
-        for (int i = lane; i < 144; i += 64) warm[i] = L.V[i];
-        if (lane == 0) *warm_age = use ? age + 1 : 1;
+    if (tid < 144) {
+        // second-order term: D^1/2 X2 + X2 D^1/2 = -X1^2
+        const int i = tid / 12, j = tid % 12;
+        double x1sq = 0.0;
+        for (int k = 0; k < 12; ++k) x1sq += M[i * 12 + k] * M[k * 12 + j];
+        m1 -= x1sq * inv_ss;
     }
-    // Square root.  The Jacobi sweeps stop at B = V' cov V = D + E with a small off-diagonal rest E
-    // (||E|| <= kJacobiTol ||D||) instead of running one more sweep to annihilate it.  The symmetric square root of
-    // B is D^1/2 + X + O(E^2) with X_ij = E_ij / (sqrt(d_i) + sqrt(d_j)) -- no eigenvalue gap in the denominator --
-    // so S = V (D^1/2 + X) satisfies S S' = cov up to O(E^2) ~ 1e-12 relative, and S equals the exact U sqrt(Lambda)
-    // times an orthogonal matrix within O(E) of the identity: the sigma set the reference draws, to rounding.
-    {
-        double* M = L.KPy;   // scratch, free until the correction computes it
-        for (int e = lane; e < 144; e += 64) {
-            const int i = e / 12, j = e % 12;
-            const double si = sqrt(fabs(L.wP[i])), sj = sqrt(fabs(L.wP[j]));
-            double m;
-            if (i == j) m = si;
-            else {
-                const double eij = 0.5 * (L.P[i * 12 + j] + L.P[j * 12 + i]);
-                m = (si + sj > 0.0) ? eij / (si + sj) : 0.0;
-            }
-            M[e] = m;
-        }
-        __syncthreads();
-        for (int e = lane; e < 144; e += 64) {
-            const int i = e / 12, j = e % 12;
-            double acc = 0.0;
-            for (int k = 0; k < 12; ++k) acc += L.V[i * 12 + k] * M[k * 12 + j];
-            L.S[e] = acc;
-        }
+    __syncthreads();
+    if (tid < 144) M[tid] = m1;            // D^1/2 + X1 + X2
+    __syncthreads();
+    if (tid < 144) {
+        const int i = tid / 12, j = tid % 12;
+        double acc = 0.0;
+        for (int k = 0; k < 12; ++k) acc += Vfull[i * 12 + k] * M[k * 12 + j];
+        L.S[tid] = acc;
+        if (warm) warm[tid] = Vfull[tid];
     }
+    if (tid < 12) L.wP[tid] = L.P[tid * 13];
+    if (warm && tid == 0) *warm_age = use ? age + 1 : 1;
     __syncthreads();
 }
 
 // ---- prediction: (L.mean, L.cov) -> (L.mean, L.cov) ------------------------------------------------
+// Square root of L.cov when the sigma set may come from any square root (see roft_config::ukf_cholesky_guard*):
+// lower Cholesky factor into L.S.  `for_correction`: the guard of the correction (else of the prediction over the
+// sampling time T).  Returns false (nothing usable in L.S) when the guard does not hold or the matrix is not
+// numerically positive definite; the caller then decomposes.
+__device__ bool cholesky_state_sqrt(UkfLds& L, bool for_correction, double T, double guard_rot, double guard_bil)
+{
+    if (!(guard_rot > 0.0)) return false;
+    const double th = fmax(L.cov[9 * 13], fmax(L.cov[10 * 13], L.cov[11 * 13]));   // var(theta)
+    const double wv = fmax(L.cov[3 * 13], fmax(L.cov[4 * 13], L.cov[5 * 13]));     // var(omega)
+    const double xx = fmax(L.cov[6 * 13], fmax(L.cov[7 * 13], L.cov[8 * 13]));     // var(x)
+    // (uniform over the workgroup; comparisons written so that NaN fails them)
+    const bool ok = for_correction ? (th <= guard_rot && wv * xx <= guard_bil) : (th + T * T * wv <= guard_rot);
+#ifdef ROFT_UKF_PROFILE
+    if (threadIdx.x == 0 && for_correction) { L.dbg[20] = (long long)(th * 1e9); L.dbg[21] = (long long)(wv * 1e9); L.dbg[22] = (long long)(xx * 1e9); }
+#endif
+    if (!ok) return false;
+    if (threadIdx.x < 144) L.S[threadIdx.x] = 0.0;
+    __syncthreads();
+    return cholesky_rows<12>(L.cov, L.S, L.rc, L);
+}
+
 __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const roft_ut_params& ut, double* warm,
-                            int* warm_age)
+                            int* warm_age, double chol_guard)
 {
     const int lane = threadIdx.x;
     const int r = 9, n = 21;
@@ -520,25 +610,31 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
     const double sc = sqrt(w.c);
 
     // process noise block Q(T) (CartesianQuaternionModel.cpp:127-141), padded to 10 x 10
-    for (int i = lane; i < 100; i += 64) { L.Q[i] = 0.0; L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0; }
+    for (int i = lane; i < 100; i += kUkfThreads) { L.Q[i] = 0.0; L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0; }
     __syncthreads();
     if (prm.q_override) {
-        for (int i = lane; i < 81; i += 64) L.Q[(i / 9) * 10 + (i % 9)] = prm.q_override[i];
+        for (int i = lane; i < 81; i += kUkfThreads) L.Q[(i / 9) * 10 + (i % 9)] = prm.q_override[i];
         __syncthreads();
-        jacobi_lds(L.Q, L.VQ, 10, L);
-        if (lane < 10) L.wQ[lane] = L.Q[lane * 11];
+        if (lane < 64) {
+            jacobi_wave(L.Q, L.VQ, 10, L);
+            if (lane < 10) L.wQ[lane] = L.Q[lane * 11];
+        }
     } else if (lane < 3) {
         // Q(T) couples only (v_i, x_i): three independent symmetric 2x2 blocks, each diagonalised
         // exactly by ONE Jacobi rotation (the same rotation the generic sweep would apply first).
         const int i = lane;
         const double app = prm.psd_lin_acc[i] * T;
-        const double aqq = prm.psd_lin_acc[i] * (pow(T, 3.0) / 3.0);
-        const double apq = prm.psd_lin_acc[i] * (pow(T, 2.0) / 2.0);
+        const double aqq = prm.psd_lin_acc[i] * (T * T * T / 3.0);
+        const double apq = prm.psd_lin_acc[i] * (T * T / 2.0);
         double c = 1.0, s = 0.0;
         if (apq != 0.0) {
-            const double tau = (aqq - app) / (2.0 * apq);
-            const double t = (tau >= 0.0) ? 1.0 / (tau + sqrt(1.0 + tau * tau)) : -1.0 / (-tau + sqrt(1.0 + tau * tau));
-            c = 1.0 / sqrt(1.0 + t * t);
+            // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = (aqq - app) / (2 apq), written division-free
+            const double a = aqq - app, b = 2.0 * apq;
+            const double h2 = a * a + b * b;
+            const double hyp = h2 * fast_rsqrt(h2);
+            const double sgn = ((a >= 0.0) == (b >= 0.0) || a == 0.0) ? 1.0 : -1.0;
+            const double t = sgn * fabs(b) * fast_rcp(fabs(a) + hyp);
+            c = fast_rsqrt(1.0 + t * t);
             s = t * c;
         }
         // columns then rows, like the generic update
@@ -552,13 +648,13 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
     }
     __syncthreads();
     TICK(L, 1);
-    decompose_state_cov(L, warm, warm_age);
+    if (!cholesky_state_sqrt(L, false, T, chol_guard, 0.0)) decompose_state_cov(L, warm, warm_age);
     TICK(L, 2);
 
     // fan-out + motion model, lane = sigma point
     if (lane < w.ncols) {
         double d[12], dn[12];
-        sigma_perturbation(lane, r, sc, true, L, d, dn);
+        sigma_perturbation(lane, r, sc, true, 0.0, L, d, dn);
         double v[3], wv[3], x[3], q[4];
         for (int i = 0; i < 3; ++i) {
             v[i] = L.mean[i] + d[i];
@@ -572,8 +668,9 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
             L.Y[(6 + i) * kCols + lane] = (x[i] + dn[6 + i]) + v[i] * T;  // v without noise (cpp:94-97)
         }
         const double norm_w = sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]) + 2.220446049250313e-16;
-        const double c = cos(norm_w * T / 2.0);
-        const double s = sin(norm_w * T / 2.0) / norm_w;
+        double sn, c;
+        sincos(norm_w * T / 2.0, &sn, &c);
+        const double s = sn / norm_w;
         L.Y[9 * kCols + lane] = c * q[0] + s * (-wv[0] * q[1] - wv[1] * q[2] - wv[2] * q[3]);
         L.Y[10 * kCols + lane] = c * q[1] + s * (wv[0] * q[0] - wv[2] * q[2] + wv[1] * q[3]);
         L.Y[11 * kCols + lane] = c * q[2] + s * (wv[1] * q[0] + wv[2] * q[1] - wv[0] * q[3]);
@@ -582,25 +679,25 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
     __syncthreads();
 
     TICK(L, 3);
-    // mean
-    if (lane < 9) {
-        double s = 0.0;
-        for (int c = 0; c < w.ncols; ++c) s += L.Y[lane * kCols + c] * (c == 0 ? w.wm0 : w.wi);
-        L.ymean[lane] = s;
+    // mean: the linear rows on wave 1 while wave 0 works on the quaternion rows
+    if (lane >= 64 && lane < 64 + 9) {
+        const double* y = L.Y + (lane - 64) * kCols;
+        double s = y[0] * w.wm0;
+        for (int c = 1; c < w.ncols; ++c) s += y[c] * w.wi;
+        L.ymean[lane - 64] = s;
     }
     double qm[4];
     quaternion_mean(L.Y, 9, w.ncols, w.wm0, w.wi, qm, L);
     TICK(L, 4);
-    if (lane == 0)
+    if (lane == 64)
         for (int i = 0; i < 4; ++i) L.ymean[9 + i] = qm[i];
-    __syncthreads();
     // deviations
     if (lane < w.ncols) {
         for (int i = 0; i < 9; ++i) L.D[i * kCols + lane] = L.Y[i * kCols + lane] - L.ymean[i];
         const double q[4] = {L.Y[9 * kCols + lane], L.Y[10 * kCols + lane], L.Y[11 * kCols + lane],
                              L.Y[12 * kCols + lane]};
         double dq[3];
-        quat_diff(q, L.ymean + 9, dq);
+        quat_diff(q, qm, dq);
         for (int i = 0; i < 3; ++i) L.D[(9 + i) * kCols + lane] = dq[i];
     }
     __syncthreads();
@@ -617,7 +714,7 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
 {
     const int lane = threadIdx.x;
     if (type == ROFT_MEAS_NONE) {
-        for (int i = lane; i < 144; i += 64) out->cov[i] = L.cov[i];
+        for (int i = lane; i < 144; i += kUkfThreads) out->cov[i] = L.cov[i];
         if (lane < 13) out->mean[lane] = L.mean[lane];
         return 1;
     }
@@ -631,23 +728,24 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
     const UtW w = ut_weights(n, ut);
     const double sc = sqrt(w.c);
 
-    // measurement vector and noise diagonal in measurement order (velocity first)
-    double meas[13];
-    {
-        int k = 0;
-        if (has_vel) { for (int i = 0; i < 6; ++i) meas[k++] = twist[i]; }
-        if (has_pose) { for (int i = 0; i < 3; ++i) meas[k++] = pose_x[i]; for (int i = 0; i < 4; ++i) meas[k++] = pose_q[i]; }
-    }
-    if (lane == 0) {
-        int k = 0;
-        if (has_vel) { for (int i = 0; i < 3; ++i) L.noise_diag[k++] = prm.R_v[i]; for (int i = 0; i < 3; ++i) L.noise_diag[k++] = prm.R_w[i]; }
-        if (has_pose) { for (int i = 0; i < 3; ++i) L.noise_diag[k++] = prm.R_x[i]; for (int i = 0; i < 3; ++i) L.noise_diag[k++] = prm.R_q[i]; }
-    }
-    __syncthreads();
-
+    // measurement vector in measurement order (velocity first)
+    auto meas_at = [&](int k) -> double {
+        if (has_vel) { if (k < 6) return twist[k]; k -= 6; }
+        return (k < 3) ? pose_x[k] : pose_q[k - 3];
+    };
     if (lane < w.ncols) {
+        // measurement noise variance of this column's noise dof, measurement order (velocity first)
+        double noise_var = 0.0;
+        {
+            const int kk = (lane > 0) ? (lane - 1) % n - 12 : -1;
+            if (kk >= 0) {
+                const double* R = has_vel ? (kk < 3 ? prm.R_v : (kk < 6 ? prm.R_w : (kk < 9 ? prm.R_x : prm.R_q)))
+                                          : (kk < 3 ? prm.R_x : prm.R_q);
+                noise_var = R[kk % 3];
+            }
+        }
         double d[12], dn[12];
-        sigma_perturbation(lane, r, sc, false, L, d, dn);
+        sigma_perturbation(lane, r, sc, false, noise_var, L, d, dn);
         double v[3], wv[3], x[3], q[4];
         for (int i = 0; i < 3; ++i) {
             v[i] = L.mean[i] + d[i];
@@ -687,45 +785,73 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
     __syncthreads();
 
     TICK(L, 8);
-    if (lane < nlin) {
-        double s = 0.0;
-        for (int c = 0; c < w.ncols; ++c) s += L.Y[lane * kCols + c] * (c == 0 ? w.wm0 : w.wi);
-        L.ymean[lane] = s;
+    // means: the linear rows on wave 1 while wave 0 works on the quaternion rows
+    if (lane >= 64 && lane < 64 + nlin) {
+        const double* y = L.Y + (lane - 64) * kCols;
+        double s = y[0] * w.wm0;
+        for (int c = 1; c < w.ncols; ++c) s += y[c] * w.wi;
+        L.ymean[lane - 64] = s;
     }
+    double qm[4] = {1.0, 0.0, 0.0, 0.0};
     if (has_pose) {
-        double qm[4];
-        quaternion_mean(L.Y, nlin, w.ncols, w.wm0, w.wi, qm, L);
-        if (lane == 0)
+        quaternion_mean(L.Y, nlin, w.ncols, w.wm0, w.wi, qm, L);   // ends with a workgroup barrier
+        if (lane == 64)
             for (int i = 0; i < 4; ++i) L.ymean[nlin + i] = qm[i];
+    } else {
+        __syncthreads();
     }
-    __syncthreads();
     if (lane < w.ncols) {
         for (int i = 0; i < nlin; ++i) L.D[i * kCols + lane] = L.Y[i * kCols + lane] - L.ymean[i];
         if (has_pose) {
             const double q[4] = {L.Y[nlin * kCols + lane], L.Y[(nlin + 1) * kCols + lane],
                                  L.Y[(nlin + 2) * kCols + lane], L.Y[(nlin + 3) * kCols + lane]};
             double dq[3];
-            quat_diff(q, L.ymean + nlin, dq);
+            quat_diff(q, qm, dq);
             for (int i = 0; i < 3; ++i) L.D[(nlin + i) * kCols + lane] = dq[i];
         }
     }
+    // innovation (idle threads of wave 3)
+    if (lane >= 224 && lane < 224 + nlin) L.innov[lane - 224] = -(L.ymean[lane - 224] - meas_at(lane - 224));
+    if (has_pose && lane == 255) {
+        const double mq[4] = {meas_at(nlin), meas_at(nlin + 1), meas_at(nlin + 2), meas_at(nlin + 3)};
+        double dq[3];
+        quat_diff(mq, qm, dq);
+        for (int i = 0; i < 3; ++i) L.innov[nlin + i] = dq[i];
+    }
     __syncthreads();
     TICK(L, 9);
-    weighted_outer(L.D, m, L.D, m, w.ncols, w.wc0, w.wi, L.Py, m);
-    weighted_outer(L.X, 12, L.D, m, w.ncols, w.wc0, w.wi, L.Pxy, m);
-    if (lane < nlin) L.innov[lane] = -(L.ymean[lane] - meas[lane]);
-    if (has_pose && lane == 0) {
-        double dq[3];
-        quat_diff(meas + nlin, L.ymean + nlin, dq);
-        for (int i = 0; i < 3; ++i) L.innov[nlin + i] = dq[i];
+    // Pxy (12 x m) on the first 12 m threads, the upper triangle of the symmetric Py (m x m) on the next
+    // m (m + 1) / 2: at most 144 + 78 threads, one pass
+    {
+        const int nxy = 12 * m, ntri = m * (m + 1) / 2;
+        if (lane < nxy) {
+            const int i = lane / m, j = lane % m;
+            const double* ar = L.X + i * kCols;
+            const double* br = L.D + j * kCols;
+            double s = ar[0] * w.wc0 * br[0];
+#pragma unroll 8
+            for (int c = 1; c < w.ncols; ++c) s += ar[c] * w.wi * br[c];
+            L.Pxy[lane] = s;
+        } else if (lane - nxy < ntri) {
+            int u = lane - nxy, i = 0;
+            while (u >= m - i) { u -= m - i; ++i; }
+            const int j = i + u;
+            const double* ar = L.D + i * kCols;
+            const double* br = L.D + j * kCols;
+            double s = ar[0] * w.wc0 * br[0];
+#pragma unroll 8
+            for (int c = 1; c < w.ncols; ++c) s += ar[c] * w.wi * br[c];
+            L.Py[i * m + j] = s;
+            L.Py[j * m + i] = s;
+        }
     }
     __syncthreads();
 
     TICK(L, 10);
     // K = Pxy Py^-1 through the Cholesky factor of the SPD innovation covariance (the reference inverts
     // Py by LU, UKFCorrection.cpp:118; same K up to rounding), then KPy = K Py
-    if (!cholesky_lds(L.Py, m, L.aug, L.rc, L)) {
-        for (int i = lane; i < 144; i += 64) out->cov[i] = L.cov[i];
+    if (!((m == 6) ? cholesky_rows<6>(L.Py, L.aug, L.rc, L) : cholesky_rows<12>(L.Py, L.aug, L.rc, L))) {
+        for (int i = lane; i < 144; i += kUkfThreads) out->cov[i] = L.cov[i];
         if (lane < 13) out->mean[lane] = L.mean[lane];
         return 2;
     }
@@ -733,29 +859,29 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
     if (m == 6) chol_solve_rows<6>(L.aug, L.rc, L.Pxy, L.K);
     else chol_solve_rows<12>(L.aug, L.rc, L.Pxy, L.K);
     __syncthreads();
-    for (int e = lane; e < 12 * m; e += 64) {
-        const int i = e / m, j = e % m;
+    if (lane < 12 * m) {
+        const int i = lane / m, j = lane % m;
         double s = 0.0;
         for (int k = 0; k < m; ++k) s += L.K[i * m + k] * L.Py[k * m + j];
         L.KPy[i * m + j] = s;
-    }
-    if (lane < 12) {
+    } else if (lane >= 192 && lane < 192 + 12) {   // K * innovation on wave 3
+        const int i = lane - 192;
         double s = 0.0;
-        for (int k = 0; k < m; ++k) s += L.K[lane * m + k] * L.innov[k];
-        L.Kin[lane] = s;
+        for (int k = 0; k < m; ++k) s += L.K[i * m + k] * L.innov[k];
+        L.Kin[i] = s;
     }
     __syncthreads();
-    if (lane < 9) out->mean[lane] = L.mean[lane] + L.Kin[lane];
-    if (lane == 9) {
+    if (lane < 144) {
+        const int i = lane / 12, j = lane % 12;
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += L.KPy[i * m + k] * L.K[j * m + k];
+        out->cov[lane] = L.cov[lane] - s;
+    } else if (lane >= 192 && lane < 192 + 9) {
+        out->mean[lane - 192] = L.mean[lane - 192] + L.Kin[lane - 192];
+    } else if (lane == 192 + 9) {
         double qo[4];
         quat_boxplus(L.mean + 9, L.Kin + 9, qo);
         for (int i = 0; i < 4; ++i) out->mean[9 + i] = qo[i];
-    }
-    for (int e = lane; e < 144; e += 64) {
-        const int i = e / 12, j = e % 12;
-        double s = 0.0;
-        for (int k = 0; k < m; ++k) s += L.KPy[i * m + k] * L.K[j * m + k];
-        out->cov[e] = L.cov[e] - s;
     }
     __syncthreads();
     TICK(L, 12);
@@ -780,33 +906,35 @@ __device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const rof
     __syncthreads();
 #endif
     const PoseBelief& src = st.belief[sd.src];
-    for (int i = lane; i < 144; i += 64) L.cov[i] = src.cov[i];
+    for (int i = lane; i < 144; i += kUkfThreads) L.cov[i] = src.cov[i];
     if (lane < 13) L.mean[lane] = src.mean[lane];
     __syncthreads();
     if (sd.save_corr_to_buf) {
         const PoseBelief& cr = st.belief[B_CORR];
         PoseBelief& bf = st.belief[B_BUF];
-        for (int i = lane; i < 144; i += 64) bf.cov[i] = cr.cov[i];
+        for (int i = lane; i < 144; i += kUkfThreads) bf.cov[i] = cr.cov[i];
         if (lane < 13) bf.mean[lane] = cr.mean[lane];
     }
 
     TICK(L, 0);
     if (sd.do_predict) {
-        ukf_predict(L, prm, c.dt, ut, st.warm_V[0], &st.warm_age[0]);
+        ukf_predict(L, prm, c.dt, ut, st.warm_V[0], &st.warm_age[0], a.ukf_chol_guard);
         PoseBelief& pr = st.belief[B_PRED];
-        for (int i = lane; i < 144; i += 64) pr.cov[i] = L.cov[i];
+        for (int i = lane; i < 144; i += kUkfThreads) pr.cov[i] = L.cov[i];
         if (lane < 13) pr.mean[lane] = L.mean[lane];
     }
     if (sd.n_corr == 0) {
         PoseBelief& d = st.belief[sd.dst[0]];
-        for (int i = lane; i < 144; i += 64) d.cov[i] = L.cov[i];
+        for (int i = lane; i < 144; i += kUkfThreads) d.cov[i] = L.cov[i];
         if (lane < 13) d.mean[lane] = L.mean[lane];
         if (roft_object_output* row = log_row(a, obj))
             if (lane < 13 && sd.dst[0] == B_CORR) row->pose[lane] = L.mean[lane];
         return;
     }
     TICK(L, 6);
-    decompose_state_cov(L, st.warm_V[1], &st.warm_age[1]);  // shared by both corrections of an outlier-rejection step
+    // square root of the predicted covariance, shared by both corrections of an outlier-rejection step
+    if (!cholesky_state_sqrt(L, true, c.dt, a.ukf_chol_guard, a.ukf_chol_guard_bil))
+        decompose_state_cov(L, st.warm_V[1], &st.warm_age[1]);
     TICK(L, 7);
     const double* twist = st.twist_hist[sd.twist_slot];
     int status = 0;
@@ -829,11 +957,13 @@ __device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const rof
 
 // One launch runs the StepDescs [step0, step1) of every object back to back (the velocity-only replays of a
 // pose re-sync need no other kernel in between, so they share one launch).
-__global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step0, int step1, roft_ut_params ut)
+__global__ __launch_bounds__(kUkfThreads) void ukf_step_kernel(EngineArrays a, int step0, int step1, roft_ut_params ut)
 {
     // static LDS on purpose: with `extern __shared__` the compiler re-reads the dynamic-LDS base address from a
     // table in global memory inside every Jacobi round (two dependent global loads per round)
     __shared__ UkfLds L;
+    jacobi12_table(L);
+    __syncthreads();
     for (int step = step0; step < step1; ++step) {
         ukf_one_step(a, blockIdx.x, step, ut, L);
         __syncthreads();   // beliefs written by this step are read by the next one (same workgroup)
@@ -842,7 +972,7 @@ __global__ __launch_bounds__(64) void ukf_step_kernel(EngineArrays a, int step0,
 
 void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s)
 {
-    hipLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(64), 0, s, a, step0, step1, ut);
+    hipLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(kUkfThreads), 0, s, a, step0, step1, ut);
 }
 
 }  // namespace roft

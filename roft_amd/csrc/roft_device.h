@@ -138,6 +138,8 @@ struct EngineArrays {
     size_t plane_words;      // wpr*H
     int tile_w, tile_h;
     int max_tris;            // largest mesh among the objects
+    double ukf_chol_guard;      // roft_config::ukf_cholesky_guard (0: always the eigen-decomposition)
+    double ukf_chol_guard_bil;  // roft_config::ukf_cholesky_guard_bilinear
     roft_object_output* out_log;  // [log_cap][n_obj] per-frame outputs, or null
     int log_cap;
 };

@@ -130,3 +130,25 @@ def test_engine_rejects_bad_calls():
     with pytest.raises(L.RoftError):
         E.ROFTFilterBatch(E.default_config(333, 240))   # width not a multiple of 32
     eng.close()
+
+
+def test_prediction_cholesky_guard_changes_nothing_measurable():
+    """roft_config::ukf_cholesky_guard: drawing the prediction's sigma points from the Cholesky factor (default,
+    while the rotational variances are small) or from the eigen-decomposition (guard = 0) gives the same
+    trajectories to ~1e-12, and both match the oracle."""
+    from oracle import binding as ob
+    st = util.stream(31, 60, 2)
+    ref = util.run_oracle_tracker(ob, st, 60)
+    out = {}
+    for guard in (2e-4, 0.0):
+        eng = make_engine([st], ukf_cholesky_guard=guard)   # (the correction's guard is void when this one is 0)
+        traj = []
+        for k in range(60):
+            depth, flow, mask, pose = util.frame_inputs(st, k)
+            eng.submit([dict(depth=depth, flow=flow, mask=mask, pose=pose, dt=st.dt)])
+            eng.step()
+            traj.append(eng.state(0)[0])
+        eng.close()
+        out[guard] = np.array(traj)
+        assert np.abs(out[guard] - np.array([r["pose"] for r in ref])).max() < 1e-8
+    assert 0.0 < np.abs(out[2e-4] - out[0.0]).max() < 1e-10
