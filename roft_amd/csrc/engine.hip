@@ -136,8 +136,8 @@ struct Arrays {
         HIP_TRY(cand.ensure((size_t)n_obj * a.cand_cap));
         HIP_TRY(recs.ensure((size_t)n_obj * a.cand_cap));
         HIP_TRY(norms.ensure((size_t)n_obj * 3 * a.cand_cap));
-        HIP_TRY(feat_pix.ensure((size_t)n_obj * a.feat_cap));
-        HIP_TRY(feat_depth.ensure((size_t)n_obj * a.feat_cap));
+        HIP_TRY(feat_pix.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
+        HIP_TRY(feat_depth.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
         HIP_TRY(zbuf.ensure((size_t)n_obj * 2 * a.tile_w * a.tile_h));
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
         a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
@@ -163,6 +163,7 @@ void clear_ctrl(FrameCtrl& c)
 {
     std::memset(&c, 0, sizeof(c));
     c.outlier_step = -1;
+    c.feat_write = c.feat_read = -1;
 }
 
 }  // namespace
@@ -186,6 +187,8 @@ struct HostObject {
     bool of_first_frame = true;        // ...::is_first_frame_
     bool flow_first_frame = true;      // ImageOpticalFlowMeasurement::is_first_frame_
     bool features_initialized = false; // ROFTFilter::outlier_rejection_features_initialized_
+    int feat_slot = 0;                 // feature ring slot holding the buffered outlier-rejection features
+    int feat_next = 0;                 // next ring slot to write
     std::deque<const void*> flow_hist; // last valid flows, newest at front
     std::deque<int> vel_buf;           // twist_hist slots (CartesianQuaternionMeasurement::buffer_velocities_)
     int last_meas_slot = 0;            // slot of measurement_.head<6>()
@@ -234,7 +237,7 @@ struct roft_engine {
     FrameCtrl* cur = nullptr;  // staging block of the submitted, not yet stepped frame
     bool submitted = false;
     int max_steps = 0;
-    bool any_new_mask = false, any_outlier = false, any_feat0 = false, any_feat1 = false;
+    bool any_new_mask = false, any_outlier = false, any_feat = false;
     int frame_counter = 0;
     // timing
     bool timing = false;
@@ -335,8 +338,16 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
     const char* one = getenv("ROFT_ONE_STREAM");
     e->two_streams = !(one && one[0] == '1');
     if (e->two_streams) {
-        HIP_TRY(hipStreamCreateWithFlags(&e->pose_stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&e->vel_stream, hipStreamNonBlocking));
+        // the pose chain is the longest of the three: give its workgroups the dispatch priority
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const char* np = getenv("ROFT_NO_STREAM_PRIORITY");
+        if (np && np[0] == '1') greatest = least;
+        HIP_TRY(hipStreamCreateWithPriority(&e->pose_stream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&e->vel_stream, hipStreamNonBlocking, (least + greatest) / 2));
+        // ... and the mask chain (thousands of short workgroups per launch) the lowest
+        HIP_TRY(hipStreamDestroy(e->stream));
+        HIP_TRY(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, least));
     } else {
         e->pose_stream = e->vel_stream = e->stream;
     }
@@ -510,14 +521,21 @@ static void build_pose_program(roft_engine* e, HostObject& o, const roft_frame_i
                 add(r);
                 first = false;
             }
-            c.buffer_features_after = 1;
+            // the test reads the features buffered at the previous pose arrival; this frame's are buffered for
+            // the next one (ROFTFilter.cpp:353)
+            c.feat_read = o.feat_slot;
+            if (c.feat_write < 0) { c.feat_write = o.feat_next; o.feat_next = (o.feat_next + 1) % kFeatRing; }
+            o.feat_slot = c.feat_write;
         } else {
             if (cfg.outlier_rejection) {
                 sd.n_corr = 2;
                 sd.type[0] = ROFT_MEAS_POSE_VELOCITY; sd.dst[0] = B_ALT0;
                 sd.type[1] = ROFT_MEAS_VELOCITY;      sd.dst[1] = B_ALT1;
                 c.outlier_step = n;
-                c.features_current = 1;
+                // without re-sync the test uses the current frame's depth and mask
+                if (c.feat_write < 0) { c.feat_write = o.feat_next; o.feat_next = (o.feat_next + 1) % kFeatRing; }
+                c.feat_read = c.feat_write;
+                o.feat_slot = c.feat_write;
             } else {
                 sd.n_corr = 1;
                 sd.type[0] = ROFT_MEAS_POSE_VELOCITY; sd.dst[0] = B_CORR;
@@ -553,7 +571,7 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
         HIP_TRY(hipEventSynchronize(e->ev_pose[(e->frame_counter - roft_engine::kMaxInFlight) % roft_engine::kCtrlRing]));
     FrameCtrl* blk = e->stage[si];
     e->max_steps = 0;
-    e->any_new_mask = e->any_outlier = e->any_feat0 = e->any_feat1 = false;
+    e->any_new_mask = e->any_outlier = e->any_feat = false;
 
     for (int id = 0; id < n_inputs; ++id) {
         HostObject& o = *e->objs[id];
@@ -624,15 +642,16 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
 
         // ---- outlier-rejection features on the first frame (ROFTFilter.cpp:313-322)
         if (cfg.use_pose_resync && !o.features_initialized) {
-            c.buffer_features_before = 1;
+            c.feat_write = o.feat_next;
+            o.feat_next = (o.feat_next + 1) % kFeatRing;
+            o.feat_slot = c.feat_write;
             o.features_initialized = true;
         }
         c.frame_idx = e->frame_counter;
         build_pose_program(e, o, in, c);
         e->max_steps = std::max(e->max_steps, c.n_steps);
         if (c.outlier_step >= 0) e->any_outlier = true;
-        if (c.buffer_features_before || c.features_current) e->any_feat0 = true;
-        if (c.buffer_features_after) e->any_feat1 = true;
+        if (c.feat_write >= 0) e->any_feat = true;
         o.frame_idx++;
     }
     e->cur = blk;
@@ -716,6 +735,7 @@ int roft_step(roft_engine* e)
     if (e->any_new_mask) { launch_mask_ingest(a, s); tmark(e, "mask_ingest", 0); }
     launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, true, s);
     tmark(e, "mask_propagate", 0);
+    if (e->any_feat) { launch_features(a, s); tmark(e, "features", 0); }
     if (multi) HIP_TRY(hipEventRecord(e->ev_mask[ci], s));
 
     // ---- pose chain (needs this frame's twist and mask planes; the next frames' image chains do not wait for it)
@@ -724,7 +744,6 @@ int roft_step(roft_engine* e)
         HIP_TRY(hipStreamWaitEvent(sp, e->ev_mask[ci], 0));
     }
     tmark(e, nullptr, 1);
-    if (e->any_feat0) { launch_features(a, 0, sp); tmark(e, "features", 1); }
     // step 0 (possibly followed by the outlier render + test), then all remaining steps in one launch
     if (e->max_steps > 0) {
         launch_ukf_step(a, 0, 1, e->cfg.ut, sp);
@@ -735,7 +754,6 @@ int roft_step(roft_engine* e)
             tmark(e, "ukf_replay_steps", 1);
         }
     }
-    if (e->any_feat1) { launch_features(a, 1, sp); tmark(e, "features", 1); }
     HIP_TRY(hipEventRecord(e->ev_pose[ci], sp));
     HIP_TRY(hipGetLastError());
     e->frame_counter++;
@@ -1257,11 +1275,12 @@ int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint
     fc.new_mask = c.b0.p;
     fc.slot_cur = kSlotNew;
     fc.depth_cur = reinterpret_cast<const float*>(c.b1.p);
-    fc.buffer_features_before = 1;
+    fc.feat_write = 0;
+    fc.feat_read = 0;
     fc.outlier_step = 0;
     if (int rc = upload_ctrl(c, fc)) return rc;
     launch_mask_ingest(c.arr.a, c.stream);
-    launch_features(c.arr.a, 0, c.stream);
+    launch_features(c.arr.a, c.stream);
     // likelihood only (the z-buffers are already filled)
     launch_outlier_only(c.arr.a, c.stream);
     ObjState* st = new ObjState();

@@ -22,20 +22,20 @@ namespace roft {
 
 constexpr int kFeatThreads = 1024;
 
-// phase 0: before the UKF steps (first frame / non-resync outlier rejection uses the current frame)
-// phase 1: after them (re-buffer at pose re-sync frames, ROFTFilter.cpp:353)
+// The reference buffers depth + mask when a pose arrives (ROFTFilter.cpp:313-322, :353) and tests the NEXT pose against
+// them; here the buffered sets live in a small ring (FrameCtrl::feat_write / feat_read name the slots), so buffering
+// is part of the mask chain of the frame and never waits for the pose chain that reads an older set.
 // Feature slot s holds the pixel of row-major rank 2s of the current obj plane (`k += 2` over the
 // findNonZero list, ROFTFilter.cpp:556) and its depth.  Plane words are in row-major order, so one block
 // scan over the word popcounts gives every word its starting rank; each thread then expands its own
 // contiguous chunk of words, issuing its depth gathers back to back.
-__global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a, int phase)
+__global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_wave[17];
     const int obj = blockIdx.x;
     const FrameCtrl& c = a.ctrl[obj];
-    const bool run = (phase == 0) ? (c.buffer_features_before || c.features_current) : c.buffer_features_after;
-    if (!run) return;
+    if (c.feat_write < 0) return;
     const int W = a.cam.W, wpr = a.cam.wpr;
     uint32_t* plane = reinterpret_cast<uint32_t*>(smem);   // staged with coalesced 16-byte loads
     {
@@ -47,8 +47,8 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a, 
         __syncthreads();
     }
     const float* depth = c.depth_cur;
-    uint32_t* fpix = a.feat_pix + (size_t)obj * a.feat_cap;
-    float* fdep = a.feat_depth + (size_t)obj * a.feat_cap;
+    uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + c.feat_write) * a.feat_cap;
+    float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + c.feat_write) * a.feat_cap;
     const int n_words = (int)a.plane_words;
     const int per = (n_words + blockDim.x - 1) / blockDim.x;
     const int w0 = min(n_words, (int)threadIdx.x * per), w1 = min(n_words, w0 + per);
@@ -76,10 +76,10 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a, 
     // depth gathers: independent per slot, spread over the whole workgroup
     const int n = min((total + 1) / 2, a.feat_cap);
     for (int s = threadIdx.x; s < n; s += blockDim.x) fdep[s] = depth[fpix[s]];
-    if (threadIdx.x == 0) a.state[obj].n_feat = min((total + 1) / 2, a.feat_cap);
+    if (threadIdx.x == 0) a.state[obj].n_feat[c.feat_write] = min((total + 1) / 2, a.feat_cap);
 }
 
-void launch_features(const EngineArrays& a, int phase, hipStream_t s)
+void launch_features(const EngineArrays& a, hipStream_t s)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -87,7 +87,7 @@ void launch_features(const EngineArrays& a, int phase, hipStream_t s)
                                   160 * 1024 - 256);
         attr_set = true;
     }
-    hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), (a.plane_words * 4 + 15) & ~(size_t)15, s, a, phase);
+    hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), (a.plane_words * 4 + 15) & ~(size_t)15, s, a);
 }
 
 // ---- rasteriser ---------------------------------------------------------------------------------
@@ -193,12 +193,13 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
     if (c.outlier_step < 0) return;
     ObjState& st = a.state[obj];
     const int W = a.cam.W, d = a.cam.divider, tw = a.tile_w;
-    const uint32_t* fpix = a.feat_pix + (size_t)obj * a.feat_cap;
-    const float* fdep = a.feat_depth + (size_t)obj * a.feat_cap;
+    const int fslot = (c.feat_read >= 0) ? c.feat_read : 0;
+    const uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
+    const float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
     const uint32_t* z0 = a.zbuf + ((size_t)obj * 2) * a.tile_w * a.tile_h;
     const uint32_t* z1 = z0 + (size_t)a.tile_w * a.tile_h;
     double err[2] = {0.0, 0.0}, cnt[2] = {0.0, 0.0};
-    const int n = st.n_feat;
+    const int n = st.n_feat[fslot];
     // four feature slots per iteration: their 4 + 4 + 8 loads are independent and go out together
     for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
         float dep[4];

@@ -311,6 +311,22 @@ __device__ void jacobi12(double* A, double* V, UkfLds& L)
     __syncthreads();
 }
 
+// sum_c a[c] w_c b[c] over the sigma columns (column 0 carries wc0, the rest the common weight wci), with four
+// independent partial sums so that the additions do not form one 40-deep dependency chain
+__device__ __forceinline__ double weighted_dot(const double* ar, const double* br, int ncols, double wc0, double wci)
+{
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int c = 1;
+    for (; c + 3 < ncols; c += 4) {
+        s0 = fma(ar[c], br[c], s0);
+        s1 = fma(ar[c + 1], br[c + 1], s1);
+        s2 = fma(ar[c + 2], br[c + 2], s2);
+        s3 = fma(ar[c + 3], br[c + 3], s3);
+    }
+    for (; c < ncols; ++c) s0 = fma(ar[c], br[c], s0);
+    return fma(ar[0] * br[0], wc0, ((s0 + s1) + (s2 + s3)) * wci);
+}
+
 // dominant eigenvector of M = sum_c wm_c q_c q_c' (rows qrow..qrow+3 of Y), sign aligned with column 0.
 // The sigma quaternions are a tight cluster, so M is a rank-one matrix plus a perturbation of the size of
 // the rotational covariance: eigenvalue gap ratio r = lambda_2 / lambda_1 << 1.  Power iteration on
@@ -326,11 +342,7 @@ __device__ void quaternion_mean(const double* Y, int qrow, int ncols, double wm0
     if (lane < 64) {
         if (lane < 16) {
             const int i = lane / 4, j = lane % 4;
-            const double* yi = Y + (qrow + i) * kCols;
-            const double* yj = Y + (qrow + j) * kCols;
-            double s = wm0 * yi[0] * yj[0];
-            for (int c = 1; c < ncols; ++c) s += wmi * yi[c] * yj[c];
-            L.M4[lane] = s;
+            L.M4[lane] = weighted_dot(Y + (qrow + i) * kCols, Y + (qrow + j) * kCols, ncols, wm0, wmi);
         }
         wave_sync();
         for (int it = 0; it < 4; ++it) {  // M <- M^2 / trace-normalised, ping-pong M4 <-> V4
@@ -364,18 +376,13 @@ __device__ void quaternion_mean(const double* Y, int qrow, int ncols, double wm0
     for (int i = 0; i < 4; ++i) out[i] = L.w4[i];
 }
 
-// C (ra x rb, leading dim ldc) = A diag(w) B'   (column 0 carries wc0, the rest the common weight)
+// C (ra x rb, leading dim ldc) = A diag(w) B'
 __device__ void weighted_outer(const double* A, int ra, const double* B, int rb, int ncols, double wc0, double wci,
                                double* C, int ldc)
 {
     for (int e = threadIdx.x; e < ra * rb; e += kUkfThreads) {
         const int i = e / rb, j = e % rb;
-        const double* ar = A + i * kCols;
-        const double* br = B + j * kCols;
-        double s = ar[0] * wc0 * br[0];
-#pragma unroll 8
-        for (int c = 1; c < ncols; ++c) s += ar[c] * wci * br[c];
-        C[i * ldc + j] = s;
+        C[i * ldc + j] = weighted_dot(A + i * kCols, B + j * kCols, ncols, wc0, wci);
     }
 }
 
@@ -826,21 +833,12 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
         const int nxy = 12 * m, ntri = m * (m + 1) / 2;
         if (lane < nxy) {
             const int i = lane / m, j = lane % m;
-            const double* ar = L.X + i * kCols;
-            const double* br = L.D + j * kCols;
-            double s = ar[0] * w.wc0 * br[0];
-#pragma unroll 8
-            for (int c = 1; c < w.ncols; ++c) s += ar[c] * w.wi * br[c];
-            L.Pxy[lane] = s;
+            L.Pxy[lane] = weighted_dot(L.X + i * kCols, L.D + j * kCols, w.ncols, w.wc0, w.wi);
         } else if (lane - nxy < ntri) {
             int u = lane - nxy, i = 0;
             while (u >= m - i) { u -= m - i; ++i; }
             const int j = i + u;
-            const double* ar = L.D + i * kCols;
-            const double* br = L.D + j * kCols;
-            double s = ar[0] * w.wc0 * br[0];
-#pragma unroll 8
-            for (int c = 1; c < w.ncols; ++c) s += ar[c] * w.wi * br[c];
+            const double s = weighted_dot(L.D + i * kCols, L.D + j * kCols, w.ncols, w.wc0, w.wi);
             L.Py[i * m + j] = s;
             L.Py[j * m + i] = s;
         }

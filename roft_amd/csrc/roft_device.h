@@ -18,6 +18,8 @@ constexpr int kTwistRing = 32;         // twist history ring (velocity deque of 
 constexpr int kMaxFlowHist = 6;        // flows a new mask can be chased through (frames between masks)
 constexpr int kMaxSteps = 10;          // UKF launches per frame (re-sync replays <= 7)
 constexpr int kPlaneSlots = ROFT_RETAIN_FRAMES;  // mask bit-plane ring per object
+constexpr int kFeatRing = 8;           // buffered outlier-rejection feature sets per object (> frames in flight between
+                                       // the mask chain that writes them and the pose chain that reads them)
 
 enum BeliefSlot { B_CORR = 0, B_PRED = 1, B_BUF = 2, B_ALT0 = 3, B_ALT1 = 4, B_SPARE = 5 };
 
@@ -67,7 +69,7 @@ struct ObjState {
     int mask_mode;         // decided by the scatter kernel: 0 copy, 1 propagate, 2 new mask
     int bbox[4];           // target bounding box of the scatter: xmin, ymin, xmax, ymax
     int n_flow_points;     // N of the velocity stage (-1: did not run)
-    int n_feat;            // buffered outlier-rejection samples (rank-even mask pixels)
+    int n_feat[kFeatRing]; // buffered outlier-rejection samples (rank-even mask pixels) per feature ring slot
     int outlier_selected;
     double outlier_L[2];
     double outlier_cnt[2];
@@ -105,9 +107,10 @@ struct alignas(16) FrameCtrl {
     int slot_prev, slot_cur;         // bit-plane ring slots
     int vel_stage;                   // run the velocity stage this frame
     int twist_slot;                  // twist_hist slot written this frame
-    int buffer_features_before;      // buffer outlier features before the UKF steps (first frame)
-    int buffer_features_after;       // ... after them (pose re-sync frames, ROFTFilter.cpp:353)
-    int features_current;            // non-resync outlier rejection: features of the current frame
+    int feat_write;                  // feature ring slot this frame's features are buffered into, -1: none
+                                     // (first frame ROFTFilter.cpp:313-322, pose re-sync frames :353, and the
+                                     // current-frame features of the outlier test without re-sync)
+    int feat_read;                   // feature ring slot this frame's outlier test reads
     int n_steps;
     double pose_x[3];
     double pose_q[4];
@@ -131,8 +134,8 @@ struct EngineArrays {
     FlowRec* cand;           // [n_obj][cand_cap] candidate scratch
     FlowRec* recs;           // [n_obj][cand_cap] kept flow records
     double* norms;           // [n_obj][3 * cand_cap] SKF scratch (innovations + norms when N > LDS capacity)
-    uint32_t* feat_pix;      // [n_obj][feat_cap] buffered feature pixel (linear index)
-    float* feat_depth;       // [n_obj][feat_cap]
+    uint32_t* feat_pix;      // [n_obj][kFeatRing][feat_cap] buffered feature pixel (linear index)
+    float* feat_depth;       // [n_obj][kFeatRing][feat_cap]
     uint32_t* zbuf;          // [n_obj][2][tile_h*tile_w] float bits, +inf = empty
     int cand_cap, feat_cap;
     size_t plane_words;      // wpr*H
@@ -206,7 +209,7 @@ void launch_skf_arrays(const double* x_pred, const double* P_pred, int N, const 
                        hipStream_t s);
 void launch_kf_predict(const double* x, const double* P, const double* qdiag, double* xo, double* Po, hipStream_t s);
 void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s);  // steps [step0, step1)
-void launch_features(const EngineArrays& a, int phase, hipStream_t s);
+void launch_features(const EngineArrays& a, hipStream_t s);   // after the mask stage of the frame
 void launch_outlier(const EngineArrays& a, hipStream_t s);       // z-buffer clear + render + likelihood + decision
 void launch_outlier_only(const EngineArrays& a, hipStream_t s);  // likelihood + decision on filled z-buffers
 
