@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void mask_scatter_kernel(EngineArrays a, int f
 }
 
 // grid: (ceil(W*H/64/4), n_obj); each wave produces 64 output pixels (two plane words) per step
-__global__ __launch_bounds__(256) void mask_gather_kernel(EngineArrays a, int frames_between)
+__device__ void mask_gather_body(const EngineArrays& a, int frames_between)
 {
     const int obj = blockIdx.y;
     const FrameCtrl& c = a.ctrl[obj];
@@ -272,6 +272,14 @@ __global__ __launch_bounds__(256) void mask_gather_kernel(EngineArrays a, int fr
             reinterpret_cast<uint2*>(dob)[word2] = make_uint2((uint32_t)b2, (uint32_t)(b2 >> 32));
         }
     }
+}
+
+// (Folding the per-object bookkeeping into this kernel -- "the last workgroup of an object does it" -- was measured
+// and dropped: the device-scope fence each of the ~4000 workgroups needs before its atomic counter increment
+// writes back the XCD's L2 and made this kernel 157 us instead of 18, slowing every concurrent kernel too.)
+__global__ __launch_bounds__(256) void mask_gather_kernel(EngineArrays a, int frames_between)
+{
+    mask_gather_body(a, frames_between);
 }
 
 // bookkeeping after the gather: flow buffer count, reset per-frame scratch state

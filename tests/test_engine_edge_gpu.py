@@ -83,3 +83,40 @@ def test_long_many_object_run():
     streams = [util.stream(600 + i, 90, scale=2, device="cuda") for i in range(16)]
     n_tests = compare(streams, 90, check_masks=False)
     assert n_tests >= 16 * 10
+
+
+def test_device_buffers_recycled_after_retain_frames():
+    """The zero-copy contract of roft_frame_input: a DEVICE buffer handed over for frame k may be overwritten once
+    roft_frame_submit() for frame k + ROFT_RETAIN_FRAMES has returned, although several frames are in flight on three
+    streams.  The caller keeps exactly ROFT_RETAIN_FRAMES input slots and refills them round-robin."""
+    from oracle import binding as ob
+    from roft_amd import _lib as L
+    from test_engine_gpu import make_engine
+    n = 70
+    st = util.stream(540, n, scale=2, device="cuda")
+    ref = util.run_oracle_tracker(ob, st, n)
+    R = L.RETAIN_FRAMES
+    depth = torch.zeros((R,) + tuple(st.depth.shape[1:]), dtype=st.depth.dtype, device="cuda")
+    flow = torch.zeros((R,) + tuple(st.flow.shape[1:]), dtype=st.flow.dtype, device="cuda")
+    mask = torch.zeros((R,) + tuple(st.mask_gt.shape[1:]), dtype=st.mask_gt.dtype, device="cuda")
+    eng = make_engine([st])
+    eng.enable_log(n)
+    for k in range(n):
+        s = k % R
+        # (the copies are synchronous with respect to the host: the data is in place before the submit)
+        depth[s].copy_(st.depth[k])
+        flow[s].copy_(st.flow[k])
+        mi = st.mask_delivery[k]
+        if mi >= 0:
+            mask[s].copy_(st.mask_gt[mi])
+        torch.cuda.synchronize()
+        pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
+        eng.submit([dict(depth=depth[s].data_ptr(), flow=flow[s].data_ptr() if st.flow_valid[k] else None,
+                         mask=mask[s].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE)])
+        eng.step()
+    pose_log, twist_log, npts, sel = eng.get_log(0, n)
+    eng.close()
+    want = np.array([r["pose"] for r in ref])
+    assert np.abs(pose_log[:, 0] - want).max() < 1e-8
+    assert np.array_equal(npts[:, 0], np.array([r["n"] for r in ref]))
+    assert np.array_equal(sel[:, 0], np.array([r["sel"] for r in ref]))
