@@ -9,6 +9,7 @@
 //   CartesianQuaternionModel + bfl::UKFPrediction            ROFT::UKFPrediction             roft_ukf_predict
 //   UKFCorrection + CartesianQuaternionMeasurement           ROFT::UKFCorrection             roft_ukf_correct
 //   ROFTFilter (ROFTFilter.h:38-194)                         ROFT::ROFTFilter                roft_engine_*
+//   ImageOpticalFlowNVOF (ImageOpticalFlowNVOF.h:24-90)      ROFT::ImageOpticalFlowHIP       roft_optical_flow
 //
 // Conventions kept from the reference: predict(prev, pred) / correct(pred, corr) on Gaussians; an
 // invalid / empty measurement leaves corr = pred (SKFCorrection.cpp:46-69, UKFCorrection.cpp:64-68);
@@ -18,6 +19,8 @@
 
 #include <cstdint>
 #include <memory>
+#include <stdexcept>
+#include <utility>
 #include <vector>
 
 #include "../roft_engine.h"
@@ -135,6 +138,53 @@ public:
 private:
     int w_, h_, fb_;
 };
+
+// ---- optical-flow source (the step before the filter) ---------------------------------------------------
+// Same interface as ImageOpticalFlowNVOF (step_frame / flow / get_grid_size / get_scaling_factor /
+// get_matrix_type, ImageOpticalFlowNVOF.cpp:100-200) over the HIP pyramidal Lucas-Kanade producer; the frame is
+// handed to step_frame() as an 8-bit gray image (what cv::cvtColor(frame, COLOR_BGR2GRAY) leaves, cpp:123).
+class ImageOpticalFlowHIP {
+public:
+    enum class Product { NVOF_1_0 = 1, NVOF_2_0 = 2 };   // CV_16SC2 S10.5 at grid 4 | CV_32FC2 at grid 1 (cpp:19-80)
+    ImageOpticalFlowHIP(int width, int height, Product product) : w_(width), h_(height), product_(product)
+    {
+        compat::throw_if(roft_default_of_params(&prm_), "ImageOpticalFlowHIP");
+        if (width <= 0 || height <= 0) throw std::runtime_error("ImageOpticalFlowHIP: bad image size");
+        const bool v1 = product == Product::NVOF_1_0;
+        flow_.resize(v1 ? static_cast<std::size_t>(width / 4) * (height / 4) * 4 : static_cast<std::size_t>(width) * height * 8);
+    }
+    // returns false on the first frame (no previous image yet), like the reference
+    bool step_frame(const std::uint8_t* gray)
+    {
+        const std::size_t n = static_cast<std::size_t>(w_) * h_;
+        if (last_.empty()) {
+            last_.assign(gray, gray + n);
+            return false;
+        }
+        compat::throw_if(roft_optical_flow(last_.data(), gray, w_, h_, &prm_, static_cast<int>(get_matrix_type() == 11 ? ROFT_FLOW_S16C2 : ROFT_FLOW_F32C2),
+                                           flow_.data()), "ImageOpticalFlowHIP::step_frame");
+        last_.assign(gray, gray + n);
+        flow_in_ = true;
+        return true;
+    }
+    std::pair<bool, const void*> flow(bool /*blocking*/ = false) const { return {flow_in_, flow_.data()}; }
+    bool is_stepping_required() const { return true; }
+    std::size_t get_grid_size() const { return product_ == Product::NVOF_1_0 ? 4 : 1; }
+    float get_scaling_factor() const { return product_ == Product::NVOF_1_0 ? 32.0f : 1.0f; }
+    int get_matrix_type() const { return product_ == Product::NVOF_1_0 ? 11 /* CV_16SC2 */ : 13 /* CV_32FC2 */; }
+    int flow_cols() const { return w_ / static_cast<int>(get_grid_size()); }
+    int flow_rows() const { return h_ / static_cast<int>(get_grid_size()); }
+    roft_of_params& parameters() { return prm_; }
+
+private:
+    int w_, h_;
+    Product product_;
+    roft_of_params prm_{};
+    std::vector<std::uint8_t> last_;
+    std::vector<unsigned char> flow_;
+    bool flow_in_ = false;
+};
+using ImageOpticalFlowNVOF = ImageOpticalFlowHIP;   // drop-in name
 
 // ---- pose filter ------------------------------------------------------------------------------------
 class UKFPrediction {

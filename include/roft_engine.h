@@ -148,6 +148,11 @@ typedef struct {
     int flow_aided_segmentation;                 /* segmentation_dataset.flow_aided */
     int mask_frames_between;                     /* original_fps / desired_fps of the mask source */
     int pose_frames_between;                     /* original_fps / desired_fps of the pose source */
+    /* 1: masks come from a live source and carry the time stamp of the image they were computed on; a new mask is
+     * propagated through the flows stored after the flow with that stamp (time-stamp keyed queue of the last 30 flows),
+     * ImageSegmentationOFAidedSourceStamped.hpp:153-268 + OpticalFlowQueueHandler.cpp.  Needs 1 <= mask_frames_between
+     * <= 6 and roft_frame_input::stamp / mask_stamp.  0: the frame-counting ImageSegmentationOFAidedSource. */
+    int stamped_masks;
     int max_objects;
     /* Square root the sigma points are drawn from.  The reference (bfl) uses U sqrt(S) of the eigen-decomposition
      * of the covariance.  Any square root reproduces the first two moments; the choice only shows in fourth-order
@@ -195,6 +200,8 @@ typedef struct {
     double pose_x[3];
     double pose_q[4];     /* (w,x,y,z) */
     int mem_kind;
+    double stamp;         /* stamped_masks: RGB time stamp of this frame (s) */
+    double mask_stamp;    /* stamped_masks: time stamp of the image `mask` was computed on */
 } roft_frame_input;
 
 typedef struct {

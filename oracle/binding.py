@@ -55,12 +55,13 @@ class TrackerConfig(C.Structure):
                 ("flow_weighting", C.c_int), ("use_pose", C.c_int), ("use_pose_resync", C.c_int),
                 ("use_velocity", C.c_int), ("outlier_rejection", C.c_int),
                 ("flow_aided_segmentation", C.c_int), ("mask_frames_between", C.c_int),
-                ("pose_frames_between", C.c_int)]
+                ("pose_frames_between", C.c_int), ("stamped_masks", C.c_int)]
 
 
 class Frame(C.Structure):
     _fields_ = [("dt", C.c_double), ("depth", C.c_void_p), ("flow", Flow), ("mask", C.c_void_p),
-                ("pose_valid", C.c_int), ("pose_x", C.c_double * 3), ("pose_q", C.c_double * 4)]
+                ("pose_valid", C.c_int), ("pose_x", C.c_double * 3), ("pose_q", C.c_double * 4),
+                ("stamp", C.c_double), ("mask_stamp", C.c_double)]
 
 
 class FrameResult(C.Structure):
@@ -257,11 +258,12 @@ class Tracker:
         self._h = lib().ro_tracker_create(C.byref(cfg), C.byref(self._mesh))
         self.H, self.W = cfg.cam.height, cfg.cam.width
 
-    def step(self, dt, depth, flow_arr, mask, pose):
-        """pose: None or (x[3], q[4]).  Returns a FrameResult."""
+    def step(self, dt, depth, flow_arr, mask, pose, stamp=0.0, mask_stamp=0.0):
+        """pose: None or (x[3], q[4]).  stamp / mask_stamp: only with cfg.stamped_masks.  Returns a FrameResult."""
         depth = np.ascontiguousarray(depth, np.float32)
         fr = Frame()
         fr.dt = dt
+        fr.stamp, fr.mask_stamp = stamp, mask_stamp
         fr.depth = depth.ctypes.data
         fr.flow = make_flow(flow_arr, self.W)
         keep = [depth, flow_arr]

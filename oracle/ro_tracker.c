@@ -48,6 +48,11 @@ struct ro_tracker {
     ro_flow* flow_buf_desc;
     int flow_buf_n, flow_buf_cap;
     int32_t* map_scratch;
+    /* OpticalFlowQueueHandler (window 30, hpp:90-92) of the stamped source */
+    void* fq_data[30];
+    ro_flow fq_desc[30];
+    double fq_stamp[30];
+    int fq_n;
 
     /* ImageSegmentationMeasurement state */
     uint8_t* seg_bin; /* segmentation_ (binarised) */
@@ -168,6 +173,7 @@ void ro_tracker_destroy(ro_tracker* t)
 {
     if (!t) return;
     for (int i = 0; i < t->flow_buf_cap; i++) free(t->flow_buf[i]);
+    for (int i = 0; i < 30; i++) free(t->fq_data[i]);
     free(t->flow_buf); free(t->flow_buf_desc);
     free(t->mesh_verts); free(t->mesh_tris);
     free(t->of_mask); free(t->seg_bin); free(t->prev_seg); free(t->buffered_seg);
@@ -242,11 +248,68 @@ static void of_aided_step(ro_tracker* t, const ro_frame* f)
     t->of_first_frame = 0;
 }
 
+/* OpticalFlowQueueHandler::add_flow (OpticalFlowQueueHandler.cpp:18-26) */
+static void flow_queue_add(ro_tracker* t, const ro_flow* f, double stamp)
+{
+    if (t->fq_n == 30) {
+        void* oldest = t->fq_data[0];
+        memmove(t->fq_data, t->fq_data + 1, sizeof(void*) * 29);
+        memmove(t->fq_desc, t->fq_desc + 1, sizeof(ro_flow) * 29);
+        memmove(t->fq_stamp, t->fq_stamp + 1, sizeof(double) * 29);
+        t->fq_data[29] = oldest;
+        t->fq_n = 29;
+    }
+    int k = t->fq_n++;
+    t->fq_data[k] = realloc(t->fq_data[k], flow_bytes(f));
+    memcpy(t->fq_data[k], f->data, flow_bytes(f));
+    t->fq_desc[k] = *f;
+    t->fq_desc[k].data = t->fq_data[k];
+    t->fq_stamp[k] = stamp;
+}
+
+/* ImageSegmentationOFAidedSourceStamped<T>::step_frame (…Stamped.hpp:153-268), wait_source_initialization=false,
+ * no source feedback.  get_buffer_region (OpticalFlowQueueHandler.cpp:29-58): the flows stored AFTER the entry whose
+ * stamp matches the mask stamp within 1 ms (`abs` taken as the floating-point absolute value). */
+static void of_aided_stamped_step(ro_tracker* t, const ro_frame* f)
+{
+    int valid_segmentation = (f->mask != NULL);
+    const uint8_t* mask = f->mask;
+    if (!t->seg_available && valid_segmentation) {
+        t->seg_available = 1;
+        memcpy(t->of_mask, mask, t->npix);
+        valid_segmentation = 0;
+    }
+    if (valid_segmentation && mask_is_empty(mask, t->npix)) valid_segmentation = 0;
+    int valid_flow = f->flow.valid && !t->of_first_frame;
+    if (valid_flow) flow_queue_add(t, &f->flow, f->stamp);
+
+    if (valid_segmentation) {
+        memcpy(t->of_mask, mask, t->npix);
+        int first = -1;
+        for (int i = 0; i < t->fq_n; i++)
+            if (fabs(t->fq_stamp[i] - f->mask_stamp) < 1e-3) { first = i + 1; break; }
+        int n = (first >= 0) ? t->fq_n - first : 0;
+        if (n > 0) {
+            ro_mask_propagate(t->of_mask, t->W, t->H, t->fq_desc + first, n, t->cfg.mask_frames_between, t->map_scratch);
+        } else if (f->flow.valid) {
+            t->of_mask[0] = 0;
+            ro_flow one = f->flow;
+            ro_mask_propagate(t->of_mask, t->W, t->H, &one, 1, t->cfg.mask_frames_between, t->map_scratch);
+        }
+    } else if (valid_flow && t->seg_available) {
+        t->of_mask[0] = 0;
+        ro_flow one = f->flow;
+        ro_mask_propagate(t->of_mask, t->W, t->H, &one, 1, t->cfg.mask_frames_between, t->map_scratch);
+    }
+    t->of_first_frame = 0;
+}
+
 /* ImageSegmentationMeasurement::freeze */
 static int segmentation_freeze(ro_tracker* t, const ro_frame* f)
 {
     if (t->cfg.flow_aided_segmentation) {
-        of_aided_step(t, f);
+        if (t->cfg.stamped_masks) of_aided_stamped_step(t, f);
+        else of_aided_step(t, f);
         if (t->seg_available) {
             t->seg_meas_available = 1;
             ro_mask_binarise(t->of_mask, t->seg_bin, t->npix);

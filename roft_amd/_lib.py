@@ -51,7 +51,7 @@ class Config(C.Structure):
                 ("subsampling_radius", C.c_double), ("flow_weighting", C.c_int), ("use_pose", C.c_int),
                 ("use_pose_resync", C.c_int), ("use_velocity", C.c_int), ("outlier_rejection", C.c_int),
                 ("flow_aided_segmentation", C.c_int), ("mask_frames_between", C.c_int),
-                ("pose_frames_between", C.c_int), ("max_objects", C.c_int), ("ukf_cholesky_guard", C.c_double),
+                ("pose_frames_between", C.c_int), ("stamped_masks", C.c_int), ("max_objects", C.c_int), ("ukf_cholesky_guard", C.c_double),
                 ("ukf_cholesky_guard_bilinear", C.c_double),
                 ("device", C.c_int)]
 
@@ -68,7 +68,7 @@ class ObjectDesc(C.Structure):
 class FrameInput(C.Structure):
     _fields_ = [("dt", C.c_double), ("depth", C.c_void_p), ("flow", C.c_void_p), ("mask", C.c_void_p),
                 ("pose_valid", C.c_int), ("pose_x", C.c_double * 3), ("pose_q", C.c_double * 4),
-                ("mem_kind", C.c_int)]
+                ("mem_kind", C.c_int), ("stamp", C.c_double), ("mask_stamp", C.c_double)]
 
 
 class ObjectOutput(C.Structure):

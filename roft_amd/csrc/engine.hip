@@ -190,6 +190,7 @@ struct HostObject {
     int feat_slot = 0;                 // feature ring slot holding the buffered outlier-rejection features
     int feat_next = 0;                 // next ring slot to write
     std::deque<const void*> flow_hist; // last valid flows, newest at front
+    std::deque<double> flow_stamps;    // stamped source: RGB stamps of the last 30 valid flows, oldest at front
     std::deque<int> vel_buf;           // twist_hist slots (CartesianQuaternionMeasurement::buffer_velocities_)
     int last_meas_slot = 0;            // slot of measurement_.head<6>()
     const float* depth_prev = nullptr;
@@ -326,6 +327,8 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
     if (cfg->mask_frames_between > kMaxFlowHist)
         return fail(ROFT_ERR_INVALID, "mask_frames_between > 6 is not supported");
     if (cfg->pose_frames_between + 2 > kTwistRing) return fail(ROFT_ERR_INVALID, "pose_frames_between too large");
+    if (cfg->stamped_masks && (cfg->mask_frames_between < 1 || cfg->mask_frames_between > kMaxFlowHist))
+        return fail(ROFT_ERR_INVALID, "stamped_masks needs 1 <= mask_frames_between <= 6");
     HIP_TRY(hipSetDevice(cfg->device));
     roft_engine* e = new roft_engine();
     e->cfg = *cfg;
@@ -625,6 +628,19 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
             while ((int)o.flow_hist.size() > kMaxFlowHist) o.flow_hist.pop_back();
         }
         c.flow_valid = valid_flow ? 1 : 0;
+        if (cfg.stamped_masks) {
+            // OpticalFlowQueueHandler: window of 30 stamped flows; get_buffer_region(mask stamp) = the flows stored
+            // after the first entry within 1 ms of it (OpticalFlowQueueHandler.cpp:18-58)
+            c.stamped = 1;
+            if (valid_flow) {
+                o.flow_stamps.push_back(in.stamp);
+                while (o.flow_stamps.size() > 30) o.flow_stamps.pop_front();
+            }
+            c.n_region = 0;
+            if (d_mask)
+                for (size_t i = 0; i < o.flow_stamps.size(); ++i)
+                    if (std::fabs(o.flow_stamps[i] - in.mask_stamp) < 1e-3) { c.n_region = (int)(o.flow_stamps.size() - (i + 1)); break; }
+        }
         for (int j = 0; j < kMaxFlowHist; ++j) c.flow[j] = j < (int)o.flow_hist.size() ? o.flow_hist[j] : nullptr;
         if (c.has_new_mask) e->any_new_mask = true;
 

@@ -104,6 +104,8 @@ struct alignas(16) FrameCtrl {
     int flow_valid;                  // this frame's flow exists and it is not the first frame
     int has_new_mask;
     int first_mask;                  // first mask ever: initialisation, not "new" (hpp:169-178)
+    int stamped;                     // time-stamped source (…Stamped.hpp): n_region replaces the device-side flow count
+    int n_region;                    // flows stored after the flow whose stamp matches the new mask's (0: none / no match)
     int slot_prev, slot_cur;         // bit-plane ring slots
     int vel_stage;                   // run the velocity stage this frame
     int twist_slot;                  // twist_hist slot written this frame
@@ -171,7 +173,14 @@ __device__ inline int decide_mode(const FrameCtrl& c, const ObjState& st, int& s
     }
     if (c.has_new_mask && !c.first_mask && st.new_mask_count > 0) {
         src_slot = kSlotNew;
-        n_flows = n_avail < kMaxFlowHist ? n_avail : kMaxFlowHist;
+        if (c.stamped && c.n_region <= 0) {
+            // …Stamped.hpp:229-236: no flow after the mask's stamp in the queue -> the NEW mask through this frame's
+            // flow only, mask(0,0) forced to 0 (mode 1 semantics on the new mask)
+            n_flows = 1;
+            return c.flow_valid ? 1 : 0;
+        }
+        const int n_use = c.stamped ? c.n_region : n_avail;
+        n_flows = n_use < kMaxFlowHist ? n_use : kMaxFlowHist;
         return 2;
     }
     src_slot = (c.has_new_mask && c.first_mask) ? kSlotNew : c.slot_prev;

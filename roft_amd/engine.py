@@ -61,6 +61,8 @@ class ROFTFilterBatch:
             kind = f.get("mem_kind", L.MEM_HOST)
             fi.mem_kind = kind
             fi.dt = f.get("dt", 0.0)
+            fi.stamp = f.get("stamp", 0.0)            # only read with cfg.stamped_masks
+            fi.mask_stamp = f.get("mask_stamp", 0.0)
             for key in ("depth", "flow", "mask"):
                 v = f.get(key)
                 if v is None:

@@ -1,6 +1,7 @@
 // Exercises the C++ facade (include/ROFT/Filters.h) over the C ABI.  Reads a tiny binary problem written
 // by tests/test_facade.py, runs KF predict + SKF correct + UKF predict through the facade classes and
 // writes the results back.  Without a HIP device every call must throw std::runtime_error.
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -38,11 +39,26 @@ int main(int argc, char** argv)
         const double one[3] = {1.0, 1.0, 1.0};
         ROFT::UKFPrediction up(one, one, 1.0 / 30.0, 1.0, 2.0, 0.0);
         up.predict(pp, pq);
+        // optical-flow source facade: a smooth pattern shifted by (2, 1) pixels
+        const int W = 64, Hh = 48;
+        std::vector<std::uint8_t> g0(W * Hh), g1(W * Hh);
+        for (int yy = 0; yy < Hh; ++yy)
+            for (int xx = 0; xx < W; ++xx) {
+                g0[yy * W + xx] = (std::uint8_t)(128 + (int)(60.0 * std::sin(0.35 * xx) * std::cos(0.27 * yy)));
+                g1[yy * W + xx] = (std::uint8_t)(128 + (int)(60.0 * std::sin(0.35 * (xx - 2)) * std::cos(0.27 * (yy - 1))));
+            }
+        ROFT::ImageOpticalFlowNVOF of(W, Hh, ROFT::ImageOpticalFlowHIP::Product::NVOF_2_0);
+        of.parameters().levels = 2;
+        of.parameters().det_min = 1.0f;
+        const bool first = of.step_frame(g0.data());
+        const bool second = of.step_frame(g1.data());
+        if (first || !second || !of.flow().first || of.get_matrix_type() != 13 || of.get_grid_size() != 1) return 4;
         FILE* o = std::fopen(argv[2], "wb");
         std::fwrite(corr.mean().data(), 8, 6, o);
         std::fwrite(corr.covariance().data(), 8, 36, o);
         std::fwrite(pq.mean().data(), 8, 13, o);
         std::fwrite(pq.covariance().data(), 8, 144, o);
+        std::fwrite(of.flow().second, 4, (size_t)W * Hh * 2, o);
         std::fclose(o);
     } catch (const std::runtime_error& e) {
         std::printf("runtime_error: %s\n", e.what());

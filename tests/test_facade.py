@@ -59,10 +59,19 @@ def test_facade_matches_operator_abi(tmp_path):
     inp, (x, P, q, y, H, pm, pP) = problem(tmp_path)
     out = str(tmp_path / "out.bin")
     subprocess.check_call([exe, inp, out])
-    got = np.fromfile(out, np.float64)
+    raw = open(out, "rb").read()
+    got = np.frombuffer(raw[:8 * (6 + 36 + 13 + 144)], np.float64)
+    flow = np.frombuffer(raw[8 * (6 + 36 + 13 + 144):], np.float32).reshape(48, 64, 2)
     xp, Pp = ops.kf_predict(x, P, q)
     rc, xc, Pc = ops.skf_correct(xp, Pp, y, H, (1.0, 1.0), True)
     Q = ops.process_noise([1.0] * 3, [1.0] * 3, 1.0 / 30.0)
     m1, P1 = ops.ukf_predict(pm, pP, Q, 1.0 / 30.0)
     assert np.array_equal(got[:6], xc) and np.array_equal(got[6:42].reshape(6, 6), Pc)
     assert np.array_equal(got[42:55], m1) and np.array_equal(got[55:].reshape(12, 12), P1)
+    # optical-flow source facade == operator ABI on the same pattern, and it sees the (2, 1) shift
+    yy, xx = np.mgrid[0:48, 0:64]
+    g0 = (128 + (60.0 * np.sin(0.35 * xx) * np.cos(0.27 * yy)).astype(np.int64)).astype(np.uint8)
+    g1 = (128 + (60.0 * np.sin(0.35 * (xx - 2)) * np.cos(0.27 * (yy - 1))).astype(np.int64)).astype(np.uint8)
+    assert np.array_equal(flow, ops.optical_flow(g0, g1, levels=2, det_min=1.0))
+    inner = flow[12:36, 16:48]
+    assert abs(np.median(inner[..., 0]) - 2.0) < 0.3 and abs(np.median(inner[..., 1]) - 1.0) < 0.3
