@@ -16,7 +16,10 @@
  *   gradient  Ix(z) = 0.5 (I0c(z + (1,0)) - I0c(z - (1,0))), Iy likewise (of the edge-extended previous image)
  *   per pixel p of level l, window offsets o in [-r, r]^2 in row-major order:
  *     G = sum [Ix^2, Ix Iy; Ix Iy, Iy^2](p + o);  d = 2 * d_{l+1}(p >> 1) (0 at the coarsest level)
- *     if det G > det_min, `iterations` times:  b = sum grad(p+o) * (I1 bilinear(p + o + d) - I0c(p + o));  d -= G^-1 b
+ *     if det G > det_min, `iterations` times:  b = sum grad(p+o) * (W(p + o) - I0c(p + o));  d -= G^-1 b
+ *     W = the current image warped by d with ONE pair of bilinear weights for the whole window (d is constant over
+ *     it): q = p + d, q0 = floor(q), a = q - q0;  h(z) = (1-ax) I1c(z) + ax I1c(z + (1,0))  (horizontal pass),
+ *     W(p + o) = (1-ay) h(q0 + o) + ay h(q0 + o + (0,1))  (vertical pass)
  *   output    level-0 field; CV_16SC2: sampled at the centre (4i+2, 4j+2) of each 4x4 block, round(32 d) saturated
  */
 #include "roft_oracle.h"
@@ -28,18 +31,6 @@
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 static inline float at(const float* I, int w, int h, int x, int y) { return I[(size_t)clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)]; }
-
-static inline float bilinear(const float* I, int w, int h, float xf, float yf)
-{
-    const float fx = floorf(xf), fy = floorf(yf);
-    const float ax = xf - fx, ay = yf - fy;
-    /* keep the integer conversion in range for wild displacements */
-    const int x0 = (int)fminf(fmaxf(fx, -4.0f), (float)w + 4.0f), y0 = (int)fminf(fmaxf(fy, -4.0f), (float)h + 4.0f);
-    const float i00 = at(I, w, h, x0, y0), i01 = at(I, w, h, x0 + 1, y0);
-    const float i10 = at(I, w, h, x0, y0 + 1), i11 = at(I, w, h, x0 + 1, y0 + 1);
-    const float top = (1.0f - ax) * i00 + ax * i01, bot = (1.0f - ax) * i10 + ax * i11;
-    return (1.0f - ay) * top + ay * bot;
-}
 
 int ro_optical_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int levels, int radius, int iterations,
                     float det_min, float* flow /* H x W x 2 */)
@@ -85,12 +76,20 @@ int ro_optical_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int l
                 if (det > det_min) {
                     const float inv = 1.0f / det;
                     for (int it = 0; it < iterations; it++) {
+                        const float xf = (float)x + dx, yf = (float)y + dy;
+                        const float fx = floorf(xf), fy = floorf(yf);
+                        const float ax = xf - fx, ay = yf - fy;
+                        /* keep the integer conversion in range for wild displacements */
+                        const int x0 = (int)fminf(fmaxf(fx, -64.0f), (float)wl + 64.0f);
+                        const int y0 = (int)fminf(fmaxf(fy, -64.0f), (float)hl + 64.0f);
                         float b1 = 0.0f, b2 = 0.0f;
                         for (int oy = -radius; oy <= radius; oy++)
                             for (int ox = -radius; ox <= radius; ox++) {
                                 const float ix = 0.5f * (at(I0, wl, hl, x + ox + 1, y + oy) - at(I0, wl, hl, x + ox - 1, y + oy));
                                 const float iy = 0.5f * (at(I0, wl, hl, x + ox, y + oy + 1) - at(I0, wl, hl, x + ox, y + oy - 1));
-                                const float it_ = bilinear(I1, wl, hl, (float)(x + ox) + dx, (float)(y + oy) + dy) - at(I0, wl, hl, x + ox, y + oy);
+                                const float top = (1.0f - ax) * at(I1, wl, hl, x0 + ox, y0 + oy) + ax * at(I1, wl, hl, x0 + ox + 1, y0 + oy);
+                                const float bot = (1.0f - ax) * at(I1, wl, hl, x0 + ox, y0 + oy + 1) + ax * at(I1, wl, hl, x0 + ox + 1, y0 + oy + 1);
+                                const float it_ = ((1.0f - ay) * top + ay * bot) - at(I0, wl, hl, x + ox, y + oy);
                                 b1 += ix * it_; b2 += iy * it_;
                             }
                         dx -= (g22 * b1 - g12 * b2) * inv;

@@ -9,9 +9,9 @@
 // nearest-neighbour x2 initialisation) and this file follows it tap for tap.
 //
 // MI355X mapping: one workgroup = a 32 x 8 pixel tile of one pyramid level of one image pair; the previous image
-// tile with an (r + 1)-pixel halo is staged in LDS once and serves the gradient and the G-matrix taps of all 256
-// pixels; only the bilinear samples of the current image (whose position depends on the evolving flow) go to the
-// vector cache.  Batched over image pairs in blockIdx.z.
+// tile with an (r + 1)-pixel halo and its two gradient tiles are staged in LDS once and serve the G-matrix and the
+// residual taps of all 256 pixels; only the pixels of the current image under the warped window (whose position
+// depends on the evolving flow) go to the vector cache.  Batched over image pairs in blockIdx.z.
 #include <algorithm>
 
 #include "opticalflow.h"
@@ -53,39 +53,44 @@ __device__ __forceinline__ float at_g(const float* I, int w, int h, int x, int y
     return I[(size_t)clampi(y, 0, h - 1) * w + clampi(x, 0, w - 1)];
 }
 
-__device__ __forceinline__ float bilinear_g(const float* I, int w, int h, float xf, float yf)
-{
-    const float fx = floorf(xf), fy = floorf(yf);
-    const float ax = xf - fx, ay = yf - fy;
-    const int x0 = (int)fminf(fmaxf(fx, -4.0f), (float)w + 4.0f), y0 = (int)fminf(fmaxf(fy, -4.0f), (float)h + 4.0f);
-    const float i00 = at_g(I, w, h, x0, y0), i01 = at_g(I, w, h, x0 + 1, y0);
-    const float i10 = at_g(I, w, h, x0, y0 + 1), i11 = at_g(I, w, h, x0 + 1, y0 + 1);
-    const float top = (1.0f - ax) * i00 + ax * i01, bot = (1.0f - ax) * i10 + ax * i11;
-    return (1.0f - ay) * top + ay * bot;
-}
-
 constexpr int kOfTx = 32, kOfTy = 8;
 
-// dynamic LDS: (kOfTx + 2R) x (kOfTy + 2R) floats, R = radius + 1
+// One pyramid level.  RT = compile-time window radius (1..4), or 0 for the generic runtime-radius version.
+// LDS: the previous-image tile with an (r + 1) halo, and from it the gradient tiles Ix, Iy with an r halo, so that a
+// tap costs three LDS reads.  The current image is warped with ONE pair of bilinear weights per pixel and iteration
+// (the displacement is constant over the window): the (2r+2)^2 pixels under the window are loaded once, combined
+// row by row (horizontal pass in registers, vertical pass against the previous row) -- 64 cached loads per iteration
+// at r = 3 instead of 4 per tap.
+template <int RT>
 __global__ __launch_bounds__(kOfTx * kOfTy) void of_lk_kernel(OfArgs a, int l)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int r = RT ? RT : a.radius, R = r + 1;
+    const int tw = kOfTx + 2 * R, th = kOfTy + 2 * R;      // I0 tile
+    const int gw = kOfTx + 2 * r, gh = kOfTy + 2 * r;      // gradient tiles
     float* tile = reinterpret_cast<float*>(smem);
+    float* gx = tile + tw * th;
+    float* gy = gx + gw * gh;
     const int pair = blockIdx.z;
-    const int w = a.lv[l].w, h = a.lv[l].h, r = a.radius, R = r + 1;
+    const int w = a.lv[l].w, h = a.lv[l].h;
     const float* I0 = a.pyr + ((size_t)pair * 2 + 0) * a.pyr_stride + a.lv[l].off;
     const float* I1 = a.pyr + ((size_t)pair * 2 + 1) * a.pyr_stride + a.lv[l].off;
     const int x0 = blockIdx.x * kOfTx, y0 = blockIdx.y * kOfTy;
-    const int tw = kOfTx + 2 * R, th = kOfTy + 2 * R;
     const int tid = threadIdx.y * kOfTx + threadIdx.x;
     for (int i = tid; i < tw * th; i += kOfTx * kOfTy) {
         const int ty = i / tw, tx = i - ty * tw;
         tile[i] = at_g(I0, w, h, x0 - R + tx, y0 - R + ty);   // edge-extended previous image
     }
     __syncthreads();
+    for (int i = tid; i < gw * gh; i += kOfTx * kOfTy) {
+        const int ty = i / gw, tx = i - ty * gw;
+        const float* t = tile + (ty + 1) * tw + (tx + 1);
+        gx[i] = 0.5f * (t[1] - t[-1]);
+        gy[i] = 0.5f * (t[tw] - t[-tw]);
+    }
+    __syncthreads();
     const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
     if (x >= w || y >= h) return;
-    const int cx = threadIdx.x + R, cy = threadIdx.y + R;   // this pixel inside the tile
 
     float dx = 0.0f, dy = 0.0f;
     if (l < a.levels - 1) {
@@ -94,27 +99,53 @@ __global__ __launch_bounds__(kOfTx * kOfTy) void of_lk_kernel(OfArgs a, int l)
         dx = 2.0f * c[0];
         dy = 2.0f * c[1];
     }
+    // window origin inside the tiles: tap (ox, oy) -> gradient tile (threadIdx + r + o), I0 tile (threadIdx + R + o)
+    const float* gx0 = gx + threadIdx.y * gw + threadIdx.x;
+    const float* gy0 = gy + threadIdx.y * gw + threadIdx.x;
+    const float* t0 = tile + (threadIdx.y + 1) * tw + (threadIdx.x + 1);
+    const int n = 2 * r + 1;
     float g11 = 0.0f, g12 = 0.0f, g22 = 0.0f;
-    for (int oy = -r; oy <= r; ++oy)
-        for (int ox = -r; ox <= r; ++ox) {
-            const float* t = tile + (cy + oy) * tw + (cx + ox);
-            const float ix = 0.5f * (t[1] - t[-1]);
-            const float iy = 0.5f * (t[tw] - t[-tw]);
+    for (int k = 0; k < n; ++k)
+        for (int j = 0; j < n; ++j) {
+            const float ix = gx0[k * gw + j], iy = gy0[k * gw + j];
             g11 += ix * ix; g12 += ix * iy; g22 += iy * iy;
         }
     const float det = g11 * g22 - g12 * g12;
     if (det > a.det_min) {
         const float inv = 1.0f / det;
+        constexpr int NMAX = RT ? 2 * RT + 1 : 15;
         for (int it = 0; it < a.iterations; ++it) {
+            const float xf = (float)x + dx, yf = (float)y + dy;
+            const float fx = floorf(xf), fy = floorf(yf);
+            const float ax = xf - fx, ay = yf - fy;
+            const int qx = (int)fminf(fmaxf(fx, -64.0f), (float)w + 64.0f) - r;
+            const int qy = (int)fminf(fmaxf(fy, -64.0f), (float)h + 64.0f) - r;
             float b1 = 0.0f, b2 = 0.0f;
-            for (int oy = -r; oy <= r; ++oy)
-                for (int ox = -r; ox <= r; ++ox) {
-                    const float* t = tile + (cy + oy) * tw + (cx + ox);
-                    const float ix = 0.5f * (t[1] - t[-1]);
-                    const float iy = 0.5f * (t[tw] - t[-tw]);
-                    const float dt = bilinear_g(I1, w, h, (float)(x + ox) + dx, (float)(y + oy) + dy) - t[0];
-                    b1 += ix * dt; b2 += iy * dt;
+            float hp[NMAX];   // horizontal pass of the previous row
+#pragma unroll 1
+            for (int k = 0; k <= n; ++k) {
+                const float* row = I1 + (size_t)clampi(qy + k, 0, h - 1) * w;
+                float hc[NMAX];
+                float left = row[clampi(qx, 0, w - 1)];
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j) {
+                    if (j >= n) break;
+                    const float right = row[clampi(qx + j + 1, 0, w - 1)];
+                    hc[j] = (1.0f - ax) * left + ax * right;
+                    left = right;
                 }
+                if (k > 0) {
+#pragma unroll
+                    for (int j = 0; j < NMAX; ++j) {
+                        if (j >= n) break;
+                        const int o = (k - 1) * gw + j;
+                        const float dt = ((1.0f - ay) * hp[j] + ay * hc[j]) - t0[(k - 1) * tw + j];
+                        b1 += gx0[o] * dt; b2 += gy0[o] * dt;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NMAX; ++j) hp[j] = hc[j];
+            }
             dx -= (g22 * b1 - g12 * b2) * inv;
             dy -= (g11 * b2 - g12 * b1) * inv;
         }
@@ -145,11 +176,18 @@ void launch_optical_flow(const OfArgs& a, hipStream_t s)
         const int npx = a.lv[l].w * a.lv[l].h;
         hipLaunchKernelGGL(of_down_kernel, dim3(std::min((npx + 255) / 256, 256), 2, a.n), dim3(256), 0, s, a, l);
     }
-    const int R = a.radius + 1;
-    const size_t lds = (size_t)(kOfTx + 2 * R) * (kOfTy + 2 * R) * sizeof(float);
-    for (int l = a.levels - 1; l >= 0; --l)
-        hipLaunchKernelGGL(of_lk_kernel, dim3((a.lv[l].w + kOfTx - 1) / kOfTx, (a.lv[l].h + kOfTy - 1) / kOfTy, a.n),
-                           dim3(kOfTx, kOfTy), lds, s, a, l);
+    const int r = a.radius, R = r + 1;
+    const size_t lds = ((size_t)(kOfTx + 2 * R) * (kOfTy + 2 * R) + 2 * (size_t)(kOfTx + 2 * r) * (kOfTy + 2 * r)) * sizeof(float);
+    for (int l = a.levels - 1; l >= 0; --l) {
+        const dim3 grid((a.lv[l].w + kOfTx - 1) / kOfTx, (a.lv[l].h + kOfTy - 1) / kOfTy, a.n), block(kOfTx, kOfTy);
+        switch (r) {
+            case 1: hipLaunchKernelGGL(of_lk_kernel<1>, grid, block, lds, s, a, l); break;
+            case 2: hipLaunchKernelGGL(of_lk_kernel<2>, grid, block, lds, s, a, l); break;
+            case 3: hipLaunchKernelGGL(of_lk_kernel<3>, grid, block, lds, s, a, l); break;
+            case 4: hipLaunchKernelGGL(of_lk_kernel<4>, grid, block, lds, s, a, l); break;
+            default: hipLaunchKernelGGL(of_lk_kernel<0>, grid, block, lds, s, a, l); break;
+        }
+    }
 }
 
 void launch_flow_quantise(const float* const* field, int16_t* const* out, int n, int W, int H, hipStream_t s)

@@ -54,7 +54,10 @@ def main():
     fp.close()
     taps = (2 * args.radius + 1) ** 2
     px = sum((W >> l) * (H >> l) for l in range(args.levels))
-    flops_px = taps * 10 + args.iterations * taps * 36 + args.iterations * 8   # G taps + (gradient, bilinear, residual, b) taps
+    n1 = 2 * args.radius + 1
+    # G taps (6 flop) + per iteration: horizontal pass (n1 + 1 rows x n1 lerps of 3 flop), vertical pass + residual + b
+    # accumulation (8 flop per tap), update
+    flops_px = taps * 6 + args.iterations * ((n1 + 1) * n1 * 3 + taps * 8 + 12)
     print(json.dumps(dict(workload="%dx%d, %d pairs, %s, L%d r%d it%d" % (W, H, n, args.flow, args.levels, args.radius, args.iterations),
                           pairs_per_s=n / dt, ms_per_batch=1e3 * dt, us_per_pair=1e6 * dt / n,
                           gflop_per_pair=1e-9 * px * flops_px, tflops=1e-12 * n * px * flops_px / dt,
