@@ -13,7 +13,9 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -228,6 +230,10 @@ struct roft_engine {
     hipEvent_t ev_pose[kCtrlRing] = {};  // pose chain of frame k complete
     bool two_streams = false;
     bool kernel_upload = true;
+    // ROFT_HOST_PROF=1: host time of the sections of roft_frame_submit / roft_step, printed by roft_engine_destroy
+    bool host_prof = false;
+    double hp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long hp_frames = 0;
     std::vector<HostObject*> objs;
     std::vector<ObjParams> h_params;
     // pinned staging ring for FrameCtrl blocks
@@ -251,6 +257,12 @@ struct roft_engine {
     std::vector<int> tmark;    // kernel id per event interval (-1 = chain start)
     std::vector<int> tstream;  // stream of each mark (0 mask chain, 1 pose chain, 2 velocity chain)
 };
+
+static inline double host_now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+#define HP_MARK(e, slot, t) do { if ((e)->host_prof) { const double _n = host_now_us(); (e)->hp_acc[slot] += _n - (t); (t) = _n; } } while (0)
 
 extern "C" {
 
@@ -378,6 +390,8 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
         HIP_TRY(hipEventCreateWithFlags(&e->stage_ev[i], hipEventDisableTiming));
     }
     e->h_params.resize(cfg->max_objects);
+    const char* hpf = getenv("ROFT_HOST_PROF");
+    e->host_prof = hpf && hpf[0] == '1';
     *out = e;
     return ROFT_OK;
 }
@@ -386,6 +400,11 @@ int roft_engine_destroy(roft_engine* e)
 {
     if (!e) return ROFT_OK;
     (void)hipSetDevice(e->cfg.device);
+    if (e->host_prof && e->hp_frames > 0) {
+        static const char* names[7] = {"submit: wait staging/in-flight", "submit: frame programs", "step: throttle", "step: FrameCtrl upload",
+                                       "step: velocity chain", "step: mask chain", "step: pose chain"};
+        for (int i = 0; i < 7; ++i) std::fprintf(stderr, "[roft host] %-32s %7.2f us/frame\n", names[i], e->hp_acc[i] / e->hp_frames);
+    }
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->vel_stream) (void)hipStreamSynchronize(e->vel_stream);
     if (e->pose_stream) (void)hipStreamSynchronize(e->pose_stream);
@@ -568,10 +587,12 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
     const size_t fbytes = flow_bytes(e->arr.a.ffmt);
 
     const int si = e->stage_idx;
+    double hp_t = e->host_prof ? host_now_us() : 0.0;
     HIP_TRY(hipEventSynchronize(e->stage_ev[si]));  // staging block free again?
     // bound the frames in flight (see roft_engine::kMaxInFlight): frame j - kMaxInFlight must have ended
     if (e->frame_counter >= roft_engine::kMaxInFlight)
         HIP_TRY(hipEventSynchronize(e->ev_pose[(e->frame_counter - roft_engine::kMaxInFlight) % roft_engine::kCtrlRing]));
+    HP_MARK(e, 0, hp_t);   // time blocked on the GPU (staging block / in-flight bound)
     FrameCtrl* blk = e->stage[si];
     e->max_steps = 0;
     e->any_new_mask = e->any_outlier = e->any_feat = false;
@@ -672,6 +693,7 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
     }
     e->cur = blk;
     e->submitted = true;
+    HP_MARK(e, 1, hp_t);
     return ROFT_OK;
 }
 
@@ -717,9 +739,11 @@ int roft_step(roft_engine* e)
     constexpr int R = roft_engine::kCtrlRing;
     const int ci = e->frame_counter % R;
     const bool multi = e->two_streams;
+    double hp_t = e->host_prof ? host_now_us() : 0.0;
     // throttle: the image chains lead the pose chain by at most kLead frames
     if (multi && e->frame_counter >= roft_engine::kLead)
         HIP_TRY(hipStreamWaitEvent(s, e->ev_pose[(e->frame_counter - roft_engine::kLead) % R], 0));
+    HP_MARK(e, 2, hp_t);
     a.ctrl = e->dctrl[ci].p;
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
     if (e->kernel_upload) {
@@ -732,6 +756,7 @@ int roft_step(roft_engine* e)
     HIP_TRY(hipEventRecord(e->stage_ev[si], s));
     if (multi) HIP_TRY(hipEventRecord(e->ev_ctrl[ci], s));
     e->stage_idx = (si + 1) % roft_engine::kStage;
+    HP_MARK(e, 3, hp_t);
 
     // ---- velocity chain: needs FrameCtrl (+ host input copies) of this frame and the mask planes of the previous one
     if (multi) {
@@ -746,6 +771,7 @@ int roft_step(roft_engine* e)
     tmark(e, "skf", 2);
     if (multi) HIP_TRY(hipEventRecord(e->ev_vel[ci], sv));
 
+    HP_MARK(e, 4, hp_t);
     // ---- mask chain
     tmark(e, nullptr, 0);
     if (e->any_new_mask) { launch_mask_ingest(a, s); tmark(e, "mask_ingest", 0); }
@@ -754,6 +780,7 @@ int roft_step(roft_engine* e)
     if (e->any_feat) { launch_features(a, s); tmark(e, "features", 0); }
     if (multi) HIP_TRY(hipEventRecord(e->ev_mask[ci], s));
 
+    HP_MARK(e, 5, hp_t);
     // ---- pose chain (needs this frame's twist and mask planes; the next frames' image chains do not wait for it)
     if (multi) {
         HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[ci], 0));
@@ -771,6 +798,8 @@ int roft_step(roft_engine* e)
         }
     }
     HIP_TRY(hipEventRecord(e->ev_pose[ci], sp));
+    HP_MARK(e, 6, hp_t);
+    if (e->host_prof) e->hp_frames++;
     HIP_TRY(hipGetLastError());
     e->frame_counter++;
     e->submitted = false;
