@@ -6,8 +6,9 @@
 //     velocities are replayed by the re-sync, ROFTFilter.cpp:327-367 and
 //     CartesianQuaternionMeasurement.cpp:92-348) is resolved here on the host into one FrameCtrl
 //     block per object; everything that depends on image content or filter state (is the new mask
-//     empty, N < 3, the outlier decision) is resolved inside the kernels.  A frame is therefore one
-//     small H2D copy plus a fixed sequence of batched launches on one HIP stream, no D2H sync.
+//     empty, N < 3, the outlier decision, which matrix square root) is resolved inside the kernels.  A frame
+//     is therefore one small H2D copy plus three in-order chains of batched launches (mask, velocity and pose
+//     chain, one HIP stream each, roft_step) with several frames in flight and no D2H sync.
 // (1) the operator-level entry points run the same kernels on a private one-object context.
 #include <hip/hip_runtime.h>
 
@@ -15,7 +16,6 @@
 #include <cfloat>
 #include <chrono>
 #include <cmath>
-#include <cstdio>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

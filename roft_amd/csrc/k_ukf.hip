@@ -1,5 +1,5 @@
-// k_ukf.hip -- pose UKF: sigma-point fan-out, prediction and correction, one wavefront per object
-// (gfx950).
+// k_ukf.hip -- pose UKF: sigma-point fan-out, prediction and correction, one workgroup of four wavefronts per
+// object (gfx950).
 //
 // Reference:
 //   bfl::UKFPrediction (generic state model) over CartesianQuaternionModel::motion / Q(T)
