@@ -308,3 +308,67 @@ class Sequence:
         dt = float(self.stamp[k] - self.stamp[k - 1]) if k > 0 else 0.0
         return dict(depth=read_depth(os.path.join(self.depth_dir, "%d.float" % k)), flow=flow if ok else None,
                     mask=mask, pose=pose, dt=dt)
+
+
+# ---- writing a stream in the Fast-YCB layout (synthetic data on disk, closes the loop with Sequence / the dumper) ----
+def write_obj(path, verts, tris):
+    with open(path, "w") as f:
+        for v in np.asarray(verts, np.float64):
+            f.write("v %.9g %.9g %.9g\n" % tuple(v))
+        for t in np.asarray(tris, np.int64):
+            f.write("f %d %d %d\n" % tuple(t + 1))
+
+
+def write_poses(path, pose7, valid=None):
+    """Rows `x y z ax ay az angle` (the layout read_poses / the reference's pose files use); invalid rows are all zero."""
+    pose7 = np.atleast_2d(pose7)
+    with open(path, "w") as f:
+        for i, r in enumerate(pose7):
+            if valid is not None and not valid[i]:
+                f.write(" ".join(["0"] * 7) + "\n")
+                continue
+            axis, angle = quat_to_axis_angle(r[3:7])
+            f.write(" ".join("%.17g" % v for v in list(r[:3]) + list(axis) + [angle]) + "\n")
+
+
+def write_sequence(root, st, object_name, mask_set="gt", pose_set="dope", flow_set=None):
+    """Writes a roft_amd.synth stream as a Fast-YCB style directory: data.txt, cam_K.json, rgb/<i>.png (when the stream
+    carries gray images), depth/<i>.float, masks/<mask_set>/<object>_<i>.png, <pose_set>/poses.txt (the per-frame
+    detections the delayed source replays), gt/poses.txt, model.obj and -- if flow_set is given -- the stream's own
+    optical_flow/<flow_set>/<i>.float.  Returns the path of the mesh."""
+    import json
+    n = int(st.n_frames)
+    for d in ("rgb", "depth", os.path.join("masks", mask_set), pose_set, "gt"):
+        os.makedirs(os.path.join(root, d), exist_ok=True)
+    with open(os.path.join(root, "data.txt"), "w") as f:
+        for k in range(n):
+            f.write("%.15g %.15g 0 0 0 1 0 0 0\n" % (k * st.dt, k * st.dt))
+    c = st.camera
+    with open(os.path.join(root, "cam_K.json"), "w") as f:
+        json.dump(dict(width=c.width, height=c.height, fx=c.fx, fy=c.fy, cx=c.cx, cy=c.cy), f)
+    depth, masks = st.depth.cpu().numpy(), st.mask_gt.cpu().numpy()
+    gray = st.gray.cpu().numpy() if getattr(st, "gray", None) is not None else None
+    flow = st.flow.cpu().numpy() if flow_set else None
+    if flow_set:
+        os.makedirs(os.path.join(root, "optical_flow", flow_set), exist_ok=True)
+    for k in range(n):
+        write_depth(os.path.join(root, "depth", "%d.float" % k), depth[k])
+        write_png(os.path.join(root, "masks", mask_set, "%s_%d.png" % (object_name, k)), masks[k])
+        if gray is not None:
+            write_png(os.path.join(root, "rgb", "%d.png" % k), np.repeat(gray[k][..., None], 3, axis=2))
+        if flow_set and st.flow_valid[k]:
+            save_flow(flow[k], os.path.join(root, "optical_flow", flow_set, "%d.float" % k))
+    # detections: the stream holds what is DELIVERED at frame k (= the detection of frame sched[k])
+    sched = delivery_schedule(n)
+    det = np.zeros((n, 7))
+    det[:, 3] = 1.0
+    ok = np.zeros(n, bool)
+    for k in range(n):
+        if sched[k] >= 0 and st.pose_valid[k]:
+            det[sched[k]] = st.pose_meas[k]
+            ok[sched[k]] = True
+    write_poses(os.path.join(root, pose_set, "poses.txt"), det, ok)
+    write_poses(os.path.join(root, "gt", "poses.txt"), np.concatenate([st.gt.x, st.gt.q], 1))
+    mesh = os.path.join(root, "model.obj")
+    write_obj(mesh, *st.mesh)
+    return mesh

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Runs the MI355X engine on one object of a Fast-YCB / HO-3D style sequence directory and writes the reference's log
+files (`pose_estimate`, `velocity_estimate`, ROFTFilter.cpp:386-394) -- what `test/test.sh` does with `ROFT-tracker`.
+
+  run_sequence.py --root DIR --object NAME --mesh model.obj [--flow-set nvof_1_slow] [--mask-set NAME]
+                  [--pose-set dope] [--out PREFIX] [--compute-flow nvof1|nvof2] [--no-delay] [--init-pose x y z qw qx qy qz]
+
+The camera comes from DIR/cam_K.json (width, height, fx, fy, cx, cy).  --compute-flow first runs tools/flow_dumper.py
+on DIR/rgb (the MI355X replacement of the NVOF dumper) into DIR/optical_flow/<flow-set>.  With DIR/gt/poses.txt present
+the ADD-S / ADD AUC and the RMSE metrics of evaluation/metrics.py are printed as one JSON line.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--root", required=True)
+    ap.add_argument("--object", required=True)
+    ap.add_argument("--mesh", required=True)
+    ap.add_argument("--flow-set", default="nvof_1_slow")
+    ap.add_argument("--mask-set", default="mrcnn_ycbv_bop_pbr")
+    ap.add_argument("--pose-set", default="dope")
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--compute-flow", choices=["nvof1", "nvof2"], default=None)
+    ap.add_argument("--no-delay", action="store_true")
+    ap.add_argument("--init-pose", type=float, nargs=7, default=None, metavar=("X", "Y", "Z", "QW", "QX", "QY", "QZ"),
+                    help="initial_condition.pose (default: the first valid detection)")
+    args = ap.parse_args(argv)
+
+    from roft_amd import _lib as L
+    from roft_amd import engine as E
+    from roft_amd import io, metrics
+
+    L.require_device()
+    cam = json.load(open(os.path.join(args.root, "cam_K.json")))
+    W, H = int(cam["width"]), int(cam["height"])
+    if args.compute_flow:
+        out = os.path.join(args.root, "optical_flow", args.flow_set)
+        rc = subprocess.call([sys.executable, os.path.join(ROOT, "tools", "flow_dumper.py"), args.root, "txt", "png", "1", "0",
+                              str(W), str(H), args.compute_flow, out])
+        if rc != 0:
+            return rc
+    seq = io.Sequence(args.root, args.object, flow_set=args.flow_set, mask_set=args.mask_set, pose_set=args.pose_set,
+                      width=W, height=H, delayed=not args.no_delay)
+    first = None
+    for k in range(len(seq)):
+        ok, first = io.read_flow(os.path.join(seq.flow_dir, "%d.float" % k))
+        if ok:
+            break
+    if first is None:
+        sys.stderr.write("no optical flow frames in %s\n" % seq.flow_dir)
+        return 1
+    ftype, grid, scale = io.flow_format(first, W)
+    cfg = E.default_config(W, H, ftype, max_objects=1)
+    cfg.cam.fx, cfg.cam.fy, cfg.cam.cx, cfg.cam.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    cfg.flow_grid, cfg.flow_scale = grid, scale
+    eng = E.ROFTFilterBatch(cfg)
+    verts, tris = io.load_obj(args.mesh)
+    d = E.default_object()
+    # initial condition: the first valid detection (ROFT-tracker takes it from the config file)
+    k0 = int(np.argmax(seq.pose_ok)) if seq.pose_ok.any() else 0
+    init = args.init_pose if args.init_pose is not None else list(seq.poses[k0])
+    for i in range(7):
+        d.p_mean0[6 + i] = init[i]
+    eng.add_object(d, verts, tris)
+    n = len(seq)
+    eng.enable_log(n)
+    for k in range(n):
+        eng.submit([seq.frame(k)])
+        eng.step()
+    pose, twist, npts, sel = eng.get_log(0, n)
+    eng.close()
+    prefix = args.out if args.out is not None else os.path.join(args.root, "roft_mi355x_")
+    io.write_estimate_logs(prefix, pose[:, 0], twist[:, 0])
+    report = dict(frames=n, logs=[prefix + "pose_estimate", prefix + "velocity_estimate"], flow_type=int(ftype), flow_grid=int(grid))
+    gt_path = os.path.join(args.root, "gt", "poses.txt")
+    if os.path.exists(gt_path):
+        gt, _ = io.read_poses(gt_path)
+        est = np.concatenate([pose[:, 0, 6:9], pose[:, 0, 9:13]], 1)
+        pts = verts.astype(np.float64)[:: max(1, len(verts) // 500)]
+        dist = metrics.trajectory_adds(est[12:], gt[12:n], pts)
+        report.update(adds_mm_mean=1e3 * float(dist.mean()), adds_auc=metrics.auc(dist),
+                      rmse_position_cm=metrics.rmse_cartesian_3d(gt[12:n, :3], est[12:, :3]),
+                      rmse_orientation_deg=metrics.rmse_angular(gt[12:n, 3:], est[12:, 3:]))
+    print(json.dumps(report))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
