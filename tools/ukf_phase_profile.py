@@ -1,5 +1,15 @@
-import sys, ctypes as C
-sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests')
+#!/usr/bin/env python3
+"""Shader-cycle profile of the phases of one ukf_step launch.  Needs a library built with -DROFT_UKF_PROFILE:
+  make -C roft_amd/csrc clean && make -C roft_amd/csrc CXXFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DROFT_UKF_PROFILE"
+Slots: 0 load, 1 process noise, 2 prediction square root, 3 fan-out + motion, 4 means, 5 covariance, 6 store,
+7 correction square root, 8 fan-out + measurement, 9 means/deviations, 10 Py/Pxy, 11 Cholesky, 12 gain + update."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, util
 from roft_amd import engine as E, synth, _lib as L
 import test_engine_gpu as T
