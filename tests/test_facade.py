@@ -75,3 +75,79 @@ def test_facade_matches_operator_abi(tmp_path):
     assert np.array_equal(flow, ops.optical_flow(g0, g1, levels=2, det_min=1.0))
     inner = flow[12:36, 16:48]
     assert abs(np.median(inner[..., 0]) - 2.0) < 0.3 and abs(np.median(inner[..., 1]) - 1.0) < 0.3
+
+
+def build_filter_exe(tmp_path):
+    from roft_amd import _lib
+    _lib.build()
+    exe = str(tmp_path / "filter_check")
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "filter_check.cpp"), "-o", exe, "-L", CSRC, "-lroft_hip",
+                           "-Wl,-rpath," + CSRC, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def dump_stream(path, st, n):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    from roft_amd import synth
+    verts, tris = st.mesh
+    c = st.camera
+    with open(path, "wb") as f:
+        f.write(struct.pack("5i", c.width, c.height, n, len(verts), len(tris)))
+        f.write(struct.pack("4d", c.fx, c.fy, c.cx, c.cy))
+        f.write(np.asarray(synth.initial_pose_from_stream(st), np.float64).tobytes())
+        f.write(np.ascontiguousarray(verts, np.float32).tobytes())
+        f.write(np.ascontiguousarray(tris, np.int32).tobytes())
+        for k in range(n):
+            depth, flow, mask, pose = util.frame_inputs(st, k)
+            f.write(struct.pack("d3i", st.dt, flow is not None, mask is not None, pose is not None))
+            f.write(np.ascontiguousarray(depth, np.float32).tobytes())
+            if flow is not None:
+                f.write(np.ascontiguousarray(flow, np.float32).tobytes())
+            if mask is not None:
+                f.write(np.ascontiguousarray(mask, np.uint8).tobytes())
+            if pose is not None:
+                f.write(np.concatenate([pose[0], pose[1]]).astype(np.float64).tobytes())
+
+
+def test_whole_filter_facade_compiles_and_fails_loudly_without_device(tmp_path):
+    from roft_amd import _lib
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    exe = build_filter_exe(tmp_path)
+    if _lib.lib().roft_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    st = util.stream(33, 3, 4)
+    dump_stream(str(tmp_path / "s.bin"), st, 3)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin")], capture_output=True, text=True)
+    assert r.returncode == 3 and "runtime_error" in r.stdout
+
+
+@pytest.mark.gpu
+def test_whole_filter_facade_equals_the_python_engine(tmp_path):
+    """ROFT::ROFTFilter (C++ facade) fed frame by frame == roft_amd.engine.ROFTFilterBatch on the same stream, and both
+    == the oracle."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    from oracle import binding as ob
+    from test_engine_gpu import make_engine
+    n = 20
+    st = util.stream(34, n, 2)
+    dump_stream(str(tmp_path / "s.bin"), st, n)
+    exe = build_filter_exe(tmp_path)
+    subprocess.check_call([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin")])
+    got = np.fromfile(str(tmp_path / "o.bin"), np.float64).reshape(n, 19)
+    eng = make_engine([st])
+    ref = util.run_oracle_tracker(ob, st, n)
+    for k in range(n):
+        depth, flow, mask, pose = util.frame_inputs(st, k)
+        eng.submit([dict(depth=depth, flow=flow, mask=mask, pose=pose, dt=st.dt)])
+        eng.step()
+        p, _, tw, _ = eng.state(0)
+        assert np.array_equal(got[k, :13], p) and np.array_equal(got[k, 13:], tw), k
+        assert np.abs(got[k, :13] - ref[k]["pose"]).max() < 1e-8
+    eng.close()
