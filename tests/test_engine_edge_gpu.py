@@ -176,3 +176,31 @@ def test_full_size_batch_is_deterministic_and_order_independent(monkeypatch):
     for x, y in zip(a, d):
         assert np.array_equal(x, y)
     assert np.isfinite(a[0]).all() and (a[2] >= 0).any() and (a[3] >= 0).any()
+
+
+def test_two_engines_interleaved_in_one_process():
+    """Two engines (different image shapes and flow types) stepped alternately give what each gives alone: no shared
+    mutable state between engine handles (streams, rings and device state are per engine)."""
+    a = [util.stream(580, 24, scale=2, device="cuda")]
+    b = [util.stream(581, 24, scale=2, flow_type=synth.FLOW_S16C2, shape="B", device="cuda")]
+    alone_a = _run_logged(a, 24)
+    alone_b = _run_logged(b, 24)
+    from roft_amd import _lib as L
+    from test_engine_gpu import make_engine
+    ea, eb = make_engine(a), make_engine(b)
+    ea.enable_log(24)
+    eb.enable_log(24)
+    for k in range(24):
+        for eng, sts in ((ea, a), (eb, b)):
+            st = sts[0]
+            mi = st.mask_delivery[k]
+            pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
+            eng.submit([dict(depth=st.depth[k].data_ptr(), flow=st.flow[k].data_ptr() if st.flow_valid[k] else None,
+                             mask=st.mask_gt[mi].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE)])
+            eng.step()
+    for x, y in zip(alone_a, ea.get_log(0, 24)):
+        assert np.array_equal(x, y)
+    for x, y in zip(alone_b, eb.get_log(0, 24)):
+        assert np.array_equal(x, y)
+    ea.close()
+    eb.close()
