@@ -9,7 +9,7 @@
 // nearest-neighbour x2 initialisation) and this file follows it tap for tap.
 //
 // MI355X mapping: one workgroup = a 32 x 8 pixel tile of one pyramid level of one image pair; the previous image
-// tile with an (r + 1)-pixel halo and its two gradient tiles are staged in LDS once and serve the G-matrix and the
+// tile with an (r + 1)-pixel halo and its gradient tile (Ix, Iy interleaved) are staged in LDS once and serve the G-matrix and the
 // residual taps of all 256 pixels; only the pixels of the current image under the warped window (whose position
 // depends on the evolving flow) go to the vector cache.  Batched over image pairs in blockIdx.z.
 #include <algorithm>
@@ -69,8 +69,7 @@ __global__ __launch_bounds__(kOfTx * kOfTy) void of_lk_kernel(OfArgs a, int l)
     const int tw = kOfTx + 2 * R, th = kOfTy + 2 * R;      // I0 tile
     const int gw = kOfTx + 2 * r, gh = kOfTy + 2 * r;      // gradient tiles
     float* tile = reinterpret_cast<float*>(smem);
-    float* gx = tile + tw * th;
-    float* gy = gx + gw * gh;
+    float2* grad = reinterpret_cast<float2*>(tile + ((tw * th + 1) & ~1));   // (Ix, Iy) interleaved: one 8-byte LDS read per tap
     const int pair = blockIdx.z;
     const int w = a.lv[l].w, h = a.lv[l].h;
     const float* I0 = a.pyr + ((size_t)pair * 2 + 0) * a.pyr_stride + a.lv[l].off;
@@ -85,8 +84,7 @@ __global__ __launch_bounds__(kOfTx * kOfTy) void of_lk_kernel(OfArgs a, int l)
     for (int i = tid; i < gw * gh; i += kOfTx * kOfTy) {
         const int ty = i / gw, tx = i - ty * gw;
         const float* t = tile + (ty + 1) * tw + (tx + 1);
-        gx[i] = 0.5f * (t[1] - t[-1]);
-        gy[i] = 0.5f * (t[tw] - t[-tw]);
+        grad[i] = make_float2(0.5f * (t[1] - t[-1]), 0.5f * (t[tw] - t[-tw]));
     }
     __syncthreads();
     const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
@@ -100,15 +98,14 @@ __global__ __launch_bounds__(kOfTx * kOfTy) void of_lk_kernel(OfArgs a, int l)
         dy = 2.0f * c[1];
     }
     // window origin inside the tiles: tap (ox, oy) -> gradient tile (threadIdx + r + o), I0 tile (threadIdx + R + o)
-    const float* gx0 = gx + threadIdx.y * gw + threadIdx.x;
-    const float* gy0 = gy + threadIdx.y * gw + threadIdx.x;
+    const float2* g0 = grad + threadIdx.y * gw + threadIdx.x;
     const float* t0 = tile + (threadIdx.y + 1) * tw + (threadIdx.x + 1);
     const int n = 2 * r + 1;
     float g11 = 0.0f, g12 = 0.0f, g22 = 0.0f;
     for (int k = 0; k < n; ++k)
         for (int j = 0; j < n; ++j) {
-            const float ix = gx0[k * gw + j], iy = gy0[k * gw + j];
-            g11 += ix * ix; g12 += ix * iy; g22 += iy * iy;
+            const float2 g = g0[k * gw + j];
+            g11 += g.x * g.x; g12 += g.x * g.y; g22 += g.y * g.y;
         }
     const float det = g11 * g22 - g12 * g12;
     if (det > a.det_min) {
@@ -140,7 +137,8 @@ __global__ __launch_bounds__(kOfTx * kOfTy) void of_lk_kernel(OfArgs a, int l)
                         if (j >= n) break;
                         const int o = (k - 1) * gw + j;
                         const float dt = ((1.0f - ay) * hp[j] + ay * hc[j]) - t0[(k - 1) * tw + j];
-                        b1 += gx0[o] * dt; b2 += gy0[o] * dt;
+                        const float2 g = g0[o];
+                        b1 += g.x * dt; b2 += g.y * dt;
                     }
                 }
 #pragma unroll
@@ -177,7 +175,7 @@ void launch_optical_flow(const OfArgs& a, hipStream_t s)
         hipLaunchKernelGGL(of_down_kernel, dim3(std::min((npx + 255) / 256, 256), 2, a.n), dim3(256), 0, s, a, l);
     }
     const int r = a.radius, R = r + 1;
-    const size_t lds = ((size_t)(kOfTx + 2 * R) * (kOfTy + 2 * R) + 2 * (size_t)(kOfTx + 2 * r) * (kOfTy + 2 * r)) * sizeof(float);
+    const size_t lds = ((((size_t)(kOfTx + 2 * R) * (kOfTy + 2 * R) + 1) & ~(size_t)1) + 2 * (size_t)(kOfTx + 2 * r) * (kOfTy + 2 * r)) * sizeof(float);
     for (int l = a.levels - 1; l >= 0; --l) {
         const dim3 grid((a.lv[l].w + kOfTx - 1) / kOfTx, (a.lv[l].h + kOfTy - 1) / kOfTy, a.n), block(kOfTx, kOfTy);
         switch (r) {
