@@ -216,12 +216,13 @@ struct roft_engine {
     // absorbs it).  The host may be kMaxInFlight frames ahead of the slowest chain; rings are sized for that:
     //   device FrameCtrl ring / events kCtrlRing > kMaxInFlight;  plane ring kPlaneSlots > kLead + 1;
     //   twist ring kTwistRing > kLead + pose_frames_between + 2;
-    //   caller buffers: frame m is read until frame m + kMaxFlowHist - 1 ends, and roft_frame_submit(j) returns
-    //   only when frame j - kMaxInFlight has ended  =>  ROFT_RETAIN_FRAMES >= kMaxInFlight + kMaxFlowHist.
+    //   caller buffers: frame m is read until the mask chain of frame m + kMaxFlowHist - 1 ends; roft_frame_submit(j)
+    //   returns only when the POSE chain of frame j - kMaxInFlight has ended, which implies the velocity chain of that
+    //   frame and the mask chain of the frame before it  =>  ROFT_RETAIN_FRAMES >= kMaxInFlight + 1 + kMaxFlowHist.
     static constexpr int kLead = 6;
-    static constexpr int kMaxInFlight = 10;
+    static constexpr int kMaxInFlight = 9;
     static constexpr int kCtrlRing = 16;
-    static_assert(kMaxInFlight + kMaxFlowHist <= ROFT_RETAIN_FRAMES, "caller buffer retention");
+    static_assert(kMaxInFlight + 1 + kMaxFlowHist <= ROFT_RETAIN_FRAMES, "caller buffer retention");
     static_assert(kLead + 1 < kPlaneSlots && kMaxInFlight < kCtrlRing, "ring sizes");
     DevBuf<FrameCtrl> dctrl[kCtrlRing];
     hipEvent_t ev_ctrl[kCtrlRing] = {};  // FrameCtrl (and host input copies) of frame k on the device
@@ -245,6 +246,7 @@ struct roft_engine {
     bool submitted = false;
     int max_steps = 0;
     bool any_new_mask = false, any_outlier = false, any_feat = false;
+    bool any_feat_now = false;   // some object's outlier test reads the feature set buffered in this same frame
     int frame_counter = 0;
     // timing
     bool timing = false;
@@ -596,6 +598,7 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
     FrameCtrl* blk = e->stage[si];
     e->max_steps = 0;
     e->any_new_mask = e->any_outlier = e->any_feat = false;
+    e->any_feat_now = false;
 
     for (int id = 0; id < n_inputs; ++id) {
         HostObject& o = *e->objs[id];
@@ -689,6 +692,7 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
         e->max_steps = std::max(e->max_steps, c.n_steps);
         if (c.outlier_step >= 0) e->any_outlier = true;
         if (c.feat_write >= 0) e->any_feat = true;
+        if (c.outlier_step >= 0 && c.feat_read == c.feat_write) e->any_feat_now = true;
         o.frame_idx++;
     }
     e->cur = blk;
@@ -784,7 +788,10 @@ int roft_step(roft_engine* e)
     // ---- pose chain (needs this frame's twist and mask planes; the next frames' image chains do not wait for it)
     if (multi) {
         HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[ci], 0));
-        HIP_TRY(hipStreamWaitEvent(sp, e->ev_mask[ci], 0));
+        // The pose chain reads mask-chain products only through the feature ring.  The set an outlier test reads was
+        // buffered at an earlier frame -- covered by ev_vel, since the velocity chain of frame k waited for the mask
+        // chain of frame k-1 -- unless it is this very frame's (outlier rejection without re-sync, or the first frame).
+        if (e->any_feat_now) HIP_TRY(hipStreamWaitEvent(sp, e->ev_mask[ci], 0));
     }
     tmark(e, nullptr, 1);
     // step 0 (possibly followed by the outlier render + test), then all remaining steps in one launch
