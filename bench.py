@@ -297,7 +297,7 @@ def main():
         "adds_vs_cpu_ref_mm": ({"mean": 1e3 * float(adds_cpu.mean()), "max": 1e3 * float(adds_cpu.max())}
                                if adds_cpu is not None else None),
         "rmse_vs_gt": rmse,
-        "pipeline": "three HIP streams per engine (mask / velocity / pose chains), up to 6 frames of lead, <= 9 in flight",
+        "pipeline": "three HIP streams per engine (mask / velocity / pose chains), up to 6 frames in flight",
         "kernels_post_run_breakdown": kernels,
         "dominant_kernel": dominant,
         "stream_generation_s": t_gen,

@@ -211,22 +211,20 @@ struct roft_engine {
     hipStream_t stream = nullptr;       // mask chain: uploads, FrameCtrl, mask ingest / scatter / gather
     hipStream_t vel_stream = nullptr;   // velocity chain: flow measurement, velocity filter
     hipStream_t pose_stream = nullptr;  // pose chain: features, UKF steps, outlier rejection
-    // Frames in flight.  The image chain of frame k+1 does not depend on the pose chain of frame k, so it runs
-    // ahead of it by up to kLead frames (a pose re-sync frame costs the pose chain ~5 ordinary frames; the lead
-    // absorbs it).  The host may be kMaxInFlight frames ahead of the slowest chain; rings are sized for that:
-    //   device FrameCtrl ring / events kCtrlRing > kMaxInFlight;  plane ring kPlaneSlots > kLead + 1;
-    //   twist ring kTwistRing > kLead + pose_frames_between + 2;
-    //   caller buffers: frame m is read until the mask chain of frame m + kMaxFlowHist - 1 ends; roft_frame_submit(j)
-    //   returns only when the POSE chain of frame j - kMaxInFlight has ended, which implies the velocity chain of that
-    //   frame and the mask chain of the frame before it  =>  ROFT_RETAIN_FRAMES >= kMaxInFlight + 1 + kMaxFlowHist.
-    static constexpr int kLead = 6;
-    static constexpr int kMaxInFlight = 9;
+    // Frames in flight.  The image chains of frame k+1 do not depend on the pose chain of frame k, so they run ahead
+    // of it (a pose re-sync frame costs the pose chain ~5 ordinary frames; the lead absorbs it).  The lead is bounded
+    // on the host: roft_frame_submit(j) returns only when the POSE chain of frame j - kMaxInFlight has ended, which
+    // implies the velocity chain of that frame and the mask chain of the frame before it.  Rings are sized for it:
+    //   device FrameCtrl ring / staging ring / events kCtrlRing > kMaxInFlight;  plane ring kPlaneSlots > kMaxInFlight + 1;
+    //   feature ring kFeatRing >= kMaxInFlight + 2;  twist ring kTwistRing > kMaxInFlight + pose_frames_between + 2;
+    //   caller buffers: frame m is read until the mask chain of frame m + kMaxFlowHist - 1 ends
+    //   =>  ROFT_RETAIN_FRAMES >= kMaxInFlight + 1 + kMaxFlowHist.
+    static constexpr int kMaxInFlight = 6;   // = the lead of the image chains over the pose chain
     static constexpr int kCtrlRing = 16;
     static_assert(kMaxInFlight + 1 + kMaxFlowHist <= ROFT_RETAIN_FRAMES, "caller buffer retention");
-    static_assert(kLead + 1 < kPlaneSlots && kMaxInFlight < kCtrlRing, "ring sizes");
+    static_assert(kMaxInFlight + 1 < kPlaneSlots && kMaxInFlight < kCtrlRing && kMaxInFlight + 2 <= kFeatRing, "ring sizes");
     DevBuf<FrameCtrl> dctrl[kCtrlRing];
-    hipEvent_t ev_ctrl[kCtrlRing] = {};  // FrameCtrl (and host input copies) of frame k on the device
-    hipEvent_t ev_mask[kCtrlRing] = {};  // mask planes of frame k complete
+    hipEvent_t ev_mask[kCtrlRing] = {};  // mask chain of frame k complete (recorded only when the pose chain needs it)
     hipEvent_t ev_vel[kCtrlRing] = {};   // twist of frame k complete
     hipEvent_t ev_pose[kCtrlRing] = {};  // pose chain of frame k complete
     bool two_streams = false;
@@ -239,6 +237,7 @@ struct roft_engine {
     std::vector<ObjParams> h_params;
     // pinned staging ring for FrameCtrl blocks
     static constexpr int kStage = 16;
+    static_assert(kStage == kCtrlRing, "the staging event of a frame doubles as its FrameCtrl-ready event");
     FrameCtrl* stage[kStage] = {};
     hipEvent_t stage_ev[kStage] = {};
     int stage_idx = 0;
@@ -370,7 +369,6 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
     }
     for (int i = 0; i < roft_engine::kCtrlRing; ++i) {
         HIP_TRY(e->dctrl[i].ensure(cfg->max_objects, true));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_ctrl[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_mask[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_vel[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&e->ev_pose[i], hipEventDisableTiming));
@@ -411,7 +409,6 @@ int roft_engine_destroy(roft_engine* e)
     if (e->vel_stream) (void)hipStreamSynchronize(e->vel_stream);
     if (e->pose_stream) (void)hipStreamSynchronize(e->pose_stream);
     for (int i = 0; i < roft_engine::kCtrlRing; ++i) {
-        if (e->ev_ctrl[i]) (void)hipEventDestroy(e->ev_ctrl[i]);
         if (e->ev_mask[i]) (void)hipEventDestroy(e->ev_mask[i]);
         if (e->ev_vel[i]) (void)hipEventDestroy(e->ev_vel[i]);
         if (e->ev_pose[i]) (void)hipEventDestroy(e->ev_pose[i]);
@@ -744,9 +741,9 @@ int roft_step(roft_engine* e)
     const int ci = e->frame_counter % R;
     const bool multi = e->two_streams;
     double hp_t = e->host_prof ? host_now_us() : 0.0;
-    // throttle: the image chains lead the pose chain by at most kLead frames
-    if (multi && e->frame_counter >= roft_engine::kLead)
-        HIP_TRY(hipStreamWaitEvent(s, e->ev_pose[(e->frame_counter - roft_engine::kLead) % R], 0));
+    // (How far the image chains lead the pose chain is bounded on the HOST: roft_frame_submit(k) returns only when the
+    //  pose chain of frame k - kMaxInFlight has ended.  Every event operation on the mask chain's stream costs ~8 us
+    //  of that chain -- it is the longest one -- so it gets exactly one per frame, below.)
     HP_MARK(e, 2, hp_t);
     a.ctrl = e->dctrl[ci].p;
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
@@ -757,16 +754,15 @@ int roft_step(roft_engine* e)
     } else {
         HIP_TRY(hipMemcpyAsync(a.ctrl, e->cur, sizeof(FrameCtrl) * a.n_obj, hipMemcpyHostToDevice, s));
     }
+    // ONE event of the mask chain per frame, recorded here: "FrameCtrl (+ host input copies) of frame k on the device
+    // and the mask chain of frame k-1 complete" -- what the velocity chain of frame k needs, and what frees the pinned
+    // staging block
     HIP_TRY(hipEventRecord(e->stage_ev[si], s));
-    if (multi) HIP_TRY(hipEventRecord(e->ev_ctrl[ci], s));
     e->stage_idx = (si + 1) % roft_engine::kStage;
     HP_MARK(e, 3, hp_t);
 
     // ---- velocity chain: needs FrameCtrl (+ host input copies) of this frame and the mask planes of the previous one
-    if (multi) {
-        HIP_TRY(hipStreamWaitEvent(sv, e->ev_ctrl[ci], 0));
-        if (e->frame_counter > 0) HIP_TRY(hipStreamWaitEvent(sv, e->ev_mask[(e->frame_counter - 1) % R], 0));
-    }
+    if (multi) HIP_TRY(hipStreamWaitEvent(sv, e->stage_ev[si], 0));
     const int radius = (int)(size_t)e->cfg.subsampling_radius;
     tmark(e, "vel_chain_start", 2);
     launch_flow_measure(a, e->cfg.depth_maximum, radius, false, sv);
@@ -782,7 +778,7 @@ int roft_step(roft_engine* e)
     launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, true, s);
     tmark(e, "mask_propagate", 0);
     if (e->any_feat) { launch_features(a, s); tmark(e, "features", 0); }
-    if (multi) HIP_TRY(hipEventRecord(e->ev_mask[ci], s));
+    if (multi && e->any_feat_now) HIP_TRY(hipEventRecord(e->ev_mask[ci], s));   // only when the pose chain waits for it
 
     HP_MARK(e, 5, hp_t);
     // ---- pose chain (needs this frame's twist and mask planes; the next frames' image chains do not wait for it)
