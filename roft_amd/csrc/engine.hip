@@ -589,8 +589,12 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
     double hp_t = e->host_prof ? host_now_us() : 0.0;
     HIP_TRY(hipEventSynchronize(e->stage_ev[si]));  // staging block free again?
     // bound the frames in flight (see roft_engine::kMaxInFlight): frame j - kMaxInFlight must have ended
-    if (e->frame_counter >= roft_engine::kMaxInFlight)
-        HIP_TRY(hipEventSynchronize(e->ev_pose[(e->frame_counter - roft_engine::kMaxInFlight) % roft_engine::kCtrlRing]));
+    if (e->frame_counter >= roft_engine::kMaxInFlight) {
+        // (the pose chain records its completion event on even frames only, see roft_step: wait for the newest even
+        //  frame that keeps at most kMaxInFlight frames in flight)
+        const int f = (e->frame_counter - roft_engine::kMaxInFlight + 1) & ~1;
+        HIP_TRY(hipEventSynchronize(e->ev_pose[f % roft_engine::kCtrlRing]));
+    }
     HP_MARK(e, 0, hp_t);   // time blocked on the GPU (staging block / in-flight bound)
     FrameCtrl* blk = e->stage[si];
     e->max_steps = 0;
@@ -800,7 +804,9 @@ int roft_step(roft_engine* e)
             tmark(e, "ukf_replay_steps", 1);
         }
     }
-    HIP_TRY(hipEventRecord(e->ev_pose[ci], sp));
+    // completion event of the pose chain: only the host reads it (bound on the frames in flight), and an event
+    // operation costs the stream it sits on ~8 us -- every other frame is enough
+    if ((e->frame_counter & 1) == 0) HIP_TRY(hipEventRecord(e->ev_pose[ci], sp));
     HP_MARK(e, 6, hp_t);
     if (e->host_prof) e->hp_frames++;
     HIP_TRY(hipGetLastError());
