@@ -177,9 +177,16 @@ void clear_ctrl(FrameCtrl& c)
 // FrameCtrl upload without the copy engine: a kernel reads the pinned (device-visible) staging block and
 // writes the device copy, so the per-frame control block travels in-order on the compute queue instead of
 // through an SDMA copy with its cross-engine signalling.
-__global__ void ctrl_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+// The same launch closes the mask stage of the PREVIOUS frame (one thread per object: flow buffer count, reset of the
+// per-frame scratch state): it runs after that frame's gather on the mask chain and before anything of the new frame
+// reads those fields, and it saves a launch per frame -- the frame time follows the number of launches and event
+// operations (~7 us each over all streams) more than the kernels' durations.
+__global__ void ctrl_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
+                                   const FrameCtrl* prev_ctrl, ObjState* state, int n_obj)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (prev_ctrl && t < (size_t)n_obj) mask_bookkeeping(prev_ctrl[t], state[t]);
+    for (size_t i = t; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 struct HostObject {
@@ -753,8 +760,10 @@ int roft_step(roft_engine* e)
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
     if (e->kernel_upload) {
         const size_t n16 = sizeof(FrameCtrl) * a.n_obj / 16;
+        // (the previous frame's FrameCtrl block is still in the device ring)
+        const FrameCtrl* prev = (e->frame_counter > 0) ? e->dctrl[(e->frame_counter - 1) % R].p : nullptr;
         hipLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
-                           reinterpret_cast<const uint4*>(e->cur), reinterpret_cast<uint4*>(a.ctrl), n16);
+                           reinterpret_cast<const uint4*>(e->cur), reinterpret_cast<uint4*>(a.ctrl), n16, prev, a.state, a.n_obj);
     } else {
         HIP_TRY(hipMemcpyAsync(a.ctrl, e->cur, sizeof(FrameCtrl) * a.n_obj, hipMemcpyHostToDevice, s));
     }
@@ -779,7 +788,7 @@ int roft_step(roft_engine* e)
     // ---- mask chain
     tmark(e, nullptr, 0);
     if (e->any_new_mask) { launch_mask_ingest(a, s); tmark(e, "mask_ingest", 0); }
-    launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, true, s);
+    launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, !e->kernel_upload, s);
     tmark(e, "mask_propagate", 0);
     if (e->any_feat) { launch_features(a, s); tmark(e, "features", 0); }
     if (multi && e->any_feat_now) HIP_TRY(hipEventRecord(e->ev_mask[ci], s));   // only when the pose chain waits for it
