@@ -152,3 +152,50 @@ def test_prediction_cholesky_guard_changes_nothing_measurable():
         out[guard] = np.array(traj)
         assert np.abs(out[guard] - np.array([r["pose"] for r in ref])).max() < 1e-8
     assert 0.0 < np.abs(out[2e-4] - out[0.0]).max() < 1e-10
+
+
+def test_square_root_switches_between_cholesky_and_eigen_within_a_run():
+    """A run that starts with a large pose covariance (var(theta) = 0.05 >> the guard 2e-4) and large angular
+    process noise: the prediction and correction square roots fall back to the eigen-decomposition at first and switch to
+    the Cholesky factor as the filter converges.  The trajectory follows the oracle (always eigen) throughout."""
+    import ctypes as C
+    from oracle import binding as ob
+    n = 40
+    st = util.stream(41, n, 2)
+    cfg = util.oracle_config(ob, st)
+    for i in range(12):
+        cfg.p_cov0_diag[i] = 5e-2
+    verts, tris = st.mesh
+    trk = ob.Tracker(cfg, verts, tris)
+    ref = []
+    for k in range(n):
+        depth, flow, mask, pose = util.frame_inputs(st, k)
+        r = trk.step(st.dt, depth, flow, mask, pose)
+        ref.append((np.array(r.pose), r.outlier_selected, r.n_flow_points, np.array(r.pose_cov).reshape(12, 12)))
+    trk.close()
+    c = st.camera
+    ecfg = E.default_config(c.width, c.height, st.flow_type, max_objects=1)
+    ecfg.cam.fx, ecfg.cam.fy, ecfg.cam.cx, ecfg.cam.cy = c.fx, c.fy, c.cx, c.cy
+    eng = E.ROFTFilterBatch(ecfg)
+    d = E.default_object()
+    m0 = synth.initial_pose_from_stream(st)
+    for i in range(13):
+        d.p_mean0[i] = m0[i]
+    for i in range(12):
+        d.p_cov0_diag[i] = 5e-2
+    eng.add_object(d, verts, tris)
+    var_theta = []
+    for k in range(n):
+        depth, flow, mask, pose = util.frame_inputs(st, k)
+        eng.submit([dict(depth=depth, flow=flow, mask=mask, pose=pose, dt=st.dt)])
+        eng.step()
+        p, P, _, _ = eng.state(0)
+        o = eng.outputs()[0]
+        assert np.abs(p - ref[k][0]).max() < 1e-7, k
+        assert np.abs(P - ref[k][3]).max() <= 1e-6 * np.abs(ref[k][3]).max(), k
+        assert o.outlier_selected == ref[k][1] and o.n_flow_points == ref[k][2], k
+        var_theta.append(P[9:, 9:].diagonal().max())
+    eng.close()
+    # frame 0 predicts and corrects from var(theta) = 5e-2 (eigen path); the pose measurement of that frame brings it
+    # below the guard, so every later step draws from the Cholesky factor
+    assert 5e-2 > 2e-4 > max(var_theta)
