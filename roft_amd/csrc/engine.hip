@@ -246,6 +246,7 @@ struct roft_engine {
     static constexpr int kStage = 16;
     static_assert(kStage == kCtrlRing, "the staging event of a frame doubles as its FrameCtrl-ready event");
     FrameCtrl* stage[kStage] = {};
+    ObjState* state_host = nullptr;   // pinned landing block of roft_get_state (velocity belief + corrected pose belief)
     hipEvent_t stage_ev[kStage] = {};
     int stage_idx = 0;
     FrameCtrl* cur = nullptr;  // staging block of the submitted, not yet stepped frame
@@ -427,6 +428,7 @@ int roft_engine_destroy(roft_engine* e)
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
         if (e->stage_ev[i]) (void)hipEventDestroy(e->stage_ev[i]);
     }
+    if (e->state_host) (void)hipHostFree(e->state_host);
     for (auto ev : e->tev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -839,17 +841,20 @@ int roft_sync(roft_engine* e)
 int roft_get_state(roft_engine* e, int id, double pose13[13], double P12[144], double twist6[6], double Pv[36])
 {
     if (!e || id < 0 || id >= (int)e->objs.size()) return fail(ROFT_ERR_INVALID, "bad object id");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    // v_mean, v_cov and belief[B_CORR] are the leading bytes of ObjState: one small copy into pinned memory, queued
+    // behind the pose chain (the last writer of all three), then the other chains are waited for as roft_sync does
+    static_assert(B_CORR == 0 && offsetof(ObjState, v_mean) == 0, "roft_get_state copies the head of ObjState");
+    constexpr size_t kHead = offsetof(ObjState, belief) + sizeof(PoseBelief);
+    if (!e->state_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->state_host), sizeof(ObjState)));
+    hipStream_t last = e->two_streams ? e->pose_stream : e->stream;
+    HIP_TRY(hipMemcpyAsync(e->state_host, e->arr.state.p + id, kHead, hipMemcpyDeviceToHost, last));
     if (int rc = roft_sync(e)) return rc;
-    ObjState* st = new ObjState();
-    hipError_t err = hipMemcpy(st, e->arr.state.p + id, sizeof(ObjState), hipMemcpyDeviceToHost);
-    if (err == hipSuccess) {
-        if (pose13) std::memcpy(pose13, st->belief[B_CORR].mean, sizeof(double) * 13);
-        if (P12) std::memcpy(P12, st->belief[B_CORR].cov, sizeof(double) * 144);
-        if (twist6) std::memcpy(twist6, st->v_mean, sizeof(double) * 6);
-        if (Pv) std::memcpy(Pv, st->v_cov, sizeof(double) * 36);
-    }
-    delete st;
-    HIP_TRY(err);
+    const ObjState* st = e->state_host;
+    if (pose13) std::memcpy(pose13, st->belief[B_CORR].mean, sizeof(double) * 13);
+    if (P12) std::memcpy(P12, st->belief[B_CORR].cov, sizeof(double) * 144);
+    if (twist6) std::memcpy(twist6, st->v_mean, sizeof(double) * 6);
+    if (Pv) std::memcpy(Pv, st->v_cov, sizeof(double) * 36);
     return ROFT_OK;
 }
 

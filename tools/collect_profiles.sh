@@ -9,6 +9,7 @@ mkdir -p $O
 cd $R
 python bench.py > $O/bench_64obj.json 2> $O/bench.err
 python tools/run_baseline_configs.py --out $O/baseline_configs.json > /dev/null 2> $O/baseline.err
+python tools/live_latency.py --out $O/live_latency.json > /dev/null 2>&1
 python tools/bench_flow_producer.py > $O/flow_producer.jsonl
 python tools/bench_flow_producer.py --pairs 1 >> $O/flow_producer.jsonl
 python tools/bench_flow_producer.py --pairs 16 --shape B --flow s16 >> $O/flow_producer.jsonl
