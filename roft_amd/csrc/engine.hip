@@ -99,7 +99,7 @@ int check_geometry(int W, int H)
         return fail(ROFT_ERR_INVALID, "image width must be a multiple of 32 and width*height a multiple of 64");
     if ((size_t)W * H >= (1u << 24))
         return fail(ROFT_ERR_INVALID, "width*height must be < 2^24 (float-accumulated sampling index, hpp:237)");
-    if ((size_t)(W / 32) * H * 4 + (H + 1) * 4 + 64 > 160 * 1024 - 256)
+    if ((size_t)(W / 32) * H * 4 + 16384 /* candidate list of the flow measurement */ + 128 > 160 * 1024 - 256)
         return fail(ROFT_ERR_INVALID, "mask bit plane does not fit the 160 KiB LDS of a CU");
     return ROFT_OK;
 }
@@ -126,7 +126,7 @@ struct Arrays {
         a.ffmt = ffmt;
         a.plane_words = (size_t)cam.wpr * cam.H;
         const size_t npix = (size_t)cam.W * cam.H;
-        a.cand_cap = (int)((npix + radius - 1) / std::max(radius, 1)) + 8;
+        a.cand_cap = ((int)((npix + radius - 1) / std::max(radius, 1)) + 9) & ~1;   // even: rows of a.cand stay 8-byte aligned
         a.feat_cap = (int)(npix / 2 + 8);
         a.tile_w = cam.W / cam.divider;
         a.tile_h = cam.H / cam.divider;

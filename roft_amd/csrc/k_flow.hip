@@ -6,11 +6,13 @@
 //   keep   = flow finite and |.| < 1e9 (OpticalFlowUtilities.h:19-22) and 0 < Z < depth_maximum
 //   y_i    = flow / scale;  H_i = T * [interaction matrix rows]  (:272-282)
 //
-// MI355X design: one workgroup per object.  The previous frame's `obj` bit plane (W*H/8 bytes) is
-// staged in LDS once; row popcounts + a block scan give the row-major rank of every set bit, so
-// candidate c is located by a binary search over the row prefix and a word walk -- no full-image
-// pass over depth or flow: only the ~N_mask/R candidate pixels are gathered from HBM.
-// Output order equals the reference's (candidates in rank order, invalid ones dropped).
+// MI355X design: one workgroup of 16 waves per object.  The previous frame's `obj` bit plane (W*H/8 bytes) is
+// staged in LDS once.  Plane words are in row-major order, so one block scan over per-thread popcounts of
+// contiguous word chunks gives every word its starting rank; a word holds candidate c iff c*R falls into its rank
+// interval, and the pixel is the (c*R - start)-th set bit of the word.  The candidate pixels go through a small
+// list (LDS, or the global scratch for very large masks), then ONE thread per candidate gathers depth and flow --
+// all gathers of an object are in flight together, and nothing but the ~N_mask/R candidate pixels is read from
+// the images.  Output order equals the reference's (candidates in rank order, invalid ones dropped).
 #include "plane_rank.h"
 
 namespace roft {
@@ -35,73 +37,226 @@ __device__ __forceinline__ bool is_flow_valid(float fx, float fy)
     return !isnan(fx) && !isnan(fy) && fabs((double)fx) < 1e9 && fabs((double)fy) < 1e9;
 }
 
-constexpr int kFlowThreads = 512;
+// phase stamps (build with -DROFT_K1_PROFILE): K1TICK(i) stores the 100 MHz wall clock ticks since the previous stamp
+#ifdef ROFT_K1_PROFILE
+#define K1TICK(i) do { __syncthreads(); if (threadIdx.x == 0) { long long _t = wall_clock64(); st.dbg[i] = _t - k1_t0; k1_t0 = _t; } } while (0)
+#else
+#define K1TICK(i) do {} while (0)
+#endif
 
-// dynamic LDS: plane words [wpr*H] | rowpref [H+1]
+constexpr int kFlowThreads = 1024;
+constexpr int kCandLds = 2048;   // candidate work items kept in LDS; larger candidate sets go through a.cand
+
+// position of the k-th (0-based) set bit of x, k < popc(x): five popcount halvings, no data-dependent loop
+__device__ __forceinline__ int select_bit(uint32_t x, int k)
+{
+    int pos = 0;
+#pragma unroll
+    for (int wdt = 16; wdt >= 1; wdt >>= 1) {
+        const int cnt = __popc((x >> pos) & ((1u << wdt) - 1u));
+        if (k >= cnt) { k -= cnt; pos += wdt; }
+    }
+    return pos;
+}
+
+// One plane word with starting rank `rank`: candidate ci is the set bit of rank next = ci * R (hpp:237); a word holds
+// it iff next falls into [rank, rank + popc).  Only a work item {word bits, word index, bit rank inside the word} is
+// queued here -- the threads that own the dense words of the mask would otherwise serialise the pixel arithmetic of
+// all their candidates.  Advances rank / next / ci.
+__device__ __forceinline__ void emit_word(uint32_t bits, int w, int& rank, int& next, int& ci, int radius, uint2* list)
+{
+    const int pc = __popc(bits);
+    if (next < rank + pc) {
+        list[ci++] = make_uint2(bits, ((uint32_t)w << 5) | (uint32_t)(next - rank));
+        next += radius;
+        if (radius < 32) {   // strides below the word size: several candidates per word
+#pragma nounroll
+            while (next < rank + pc) {
+                list[ci++] = make_uint2(bits, ((uint32_t)w << 5) | (uint32_t)(next - rank));
+                next += radius;
+                asm volatile("" : "+v"(next));   // keeps the loop a plain loop (no trip-count division, no unrolling)
+            }
+        }
+    }
+    rank += pc;
+}
+
+// One thread per candidate: pixel of the work item, gather depth + flow, validity, ordered compaction (rank order is
+// thread order).
+__device__ __forceinline__ int gather_candidates(const EngineArrays& a, const float* depth, const void* flow, int obj,
+                                                 const uint2* list, int C, double depth_max, int* s_wave)
+{
+    const int W = a.cam.W, wpr = a.cam.wpr;
+    FlowRec* recs = a.recs + (size_t)obj * a.cand_cap;
+    int base = 0;
+    for (int c0 = 0; c0 < C; c0 += blockDim.x) {
+        const int ci = c0 + threadIdx.x;
+        FlowRec r;
+        bool ok = false;
+        if (ci < C) {
+            const uint2 item = list[ci];
+            const int w = (int)(item.y >> 5);
+            const int v = w / wpr, u = (w - v * wpr) * 32 + select_bit(item.x, (int)(item.y & 31u));
+            const float z = depth[(size_t)v * W + u];
+            float dx, dy;
+            flow_at(flow, a.ffmt, v / a.ffmt.grid, u / a.ffmt.grid, dx, dy);
+            ok = is_flow_valid(dx, dy) && z > 0 && (double)z < depth_max;
+            r.u = u; r.v = v; r.z = z; r.dx = dx; r.dy = dy;
+        }
+        int total;
+        const int pos = block_exclusive_scan(ok ? 1 : 0, s_wave, &total);
+        if (ok) recs[base + pos] = r;
+        base += total;
+    }
+    return base;
+}
+
+// The control-block fields of the kernel, fetched together at its start: the empty asm pins all four loads before the
+// first barrier (the compiler would otherwise sink each to its first use and pay the memory latency once per field).
+struct FlowCtrl {
+    int vel_stage, slot_prev;
+    const float* depth;
+    const void* flow;
+};
+
+__device__ __forceinline__ FlowCtrl load_flow_ctrl(const FrameCtrl& c)
+{
+    FlowCtrl k{c.vel_stage, c.slot_prev, c.depth_prev, c.flow[0]};
+    asm volatile("" : "+v"(k.vel_stage), "+v"(k.slot_prev), "+v"(k.depth), "+v"(k.flow));
+    return k;
+}
+
+// Plane words held in registers: thread t owns the PER4 consecutive 16-byte groups starting at t * PER4 (no LDS copy
+// of the plane at all).  Needs plane_words % 4 == 0 and plane_words / 4 <= PER4 * kFlowThreads.
+template <int PER4>
 __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays a, double depth_max, int radius,
                                                                    int mask_finish)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_wave[17];
+    __shared__ int s_wave[16];
+    __shared__ uint2 s_item[kCandLds];
     const int obj = blockIdx.x;
     const FrameCtrl& c = a.ctrl[obj];
     ObjState& st = a.state[obj];
-    // the mask stage's per-object bookkeeping rides along (saves a launch per frame); this kernel reads
-    // none of the fields it touches
+#ifdef ROFT_K1_PROFILE
+    long long k1_t0 = wall_clock64();
+#endif
+    const FlowCtrl k = load_flow_ctrl(c);
+    // the mask stage's per-object bookkeeping rides along when asked to; this kernel reads none of the fields it touches
+    if (mask_finish && threadIdx.x == 0) mask_bookkeeping(c, st);
+    if (!k.vel_stage) {
+        if (threadIdx.x == 0) st.n_flow_points = -1;
+        return;
+    }
+    // 1. this thread's words of the previous frame's obj plane (unconditional loads, all in flight together)
+    const uint4* g4 = reinterpret_cast<const uint4*>(a.planes + plane_offset(a, obj, k.slot_prev, 1));
+    const int n4 = (int)(a.plane_words / 4), i0 = (int)threadIdx.x * PER4;
+    uint4 q[PER4];
+#pragma unroll
+    for (int j = 0; j < PER4; ++j) q[j] = g4[min(i0 + j, n4 - 1)];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < PER4; ++j) {
+        if (i0 + j >= n4) q[j] = make_uint4(0u, 0u, 0u, 0u);
+        cnt += __popc(q[j].x) + __popc(q[j].y) + __popc(q[j].z) + __popc(q[j].w);
+    }
+    K1TICK(1);
+    // 2. starting rank of the thread's chunk (plane words are in row-major order)
+    int M;
+    int rank = block_exclusive_scan(cnt, s_wave, &M);
+    const int C = (M + radius - 1) / radius;
+    K1TICK(2);
+    // 3. candidate work items of the chunk -> list, 4. gathers + compaction.  Two instances so that the common
+    //    case addresses the list as LDS and not through flat pointers.
+    auto tail = [&](uint2* list) {
+        if (cnt) {
+            int ci = (rank + radius - 1) / radius, next = ci * radius;
+#pragma unroll
+            for (int j = 0; j < PER4; ++j) {
+                const int w = (i0 + j) * 4;
+                emit_word(q[j].x, w, rank, next, ci, radius, list);
+                emit_word(q[j].y, w + 1, rank, next, ci, radius, list);
+                emit_word(q[j].z, w + 2, rank, next, ci, radius, list);
+                emit_word(q[j].w, w + 3, rank, next, ci, radius, list);
+            }
+        }
+        __syncthreads();   // the list is written and read by this workgroup only
+        K1TICK(3);
+        return gather_candidates(a, k.depth, k.flow, obj, list, C, depth_max, s_wave);
+    };
+    const int n = (C <= kCandLds) ? tail(s_item) : tail(reinterpret_cast<uint2*>(a.cand + (size_t)obj * a.cand_cap));
+    K1TICK(5);
+    if (threadIdx.x == 0) st.n_flow_points = n;
+}
+
+// Any plane size: the plane is staged in dynamic LDS, every thread walks a contiguous chunk of its words.
+__global__ __launch_bounds__(kFlowThreads) void flow_measure_lds_kernel(EngineArrays a, double depth_max, int radius,
+                                                                       int mask_finish)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_wave[16];
+    __shared__ uint2 s_item[kCandLds];
+    const int obj = blockIdx.x;
+    const FrameCtrl& c = a.ctrl[obj];
+    ObjState& st = a.state[obj];
     if (mask_finish && threadIdx.x == 0) mask_bookkeeping(c, st);
     if (!c.vel_stage) {
         if (threadIdx.x == 0) st.n_flow_points = -1;
         return;
     }
-    const int W = a.cam.W, H = a.cam.H, wpr = a.cam.wpr;
     uint32_t* s_plane = reinterpret_cast<uint32_t*>(smem);
-    int* s_rowpref = reinterpret_cast<int*>(smem + ((a.plane_words * 4 + 15) & ~(size_t)15));
-
-    // 1+2. stage the previous frame's obj plane in LDS, row popcounts -> exclusive row prefix
-    const int M = stage_plane(a.planes + plane_offset(a, obj, c.slot_prev, 1), a.plane_words, H, wpr, s_plane, s_rowpref,
-                              s_wave);
+    {
+        const uint32_t* gplane = a.planes + plane_offset(a, obj, c.slot_prev, 1);
+        for (size_t i = threadIdx.x; i < a.plane_words; i += blockDim.x) s_plane[i] = gplane[i];
+        __syncthreads();
+    }
+    const int n_words = (int)a.plane_words;
+    const int per = (n_words + blockDim.x - 1) / blockDim.x;
+    const int w0 = min(n_words, (int)threadIdx.x * per), w1 = min(n_words, w0 + per);
+    int cnt = 0;
+    for (int w = w0; w < w1; ++w) cnt += __popc(s_plane[w]);
+    int M;
+    int rank = block_exclusive_scan(cnt, s_wave, &M);
     const int C = (M + radius - 1) / radius;
-
-    // 3. candidates, blocked assignment so that the compaction keeps rank order
-    FlowRec* cand = a.cand + (size_t)obj * a.cand_cap;
-    const int per = (C + blockDim.x - 1) / blockDim.x;
-    const int c_begin = min(C, (int)threadIdx.x * per), c_end = min(C, c_begin + per);
-    const float* depth = c.depth_prev;
-    int n_valid = 0;
-    for (int ci = c_begin; ci < c_end; ++ci) {
-        int u, v;
-        select_rank(s_plane, s_rowpref, H, wpr, ci * radius, u, v);
-
-        const float z = depth[(size_t)v * W + u];
-        float dx, dy;
-        flow_at(c.flow[0], a.ffmt, v / a.ffmt.grid, u / a.ffmt.grid, dx, dy);
-        const bool ok = is_flow_valid(dx, dy) && z > 0 && (double)z < depth_max;
-        FlowRec r;
-        r.u = ok ? u : -1; r.v = v; r.z = z; r.dx = dx; r.dy = dy;
-        cand[ci] = r;
-        n_valid += ok ? 1 : 0;
+    uint2* list = (C <= kCandLds) ? s_item : reinterpret_cast<uint2*>(a.cand + (size_t)obj * a.cand_cap);
+    if (cnt) {
+        int ci = (rank + radius - 1) / radius, next = ci * radius;
+        for (int w = w0; w < w1; ++w) emit_word(s_plane[w], w, rank, next, ci, radius, list);
     }
-    int total;
-    int pos = block_exclusive_scan(n_valid, s_wave, &total);
-    FlowRec* recs = a.recs + (size_t)obj * a.cand_cap;
-    for (int ci = c_begin; ci < c_end; ++ci) {
-        const FlowRec r = cand[ci];
-        if (r.u >= 0) recs[pos++] = r;
-    }
-    if (threadIdx.x == 0) st.n_flow_points = total;
+    __syncthreads();
+    const int n = gather_candidates(a, c.depth_prev, c.flow[0], obj, list, C, depth_max, s_wave);
+    if (threadIdx.x == 0) st.n_flow_points = n;
+}
+
+template <int PER4>
+static void launch_flow_reg(const EngineArrays& a, double depth_max, int radius, int mask_finish, hipStream_t s)
+{
+    hipLaunchKernelGGL(flow_measure_kernel<PER4>, dim3(a.n_obj), dim3(kFlowThreads), 0, s, a, depth_max, radius, mask_finish);
 }
 
 void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bool mask_finish, hipStream_t s)
 {
-    const size_t lds = plane_lds_bytes(a.plane_words, a.cam.H);
+    const int mf = mask_finish ? 1 : 0;
+    const size_t n4 = a.plane_words / 4;
+    const int per4 = (int)((n4 + kFlowThreads - 1) / kFlowThreads);
+    if (a.plane_words % 4 == 0 && per4 <= 10) {
+        if (per4 <= 1) launch_flow_reg<1>(a, depth_max, radius, mf, s);
+        else if (per4 <= 2) launch_flow_reg<2>(a, depth_max, radius, mf, s);
+        else if (per4 <= 3) launch_flow_reg<3>(a, depth_max, radius, mf, s);
+        else if (per4 <= 4) launch_flow_reg<4>(a, depth_max, radius, mf, s);
+        else if (per4 <= 6) launch_flow_reg<6>(a, depth_max, radius, mf, s);
+        else if (per4 <= 8) launch_flow_reg<8>(a, depth_max, radius, mf, s);
+        else launch_flow_reg<10>(a, depth_max, radius, mf, s);
+        return;
+    }
+    const size_t lds = (a.plane_words * 4 + 15) & ~(size_t)15;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_measure_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_measure_lds_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 256 - kCandLds * (int)sizeof(uint2) - 128);
         attr_set = true;
     }
-    hipLaunchKernelGGL(flow_measure_kernel, dim3(a.n_obj), dim3(kFlowThreads), lds, s, a, depth_max, radius,
-                       mask_finish ? 1 : 0);
+    hipLaunchKernelGGL(flow_measure_lds_kernel, dim3(a.n_obj), dim3(kFlowThreads), lds, s, a, depth_max, radius, mf);
 }
 
 // ---- records -> (uv, y, H) exactly as the reference assembles them (hpp:258-283) -------------

@@ -71,6 +71,18 @@ def test_flow_measurement_edge_cases(oracle):
             n1, uv1, y1, H1 = ops.flow_measurement(cam, mask, depth, flow, st.dt, radius=radius)
             assert n1 == n0, (name, radius)
             assert np.array_equal(uv0, uv1) and np.array_equal(y0, y1) and np.array_equal(H0, H1), (name, radius)
+    # plane sizes that are not a multiple of 16 bytes take the LDS variant of the kernel
+    for W2, H2 in ((96, 54), (32, 6), (160, 90)):
+        c2 = synth.Camera(W2, H2, 1.2 * W2, 1.2 * W2, W2 / 2.0, H2 / 2.0)
+        ocam2, cam2 = util.oracle_camera(oracle, c2), L.Camera(W2, H2, c2.fx, c2.fy, c2.cx, c2.cy)
+        mask2 = (rng.random((H2, W2)) < 0.4).astype(np.uint8) * 255
+        depth2 = rng.uniform(0.3, 1.5, (H2, W2)).astype(np.float32)
+        flow2 = (3.0 * rng.standard_normal((H2, W2, 2))).astype(np.float32)
+        for radius in (1.0, 3.0, 35.0):
+            n0, uv0, y0, H0 = oracle.flow_measurement(ocam2, mask2, depth2, flow2, st.dt, radius=radius)
+            n1, uv1, y1, H1 = ops.flow_measurement(cam2, mask2, depth2, flow2, st.dt, radius=radius)
+            assert n1 == n0 and n0 > 0, (W2, H2, radius)
+            assert np.array_equal(uv0, uv1) and np.array_equal(y0, y1) and np.array_equal(H0, H1), (W2, H2, radius)
     # all depth invalid / beyond the gate -> nothing kept
     for bad in (np.zeros_like(depth), np.full_like(depth, 2.5), np.full_like(depth, np.nan)):
         n1, *_ = ops.flow_measurement(cam, st.mask_gt[0].numpy(), bad, flow, st.dt)

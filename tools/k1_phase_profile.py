@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Wall-clock profile (100 MHz ticks -> microseconds) of the phases of one flow_measure (K1) launch at the metric shape.
+Needs a library built with -DROFT_K1_PROFILE:
+  make -C roft_amd/csrc clean && make -C roft_amd/csrc CXXFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DROFT_K1_PROFILE"
+Slots: 0 control block read, 1 plane -> LDS, 2 chunk popcounts + block scan, 3 candidate list, 4 depth + flow gathers,
+5 validity scan + record writes."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+import torch
+from roft_amd import _lib as L, synth
+import run_baseline_configs as rb
+
+n_obj = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n = 12
+dev = torch.device("cuda", 0)
+streams = [synth.make_stream(4000 + i, n, synth.Camera.shape_a(), device=dev) for i in range(n_obj)]
+eng = rb.make_engine(streams)
+names = ["ctrl", "plane->LDS", "popc+scan", "cand list", "gathers", "scan+write"]
+for k in range(n):
+    frames = []
+    for st in streams:
+        mi = st.mask_delivery[k]
+        pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
+        frames.append(dict(depth=st.depth[k].data_ptr(), flow=st.flow[k].data_ptr() if st.flow_valid[k] else None,
+                           mask=st.mask_gt[mi].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE))
+    eng.submit_raw(eng.build_inputs(frames)[0])
+    eng.step()
+    eng.sync()
+    if k >= 8:
+        rows = []
+        for o in range(n_obj):
+            buf = (C.c_longlong * 32)()
+            L.lib().roft_debug_get_dbg(eng._h, o, buf)
+            rows.append([buf[i] / 100.0 for i in range(6)])
+        r = np.array(rows)
+        print("frame %d  mean us per phase: " % k + ", ".join("%s %.2f" % (nm, v) for nm, v in zip(names, r.mean(0))) +
+              "  | sum %.2f (max over objects %.2f)" % (r.sum(1).mean(), r.sum(1).max()))
+eng.close()
