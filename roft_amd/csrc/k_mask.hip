@@ -40,6 +40,26 @@ __device__ __forceinline__ void flow_at(const void* data, const DevFlowFmt& f, i
     }
 }
 
+// the same element in two steps -- load, then decode -- so that several loads can be in flight before the first use
+template <int FT>
+__device__ __forceinline__ uint2 flow_raw(const void* data, size_t idx)
+{
+    if (FT == ROFT_FLOW_S16C2) return make_uint2(reinterpret_cast<const uint32_t*>(data)[idx], 0u);
+    return reinterpret_cast<const uint2*>(data)[idx];
+}
+
+template <int FT>
+__device__ __forceinline__ void flow_decode(uint2 raw, float scale, float& dx, float& dy)
+{
+    if (FT == ROFT_FLOW_S16C2) {
+        dx = (float)(short)(raw.x & 0xFFFFu) / scale;
+        dy = (float)(short)(raw.x >> 16) / scale;
+    } else {
+        dx = __uint_as_float(raw.x) / scale;
+        dy = __uint_as_float(raw.y) / scale;
+    }
+}
+
 // ---- ingest: raw u8 mask -> (nz, obj) bit planes + non-zero count -------------------------------
 // One thread converts 64 consecutive pixels: four 16-byte loads, two 64-bit masks built in registers,
 // two coalesced 8-byte stores.  grid: (ceil(W*H/64/256), n_obj).
@@ -89,6 +109,7 @@ constexpr int kScatterBlocks = 96;  // per object; x 4 waves x ~25 groups each a
 // strides over the image (interleaved, so the object's rows spread over all waves); its lanes chase their
 // pixel through the flows in parallel: the flow reads of a wave are row-contiguous (64 x 8 B), the map
 // atomics land on neighbouring addresses.  Empty 64-pixel groups cost one wave-uniform 8-byte load.
+template <int FT>
 __global__ __launch_bounds__(256) void mask_scatter_kernel(EngineArrays a, int frames_between)
 {
     const int obj = blockIdx.y;
@@ -116,31 +137,69 @@ __global__ __launch_bounds__(256) void mask_scatter_kernel(EngineArrays a, int f
     const int my_grp = wave_first + lane * wave_stride;
     uint2 mine = make_uint2(0u, 0u);
     if (my_grp < n_grp) mine = plane2[my_grp];
-    for (int it = 0, grp = wave_first; grp < n_grp; ++it, grp += wave_stride) {
-        unsigned long long bits = ((unsigned long long)(uint32_t)__shfl((int)mine.y, it, 64) << 32) |
-                                  (uint32_t)__shfl((int)mine.x, it, 64);
-        if (mode == 1 && grp == 0) bits &= ~1ull;                         // mask_.at<uchar>(0,0) = 0
-        if (bits == 0) continue;
-        if (!((bits >> lane) & 1ull)) continue;
-        const int p = grp * 64 + lane;
-        const int py = p / W, px = p - py * W;
-        float t_x = (float)px, t_y = (float)py;
-        bool error = false;
-        // flows in chronological order: oldest buffered first (c.flow[n_flows-1]) ... current
-        for (int j = n_flows - 1; j >= 0; --j) {
-            const int ix = trunc_int_x86(t_x), iy = trunc_int_x86(t_y);
-            if (ix < 0 || ix >= W || iy < 0 || iy >= H) { error = true; break; }
-            float dx, dy;
-            flow_at(c.flow[j], a.ffmt, trunc_int_x86(t_y / (float)a.ffmt.grid), trunc_int_x86(t_x / (float)a.ffmt.grid),
-                    dx, dy);
-            t_x += dx;
-            t_y += dy;
+    // Non-empty groups of this wave (bit i <-> lane i's prefetched group).  They are chased kChase at a time: a
+    // pixel's walk through the buffered flows is a chain of dependent loads, and the chains of different groups
+    // are independent -- issuing them together divides the exposed memory latency by kChase.
+    constexpr int kChase = 4;
+    unsigned long long pending = __ballot((mine.x | mine.y) != 0u);
+    const void* flows[kMaxFlowHist];   // fetched once: a pointer load per flow step would sit in every chain
+#pragma unroll
+    for (int j = 0; j < kMaxFlowHist; ++j) flows[j] = c.flow[j];
+    const float grid_f = (float)a.ffmt.grid;
+    while (pending) {
+        float t_x[kChase], t_y[kChase];
+        int p[kChase];
+        bool act[kChase];
+#pragma unroll
+        for (int u = 0; u < kChase; ++u) {
+            act[u] = false;
+            p[u] = 0;
+            t_x[u] = t_y[u] = 0.0f;
+            if (pending) {
+                const int it = __builtin_ctzll(pending);
+                pending &= pending - 1;
+                const int grp = wave_first + it * wave_stride;
+                unsigned long long bits = ((unsigned long long)(uint32_t)__shfl((int)mine.y, it, 64) << 32) |
+                                          (uint32_t)__shfl((int)mine.x, it, 64);
+                if (mode == 1 && grp == 0) bits &= ~1ull;                 // mask_.at<uchar>(0,0) = 0
+                act[u] = (bits >> lane) & 1ull;
+                p[u] = grp * 64 + lane;
+                const int py = p[u] / W, px = p[u] - py * W;
+                t_x[u] = (float)px;
+                t_y[u] = (float)py;
+            }
         }
-        const int ix = trunc_int_x86(t_x), iy = trunc_int_x86(t_y);
-        if (error || ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
-        atomicMax(&map[iy * W + ix], p);
-        bx0 = min(bx0, ix); bx1 = max(bx1, ix);
-        by0 = min(by0, iy); by1 = max(by1, iy);
+        // flows in chronological order: oldest buffered first (c.flow[n_flows-1]) ... current
+#pragma unroll
+        for (int j = kMaxFlowHist - 1; j >= 0; --j) {
+            if (j >= n_flows) continue;
+            const void* fl = flows[j];
+            uint2 raw[kChase];
+#pragma unroll
+            for (int u = 0; u < kChase; ++u) {
+                const int ix = trunc_int_x86(t_x[u]), iy = trunc_int_x86(t_y[u]);
+                if (ix < 0 || ix >= W || iy < 0 || iy >= H) act[u] = false;   // left the image: the pixel is dropped
+                // inactive lanes read element (0, 0): the loads stay unconditional and in flight together
+                const int fr = act[u] ? trunc_int_x86(t_y[u] / grid_f) : 0;
+                const int fc = act[u] ? trunc_int_x86(t_x[u] / grid_f) : 0;
+                raw[u] = flow_raw<FT>(fl, (size_t)fr * (size_t)a.ffmt.cols + (size_t)fc);
+            }
+#pragma unroll
+            for (int u = 0; u < kChase; ++u) {
+                float dx, dy;
+                flow_decode<FT>(raw[u], a.ffmt.scale, dx, dy);
+                t_x[u] += dx;
+                t_y[u] += dy;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kChase; ++u) {
+            const int ix = trunc_int_x86(t_x[u]), iy = trunc_int_x86(t_y[u]);
+            if (!act[u] || ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
+            atomicMax(&map[iy * W + ix], p[u]);
+            bx0 = min(bx0, ix); bx1 = max(bx1, ix);
+            by0 = min(by0, iy); by1 = max(by1, iy);
+        }
     }
     // bounding box of the targets: wave shuffle -> LDS -> one set of global atomics per block
     for (int off = 32; off > 0; off >>= 1) {
@@ -318,7 +377,10 @@ void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_a
     const int n_grp = a.cam.W * a.cam.H / 64;
     int sblocks = kScatterBlocks;
     while (sblocks * 4 * 64 < n_grp) sblocks *= 2;   // each wave prefetches at most 64 groups
-    hipLaunchKernelGGL(mask_scatter_kernel, dim3(sblocks, a.n_obj), dim3(256), 0, s, a, frames_between);
+    if (a.ffmt.type == ROFT_FLOW_S16C2)
+        hipLaunchKernelGGL(mask_scatter_kernel<ROFT_FLOW_S16C2>, dim3(sblocks, a.n_obj), dim3(256), 0, s, a, frames_between);
+    else
+        hipLaunchKernelGGL(mask_scatter_kernel<ROFT_FLOW_F32C2>, dim3(sblocks, a.n_obj), dim3(256), 0, s, a, frames_between);
     const size_t waves = ((size_t)a.cam.W * a.cam.H + 63) / 64;
     int gx = (int)((waves + 3) / 4);
     if (gx > 64) gx = 64;
