@@ -19,7 +19,7 @@
 // sqrt(e[k]^2 + e[N+k]^2) while the likelihoods use the true per-point norm (cpp:111).
 // The median is an exact order statistic found by an 8-pass radix select over the IEEE bit
 // patterns (non-negative doubles order like unsigned integers) -- no sort.
-#include "roft_device.h"
+#include "plane_rank.h"
 
 namespace roft {
 
@@ -97,11 +97,52 @@ __device__ __forceinline__ double innov_at(const Acc& acc, int k, const double* 
 
 constexpr int kSkfThreads = 256;
 
+// phase stamps (build with -DROFT_SKF_PROFILE): SKFTICK(i) stores the 100 MHz wall clock ticks since the previous stamp
+#ifdef ROFT_SKF_PROFILE
+#define SKFTICK(i) do { __syncthreads(); if (threadIdx.x == 0) { long long _t = wall_clock64(); S.dbg[i] = _t - S.t0; S.t0 = _t; } } while (0)
+#else
+#define SKFTICK(i) do {} while (0)
+#endif
+
+// Wave reductions of doubles on the DPP network (no LDS traffic): both halves of the double travel as 32-bit DPP
+// moves -- row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31 across rows -- and lane 63
+// ends up with the reduction over all 64 lanes.  Lanes without a source receive `fill`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move_f64(double v, double fill)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(fill), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(fill), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum_to_lane63(double v)
+{
+    v += dpp_move_f64<0x111, 0xf>(v, 0.0);
+    v += dpp_move_f64<0x112, 0xf>(v, 0.0);
+    v += dpp_move_f64<0x114, 0xf>(v, 0.0);
+    v += dpp_move_f64<0x118, 0xf>(v, 0.0);
+    v += dpp_move_f64<0x142, 0xa>(v, 0.0);
+    v += dpp_move_f64<0x143, 0xc>(v, 0.0);
+    return v;
+}
+
+__device__ __forceinline__ double wave_max_to_lane63(double v)
+{
+    const double ninf = -INFINITY;
+    v = fmax(v, dpp_move_f64<0x111, 0xf>(v, ninf));
+    v = fmax(v, dpp_move_f64<0x112, 0xf>(v, ninf));
+    v = fmax(v, dpp_move_f64<0x114, 0xf>(v, ninf));
+    v = fmax(v, dpp_move_f64<0x118, 0xf>(v, ninf));
+    v = fmax(v, dpp_move_f64<0x142, 0xa>(v, ninf));
+    v = fmax(v, dpp_move_f64<0x143, 0xc>(v, ninf));
+    return v;
+}
+
 __device__ double block_sum(double v, double* s_red)
 {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    v = wave_sum_to_lane63(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
     double t = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += s_red[w];
@@ -110,9 +151,9 @@ __device__ double block_sum(double v, double* s_red)
 
 __device__ double block_max(double v, double* s_red)
 {
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    v = wave_max_to_lane63(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 63) s_red[threadIdx.x >> 6] = v;
     __syncthreads();
     double t = s_red[0];
     for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, s_red[w]);
@@ -159,41 +200,34 @@ __device__ unsigned long long radix_select(const double* vals, int N, int rank, 
     return prefix;
 }
 
-// A (6x6 SPD, row-major) -> A^-1 via Cholesky; returns false if not positive definite
-__device__ bool spd_inverse6(const double* A, double* Ainv)
+// In-place inverse of a 6x6 SPD matrix held in LDS (row-major M[36]) by ONE wave, lane (i, j) = 6 i + j owning one
+// entry: six sweeps (Gauss-Jordan without pivoting -- the pivots of an SPD matrix are its positive Schur
+// complements), then the lower triangle is overwritten by the upper one so that the result is exactly symmetric.
+// Every lane of the wave must call; returns (wave-uniform) false if a pivot is not positive.
+__device__ bool spd_inverse6_wave(double* M)
 {
-    double L[36];
-    for (int i = 0; i < 36; ++i) L[i] = 0.0;
-    for (int j = 0; j < 6; ++j) {
-        double d = A[j * 6 + j];
-        for (int k = 0; k < j; ++k) d -= L[j * 6 + k] * L[j * 6 + k];
-        if (!(d > 0.0)) return false;
-        const double ljj = sqrt(d);
-        L[j * 6 + j] = ljj;
-        for (int i = j + 1; i < 6; ++i) {
-            double s = A[i * 6 + j];
-            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
-            L[i * 6 + j] = s / ljj;
-        }
+    const int l = threadIdx.x & 63;
+    const bool on = l < 36;
+    const int i = on ? l / 6 : 0, j = on ? l % 6 : 0;
+    double a = M[on ? l : 0];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const double d = M[k * 7], rk = M[k * 6 + j], ck = M[i * 6 + k];
+        if (!(d > 0.0)) ok = false;
+        const double inv = 1.0 / d;          // one division per sweep; the four cases are selects, not branches
+        const double scaled = a * inv;
+        const double swept = a - ck * (rk * inv);
+        a = (i == k) ? ((j == k) ? inv : scaled) : ((j == k) ? -scaled : swept);
+        __builtin_amdgcn_wave_barrier();   // LDS operations of a wave execute in order: all reads above precede the writes
+        if (on) M[l] = a;
+        __builtin_amdgcn_wave_barrier();
     }
-    double Li[36];  // inverse of lower-triangular L
-    for (int i = 0; i < 36; ++i) Li[i] = 0.0;
-    for (int j = 0; j < 6; ++j) {
-        Li[j * 6 + j] = 1.0 / L[j * 6 + j];
-        for (int i = j + 1; i < 6; ++i) {
-            double s = 0.0;
-            for (int k = j; k < i; ++k) s -= L[i * 6 + k] * Li[k * 6 + j];
-            Li[i * 6 + j] = s / L[i * 6 + i];
-        }
-    }
-    for (int i = 0; i < 6; ++i)
-        for (int j = i; j < 6; ++j) {
-            double s = 0.0;
-            for (int k = j; k < 6; ++k) s += Li[k * 6 + i] * Li[k * 6 + j];
-            Ainv[i * 6 + j] = s;
-            Ainv[j * 6 + i] = s;
-        }
-    return true;
+    const double up = M[i <= j ? i * 6 + j : j * 6 + i];
+    __builtin_amdgcn_wave_barrier();
+    if (on) M[l] = up;
+    __builtin_amdgcn_wave_barrier();
+    return ok;
 }
 
 constexpr int kSkfLdsN = 1024;  // measurement counts up to this keep innovations + norms in LDS
@@ -202,7 +236,7 @@ constexpr int kBucketCap = 256;
 static_assert(kBins == 4 * 256, "bucket_select2 scans 4 bins per thread of a 256-thread block");
 
 struct SkfShared {
-    double red[kSkfThreads / 64];
+    double red[kSkfThreads / 64], red2[kSkfThreads / 64];
     double acc[27][kSkfThreads / 64];
     int hist[kBins];
     int sel[2];
@@ -210,31 +244,13 @@ struct SkfShared {
     int bin[2], base[2], cnt[2];
     double list[2][kBucketCap];
     double med[2];
+    double Lm[36], Ppi[36], eta[6], xo[6];   // information matrix -> posterior covariance, prior information, ...
     double ein[2 * kSkfLdsN];
     double qn[kSkfLdsN];
+#ifdef ROFT_SKF_PROFILE
+    long long t0, dbg[16];
+#endif
 };
-
-__device__ int skf_block_scan(int v, int* s_wave, int* total)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    int inc = v;
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += t;
-    }
-    if (lane == 63) s_wave[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int w = 0; w < nw; ++w) { int t = s_wave[w]; s_wave[w] = run; run += t; }
-        s_wave[16] = run;
-    }
-    __syncthreads();
-    const int res = s_wave[wave] + inc - v;
-    *total = s_wave[16];
-    __syncthreads();
-    return res;
-}
 
 // Exact order statistics of ranks ra <= rb (rb - ra <= 1) of N non-negative doubles in ~5 barrier phases:
 // a monotone 1024-bin histogram over [min, max] locates the bucket of each rank, the (few) members of that
@@ -243,13 +259,20 @@ __device__ bool bucket_select2(const double* vals, int N, int ra, int rb, SkfSha
 {
     double lo = INFINITY, hi = 0.0;
     for (int k = threadIdx.x; k < N; k += blockDim.x) { const double v = vals[k]; lo = fmin(lo, v); hi = fmax(hi, v); }
-    lo = -block_max(-lo, S.red);
-    hi = block_max(hi, S.red);
-    if (!(hi > lo)) { va = vb = lo; return true; }
+    {   // both extremes through one pair of barriers; the histogram is cleared under the same pair
+        const double wl = wave_max_to_lane63(-lo), wh = wave_max_to_lane63(hi);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 63) { S.red[threadIdx.x >> 6] = wl; S.red2[threadIdx.x >> 6] = wh; }
+        for (int i = threadIdx.x; i < kBins; i += blockDim.x) S.hist[i] = 0;
+        if (threadIdx.x < 2) S.cnt[threadIdx.x] = 0;
+        __syncthreads();
+        double tl = S.red[0], th = S.red2[0];
+        for (int w = 1; w < kSkfThreads / 64; ++w) { tl = fmax(tl, S.red[w]); th = fmax(th, S.red2[w]); }
+        lo = -tl;
+        hi = th;
+    }
+    if (!(hi > lo)) { va = vb = lo; __syncthreads(); return true; }
     const double scale = (double)(kBins - 1) / (hi - lo);
-    for (int i = threadIdx.x; i < kBins; i += blockDim.x) S.hist[i] = 0;
-    if (threadIdx.x < 2) S.cnt[threadIdx.x] = 0;
-    __syncthreads();
     for (int k = threadIdx.x; k < N; k += blockDim.x) {
         int b = (int)((vals[k] - lo) * scale);   // monotone in vals[k]
         b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
@@ -260,7 +283,7 @@ __device__ bool bucket_select2(const double* vals, int N, int ra, int rb, SkfSha
         const int t = threadIdx.x;
         const int h0 = S.hist[4 * t], h1 = S.hist[4 * t + 1], h2 = S.hist[4 * t + 2], h3 = S.hist[4 * t + 3];
         int total;
-        const int ex = skf_block_scan(h0 + h1 + h2 + h3, S.wave, &total);
+        const int ex = block_exclusive_scan(h0 + h1 + h2 + h3, S.wave, &total);
         const int pre[5] = {ex, ex + h0, ex + h0 + h1, ex + h0 + h1 + h2, ex + h0 + h1 + h2 + h3};
         for (int q = 0; q < 2; ++q) {
             const int r = q ? rb : ra;
@@ -295,12 +318,12 @@ __device__ bool bucket_select2(const double* vals, int N, int ra, int rb, SkfSha
     return true;
 }
 
-// Correction of (x, P_pred) with N measurements; thread 0 returns the result in x_out / P_out.
+// Correction of (x, P_pred) with N measurements; the result is left in S.xo / S.Lm (valid if 0 is returned).
 // Returns (to every thread) 0 = corrected, 3 = numerically singular.
 // scratch: 3 * N doubles of global memory, used only when N > kSkfLdsN.
 template <class Acc>
 __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const double* P_pred, const double r_flow[2],
-                        int reweight, double* scratch, SkfShared& S, double x_out[6], double* P_out)
+                        int reweight, double* scratch, SkfShared& S)
 {
     double mi = 0.0, b = 0.0, lmax = 1.0;
     bool weighted = false;
@@ -317,11 +340,13 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
             ein[2 * j + 1] = -(p1 - y[1]);
         }
         __syncthreads();  // (scratch is written and read by this workgroup only)
+        SKFTICK(1);
         for (int k = threadIdx.x; k < N; k += blockDim.x) {
             const double e0 = ein[k], e1 = ein[N + k];   // column-major pairing of the reference (cpp:93)
             qn[k] = sqrt(e0 * e0 + e1 * e1);
         }
         __syncthreads();
+        SKFTICK(2);
         const int ra = (N % 2 == 0) ? N / 2 - 1 : N / 2, rb = N / 2;
         double va, vb;
         if (!bucket_select2(qn, N, ra, rb, S, va, vb)) {
@@ -340,10 +365,12 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
                 vb = (cnt_le > (double)(N / 2)) ? va : min_gt;
             }
         }
+        SKFTICK(3);
         mi = (N % 2 == 0) ? 0.5 * (va + vb) : vb;
         double sabs = 0.0;
         for (int k = threadIdx.x; k < N; k += blockDim.x) sabs += fabs(qn[k] - mi);
         b = block_sum(sabs, S.red) / N;
+        SKFTICK(4);
         if (b > 1e-4) {
             weighted = true;
             double m = 0.0;
@@ -358,6 +385,7 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
         }
     }
 
+    SKFTICK(5);
     // information accumulation: 21 unique entries of sum l H'R^-1 H and 6 of sum l H'R^-1 e
     double acc[27];
     for (int i = 0; i < 27; ++i) acc[i] = 0.0;
@@ -381,47 +409,54 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
             for (int k = i; k < 6; ++k) acc[t++] += w0 * h[i] * h[k] + w1 * h[6 + i] * h[6 + k];
         for (int i = 0; i < 6; ++i) acc[21 + i] += w0 * h[i] * e0 + w1 * h[6 + i] * e1;
     }
+    SKFTICK(6);
     __syncthreads();
+#pragma unroll
     for (int i = 0; i < 27; ++i) {
-        double v = acc[i];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0) S.acc[i][threadIdx.x >> 6] = v;
+        const double v = wave_sum_to_lane63(acc[i]);
+        if ((threadIdx.x & 63) == 63) S.acc[i][threadIdx.x >> 6] = v;
     }
     __syncthreads();
+    SKFTICK(7);
 
-    if (threadIdx.x == 0) {
-        double Lm[36], eta[6];
-        int t = 0;
-        for (int i = 0; i < 6; ++i)
-            for (int k = i; k < 6; ++k) {
-                double v = 0.0;
-                for (int w = 0; w < kSkfThreads / 64; ++w) v += S.acc[t][w];
-                Lm[i * 6 + k] = v;
-                Lm[k * 6 + i] = v;
-                ++t;
-            }
-        for (int i = 0; i < 6; ++i) {
+    // posterior: P = (P_pred^-1 + sum l H'R^-1 H)^-1, x = x_pred + P eta.  Wave 0 assembles the sums while wave 1
+    // inverts the prior covariance; wave 0 then inverts the information matrix.
+    {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (wave == 0 && lane < 27) {
             double v = 0.0;
-            for (int w = 0; w < kSkfThreads / 64; ++w) v += S.acc[21 + i][w];
-            eta[i] = v;
-        }
-        double Ppi[36], Pn[36];
-        bool ok = spd_inverse6(P_pred, Ppi);
-        if (ok) {
-            for (int i = 0; i < 36; ++i) Lm[i] += Ppi[i];
-            ok = spd_inverse6(Lm, Pn);
-        }
-        if (ok) {
-            for (int i = 0; i < 6; ++i) {
-                double s = 0.0;
-                for (int k = 0; k < 6; ++k) s += Pn[i * 6 + k] * eta[k];
-                x_out[i] = x[i] + s;
+            for (int w = 0; w < kSkfThreads / 64; ++w) v += S.acc[lane][w];
+            if (lane < 21) {
+                int i = 0, k = lane;          // lane -> (i, k), k >= i, of the upper triangle in row-major order
+                while (k >= 6 - i) { k -= 6 - i; ++i; }
+                k += i;
+                S.Lm[i * 6 + k] = v;
+                S.Lm[k * 6 + i] = v;
+            } else {
+                S.eta[lane - 21] = v;
             }
-            for (int i = 0; i < 36; ++i) P_out[i] = Pn[i];
         }
-        S.sel[0] = ok ? 0 : 3;
+        if (wave == 1) {
+            if (lane < 36) S.Ppi[lane] = P_pred[lane];
+            __builtin_amdgcn_wave_barrier();
+            const bool ok = spd_inverse6_wave(S.Ppi);
+            if (lane == 0) S.sel[1] = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            if (lane < 36) S.Lm[lane] += S.Ppi[lane];
+            __builtin_amdgcn_wave_barrier();
+            const bool ok = spd_inverse6_wave(S.Lm) && S.sel[1] != 0;
+            if (lane < 6) {
+                double sum = 0.0;
+                for (int k = 0; k < 6; ++k) sum += S.Lm[lane * 6 + k] * S.eta[k];
+                S.xo[lane] = x[lane] + sum;
+            }
+            if (lane == 0) S.sel[0] = ok ? 0 : 3;
+        }
     }
     __syncthreads();
+    SKFTICK(8);
     return S.sel[0];
 }
 
@@ -450,6 +485,9 @@ __global__ __launch_bounds__(kSkfThreads) void skf_kernel(EngineArrays a, int re
         }
         return;
     }
+#ifdef ROFT_SKF_PROFILE
+    if (threadIdx.x == 0) S.t0 = wall_clock64();
+#endif
     if (threadIdx.x < 6) s_x[threadIdx.x] = st.v_mean[threadIdx.x];  // s^- = s (F = I)
     if (threadIdx.x < 36) {
         const int i = threadIdx.x;
@@ -458,19 +496,24 @@ __global__ __launch_bounds__(kSkfThreads) void skf_kernel(EngineArrays a, int re
     __syncthreads();
     double x[6];
     for (int i = 0; i < 6; ++i) x[i] = s_x[i];
+    SKFTICK(0);
 
     RecAccessor acc{a.recs + (size_t)obj * a.cand_cap, a.cam, c.dt};
-    double xo[6], Po[36];
-    const int rc = skf_core(acc, N, x, s_P, prm.r_flow, reweight, a.norms + (size_t)obj * 3 * a.cand_cap, S, xo, Po);
+    const int rc = skf_core(acc, N, x, s_P, prm.r_flow, reweight, a.norms + (size_t)obj * 3 * a.cand_cap, S);
+    // rc 3: numerically singular, belief left unchanged
+    if (rc == 0 && threadIdx.x < 36) st.v_cov[threadIdx.x] = S.Lm[threadIdx.x];
+    if (threadIdx.x < 6) {
+        const double v = (rc == 0) ? S.xo[threadIdx.x] : s_x[threadIdx.x];
+        if (rc == 0) st.v_mean[threadIdx.x] = v;
+        st.twist_hist[c.twist_slot][threadIdx.x] = v;
+        if (roft_object_output* row = log_row(a, obj)) row->twist[threadIdx.x] = v;
+    }
     if (threadIdx.x == 0) {
-        if (rc == 0) {
-            for (int i = 0; i < 6; ++i) st.v_mean[i] = xo[i];
-            for (int i = 0; i < 36; ++i) st.v_cov[i] = Po[i];
-        }
-        st.skf_status = rc;  // 3: numerically singular, belief left unchanged
-        for (int i = 0; i < 6; ++i) st.twist_hist[c.twist_slot][i] = st.v_mean[i];
+        st.skf_status = rc;
+#ifdef ROFT_SKF_PROFILE
+        for (int i = 0; i < 9; ++i) st.dbg[i] = S.dbg[i];
+#endif
         if (roft_object_output* row = log_row(a, obj)) {
-            for (int i = 0; i < 6; ++i) row->twist[i] = st.v_mean[i];
             row->n_flow_points = st.n_flow_points;
             row->outlier_selected = -1;
         }
@@ -498,13 +541,10 @@ __global__ __launch_bounds__(kSkfThreads) void skf_arrays_kernel(const double* x
     double x[6], r[2] = {Rdiag[0], Rdiag[1]};
     for (int i = 0; i < 6; ++i) x[i] = x_pred[i];
     ArrayAccessor acc{y, H};
-    double xo[6], Po[36];
-    const int rc = skf_core(acc, N, x, P_pred, r, reweight, norms, S, xo, Po);
-    if (threadIdx.x == 0) {
-        for (int i = 0; i < 6; ++i) x_out[i] = (rc == 0) ? xo[i] : x_pred[i];
-        for (int i = 0; i < 36; ++i) P_out[i] = (rc == 0) ? Po[i] : P_pred[i];
-        *status = rc;
-    }
+    const int rc = skf_core(acc, N, x, P_pred, r, reweight, norms, S);
+    if (threadIdx.x < 6) x_out[threadIdx.x] = (rc == 0) ? S.xo[threadIdx.x] : x_pred[threadIdx.x];
+    if (threadIdx.x < 36) P_out[threadIdx.x] = (rc == 0) ? S.Lm[threadIdx.x] : P_pred[threadIdx.x];
+    if (threadIdx.x == 0) *status = rc;
 }
 
 void launch_skf_arrays(const double* x_pred, const double* P_pred, int N, const double* y, const double* H,

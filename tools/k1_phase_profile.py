@@ -22,6 +22,8 @@ dev = torch.device("cuda", 0)
 streams = [synth.make_stream(4000 + i, n, synth.Camera.shape_a(), device=dev) for i in range(n_obj)]
 eng = rb.make_engine(streams)
 names = ["ctrl", "plane->LDS", "popc+scan", "cand list", "gathers", "scan+write"]
+if os.environ.get("PHASES") == "skf":
+    names = ["load", "innovations", "norms", "median", "mean abs dev", "max weight", "accumulate", "reduce", "solve"]
 for k in range(n):
     frames = []
     for st in streams:
@@ -37,7 +39,7 @@ for k in range(n):
         for o in range(n_obj):
             buf = (C.c_longlong * 32)()
             L.lib().roft_debug_get_dbg(eng._h, o, buf)
-            rows.append([buf[i] / 100.0 for i in range(6)])
+            rows.append([buf[i] / 100.0 for i in range(len(names))])
         r = np.array(rows)
         print("frame %d  mean us per phase: " % k + ", ".join("%s %.2f" % (nm, v) for nm, v in zip(names, r.mean(0))) +
               "  | sum %.2f (max over objects %.2f)" % (r.sum(1).mean(), r.sum(1).max()))
