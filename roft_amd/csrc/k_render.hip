@@ -27,56 +27,93 @@ constexpr int kFeatThreads = 1024;
 // is part of the mask chain of the frame and never waits for the pose chain that reads an older set.
 // Feature slot s holds the pixel of row-major rank 2s of the current obj plane (`k += 2` over the
 // findNonZero list, ROFTFilter.cpp:556) and its depth.  Plane words are in row-major order, so one block
-// scan over the word popcounts gives every word its starting rank; each thread then expands its own
-// contiguous chunk of words, issuing its depth gathers back to back.
+// scan over the popcounts of contiguous word chunks gives every chunk its starting rank; the expansion of the
+// words into (pixel, depth) slots is described at the loop below.
+#ifdef ROFT_FEAT_PROFILE
+#define FTICK(i) do { __syncthreads(); if (threadIdx.x == 0) { long long _t = wall_clock64(); a.state[obj].dbg[i] = _t - f_t0; f_t0 = _t; } } while (0)
+#else
+#define FTICK(i) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ int s_wave[17];
+    __shared__ int s_wave[16];
+    __shared__ int s_chunk[kFeatThreads];
     const int obj = blockIdx.x;
     const FrameCtrl& c = a.ctrl[obj];
-    if (c.feat_write < 0) return;
+#ifdef ROFT_FEAT_PROFILE
+    long long f_t0 = wall_clock64();
+#endif
+    int feat_write = c.feat_write, slot_cur = c.slot_cur;
+    const float* depth = c.depth_cur;
+    asm volatile("" : "+v"(feat_write), "+v"(slot_cur), "+v"(depth));   // all three fetched before the first barrier
+    if (feat_write < 0) return;
     const int W = a.cam.W, wpr = a.cam.wpr;
-    uint32_t* plane = reinterpret_cast<uint32_t*>(smem);   // staged with coalesced 16-byte loads
+    uint32_t* s_plane = reinterpret_cast<uint32_t*>(smem);   // staged with coalesced 16-byte loads
     {
-        const uint32_t* gplane = a.planes + plane_offset(a, obj, c.slot_cur, 1);
+        const uint32_t* gplane = a.planes + plane_offset(a, obj, slot_cur, 1);
         const size_t n4 = a.plane_words / 4;
         for (size_t i = threadIdx.x; i < n4; i += blockDim.x)
-            reinterpret_cast<uint4*>(plane)[i] = reinterpret_cast<const uint4*>(gplane)[i];
-        for (size_t i = n4 * 4 + threadIdx.x; i < a.plane_words; i += blockDim.x) plane[i] = gplane[i];
+            reinterpret_cast<uint4*>(s_plane)[i] = reinterpret_cast<const uint4*>(gplane)[i];
+        for (size_t i = n4 * 4 + threadIdx.x; i < a.plane_words; i += blockDim.x) s_plane[i] = gplane[i];
         __syncthreads();
     }
-    const float* depth = c.depth_cur;
-    uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + c.feat_write) * a.feat_cap;
-    float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + c.feat_write) * a.feat_cap;
+    FTICK(0);
+    uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + feat_write) * a.feat_cap;
+    float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + feat_write) * a.feat_cap;
     const int n_words = (int)a.plane_words;
     const int per = (n_words + blockDim.x - 1) / blockDim.x;
     const int w0 = min(n_words, (int)threadIdx.x * per), w1 = min(n_words, w0 + per);
     int cnt = 0;
-    for (int w = w0; w < w1; ++w) cnt += __popc(plane[w]);
+    for (int w = w0; w < w1; ++w) cnt += __popc(s_plane[w]);
     int total;
-    int rank = block_exclusive_scan(cnt, s_wave, &total);
-    if (cnt) {
-        for (int w = w0; w < w1; ++w) {
-            uint32_t bits = plane[w];
-            const int row = w / wpr, col0 = (w - row * wpr) * 32;
-            // keep the bits whose rank is even: parity alternates along the set bits of the word
-            while (bits) {
-                const int bpos = __builtin_ctz(bits);
-                bits &= bits - 1;
-                if ((rank & 1) == 0) {
-                    const int slot = rank >> 1;
-                    if (slot < a.feat_cap) fpix[slot] = (uint32_t)(row * W + col0 + bpos);
-                }
-                ++rank;
-            }
+    s_chunk[threadIdx.x] = block_exclusive_scan(cnt, s_wave, &total);   // starting rank of the thread's chunk
+    __syncthreads();
+    FTICK(1);
+    // Expansion with the words dealt out round-robin -- the dense words of the mask are neighbours, so a contiguous
+    // split would leave the whole expansion to a few threads.  A word's starting rank = its chunk's + the popcounts
+    // of the chunk's earlier words; the bits whose rank is even are kept (parity alternates along the set bits).
+    for (int w = threadIdx.x; w < n_words; w += blockDim.x) {
+        uint32_t bits = s_plane[w];
+        if (!bits) continue;
+        const int chunk = w / per;
+        int r0 = s_chunk[chunk];
+        for (int v = chunk * per; v < w; ++v) r0 += __popc(s_plane[v]);
+        if (r0 & 1) bits &= bits - 1;                 // first set bit has an odd rank: skip it
+        int slot = (r0 + 1) >> 1;
+        const int row = w / wpr, pix0 = row * W + (w - row * wpr) * 32;
+        while (bits) {
+            if (slot < a.feat_cap) fpix[slot] = (uint32_t)(pix0 + __builtin_ctz(bits));
+            ++slot;
+            bits &= bits - 1;                         // the kept bit ...
+            bits &= bits - 1;                         // ... and its odd-ranked successor (no-op on 0)
         }
     }
     __syncthreads();  // fpix is written and read by this workgroup only
-    // depth gathers: independent per slot, spread over the whole workgroup
+    FTICK(2);
+    // depth gathers, kBatch per thread in flight together (a loop that consumes each index right after loading it
+    // pays two memory latencies per element)
+    constexpr int kBatch = 16;
     const int n = min((total + 1) / 2, a.feat_cap);
-    for (int s = threadIdx.x; s < n; s += blockDim.x) fdep[s] = depth[fpix[s]];
-    if (threadIdx.x == 0) a.state[obj].n_feat[c.feat_write] = min((total + 1) / 2, a.feat_cap);
+    for (int sb = threadIdx.x; sb < n; sb += kBatch * blockDim.x) {
+        uint32_t px[kBatch];
+        float d[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int sl = sb + u * (int)blockDim.x;
+            px[u] = (sl < n) ? fpix[sl] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) d[u] = depth[px[u]];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int sl = sb + u * (int)blockDim.x;
+            if (sl < n) fdep[sl] = d[u];
+        }
+    }
+    FTICK(3);
+    if (threadIdx.x == 0) a.state[obj].n_feat[feat_write] = n;
 }
 
 void launch_features(const EngineArrays& a, hipStream_t s)
@@ -84,7 +121,7 @@ void launch_features(const EngineArrays& a, hipStream_t s)
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - 256);
+                                  160 * 1024 - 256 - kFeatThreads * (int)sizeof(int) - 128);
         attr_set = true;
     }
     hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), (a.plane_words * 4 + 15) & ~(size_t)15, s, a);

@@ -22,6 +22,8 @@ dev = torch.device("cuda", 0)
 streams = [synth.make_stream(4000 + i, n, synth.Camera.shape_a(), device=dev) for i in range(n_obj)]
 eng = rb.make_engine(streams)
 names = ["ctrl", "plane->LDS", "popc+scan", "cand list", "gathers", "scan+write"]
+if os.environ.get("PHASES") == "feat":
+    names = ["count", "scan+ranks", "expand", "gathers"]
 if os.environ.get("PHASES") == "skf":
     names = ["load", "innovations", "norms", "median", "mean abs dev", "max weight", "accumulate", "reduce", "solve"]
 for k in range(n):
