@@ -255,7 +255,7 @@ def main():
         if os.path.exists(pmc_path) and (n_obj, args.shape, args.flow) == (64, "A", "f32"):
             for line in open(pmc_path):
                 f = line.strip().split(",")
-                if f[0] == "roft::flow_measure_kernel" and f[1] == "FETCH_SIZE":
+                if "roft::flow_measure_kernel" in f[0] and f[1] == "FETCH_SIZE":
                     traffic = float(f[3]) * 1024.0
         roofline = dict(kernel="flow_measure_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic,

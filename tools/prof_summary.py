@@ -17,7 +17,7 @@ def stats(src, dst):
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "share_of_roft_time"])
         for r in sorted(keep, key=lambda r: -float(r["TotalDurationNs"])):
-            name = r["Name"].split("(")[0]
+            name = r["Name"].split("(")[0].replace("void ", "")
             w.writerow([name, r["Calls"], "%.1f" % (float(r["TotalDurationNs"]) / 1e3), "%.2f" % (float(r["AverageNs"]) / 1e3),
                         "%.2f" % (float(r["MinNs"]) / 1e3), "%.2f" % (float(r["MaxNs"]) / 1e3),
                         "%.3f" % (float(r["TotalDurationNs"]) / total)])
@@ -29,7 +29,7 @@ def pmc(src, dst):
         k = r.get("Kernel_Name", "")
         if "roft::" not in k:
             continue
-        key = (k.split("(")[0], r["Counter_Name"])
+        key = (k.split("(")[0].replace("void ", ""), r["Counter_Name"])
         acc[key][0] += float(r["Counter_Value"])
         acc[key][1] += 1
     with open(dst, "w", newline="") as f:
