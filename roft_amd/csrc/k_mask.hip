@@ -102,10 +102,9 @@ __global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a)
     if ((threadIdx.x & 63) == 0 && count) atomicAdd(&a.state[obj].new_mask_count, count);
 }
 
-constexpr int kScatterBlocks = 96;  // per object; x 4 waves x ~25 groups each at 640x480
 
 // ---- scatter (mode decision: decide_mode() in roft_device.h) --------------------------------------
-// grid: (kScatterBlocks, n_obj), block 256 = 4 waves; a wave owns 64 consecutive pixels per iteration and
+// grid: (power of two >= n_grp/256, n_obj), block 256 = 4 waves; a wave owns 64 consecutive pixels per iteration and
 // strides over the image (interleaved, so the object's rows spread over all waves); its lanes chase their
 // pixel through the flows in parallel: the flow reads of a wave are row-contiguous (64 x 8 B), the map
 // atomics land on neighbouring addresses.  Empty 64-pixel groups cost one wave-uniform 8-byte load.
@@ -375,7 +374,12 @@ void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_a
         return;
     }
     const int n_grp = a.cam.W * a.cam.H / 64;
-    int sblocks = kScatterBlocks;
+    // Few, long-lived workgroups: every wave prefetches its (at most 64) plane groups with one load and chases the
+    // non-empty ones kChase at a time, so a grid that is resident all at once (64 objects x 32 blocks at 640x480)
+    // beats one that needs several rounds of workgroup launches (96 blocks: 0.106 vs 0.097 ms per frame).  A power
+    // of two keeps the wave stride from being a multiple of the groups per row -- with 30 blocks (stride 120 = 12
+    // rows of 640 pixels) each wave stays in one image column and a few waves get all of the object.
+    int sblocks = 8;
     while (sblocks * 4 * 64 < n_grp) sblocks *= 2;   // each wave prefetches at most 64 groups
     if (a.ffmt.type == ROFT_FLOW_S16C2)
         hipLaunchKernelGGL(mask_scatter_kernel<ROFT_FLOW_S16C2>, dim3(sblocks, a.n_obj), dim3(256), 0, s, a, frames_between);
