@@ -717,14 +717,7 @@ int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inpu
 static void tmark(roft_engine* e, const char* name, int which = 0)
 {
     if (!e->timing) return;
-    // "vel_chain_start" is the mark in front of flow_measure_kernel: it opens that kernel's interval
-    const bool opens = name && std::strcmp(name, "vel_chain_start") == 0;
-    if (opens) name = nullptr;
-    if (e->timing_level == 1) {
-        // only the roofline kernel: the mark before it opens the interval, its own mark closes it
-        const bool closes = name && std::strcmp(name, "flow_measure") == 0;
-        if (!opens && !closes) return;
-    }
+    if (e->timing_level == 1) return;   // only the roofline kernel is timed (tmark_kernel)
     const size_t idx = e->tmark.size();
     while (e->tev.size() <= idx) {
         hipEvent_t ev;
@@ -740,6 +733,29 @@ static void tmark(roft_engine* e, const char* name, int which = 0)
     e->tmark.push_back(id);
     e->tstream.push_back(which);
     (void)hipEventRecord(e->tev[idx], which == 1 ? e->pose_stream : (which == 2 ? e->vel_stream : e->stream));
+}
+
+// Timing of ONE kernel by a start / stop event pair bound to its dispatch (two consecutive marks: the first opens the
+// interval, the second closes it and attributes it to `name`).  Leaves the events null when timing is off.
+static void tmark_kernel(roft_engine* e, const char* name, int which, hipEvent_t* start, hipEvent_t* stop)
+{
+    if (!e->timing) return;
+    const size_t idx = e->tmark.size();
+    while (e->tev.size() <= idx + 1) {
+        hipEvent_t ev;
+        (void)hipEventCreate(&ev);
+        e->tev.push_back(ev);
+    }
+    int id = -1;
+    for (size_t i = 0; i < e->tnames_s.size(); ++i)
+        if (e->tnames_s[i] == name) id = (int)i;
+    if (id < 0) { e->tnames_s.push_back(name); id = (int)e->tnames_s.size() - 1; }
+    e->tmark.push_back(-1);
+    e->tstream.push_back(which);
+    e->tmark.push_back(id);
+    e->tstream.push_back(which);
+    *start = e->tev[idx];
+    *stop = e->tev[idx + 1];
 }
 
 int roft_step(roft_engine* e)
@@ -764,27 +780,34 @@ int roft_step(roft_engine* e)
         const size_t n16 = sizeof(FrameCtrl) * a.n_obj / 16;
         // (the previous frame's FrameCtrl block is still in the device ring)
         const FrameCtrl* prev = (e->frame_counter > 0) ? e->dctrl[(e->frame_counter - 1) % R].p : nullptr;
-        hipLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
-                           reinterpret_cast<const uint4*>(e->cur), reinterpret_cast<uint4*>(a.ctrl), n16, prev, a.state, a.n_obj);
+        // ONE event of the mask chain per frame, bound to this kernel's dispatch: "FrameCtrl (+ host input copies) of
+        // frame k on the device and the mask chain of frame k-1 complete" -- what the velocity chain of frame k needs,
+        // and what frees the pinned staging block.  (Events that complete with a kernel cost neither the barrier
+        // packet nor the host call of a hipEventRecord behind it.)
+        hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
+                              nullptr, e->stage_ev[si], 0, reinterpret_cast<const uint4*>(e->cur),
+                              reinterpret_cast<uint4*>(a.ctrl), n16, prev, a.state, a.n_obj);
     } else {
         HIP_TRY(hipMemcpyAsync(a.ctrl, e->cur, sizeof(FrameCtrl) * a.n_obj, hipMemcpyHostToDevice, s));
+        HIP_TRY(hipEventRecord(e->stage_ev[si], s));
     }
-    // ONE event of the mask chain per frame, recorded here: "FrameCtrl (+ host input copies) of frame k on the device
-    // and the mask chain of frame k-1 complete" -- what the velocity chain of frame k needs, and what frees the pinned
-    // staging block
-    HIP_TRY(hipEventRecord(e->stage_ev[si], s));
     e->stage_idx = (si + 1) % roft_engine::kStage;
     HP_MARK(e, 3, hp_t);
 
     // ---- velocity chain: needs FrameCtrl (+ host input copies) of this frame and the mask planes of the previous one
     if (multi) HIP_TRY(hipStreamWaitEvent(sv, e->stage_ev[si], 0));
     const int radius = (int)(size_t)e->cfg.subsampling_radius;
-    tmark(e, "vel_chain_start", 2);
-    launch_flow_measure(a, e->cfg.depth_maximum, radius, false, sv);
-    tmark(e, "flow_measure", 2);
-    launch_skf(a, e->cfg.flow_weighting, sv);
+    {
+        // the roofline kernel is timed by a start / stop event pair on its own dispatch: its duration as rocprofv3
+        // reports it, with no marker packets around it
+        hipEvent_t k1_start = nullptr, k1_stop = nullptr;
+        tmark_kernel(e, "flow_measure", 2, &k1_start, &k1_stop);
+        launch_flow_measure(a, e->cfg.depth_maximum, radius, false, sv, k1_start, k1_stop);
+    }
+    const bool time_skf = e->timing && e->timing_level > 1;   // a marker behind skf then carries ev_vel's role as well
+    launch_skf(a, e->cfg.flow_weighting, sv, (multi && !time_skf) ? e->ev_vel[ci] : nullptr);
     tmark(e, "skf", 2);
-    if (multi) HIP_TRY(hipEventRecord(e->ev_vel[ci], sv));
+    if (multi && time_skf) HIP_TRY(hipEventRecord(e->ev_vel[ci], sv));
 
     HP_MARK(e, 4, hp_t);
     // ---- mask chain
@@ -792,8 +815,14 @@ int roft_step(roft_engine* e)
     if (e->any_new_mask) { launch_mask_ingest(a, s); tmark(e, "mask_ingest", 0); }
     launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, !e->kernel_upload, s);
     tmark(e, "mask_propagate", 0);
-    if (e->any_feat) { launch_features(a, s); tmark(e, "features", 0); }
-    if (multi && e->any_feat_now) HIP_TRY(hipEventRecord(e->ev_mask[ci], s));   // only when the pose chain waits for it
+    // ev_mask: only when the pose chain waits for this frame's features
+    const bool want_ev_mask = multi && e->any_feat_now;
+    if (e->any_feat) {
+        launch_features(a, s, want_ev_mask ? e->ev_mask[ci] : nullptr);
+        tmark(e, "features", 0);
+    } else if (want_ev_mask) {
+        HIP_TRY(hipEventRecord(e->ev_mask[ci], s));
+    }
 
     HP_MARK(e, 5, hp_t);
     // ---- pose chain (needs this frame's twist and mask planes; the next frames' image chains do not wait for it)
@@ -806,18 +835,21 @@ int roft_step(roft_engine* e)
     }
     tmark(e, nullptr, 1);
     // step 0 (possibly followed by the outlier render + test), then all remaining steps in one launch
+    // Completion event of the pose chain: only the host reads it (bound on the frames in flight) -- every other frame
+    // is enough; it rides on the chain's last kernel of the frame.
+    hipEvent_t ev_pose = ((e->frame_counter & 1) == 0) ? e->ev_pose[ci] : nullptr;
     if (e->max_steps > 0) {
-        launch_ukf_step(a, 0, 1, e->cfg.ut, sp);
+        const bool replay = e->max_steps > 1;
+        launch_ukf_step(a, 0, 1, e->cfg.ut, sp, (!e->any_outlier && !replay) ? ev_pose : nullptr);
         tmark(e, "ukf_step", 1);
-        if (e->any_outlier) { launch_outlier(a, sp); tmark(e, "outlier_render_likelihood", 1); }
-        if (e->max_steps > 1) {
-            launch_ukf_step(a, 1, e->max_steps, e->cfg.ut, sp);
+        if (e->any_outlier) { launch_outlier(a, sp, !replay ? ev_pose : nullptr); tmark(e, "outlier_render_likelihood", 1); }
+        if (replay) {
+            launch_ukf_step(a, 1, e->max_steps, e->cfg.ut, sp, ev_pose);
             tmark(e, "ukf_replay_steps", 1);
         }
+    } else if (ev_pose) {
+        HIP_TRY(hipEventRecord(ev_pose, sp));
     }
-    // completion event of the pose chain: only the host reads it (bound on the frames in flight), and an event
-    // operation costs the stream it sits on ~8 us -- every other frame is enough
-    if ((e->frame_counter & 1) == 0) HIP_TRY(hipEventRecord(e->ev_pose[ci], sp));
     HP_MARK(e, 6, hp_t);
     if (e->host_prof) e->hp_frames++;
     HIP_TRY(hipGetLastError());

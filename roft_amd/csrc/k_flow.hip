@@ -228,24 +228,27 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_lds_kernel(EngineAr
 }
 
 template <int PER4>
-static void launch_flow_reg(const EngineArrays& a, double depth_max, int radius, int mask_finish, hipStream_t s)
+static void launch_flow_reg(const EngineArrays& a, double depth_max, int radius, int mask_finish, hipStream_t s,
+                            hipEvent_t start, hipEvent_t stop)
 {
-    hipLaunchKernelGGL(flow_measure_kernel<PER4>, dim3(a.n_obj), dim3(kFlowThreads), 0, s, a, depth_max, radius, mask_finish);
+    hipExtLaunchKernelGGL(flow_measure_kernel<PER4>, dim3(a.n_obj), dim3(kFlowThreads), 0, s, start, stop, 0, a, depth_max,
+                          radius, mask_finish);
 }
 
-void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bool mask_finish, hipStream_t s)
+void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bool mask_finish, hipStream_t s,
+                         hipEvent_t start, hipEvent_t stop)
 {
     const int mf = mask_finish ? 1 : 0;
     const size_t n4 = a.plane_words / 4;
     const int per4 = (int)((n4 + kFlowThreads - 1) / kFlowThreads);
     if (a.plane_words % 4 == 0 && per4 <= 10) {
-        if (per4 <= 1) launch_flow_reg<1>(a, depth_max, radius, mf, s);
-        else if (per4 <= 2) launch_flow_reg<2>(a, depth_max, radius, mf, s);
-        else if (per4 <= 3) launch_flow_reg<3>(a, depth_max, radius, mf, s);
-        else if (per4 <= 4) launch_flow_reg<4>(a, depth_max, radius, mf, s);
-        else if (per4 <= 6) launch_flow_reg<6>(a, depth_max, radius, mf, s);
-        else if (per4 <= 8) launch_flow_reg<8>(a, depth_max, radius, mf, s);
-        else launch_flow_reg<10>(a, depth_max, radius, mf, s);
+        if (per4 <= 1) launch_flow_reg<1>(a, depth_max, radius, mf, s, start, stop);
+        else if (per4 <= 2) launch_flow_reg<2>(a, depth_max, radius, mf, s, start, stop);
+        else if (per4 <= 3) launch_flow_reg<3>(a, depth_max, radius, mf, s, start, stop);
+        else if (per4 <= 4) launch_flow_reg<4>(a, depth_max, radius, mf, s, start, stop);
+        else if (per4 <= 6) launch_flow_reg<6>(a, depth_max, radius, mf, s, start, stop);
+        else if (per4 <= 8) launch_flow_reg<8>(a, depth_max, radius, mf, s, start, stop);
+        else launch_flow_reg<10>(a, depth_max, radius, mf, s, start, stop);
         return;
     }
     const size_t lds = (a.plane_words * 4 + 15) & ~(size_t)15;
@@ -256,7 +259,8 @@ void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bo
                                   160 * 1024 - 256 - kCandLds * (int)sizeof(uint2) - 128);
         attr_set = true;
     }
-    hipLaunchKernelGGL(flow_measure_lds_kernel, dim3(a.n_obj), dim3(kFlowThreads), lds, s, a, depth_max, radius, mf);
+    hipExtLaunchKernelGGL(flow_measure_lds_kernel, dim3(a.n_obj), dim3(kFlowThreads), lds, s, start, stop, 0, a, depth_max,
+                          radius, mf);
 }
 
 // ---- records -> (uv, y, H) exactly as the reference assembles them (hpp:258-283) -------------

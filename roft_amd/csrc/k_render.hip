@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
     if (threadIdx.x == 0) a.state[obj].n_feat[feat_write] = n;
 }
 
-void launch_features(const EngineArrays& a, hipStream_t s)
+void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop)
 {
     static bool attr_set = false;
     if (!attr_set) {
@@ -124,7 +124,8 @@ void launch_features(const EngineArrays& a, hipStream_t s)
                                   160 * 1024 - 256 - kFeatThreads * (int)sizeof(int) - 128);
         attr_set = true;
     }
-    hipLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), (a.plane_words * 4 + 15) & ~(size_t)15, s, a);
+    hipExtLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), (uint32_t)((a.plane_words * 4 + 15) & ~(size_t)15), s,
+                          nullptr, stop, 0, a);
 }
 
 // ---- rasteriser ---------------------------------------------------------------------------------
@@ -301,12 +302,12 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
     }
 }
 
-void launch_outlier(const EngineArrays& a, hipStream_t s)
+void launch_outlier(const EngineArrays& a, hipStream_t s, hipEvent_t stop)
 {
     // objects that do not test this frame return immediately
     (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.zbuf), 0x7F800000, (size_t)a.n_obj * 2 * a.tile_w * a.tile_h, s);
     hipLaunchKernelGGL(raster_engine_kernel, dim3((a.max_tris + 255) / 256, 2, a.n_obj), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(kOutlierThreads), 0, s, a);
+    hipExtLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(kOutlierThreads), 0, s, nullptr, stop, 0, a);
 }
 
 void launch_outlier_only(const EngineArrays& a, hipStream_t s)

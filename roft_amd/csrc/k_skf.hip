@@ -520,9 +520,9 @@ __global__ __launch_bounds__(kSkfThreads) void skf_kernel(EngineArrays a, int re
     }
 }
 
-void launch_skf(const EngineArrays& a, int reweight, hipStream_t s)
+void launch_skf(const EngineArrays& a, int reweight, hipStream_t s, hipEvent_t stop)
 {
-    hipLaunchKernelGGL(skf_kernel, dim3(a.n_obj), dim3(kSkfThreads), 0, s, a, reweight);
+    hipExtLaunchKernelGGL(skf_kernel, dim3(a.n_obj), dim3(kSkfThreads), 0, s, nullptr, stop, 0, a, reweight);
 }
 
 // ---- operator level ---------------------------------------------------------------------------

@@ -968,9 +968,9 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_step_kernel(EngineArrays a, i
     }
 }
 
-void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s)
+void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s, hipEvent_t stop)
 {
-    hipLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(kUkfThreads), 0, s, a, step0, step1, ut);
+    hipExtLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(kUkfThreads), 0, s, nullptr, stop, 0, a, step0, step1, ut);
 }
 
 }  // namespace roft

@@ -6,6 +6,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "../../include/roft_engine.h"
@@ -210,16 +211,20 @@ void launch_mask_ingest(const EngineArrays& a, hipStream_t s);
 // finish = false: the caller guarantees that flow_measure_kernel (which then does the bookkeeping) follows
 void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_aided, bool finish, hipStream_t s);
 void launch_planes_to_mask(const uint32_t* nz, const uint32_t* ob, int npix, uint8_t* mask, hipStream_t s);
-void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bool mask_finish, hipStream_t s);
-void launch_skf(const EngineArrays& a, int reweight, hipStream_t s);
+// `stop` / `start` (optional): HIP events bound to the kernel's own dispatch (hipExtLaunchKernelGGL) -- they complete
+// with the kernel, without the extra barrier packet and host call of a hipEventRecord behind it.
+void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bool mask_finish, hipStream_t s,
+                         hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
+void launch_skf(const EngineArrays& a, int reweight, hipStream_t s, hipEvent_t stop = nullptr);
 // operator level: explicit (y, H) arrays, x_pred/P_pred in, x/P out (all device pointers)
 void launch_skf_arrays(const double* x_pred, const double* P_pred, int N, const double* y, const double* H,
                        const double* Rdiag, int reweight, double* norms, double* x_out, double* P_out, int* status,
                        hipStream_t s);
 void launch_kf_predict(const double* x, const double* P, const double* qdiag, double* xo, double* Po, hipStream_t s);
-void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s);  // steps [step0, step1)
-void launch_features(const EngineArrays& a, hipStream_t s);   // after the mask stage of the frame
-void launch_outlier(const EngineArrays& a, hipStream_t s);       // z-buffer clear + render + likelihood + decision
+void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s,
+                     hipEvent_t stop = nullptr);  // steps [step0, step1)
+void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // after the mask stage of the frame
+void launch_outlier(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // z-buffer clear + render + likelihood + decision
 void launch_outlier_only(const EngineArrays& a, hipStream_t s);  // likelihood + decision on filled z-buffers
 
 // operator-level helpers on raw device buffers (used by the C ABI operator entry points)
