@@ -238,26 +238,28 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
     const uint32_t* z1 = z0 + (size_t)a.tile_w * a.tile_h;
     double err[2] = {0.0, 0.0}, cnt[2] = {0.0, 0.0};
     const int n = st.n_feat[fslot];
-    // four feature slots per iteration: their 4 + 4 + 8 loads are independent and go out together
-    for (int i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
-        float dep[4];
-        uint32_t pix[4];
+    // kBatch feature slots per thread and iteration: their loads are independent and go out together (one iteration
+    // covers 16 k features; per-thread accumulation order is the slot order either way)
+    constexpr int kBatch = 16;
+    for (int i0 = threadIdx.x; i0 < n; i0 += kBatch * blockDim.x) {
+        float dep[kBatch];
+        uint32_t pix[kBatch];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kBatch; ++k) {
             const int i = i0 + k * blockDim.x;
             dep[k] = (i < n) ? fdep[i] : 0.0f;
             pix[k] = (i < n) ? fpix[i] : 0u;
         }
-        uint32_t b0[4], b1[4];
+        uint32_t b0[kBatch], b1[kBatch];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kBatch; ++k) {
             const int v = (int)(pix[k] / W), u = (int)(pix[k] - v * W);
             const size_t ti = (size_t)(v / d) * tw + (u / d);
             b0[k] = z0[ti];
             b1[k] = z1[ti];
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kBatch; ++k) {
             if (!((dep[k] > 0) && ((double)dep[k] < 2.0))) continue;  // hard-coded 2.0 (ROFTFilter.cpp:561)
             if (b0[k] != 0x7F800000u) { err[0] += (double)fabsf(dep[k] - __uint_as_float(b0[k])); cnt[0] += 1.0; }
             if (b1[k] != 0x7F800000u) { err[1] += (double)fabsf(dep[k] - __uint_as_float(b1[k])); cnt[1] += 1.0; }
