@@ -107,6 +107,9 @@ struct UkfLds {
     double Py[144], Pxy[144], K[144], KPy[144];
     double aug[12 * 24];
     double innov[12], Kin[12];
+    // staged once per step together with the belief (a global load inside a phase costs that phase ~2 k cycles):
+    double par[24];      // head of ObjParams: sigma_ang_vel[3] psd_lin_acc[3] v_q[6] R_v[3] R_w[3] R_x[3] R_q[3]
+    double meas[13];     // twist of the step [6], pose measurement x [3], q [4]
     double red[4];
     int flag;
     long long t0;
@@ -185,7 +188,7 @@ __device__ __forceinline__ void jacobi_pair(int n, int round, int i, int& p, int
 // jacobi_wave(): generic n, executed by the lanes of WAVE 0 only (the other waves must not call it); lane (a, b)
 // owns one block of A and one of V, rotations travel by wave shuffle.  Used for the 10x10 explicit process noise
 // of the operator-level entry point.
-__device__ void jacobi_wave(double* A, double* V, int n, UkfLds& L)
+__device__ __noinline__ void jacobi_wave(double* A, double* V, int n, UkfLds& L)
 {
     const int lane = threadIdx.x;
     for (int i = lane; i < n * n; i += 64) V[i] = ((i / n) == (i % n)) ? 1.0 : 0.0;
@@ -249,7 +252,7 @@ __device__ void jacobi12_table(UkfLds& L)
 // cross from wave 0 to wave 1 through L.cs (double-buffered by round parity), so a round costs ONE workgroup
 // barrier and each wave issues about half of the instructions a single wave would (the rounds are bound by the
 // instruction latency of one wave, not by throughput).  Waves 2 and 3 only keep the barrier count.
-__device__ void jacobi12(double* A, double* V, UkfLds& L)
+__device__ __noinline__ void jacobi12(double* A, double* V, UkfLds& L)
 {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < 144; i += kUkfThreads) V[i] = ((i / 12) == (i % 12)) ? 1.0 : 0.0;
@@ -312,11 +315,19 @@ __device__ void jacobi12(double* A, double* V, UkfLds& L)
 }
 
 // sum_c a[c] w_c b[c] over the sigma columns (column 0 carries wc0, the rest the common weight wci), with four
-// independent partial sums so that the additions do not form one 40-deep dependency chain
+// independent partial sums so that the additions do not form one 40-deep dependency chain; eight columns (16 LDS
+// reads) per iteration of the main loop.
 __device__ __forceinline__ double weighted_dot(const double* ar, const double* br, int ncols, double wc0, double wci)
 {
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int c = 1;
+    for (; c + 7 < ncols; c += 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { av[u] = ar[c + u]; bv[u] = br[c + u]; }
+        s0 = fma(av[0], bv[0], s0); s1 = fma(av[1], bv[1], s1); s2 = fma(av[2], bv[2], s2); s3 = fma(av[3], bv[3], s3);
+        s0 = fma(av[4], bv[4], s0); s1 = fma(av[5], bv[5], s1); s2 = fma(av[6], bv[6], s2); s3 = fma(av[7], bv[7], s3);
+    }
     for (; c + 3 < ncols; c += 4) {
         s0 = fma(ar[c], br[c], s0);
         s1 = fma(ar[c + 1], br[c + 1], s1);
@@ -325,6 +336,36 @@ __device__ __forceinline__ double weighted_dot(const double* ar, const double* b
     }
     for (; c < ncols; ++c) s0 = fma(ar[c], br[c], s0);
     return fma(ar[0] * br[0], wc0, ((s0 + s1) + (s2 + s3)) * wci);
+}
+
+// Weighted means of `nrows` linear rows of Y (row stride kCols), eight lanes per row: lane l of the calling group
+// (l = 0 .. 8 nrows - 1, all inside one wave and 8-aligned) sums the columns l % 8, l % 8 + 8, ..., then the eight
+// partial sums meet through row_shr DPP moves.  One lane per row reading 40-odd columns one after the other paid an
+// LDS latency per column.
+__device__ __forceinline__ void linear_means8(const double* Y, int nrows, int ncols, double wm0, double wmi, int l,
+                                              double* out)
+{
+    const int row = l >> 3, part = l & 7;
+    double sum = 0.0;
+    if (row < nrows) {
+        const double* y = Y + row * kCols;
+        double v[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) v[u] = y[min(part + 8 * u, ncols - 1)];   // kCols <= 56 columns
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int c = part + 8 * u;
+            if (c < ncols) sum = fma(v[u], (c == 0) ? wm0 : wmi, sum);
+        }
+    }
+    // lanes 8k .. 8k+7 -> lane 8k+7 (row_shr stays inside a 16-lane DPP row; 8-aligned groups never straddle one)
+    sum += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sum), 0x111, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(sum), 0x111, 0xf, 0xf, false));
+    sum += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sum), 0x112, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(sum), 0x112, 0xf, 0xf, false));
+    sum += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(sum), 0x114, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(sum), 0x114, 0xf, 0xf, false));
+    if (row < nrows && part == 7) out[row] = sum;
 }
 
 // dominant eigenvector of M = sum_c wm_c q_c q_c' (rows qrow..qrow+3 of Y), sign aligned with column 0.
@@ -459,10 +500,15 @@ __device__ void chol_solve_rows(const double* Lc, const double* inv_diag, const 
 
 struct UtW {
     double c, wm0, wc0, wi;
+    double sc;          // sqrt(c): scale of the square-root columns
     int ncols;
 };
 
-__device__ __forceinline__ UtW ut_weights(int n, const roft_ut_params& ut)
+// Unscented-transform weights for an augmented dimension n.  Evaluated on the HOST at launch for the three
+// dimensions the filter uses (12 + 6, 12 + 9, 12 + 12) and handed to the kernel by value: three double divisions
+// and a square root at the top of the prediction and of every correction are ~1 k cycles of a single wave each.
+// (Host and device both round these IEEE operations correctly, so the values are the same.)
+inline UtW ut_weights(int n, const roft_ut_params& ut)
 {
     UtW w;
     const double lambda = ut.alpha * ut.alpha * (n + ut.kappa) - n;
@@ -471,8 +517,15 @@ __device__ __forceinline__ UtW ut_weights(int n, const roft_ut_params& ut)
     w.wm0 = lambda / (n + lambda);
     w.wc0 = lambda / (n + lambda) + (1.0 - ut.alpha * ut.alpha + ut.beta);
     w.wi = 1.0 / (2.0 * (n + lambda));
+    w.sc = std::sqrt(w.c);
     return w;
 }
+
+struct UtTable {
+    UtW w[3];           // n = 18, 21, 24
+};
+
+__device__ __forceinline__ const UtW& ut_lookup(const UtTable& t, int n) { return t.w[(n - 18) / 3]; }
 
 // perturbation of sigma column `col`: state part d[12] (from the decomposition of L.P, already done)
 // and noise part dn[r].  noise_eig: use (L.VQ, L.wQ) (process noise) else a diagonal noise covariance whose
@@ -481,19 +534,24 @@ __device__ void sigma_perturbation(int col, int r, double sc, bool noise_eig, do
                                    const UkfLds& L, double d[12], double dn[12])
 {
     const int n = 12 + r;
+    // column 0 is the mean; columns 1..n add, columns n+1..2n subtract the k-th square-root column
+    const int k = (col <= n) ? col - 1 : col - 1 - n;
+    const double amp = (col == 0) ? 0.0 : ((col <= n) ? sc : -sc);
+    const bool state_col = (col > 0) && (k < 12);
+    const int kk = (k >= 12) ? k - 12 : 0;
+    // one square root for every lane, in front of the divergent part (noise columns only use it)
+    const double var = noise_eig ? L.wQ[min(kk, 9)] : noise_var;
+    const double sdev = sqrt(fabs(var));
+#pragma unroll
     for (int i = 0; i < 12; ++i) { d[i] = 0.0; dn[i] = 0.0; }
-    if (col == 0) return;
-    const int k = (col - 1) % n;
-    const double sgn = (col <= n) ? 1.0 : -1.0;
-    if (k < 12) {
-        for (int i = 0; i < 12; ++i) d[i] = sgn * sc * L.S[i * 12 + k];
-    } else {
-        const int kk = k - 12;
+    if (state_col) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) d[i] = amp * L.S[i * 12 + k];
+    } else if (col > 0) {
         if (noise_eig) {
-            const double s = sqrt(fabs(L.wQ[kk]));
-            for (int i = 0; i < r; ++i) dn[i] = sgn * sc * L.VQ[i * 10 + kk] * s;
+            for (int i = 0; i < r; ++i) dn[i] = amp * L.VQ[i * 10 + kk] * sdev;
         } else {
-            const double v = sgn * sc * 1.0 * sqrt(fabs(noise_var));
+            const double v = amp * 1.0 * sdev;
 #pragma unroll
             for (int i = 0; i < 12; ++i) if (i == kk) dn[i] = v;
         }
@@ -514,7 +572,7 @@ __device__ void sigma_perturbation(int col, int r, double sc, bool noise_eig, do
 // sqrt(d_j)) -- no eigenvalue gap in any denominator -- so S = V (D^1/2 + X1 + X2) satisfies S S' = cov up to
 // O(E^3), and S equals the exact U sqrt(Lambda) times an orthogonal matrix within O(E) of the identity: the sigma
 // set the reference draws, to rounding.
-__device__ void decompose_state_cov(UkfLds& L, double* warm, int* warm_age)
+__device__ __noinline__ void decompose_state_cov(UkfLds& L, double* warm, int* warm_age)
 {
     const int tid = threadIdx.x;
     const int age = warm ? *warm_age : 0;
@@ -591,7 +649,7 @@ __device__ void decompose_state_cov(UkfLds& L, double* warm, int* warm_age)
 // lower Cholesky factor into L.S.  `for_correction`: the guard of the correction (else of the prediction over the
 // sampling time T).  Returns false (nothing usable in L.S) when the guard does not hold or the matrix is not
 // numerically positive definite; the caller then decomposes.
-__device__ bool cholesky_state_sqrt(UkfLds& L, bool for_correction, double T, double guard_rot, double guard_bil)
+__device__ __noinline__ bool cholesky_state_sqrt(UkfLds& L, bool for_correction, double T, double guard_rot, double guard_bil)
 {
     if (!(guard_rot > 0.0)) return false;
     const double th = fmax(L.cov[9 * 13], fmax(L.cov[10 * 13], L.cov[11 * 13]));   // var(theta)
@@ -608,13 +666,13 @@ __device__ bool cholesky_state_sqrt(UkfLds& L, bool for_correction, double T, do
     return cholesky_rows<12>(L.cov, L.S, L.rc, L);
 }
 
-__device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const roft_ut_params& ut, double* warm,
+__device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const UtTable& ut, double* warm,
                             int* warm_age, double chol_guard)
 {
     const int lane = threadIdx.x;
     const int r = 9, n = 21;
-    const UtW w = ut_weights(n, ut);
-    const double sc = sqrt(w.c);
+    const UtW& w = ut_lookup(ut, n);
+    const double sc = w.sc;
 
     // process noise block Q(T) (CartesianQuaternionModel.cpp:127-141), padded to 10 x 10
     for (int i = lane; i < 100; i += kUkfThreads) { L.Q[i] = 0.0; L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0; }
@@ -630,9 +688,10 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
         // Q(T) couples only (v_i, x_i): three independent symmetric 2x2 blocks, each diagonalised
         // exactly by ONE Jacobi rotation (the same rotation the generic sweep would apply first).
         const int i = lane;
-        const double app = prm.psd_lin_acc[i] * T;
-        const double aqq = prm.psd_lin_acc[i] * (T * T * T / 3.0);
-        const double apq = prm.psd_lin_acc[i] * (T * T / 2.0);
+        const double psd = L.par[3 + i];
+        const double app = psd * T;
+        const double aqq = psd * (T * T * T / 3.0);
+        const double apq = psd * (T * T / 2.0);
         double c = 1.0, s = 0.0;
         if (apq != 0.0) {
             // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = (aqq - app) / (2 apq), written division-free
@@ -649,7 +708,7 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
         const double b10 = c * apq - s * aqq, b11 = s * apq + c * aqq;
         L.wQ[i] = c * b00 - s * b10;
         L.wQ[6 + i] = s * b01 + c * b11;
-        L.wQ[3 + i] = prm.sigma_ang_vel[i];
+        L.wQ[3 + i] = L.par[i];
         L.VQ[i * 10 + i] = c;       L.VQ[i * 10 + (6 + i)] = s;
         L.VQ[(6 + i) * 10 + i] = -s; L.VQ[(6 + i) * 10 + (6 + i)] = c;
     }
@@ -687,12 +746,7 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
 
     TICK(L, 3);
     // mean: the linear rows on wave 1 while wave 0 works on the quaternion rows
-    if (lane >= 64 && lane < 64 + 9) {
-        const double* y = L.Y + (lane - 64) * kCols;
-        double s = y[0] * w.wm0;
-        for (int c = 1; c < w.ncols; ++c) s += y[c] * w.wi;
-        L.ymean[lane - 64] = s;
-    }
+    if (lane >= 64 && lane < 192) linear_means8(L.Y, 9, w.ncols, w.wm0, w.wi, lane - 64, L.ymean);   // waves 1 and 2
     double qm[4];
     quaternion_mean(L.Y, 9, w.ncols, w.wm0, w.wi, qm, L);
     TICK(L, 4);
@@ -716,8 +770,7 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const rof
 
 // ---- correction of (L.mean, L.cov) [decomposition already in L.S] -> out ------------------------
 // returns status: 0 corrected, 1 no measurement, 2 singular Py
-__device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const double* twist, const double* pose_x,
-                           const double* pose_q, const roft_ut_params& ut, PoseBelief* out)
+__device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* out)
 {
     const int lane = threadIdx.x;
     if (type == ROFT_MEAS_NONE) {
@@ -732,13 +785,12 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
     const int mtot = (has_vel ? 6 : 0) + (has_pose ? 7 : 0);
     const int nlin = mtot - (has_pose ? 4 : 0);
     const int n = 12 + r;
-    const UtW w = ut_weights(n, ut);
-    const double sc = sqrt(w.c);
+    const UtW& w = ut_lookup(ut, n);
+    const double sc = w.sc;
 
     // measurement vector in measurement order (velocity first)
     auto meas_at = [&](int k) -> double {
-        if (has_vel) { if (k < 6) return twist[k]; k -= 6; }
-        return (k < 3) ? pose_x[k] : pose_q[k - 3];
+        return L.meas[has_vel ? k : 6 + k];
     };
     if (lane < w.ncols) {
         // measurement noise variance of this column's noise dof, measurement order (velocity first)
@@ -746,13 +798,15 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
         {
             const int kk = (lane > 0) ? (lane - 1) % n - 12 : -1;
             if (kk >= 0) {
-                const double* R = has_vel ? (kk < 3 ? prm.R_v : (kk < 6 ? prm.R_w : (kk < 9 ? prm.R_x : prm.R_q)))
-                                          : (kk < 3 ? prm.R_x : prm.R_q);
-                noise_var = R[kk % 3];
+                // R_v R_w R_x R_q sit at L.par[12 ..]; without a velocity measurement the order starts at R_x
+                noise_var = L.par[(has_vel ? 12 : 18) + kk];
             }
         }
         double d[12], dn[12];
         sigma_perturbation(lane, r, sc, false, noise_var, L, d, dn);
+#ifdef ROFT_UKF_PROFILE
+        if (lane == 0) { long long _t = clock64(); L.dbg[24] += _t - L.t0; L.t0 = _t; }
+#endif
         double v[3], wv[3], x[3], q[4];
         for (int i = 0; i < 3; ++i) {
             v[i] = L.mean[i] + d[i];
@@ -793,12 +847,7 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
 
     TICK(L, 8);
     // means: the linear rows on wave 1 while wave 0 works on the quaternion rows
-    if (lane >= 64 && lane < 64 + nlin) {
-        const double* y = L.Y + (lane - 64) * kCols;
-        double s = y[0] * w.wm0;
-        for (int c = 1; c < w.ncols; ++c) s += y[c] * w.wi;
-        L.ymean[lane - 64] = s;
-    }
+    if (lane >= 64 && lane < 192) linear_means8(L.Y, nlin, w.ncols, w.wm0, w.wi, lane - 64, L.ymean);   // waves 1 and 2
     double qm[4] = {1.0, 0.0, 0.0, 0.0};
     if (has_pose) {
         quaternion_mean(L.Y, nlin, w.ncols, w.wm0, w.wi, qm, L);   // ends with a workgroup barrier
@@ -807,6 +856,7 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
     } else {
         __syncthreads();
     }
+    TICK(L, 23);
     if (lane < w.ncols) {
         for (int i = 0; i < nlin; ++i) L.D[i * kCols + lane] = L.Y[i * kCols + lane] - L.ymean[i];
         if (has_pose) {
@@ -857,6 +907,7 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
     if (m == 6) chol_solve_rows<6>(L.aug, L.rc, L.Pxy, L.K);
     else chol_solve_rows<12>(L.aug, L.rc, L.Pxy, L.K);
     __syncthreads();
+    TICK(L, 25);
     if (lane < 12 * m) {
         const int i = lane / m, j = lane % m;
         double s = 0.0;
@@ -869,6 +920,7 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
         L.Kin[i] = s;
     }
     __syncthreads();
+    TICK(L, 26);
     if (lane < 144) {
         const int i = lane / 12, j = lane % 12;
         double s = 0.0;
@@ -887,7 +939,7 @@ __device__ int ukf_correct(UkfLds& L, const ObjParams& prm, int type, const doub
 }
 
 // One launch = one StepDesc per object: optional prediction, then 0, 1 or 2 corrections of it.
-__device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const roft_ut_params& ut, UkfLds& L)
+__device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const UtTable& ut, UkfLds& L)
 {
     const FrameCtrl& c = a.ctrl[obj];
     ObjState& st = a.state[obj];
@@ -906,6 +958,12 @@ __device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const rof
     const PoseBelief& src = st.belief[sd.src];
     for (int i = lane; i < 144; i += kUkfThreads) L.cov[i] = src.cov[i];
     if (lane < 13) L.mean[lane] = src.mean[lane];
+    static_assert(offsetof(ObjParams, R_q) == 21 * sizeof(double), "L.par mirrors the head of ObjParams");
+    if (lane >= 160 && lane < 184) L.par[lane - 160] = reinterpret_cast<const double*>(&prm)[lane - 160];
+    if (lane >= 192 && lane < 205) {
+        const int i = lane - 192;
+        L.meas[i] = (i < 6) ? st.twist_hist[sd.twist_slot][i] : ((i < 9) ? c.pose_x[i - 6] : c.pose_q[i - 9]);
+    }
     __syncthreads();
     if (sd.save_corr_to_buf) {
         const PoseBelief& cr = st.belief[B_CORR];
@@ -934,10 +992,9 @@ __device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const rof
     if (!cholesky_state_sqrt(L, true, c.dt, a.ukf_chol_guard, a.ukf_chol_guard_bil))
         decompose_state_cov(L, st.warm_V[1], &st.warm_age[1]);
     TICK(L, 7);
-    const double* twist = st.twist_hist[sd.twist_slot];
     int status = 0;
     for (int k = 0; k < sd.n_corr; ++k) {
-        const int rc = ukf_correct(L, prm, sd.type[k], twist, c.pose_x, c.pose_q, ut, &st.belief[sd.dst[k]]);
+        const int rc = ukf_correct(L, sd.type[k], ut, &st.belief[sd.dst[k]]);
         status |= rc << (4 * k);
         __syncthreads();
     }
@@ -955,7 +1012,7 @@ __device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const rof
 
 // One launch runs the StepDescs [step0, step1) of every object back to back (the velocity-only replays of a
 // pose re-sync need no other kernel in between, so they share one launch).
-__global__ __launch_bounds__(kUkfThreads) void ukf_step_kernel(EngineArrays a, int step0, int step1, roft_ut_params ut)
+__global__ __launch_bounds__(kUkfThreads) void ukf_step_kernel(EngineArrays a, int step0, int step1, UtTable ut)
 {
     // static LDS on purpose: with `extern __shared__` the compiler re-reads the dynamic-LDS base address from a
     // table in global memory inside every Jacobi round (two dependent global loads per round)
@@ -970,7 +1027,9 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_step_kernel(EngineArrays a, i
 
 void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s, hipEvent_t stop)
 {
-    hipExtLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(kUkfThreads), 0, s, nullptr, stop, 0, a, step0, step1, ut);
+    UtTable tab;
+    for (int k = 0; k < 3; ++k) tab.w[k] = ut_weights(18 + 3 * k, ut);
+    hipExtLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(kUkfThreads), 0, s, nullptr, stop, 0, a, step0, step1, tab);
 }
 
 }  // namespace roft

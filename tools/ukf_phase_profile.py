@@ -22,4 +22,4 @@ for k in range(14):
         # read ObjState.dbg: find offset via struct size: use hipMemcpy through roft_get_state? not exposed -> use debug export
         buf=(C.c_longlong*32)()
         L.lib().roft_debug_get_dbg(eng._h,0,buf)
-        print(k,[int(x) for x in buf][:13], 'sweeps n12/n4/n10:', [int(x) for x in buf][16:19], 'corr guard th/wv/xx (1e-9):', [int(x) for x in buf][20:23])
+        print(k,[int(x) for x in buf][:13], 'sweeps n12/n4/n10:', [int(x) for x in buf][16:19], 'corr guard th/wv/xx (1e-9):', [int(x) for x in buf][20:23], 'sub 23..26 (means | sigma perturbation | K solve | KPy):', [int(x) for x in buf][23:27])
