@@ -675,19 +675,23 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const UtT
     const double sc = w.sc;
 
     // process noise block Q(T) (CartesianQuaternionModel.cpp:127-141), padded to 10 x 10
-    for (int i = lane; i < 100; i += kUkfThreads) { L.Q[i] = 0.0; L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0; }
-    __syncthreads();
     if (prm.q_override) {
+        for (int i = lane; i < 100; i += kUkfThreads) { L.Q[i] = 0.0; L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0; }
+        __syncthreads();
         for (int i = lane; i < 81; i += kUkfThreads) L.Q[(i / 9) * 10 + (i % 9)] = prm.q_override[i];
         __syncthreads();
         if (lane < 64) {
             jacobi_wave(L.Q, L.VQ, 10, L);
             if (lane < 10) L.wQ[lane] = L.Q[lane * 11];
         }
-    } else if (lane < 3) {
+        __syncthreads();
+    } else if (lane >= 192 && lane < 195) {
         // Q(T) couples only (v_i, x_i): three independent symmetric 2x2 blocks, each diagonalised
         // exactly by ONE Jacobi rotation (the same rotation the generic sweep would apply first).
-        const int i = lane;
+        // Three lanes of wave 3, concurrently with the square root of the state covariance on wave 0: L.VQ is the
+        // identity from the kernel's start and only these twelve entries (and L.wQ) change; the barrier that closes
+        // the square-root phase orders them before the fan-out.
+        const int i = lane - 192;
         const double psd = L.par[3 + i];
         const double app = psd * T;
         const double aqq = psd * (T * T * T / 3.0);
@@ -712,7 +716,6 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const UtT
         L.VQ[i * 10 + i] = c;       L.VQ[i * 10 + (6 + i)] = s;
         L.VQ[(6 + i) * 10 + i] = -s; L.VQ[(6 + i) * 10 + (6 + i)] = c;
     }
-    __syncthreads();
     TICK(L, 1);
     if (!cholesky_state_sqrt(L, false, T, chol_guard, 0.0)) decompose_state_cov(L, warm, warm_age);
     TICK(L, 2);
@@ -1018,6 +1021,8 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_step_kernel(EngineArrays a, i
     // table in global memory inside every Jacobi round (two dependent global loads per round)
     __shared__ UkfLds L;
     jacobi12_table(L);
+    for (int i = threadIdx.x; i < 100; i += kUkfThreads) L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0;   // see ukf_predict
+    if (threadIdx.x < 10) L.wQ[threadIdx.x] = 0.0;
     __syncthreads();
     for (int step = step0; step < step1; ++step) {
         ukf_one_step(a, blockIdx.x, step, ut, L);
