@@ -386,6 +386,33 @@ __device__ void quaternion_mean(const double* Y, int qrow, int ncols, double wm0
             L.M4[lane] = weighted_dot(Y + (qrow + i) * kCols, Y + (qrow + j) * kCols, ncols, wm0, wmi);
         }
         wave_sync();
+        // Tight cluster (the usual case: eigenvalue ratio ~ var(theta) / 4): plain power iteration from the central
+        // sigma point gains five digits per step and is at its fixed point after three or four -- every lane of the
+        // wave runs it redundantly, so the outcome is wave-uniform without a broadcast.  Wide clusters fall through
+        // to the squaring scheme below.
+        {
+            double m[16], v[4];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m[i] = L.M4[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = Y[(qrow + i) * kCols + 0];
+            bool done = false;
+            for (int it = 0; it < 6 && !done; ++it) {
+                double w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = m[i * 4] * v[0] + m[i * 4 + 1] * v[1] + m[i * 4 + 2] * v[2] + m[i * 4 + 3] * v[3];
+                const double inv = fast_rsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + w[3] * w[3]);
+                double diff = 0.0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { w[i] *= inv; diff = fmax(diff, fabs(w[i] - v[i])); v[i] = w[i]; }
+                done = diff < 4e-16;
+            }
+            if (done) {
+                if (lane == 0)
+                    for (int i = 0; i < 4; ++i) L.w4[i] = v[i];
+                goto finished;
+            }
+        }
         for (int it = 0; it < 4; ++it) {  // M <- M^2 / trace-normalised, ping-pong M4 <-> V4
             double* src = (it & 1) ? L.V4 : L.M4;
             double* dst = (it & 1) ? L.M4 : L.V4;
@@ -412,6 +439,7 @@ __device__ void quaternion_mean(const double* Y, int qrow, int ncols, double wm0
             }
             for (int i = 0; i < 4; ++i) L.w4[i] = v[i];
         }
+    finished:;
     }
     __syncthreads();
     for (int i = 0; i < 4; ++i) out[i] = L.w4[i];
