@@ -57,15 +57,31 @@ __device__ __forceinline__ void quat_mul(const double a[4], const double b[4], d
     o[0] = w; o[1] = x; o[2] = y; o[3] = z;
 }
 
+// sin(n/2)/n and cos(n/2).  The sigma-point rotations are small (a few hundredths of a radian): below a half angle of
+// 0.25 rad the Taylor polynomials are exact to the last bit or two (first dropped terms 3e-21 / 1e-23) and replace two
+// libm calls, a square root's worth of argument handling and a division; larger angles take the library path.
+__device__ __forceinline__ void half_angle(double n, double& sin_over_n, double& c)
+{
+    const double h = 0.5 * n;
+    if (h < 0.25) {
+        const double x = h * h;
+        const double sinc = 1.0 + x * (-1.0 / 6.0 + x * (1.0 / 120.0 + x * (-1.0 / 5040.0 + x * (1.0 / 362880.0 +
+                            x * (-1.0 / 39916800.0 + x * (1.0 / 6227020800.0))))));
+        c = 1.0 + x * (-0.5 + x * (1.0 / 24.0 + x * (-1.0 / 720.0 + x * (1.0 / 40320.0 + x * (-1.0 / 3628800.0 +
+            x * (1.0 / 479001600.0 + x * (-1.0 / 87178291200.0)))))));
+        sin_over_n = 0.5 * sinc;
+    } else {
+        sin_over_n = sin(h) / n;
+        c = cos(h);
+    }
+}
+
 __device__ __forceinline__ void quat_boxplus(const double q[4], const double r[3], double o[4])
 {
     const double n = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    double qr[4] = {1.0, 0.0, 0.0, 0.0};
-    if (n > 0.0) {
-        const double s = sin(n / 2.0) / n;
-        qr[0] = cos(n / 2.0);
-        qr[1] = s * r[0]; qr[2] = s * r[1]; qr[3] = s * r[2];
-    }
+    double s, c;
+    half_angle(n, s, c);   // n = 0 gives (0.5, 1): the identity rotation, as the reference's branch does
+    const double qr[4] = {c, s * r[0], s * r[1], s * r[2]};
     quat_mul(qr, q, o);
 }
 
@@ -74,11 +90,22 @@ __device__ __forceinline__ void quat_diff(const double a[4], const double b[4], 
     const double bc[4] = {b[0], -b[1], -b[2], -b[3]};
     double p[4];
     quat_mul(a, bc, p);
-    const double n = sqrt(p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
-    if (n == 0.0) { o[0] = o[1] = o[2] = 0.0; return; }
-    const double angle = 2.0 * atan2(n, fabs(p[0]));
+    const double n2 = p[1] * p[1] + p[2] * p[2] + p[3] * p[3];
     const double sgn = (p[0] < 0.0) ? -1.0 : 1.0;
-    const double k = sgn * angle / n;
+    double k;
+    // rotation vector = (2 atan2(n, |p0|) / n) p_vec.  With t = n / |p0| this is (2 / |p0|) (atan t / t) p_vec, and for
+    // t^2 <= 0.01 (angles below 0.2 rad) nine terms of the alternating series give atan t / t to 5e-20: no square
+    // root, no atan2
+    const double t2 = n2 / (p[0] * p[0]);
+    if (t2 <= 0.01) {
+        const double at = 1.0 + t2 * (-1.0 / 3.0 + t2 * (1.0 / 5.0 + t2 * (-1.0 / 7.0 + t2 * (1.0 / 9.0 + t2 * (-1.0 / 11.0 +
+                          t2 * (1.0 / 13.0 + t2 * (-1.0 / 15.0 + t2 * (1.0 / 17.0))))))));
+        k = sgn * 2.0 * at / fabs(p[0]);
+    } else {
+        const double n = sqrt(n2);
+        if (n == 0.0) { o[0] = o[1] = o[2] = 0.0; return; }
+        k = sgn * 2.0 * atan2(n, fabs(p[0])) / n;
+    }
     o[0] = k * p[1]; o[1] = k * p[2]; o[2] = k * p[3];
 }
 
@@ -765,9 +792,9 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const UtT
             L.Y[(6 + i) * kCols + lane] = (x[i] + dn[6 + i]) + v[i] * T;  // v without noise (cpp:94-97)
         }
         const double norm_w = sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]) + 2.220446049250313e-16;
-        double sn, c;
-        sincos(norm_w * T / 2.0, &sn, &c);
-        const double s = sn / norm_w;
+        double s, c;   // sin(|w| T / 2) / |w| and cos(|w| T / 2)
+        half_angle(norm_w * T, s, c);
+        s *= T;
         L.Y[9 * kCols + lane] = c * q[0] + s * (-wv[0] * q[1] - wv[1] * q[2] - wv[2] * q[3]);
         L.Y[10 * kCols + lane] = c * q[1] + s * (wv[0] * q[0] - wv[2] * q[2] + wv[1] * q[3]);
         L.Y[11 * kCols + lane] = c * q[2] + s * (wv[1] * q[0] + wv[2] * q[1] - wv[0] * q[3]);
