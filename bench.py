@@ -73,6 +73,16 @@ def main():
     cam = synth.Camera.shape_a() if args.shape == "A" else synth.Camera.shape_b()
     ftype = synth.FLOW_F32C2 if args.flow == "f32" else synth.FLOW_S16C2
 
+    # The streams stay resident in HBM for the whole run (depth 4 B + mask 1 B per pixel, flow per grid cell): refuse a
+    # K + W that cannot fit instead of running the box out of memory.
+    g = 1 if args.flow == "f32" else 4
+    per_frame = cam.width * cam.height * 5 + (cam.width // g) * (cam.height // g) * (8 if args.flow == "f32" else 4)
+    need = per_frame * n_frames * n_obj
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    if need > 0.8 * free_b:
+        raise SystemExit("bench.py: %d frames x %d objects of synthetic input need %.0f GB of HBM, %.0f GB are free; "
+                         "lower --steps / --warmup / --objects-per-gpu" % (n_frames, n_obj, need / 1e9, free_b / 1e9))
+
     # ---- synthetic streams, generated on the GPU and left resident in HBM
     t_gen = time.time()
     streams = []
