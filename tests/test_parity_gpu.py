@@ -263,6 +263,29 @@ def test_ukf_correct_parity(oracle, mtype):
         np.testing.assert_allclose(P1, P0, rtol=0, atol=UKF_ATOL)
 
 
+def test_ukf_wide_sigma_clusters_take_the_general_paths(oracle):
+    """Rotational standard deviations of ~0.35 rad: the sigma rotations (1.5 rad and more) are far outside the
+    small-angle polynomials of k_ukf.hip and the sigma quaternions are a wide cluster, so the library sine / cosine /
+    atan2 paths and the squaring scheme of the quaternion mean run instead of the fast paths."""
+    rng = np.random.default_rng(77)
+    rp = [1e-3] * 3 + [1e-4] * 3
+    for i in range(4):
+        mean, P = _random_belief(rng, scale=1e-2)
+        T = 1.0 / 30.0
+        Q = oracle.process_noise([1.0, 1.0, 1.0], [1.0, 1.0, 1.0], T)
+        m0, P0 = oracle.ukf_predict(mean, P, Q, T)
+        m1, P1 = ops.ukf_predict(mean, P, Q, T)
+        np.testing.assert_allclose(m1, m0, rtol=0, atol=UKF_ATOL)
+        np.testing.assert_allclose(P1, P0, rtol=0, atol=UKF_ATOL)
+        q = mean[9:] + rng.normal(size=4) * 0.05
+        pose = np.concatenate([mean[6:9] + rng.normal(size=3) * 0.01, q / np.linalg.norm(q)])
+        rc0, m0, P0 = oracle.ukf_correct(mean, P, L.MEAS_POSE, pose, rp)
+        rc1, m1, P1 = ops.ukf_correct(mean, P, L.MEAS_POSE, pose, rp)
+        assert rc0 == rc1 == 0
+        np.testing.assert_allclose(m1, m0, rtol=0, atol=UKF_ATOL)
+        np.testing.assert_allclose(P1, P0, rtol=0, atol=UKF_ATOL)
+
+
 def test_ukf_correct_no_measurement(oracle):
     rng = np.random.default_rng(2)
     mean, P = _random_belief(rng)
