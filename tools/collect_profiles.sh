@@ -19,6 +19,12 @@ python3 $R/tools/prof_summary.py stats $O/stats/*/*kernel_stats.csv $O/bench_ker
 python3 $R/tools/trace_timeline.py $O/stats/*/*kernel_trace.csv 600 > $O/pipeline_timeline.txt
 python3 $R/tools/trace_timeline.py $O/stats/*/*kernel_trace.csv 120 --list | head -130 >> $O/pipeline_timeline.txt
 rm -rf $O/stats
+# the same kernels with the three chains serialised on one stream (the "alone" durations quoted in DESIGN.md section 5)
+export ROFT_ONE_STREAM=1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2>&1
+unset ROFT_ONE_STREAM
+python3 $R/tools/prof_summary.py stats $O/stats1/*/*kernel_stats.csv $O/bench_kernel_stats_one_stream.csv
+rm -rf $O/stats1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc -- python3 $R/bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
   python3 $R/tools/prof_summary.py pmc $O/pmc/*/*counter_collection.csv $O/pmc_$c.csv
