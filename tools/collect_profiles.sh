@@ -14,8 +14,11 @@ python tools/bench_flow_producer.py > $O/flow_producer.jsonl
 python tools/bench_flow_producer.py --pairs 1 >> $O/flow_producer.jsonl
 python tools/bench_flow_producer.py --pairs 16 --shape B --flow s16 >> $O/flow_producer.jsonl
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> /dev/null
 python3 $R/tools/prof_summary.py stats $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv
+# the roofline kernel over exactly the timed launches of that run (12 warm-up frames, then 60): compare with roofline.avg_launch_us
+# of bench_under_rocprof.json
+python3 $R/tools/prof_summary.py window $O/stats/*/*kernel_trace.csv flow_measure_kernel 12 60 > $O/k1_timed_launches_under_rocprof.txt
 python3 $R/tools/trace_timeline.py $O/stats/*/*kernel_trace.csv 600 > $O/pipeline_timeline.txt
 python3 $R/tools/trace_timeline.py $O/stats/*/*kernel_trace.csv 120 --list | head -130 >> $O/pipeline_timeline.txt
 rm -rf $O/stats

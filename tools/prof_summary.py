@@ -3,6 +3,8 @@
 
   tools/prof_summary.py stats <*_kernel_stats.csv> <out.csv>        keep only the roft:: kernels
   tools/prof_summary.py pmc   <*_counter_collection.csv> <out.csv>  per-kernel mean of each counter
+  tools/prof_summary.py window <*_kernel_trace.csv> <name part> <first> <count>
+                                                  mean duration of launches [first, first+count) of one kernel
 """
 import csv
 import sys
@@ -39,5 +41,17 @@ def pmc(src, dst):
             w.writerow([k, c, n, "%.3f" % (s / n)])
 
 
+def window(src, part, first, count):
+    rows = [r for r in csv.DictReader(open(src)) if part in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    sel = rows[first:first + count]
+    d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in sel]
+    print("%s: launches %d..%d of %d: mean %.2f us, min %.2f, max %.2f" % (part, first, first + len(sel) - 1, len(rows),
+                                                                         sum(d) / len(d), min(d), max(d)))
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    if sys.argv[1] == "window":
+        window(sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]))
+    else:
+        {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
