@@ -27,7 +27,10 @@
  *                                   src/roft-lib/src/ROFTFilter.cpp:553-577
  *  (2) the batched engine -- ROFTFilter::filtering_step (src/roft-lib/src/ROFTFilter.cpp:255-452)
  *      for many objects at once with all filter state resident in HBM:
- *        roft_engine_create / roft_object_add / roft_frame_submit / roft_step / roft_get_state.
+ *        roft_engine_create / roft_object_add / roft_frame_submit | roft_frames_submit / roft_step / roft_get_state.
+ *      roft_frames_submit hands over a BATCH of consecutive frames (a recorded sequence, or a live source read a few
+ *      frames at a time): the engine then runs each of its three per-object chains (masks, velocity, pose) over the
+ *      whole batch in one persistent kernel instead of a handful of launches per frame.
  */
 #ifndef ROFT_ENGINE_H
 #define ROFT_ENGINE_H
@@ -59,6 +62,13 @@ extern "C" {
 /* memory kind of image pointers handed to the engine */
 #define ROFT_MEM_HOST 0
 #define ROFT_MEM_DEVICE 1
+
+/* frames per roft_frames_submit call (roft_config::max_batch_frames) */
+#define ROFT_MAX_BATCH_FRAMES 8
+/* optical-flow frames one mask can be chased through: the 30-entry queue of the time-stamped source
+ * (OpticalFlowQueueHandler.cpp:18-26, at most 29 follow the matching entry) and the bound on "all buffered flows" of
+ * ImageSegmentationOFAidedSource with an unknown number of frames between masks (hpp:186-198, 239-245) */
+#define ROFT_MAX_FLOW_CHASE 30
 
 typedef struct {
     int width, height;
@@ -105,6 +115,13 @@ int roft_skf_correct(const double x_pred[6], const double P_pred[36], int N, con
                      const double* H, const double Rdiag[2], int reweight, double x_out[6],
                      double P_out[36], int* status_out);
 
+/* The same correction fed with the kept flow points themselves -- the form the engine's velocity filter consumes (H rows
+ * rebuilt on the device from pixel, depth and camera): uv 2N ints (u, v), z N floats, flow_xy 2N floats (pixels, i.e.
+ * already divided by the flow scale). */
+int roft_skf_correct_points(const roft_camera* cam, double dt, const double x_pred[6], const double P_pred[36], int N,
+                            const int32_t* uv, const float* z, const float* flow_xy, const double Rdiag[2],
+                            int reweight, double x_out[6], double P_out[36], int* status_out);
+
 /* mask (W*H u8) is propagated in place through flows[0..n_flows) (chronological); only the last
  * `frames_between` flows are used when frames_between > 0. */
 int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int n_flows,
@@ -146,12 +163,17 @@ typedef struct {
     int use_pose, use_pose_resync, use_velocity; /* measurement_model.use_* */
     int outlier_rejection;                       /* outlier_rejection.enable */
     int flow_aided_segmentation;                 /* segmentation_dataset.flow_aided */
-    int mask_frames_between;                     /* original_fps / desired_fps of the mask source */
+    /* original_fps / desired_fps of the mask source = segm_frames_between_iterations_: a new mask is chased through the
+     * last mask_frames_between buffered flows; <= 0 = unknown: through ALL flows buffered since the last mask
+     * (ImageSegmentationOFAidedSource.hpp:186-198, 239-245; at most ROFT_MAX_FLOW_CHASE, else roft_frames_submit fails
+     * with ROFT_ERR_CAPACITY).  Values above ROFT_MAX_FLOW_CHASE are refused. */
+    int mask_frames_between;
     int pose_frames_between;                     /* original_fps / desired_fps of the pose source */
     /* 1: masks come from a live source and carry the time stamp of the image they were computed on; a new mask is
-     * propagated through the flows stored after the flow with that stamp (time-stamp keyed queue of the last 30 flows),
-     * ImageSegmentationOFAidedSourceStamped.hpp:153-268 + OpticalFlowQueueHandler.cpp.  Needs 1 <= mask_frames_between
-     * <= 6 and roft_frame_input::stamp / mask_stamp.  0: the frame-counting ImageSegmentationOFAidedSource. */
+     * propagated through the flows stored after the flow with that stamp (time-stamp keyed queue of the last 30 flows,
+     * i.e. up to 29 flows; only the last mask_frames_between of them when that is > 0),
+     * ImageSegmentationOFAidedSourceStamped.hpp:153-268 + OpticalFlowQueueHandler.cpp.  Needs
+     * roft_frame_input::stamp / mask_stamp.  0: the frame-counting ImageSegmentationOFAidedSource. */
     int stamped_masks;
     int max_objects;
     /* Square root the sigma points are drawn from.  The reference (bfl) uses U sqrt(S) of the eigen-decomposition
@@ -168,6 +190,9 @@ typedef struct {
     double ukf_cholesky_guard;
     double ukf_cholesky_guard_bilinear;
     int device;                                  /* HIP device ordinal */
+    /* largest number of frames one roft_frames_submit may carry (1 .. ROFT_MAX_BATCH_FRAMES; 0 means 1).  Sizes the
+     * engine's rings and, for zero-copy DEVICE inputs, the retention window (roft_engine_retain_frames). */
+    int max_batch_frames;
 } roft_config;
 
 typedef struct {
@@ -187,9 +212,13 @@ typedef struct {
  * mem_kind.  DEVICE buffers are used in place (zero copy): previous depth, the buffered flows a new mask is
  * chased through and the outlier-rejection features of ROFTFilter.cpp:624-646 are references into them, and
  * the engine keeps several frames in flight.  A DEVICE buffer handed over for frame k must therefore stay
- * valid and unmodified until roft_frame_submit() for frame k + ROFT_RETAIN_FRAMES has returned (that call
- * blocks until every frame that can still read it has finished on the GPU).  HOST buffers are copied into the
- * engine's own ring before roft_frame_submit returns. */
+ * valid and unmodified until the submit call that carries frame k + roft_engine_retain_frames() has returned (that
+ * call blocks until every frame that can still read it has finished on the GPU).  ROFT_RETAIN_FRAMES is that number
+ * for the default configuration (max_batch_frames 1, mask_frames_between 6).  A flow that outlives the window
+ * because later flows were dropped (the reference clones every buffered flow) is copied into engine memory before
+ * the window closes.  HOST buffers are copied into the engine's own ring before the submit call returns (the call
+ * waits for the copies: the caller may re-use a HOST buffer as soon as it has returned); identical HOST pointers
+ * within one frame -- a scene shared by several objects -- are uploaded once. */
 #define ROFT_RETAIN_FRAMES 16
 typedef struct {
     double dt;            /* RGB stamp delta; <= 0 means cfg.sample_time */
@@ -219,10 +248,16 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out);
 int roft_engine_destroy(roft_engine* e);
 int roft_object_add(roft_engine* e, const roft_object_desc* desc, int* obj_id);
 
-/* inputs: one entry per object, in obj_id order.  Enqueues uploads and builds the frame program. */
+/* inputs: one entry per object, in obj_id order.  Enqueues uploads and builds the frame program.  On an error
+ * nothing of the frame has been consumed: the call can be repeated with corrected inputs. */
 int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inputs);
-/* Enqueues every kernel of ROFTFilter::filtering_step for all objects; returns without waiting. */
+/* A batch of n_frames consecutive frames (1 .. roft_config::max_batch_frames): inputs[t * n_objects + obj]. */
+int roft_frames_submit(roft_engine* e, const roft_frame_input* inputs, int n_objects, int n_frames);
+/* Enqueues every kernel of ROFTFilter::filtering_step for all objects and all submitted frames; returns without
+ * waiting. */
 int roft_step(roft_engine* e);
+/* retention window of zero-copy DEVICE inputs in frames (see roft_frame_input) */
+int roft_engine_retain_frames(const roft_engine* e);
 int roft_sync(roft_engine* e);
 /* Blocks until the last step has finished.  Any of the output pointers may be NULL. */
 int roft_get_state(roft_engine* e, int obj_id, double pose13[13], double P12[144], double twist6[6],
@@ -236,6 +271,16 @@ int roft_get_mask(roft_engine* e, int obj_id, uint8_t* mask_out);
  * a ring of n_frames x n_objects records written by the step itself, read back in one copy. */
 int roft_engine_enable_log(roft_engine* e, int n_frames);
 int roft_engine_get_log(roft_engine* e, int first_frame, int n_frames, roft_object_output* outs);
+
+/* work enqueued since roft_engine_create */
+typedef struct {
+    long long frames;          /* frames stepped */
+    long long batches;         /* roft_step calls */
+    long long launches;        /* kernel launches + memsets + copies enqueued by roft_step */
+    long long event_ops;       /* cross-stream waits + explicit event records enqueued by roft_step */
+    long long h2d_bytes;       /* bytes of HOST inputs uploaded by the submit calls */
+} roft_engine_stats;
+int roft_engine_get_stats(roft_engine* e, roft_engine_stats* out);
 
 /* HIP stream the engine enqueues on (as void*), for timing with hipEvents */
 void* roft_engine_stream(roft_engine* e);

@@ -153,7 +153,7 @@ ro_tracker* ro_tracker_create(const ro_tracker_config* cfg, const ro_mesh* mesh)
     t->y = (double*)malloc(sizeof(double) * 2 * t->capacity);
     t->Hm = (double*)malloc(sizeof(double) * 12 * t->capacity);
     t->tiles = (float*)malloc(sizeof(float) * 2 * (t->W / t->divider) * (t->H / t->divider));
-    t->flow_buf_cap = 8;
+    t->flow_buf_cap = 32;
     t->flow_buf = (void**)calloc(t->flow_buf_cap, sizeof(void*));
     t->flow_buf_desc = (ro_flow*)calloc(t->flow_buf_cap, sizeof(ro_flow));
 
@@ -191,15 +191,23 @@ static size_t flow_bytes(const ro_flow* f)
 
 static void flow_buf_push(ro_tracker* t, const ro_flow* f)
 {
-    /* only the last mask_frames_between flows can ever be used (hpp:239-245) */
-    int keep = t->cfg.mask_frames_between > 0 ? t->cfg.mask_frames_between : t->flow_buf_cap;
-    if (keep > t->flow_buf_cap) keep = t->flow_buf_cap;
-    if (t->flow_buf_n == keep) {
+    /* flow_buffer_.push_back(flow.clone()) (hpp:205-209).  The reference's vector is unbounded; only the last
+     * mask_frames_between entries can ever be used when that number is known (hpp:239-245), so older ones are dropped
+     * here.  When it is unknown (<= 0) every buffered flow is used: the buffer grows. */
+    const int keep = t->cfg.mask_frames_between;
+    if (keep > 0 && t->flow_buf_n == keep) {
         void* oldest = t->flow_buf[0];
         memmove(t->flow_buf, t->flow_buf + 1, sizeof(void*) * (keep - 1));
         memmove(t->flow_buf_desc, t->flow_buf_desc + 1, sizeof(ro_flow) * (keep - 1));
         t->flow_buf[keep - 1] = oldest;
         t->flow_buf_n--;
+    }
+    if (t->flow_buf_n == t->flow_buf_cap) {
+        const int cap = t->flow_buf_cap * 2;
+        t->flow_buf = (void**)realloc(t->flow_buf, sizeof(void*) * cap);
+        t->flow_buf_desc = (ro_flow*)realloc(t->flow_buf_desc, sizeof(ro_flow) * cap);
+        for (int i = t->flow_buf_cap; i < cap; i++) t->flow_buf[i] = NULL;
+        t->flow_buf_cap = cap;
     }
     int k = t->flow_buf_n++;
     t->flow_buf[k] = realloc(t->flow_buf[k], flow_bytes(f));

@@ -16,7 +16,9 @@ FLOW_S16C2 = 11
 FLOW_F32C2 = 13
 MEAS_NONE, MEAS_VELOCITY, MEAS_POSE, MEAS_POSE_VELOCITY = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
-RETAIN_FRAMES = 16
+RETAIN_FRAMES = 16        # default configuration (roft_engine_retain_frames otherwise)
+MAX_BATCH_FRAMES = 8
+MAX_FLOW_CHASE = 30
 
 
 class RoftError(RuntimeError):
@@ -53,7 +55,7 @@ class Config(C.Structure):
                 ("flow_aided_segmentation", C.c_int), ("mask_frames_between", C.c_int),
                 ("pose_frames_between", C.c_int), ("stamped_masks", C.c_int), ("max_objects", C.c_int), ("ukf_cholesky_guard", C.c_double),
                 ("ukf_cholesky_guard_bilinear", C.c_double),
-                ("device", C.c_int)]
+                ("device", C.c_int), ("max_batch_frames", C.c_int)]
 
 
 class ObjectDesc(C.Structure):
@@ -71,6 +73,11 @@ class FrameInput(C.Structure):
                 ("mem_kind", C.c_int), ("stamp", C.c_double), ("mask_stamp", C.c_double)]
 
 
+class EngineStats(C.Structure):
+    _fields_ = [("frames", C.c_longlong), ("batches", C.c_longlong), ("launches", C.c_longlong),
+                ("event_ops", C.c_longlong), ("h2d_bytes", C.c_longlong)]
+
+
 class ObjectOutput(C.Structure):
     _fields_ = [("pose", C.c_double * 13), ("twist", C.c_double * 6), ("n_flow_points", C.c_int),
                 ("outlier_selected", C.c_int), ("outlier_L", C.c_double * 2)]
@@ -79,10 +86,10 @@ class ObjectOutput(C.Structure):
 # every symbol include/roft_engine.h declares
 ABI_SYMBOLS = [
     "roft_last_error_string", "roft_device_count", "roft_flow_measurement", "roft_kf_predict",
-    "roft_skf_correct", "roft_mask_propagate", "roft_pose_process_noise", "roft_ukf_predict",
+    "roft_skf_correct", "roft_skf_correct_points", "roft_mask_propagate", "roft_pose_process_noise", "roft_ukf_predict",
     "roft_ukf_correct", "roft_render_depth", "roft_depth_likelihood", "roft_default_config",
     "roft_default_object", "roft_engine_create", "roft_engine_destroy", "roft_object_add",
-    "roft_frame_submit", "roft_step", "roft_sync", "roft_get_state", "roft_get_outputs", "roft_get_mask",
+    "roft_frame_submit", "roft_frames_submit", "roft_engine_retain_frames", "roft_engine_get_stats", "roft_step", "roft_sync", "roft_get_state", "roft_get_outputs", "roft_get_mask",
     "roft_engine_enable_log", "roft_engine_get_log", "roft_engine_stream", "roft_engine_enable_timing",
     "roft_engine_get_timing", "roft_default_of_params", "roft_optical_flow", "roft_flow_producer_create",
     "roft_flow_producer_destroy", "roft_flow_producer_run", "roft_flow_producer_sync", "roft_flow_producer_stream",
@@ -119,6 +126,7 @@ def lib():
                                         C.c_double, C.c_int, vp, vp, vp, ip]
     L.roft_kf_predict.argtypes = [vp] * 5
     L.roft_skf_correct.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, ip]
+    L.roft_skf_correct_points.argtypes = [C.POINTER(Camera), C.c_double, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp, ip]
     L.roft_mask_propagate.argtypes = [vp, C.c_int, C.c_int, C.POINTER(Flow), C.c_int, C.c_int]
     L.roft_pose_process_noise.argtypes = [vp, vp, C.c_double, vp]
     L.roft_ukf_predict.argtypes = [vp, vp, vp, C.c_double, C.POINTER(UT), vp, vp]
@@ -131,6 +139,9 @@ def lib():
     L.roft_engine_destroy.argtypes = [vp]
     L.roft_object_add.argtypes = [vp, C.POINTER(ObjectDesc), ip]
     L.roft_frame_submit.argtypes = [vp, C.POINTER(FrameInput), C.c_int]
+    L.roft_frames_submit.argtypes = [vp, C.POINTER(FrameInput), C.c_int, C.c_int]
+    L.roft_engine_retain_frames.argtypes = [vp]
+    L.roft_engine_get_stats.argtypes = [vp, C.POINTER(EngineStats)]
     L.roft_step.argtypes = [vp]
     L.roft_sync.argtypes = [vp]
     L.roft_get_state.argtypes = [vp, C.c_int, vp, vp, vp, vp]

@@ -99,7 +99,10 @@ int check_geometry(int W, int H)
         return fail(ROFT_ERR_INVALID, "image width must be a multiple of 32 and width*height a multiple of 64");
     if ((size_t)W * H >= (1u << 24))
         return fail(ROFT_ERR_INVALID, "width*height must be < 2^24 (float-accumulated sampling index, hpp:237)");
-    if ((size_t)(W / 32) * H * 4 + 16384 /* candidate list of the flow measurement */ + 128 > 160 * 1024 - 256)
+    // LDS of the mask chain kernel: the OR target plane + the list of non-empty 64-pixel groups (2 B each); of the flow
+    // measurement / feature kernels: the plane + their work lists
+    const size_t plane = (size_t)(W / 32) * H * 4;
+    if (plane + std::max<size_t>((size_t)W * H / 64 * 2 + 1024, 16384 + 128) > 160 * 1024 - 256)
         return fail(ROFT_ERR_INVALID, "mask bit plane does not fit the 160 KiB LDS of a CU");
     return ROFT_OK;
 }
@@ -114,14 +117,16 @@ struct Arrays {
     DevBuf<int32_t> map;
     DevBuf<FlowRec> cand, recs;
     DevBuf<double> norms;
+    DevBuf<int> npts;
     DevBuf<uint32_t> feat_pix;
     DevBuf<float> feat_depth;
     DevBuf<uint32_t> zbuf;
     DevBuf<roft_object_output> log;
 
-    int alloc(int n_obj, const DevCamera& cam, const DevFlowFmt& ffmt, int radius)
+    int alloc(int n_obj, int T, const DevCamera& cam, const DevFlowFmt& ffmt, int radius)
     {
         a.n_obj = n_obj;
+        a.T = 1;
         a.cam = cam;
         a.ffmt = ffmt;
         a.plane_words = (size_t)cam.wpr * cam.H;
@@ -132,17 +137,18 @@ struct Arrays {
         a.tile_h = cam.H / cam.divider;
         HIP_TRY(params.ensure(n_obj, true));
         HIP_TRY(state.ensure(n_obj, true));
-        HIP_TRY(ctrl.ensure(n_obj, true));
+        HIP_TRY(ctrl.ensure((size_t)n_obj * T, true));
         HIP_TRY(planes.ensure((size_t)n_obj * (kPlaneSlots + 2) * 2 * a.plane_words, true));
         HIP_TRY(map.ensure((size_t)n_obj * npix, true));
-        HIP_TRY(cand.ensure((size_t)n_obj * a.cand_cap));
-        HIP_TRY(recs.ensure((size_t)n_obj * a.cand_cap));
+        HIP_TRY(cand.ensure((size_t)n_obj * T * a.cand_cap));
+        HIP_TRY(recs.ensure((size_t)n_obj * T * a.cand_cap));
+        HIP_TRY(npts.ensure((size_t)n_obj * T, true));
         HIP_TRY(norms.ensure((size_t)n_obj * 3 * a.cand_cap));
         HIP_TRY(feat_pix.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
         HIP_TRY(feat_depth.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
         HIP_TRY(zbuf.ensure((size_t)n_obj * 2 * a.tile_w * a.tile_h));
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
-        a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
+        a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
         a.zbuf = zbuf.p;
         a.out_log = nullptr;
         a.log_cap = 0;
@@ -156,7 +162,7 @@ struct Arrays {
 void init_state(ObjState& st)
 {
     std::memset(&st, 0, sizeof(st));
-    st.bbox[0] = INT32_MAX; st.bbox[1] = INT32_MAX; st.bbox[2] = -1; st.bbox[3] = -1;
+    st.pending_frame = -1;
     st.n_flow_points = -1;
     st.outlier_selected = -1;
 }
@@ -175,22 +181,25 @@ void clear_ctrl(FrameCtrl& c)
 // =================================================================================================
 
 // FrameCtrl upload without the copy engine: a kernel reads the pinned (device-visible) staging block and
-// writes the device copy, so the per-frame control block travels in-order on the compute queue instead of
+// writes the device copy, so the control blocks of a batch travel in-order on the compute queue instead of
 // through an SDMA copy with its cross-engine signalling.
-// The same launch closes the mask stage of the PREVIOUS frame (one thread per object: flow buffer count, reset of the
-// per-frame scratch state): it runs after that frame's gather on the mask chain and before anything of the new frame
-// reads those fields, and it saves a launch per frame -- the frame time follows the number of launches and event
-// operations (~7 us each over all streams) more than the kernels' durations.
-__global__ void ctrl_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16,
-                                   const FrameCtrl* prev_ctrl, ObjState* state, int n_obj)
+__global__ void ctrl_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
 {
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (prev_ctrl && t < (size_t)n_obj) mask_bookkeeping(prev_ctrl[t], state[t]);
-    for (size_t i = t; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
-struct HostObject {
-    // schedule-driven mirrors of the reference's source / measurement-model state machines
+namespace {
+
+struct FlowEntry {
+    const void* ptr;
+    int frame;   // frame index the flow was delivered with
+    int owned;   // index into HostObject::owned when the engine holds its own copy, else -1
+};
+
+// Schedule-driven mirrors of the reference's source / measurement-model state machines.  Trivially copyable: a submit
+// call works on the live copy and restores the snapshot taken at its start if it fails, so a failed call consumes
+// nothing.
+struct Sched {
     int frame_idx = 0;
     bool seg_available = false;        // ImageSegmentationOFAidedSource::segmentation_available_
     bool of_first_frame = true;        // ...::is_first_frame_
@@ -198,66 +207,93 @@ struct HostObject {
     bool features_initialized = false; // ROFTFilter::outlier_rejection_features_initialized_
     int feat_slot = 0;                 // feature ring slot holding the buffered outlier-rejection features
     int feat_next = 0;                 // next ring slot to write
-    std::deque<const void*> flow_hist; // last valid flows, newest at front
-    std::deque<double> flow_stamps;    // stamped source: RGB stamps of the last 30 valid flows, oldest at front
-    std::deque<int> vel_buf;           // twist_hist slots (CartesianQuaternionMeasurement::buffer_velocities_)
+    int feat_use[kFeatRing];           // last batch that reads or writes each feature ring slot (-1: never used)
+    int n_hist = 0;
+    FlowEntry hist[kMaxFlowHist];      // last valid flows, newest first
+    int n_stamps = 0;
+    double stamps[30];                 // stamped source: RGB stamps of the last 30 valid flows, oldest first
+    int n_vel = 0;
+    int vel_buf[kTwistRing];           // twist_hist slots (CartesianQuaternionMeasurement::buffer_velocities_), oldest first
     int last_meas_slot = 0;            // slot of measurement_.head<6>()
+    int flows_since_mask = 0;          // upper bound of the flows buffered since the last delivered mask
     const float* depth_prev = nullptr;
-    // engine-owned copies of HOST inputs
-    DevBuf<float> depth_ring[kPlaneSlots];
-    DevBuf<unsigned char> flow_ring[kPlaneSlots];
-    DevBuf<uint8_t> mask_stage;
+    Sched() { for (int& u : feat_use) u = -1; }
+};
+
+struct OwnedFlow {
+    DevBuf<unsigned char> buf;
+    int last_ref_frame = -1;   // last frame whose control block references the copy
+};
+
+struct HostObject {
+    Sched s;
+    std::vector<OwnedFlow*> owned;   // engine copies of flows that outlived the zero-copy retention window
     DevBuf<float> verts;
     DevBuf<int32_t> tris;
+    ~HostObject() { for (auto* o : owned) delete o; }
 };
+
+// Device copies of HOST inputs: one list of buffers per frame of the retention window, handed out in order; identical
+// host pointers within a frame (a scene shared by several objects) share one upload.
+struct StageFrame {
+    std::vector<DevBuf<unsigned char>*> bufs;
+    size_t used = 0;
+    std::vector<std::pair<const void*, void*>> seen;
+    ~StageFrame() { for (auto* b : bufs) delete b; }
+};
+
+}  // namespace
 
 struct roft_engine {
     roft_config cfg{};
     Arrays arr;
-    // Three in-order chains per frame, one HIP stream each (ROFT_ONE_STREAM=1 puts them on one stream):
-    hipStream_t stream = nullptr;       // mask chain: uploads, FrameCtrl, mask ingest / scatter / gather
+    // Three in-order chains per batch, one HIP stream each (ROFT_ONE_STREAM=1 puts them on one stream):
+    hipStream_t stream = nullptr;       // mask chain: FrameCtrl upload, mask chain kernel, features
     hipStream_t vel_stream = nullptr;   // velocity chain: flow measurement, velocity filter
-    hipStream_t pose_stream = nullptr;  // pose chain: features, UKF steps, outlier rejection
-    // Frames in flight.  The image chains of frame k+1 do not depend on the pose chain of frame k, so they run ahead
-    // of it (a pose re-sync frame costs the pose chain ~5 ordinary frames; the lead absorbs it).  The lead is bounded
-    // on the host: roft_frame_submit(j) returns only when the POSE chain of frame j - kMaxInFlight has ended, which
-    // implies the velocity chain of that frame and the mask chain of the frame before it.  Rings are sized for it:
-    //   device FrameCtrl ring / staging ring / events kCtrlRing > kMaxInFlight;  plane ring kPlaneSlots > kMaxInFlight + 1;
-    //   feature ring kFeatRing >= kMaxInFlight + 2;  twist ring kTwistRing > kMaxInFlight + pose_frames_between + 2;
-    //   caller buffers: frame m is read until the mask chain of frame m + kMaxFlowHist - 1 ends
-    //   =>  ROFT_RETAIN_FRAMES >= kMaxInFlight + 1 + kMaxFlowHist.
-    static constexpr int kMaxInFlight = 6;   // = the lead of the image chains over the pose chain
-    static constexpr int kCtrlRing = 16;
-    static_assert(kMaxInFlight + 1 + kMaxFlowHist <= ROFT_RETAIN_FRAMES, "caller buffer retention");
-    static_assert(kMaxInFlight + 1 < kPlaneSlots && kMaxInFlight < kCtrlRing && kMaxInFlight + 2 <= kFeatRing, "ring sizes");
-    DevBuf<FrameCtrl> dctrl[kCtrlRing];
-    hipEvent_t ev_mask[kCtrlRing] = {};  // mask chain of frame k complete (recorded only when the pose chain needs it)
-    hipEvent_t ev_vel[kCtrlRing] = {};   // twist of frame k complete
-    hipEvent_t ev_pose[kCtrlRing] = {};  // pose chain of frame k complete
-    bool two_streams = false;
-    bool kernel_upload = true;
-    // ROFT_HOST_PROF=1: host time of the sections of roft_frame_submit / roft_step, printed by roft_engine_destroy
+    hipStream_t pose_stream = nullptr;  // pose chain: UKF segments, outlier rejection
+    hipStream_t up_stream = nullptr;    // uploads of HOST inputs and the copies of aged-out flows
+    // Batches in flight.  The image chains of batch b+1 do not depend on the pose chain of batch b, so they run ahead
+    // of it.  The lead is bounded on the host: the submit call of batch b returns only when batch b - lead has ended
+    // (its pose chain, which implies its other chains).  Rings are sized for it:
+    //   batch ring (device FrameCtrl blocks, staging, events) kBatchRing > lead;
+    //   plane ring kPlaneSlots > lead * T + T + 1;  twist ring kTwistRing > lead * T + pose_frames_between + 2;
+    //   feature ring kFeatRing >= T + 2 (re-use is ordered by feat_use);
+    //   caller buffers / HOST staging: retain = hist_cap + lead * T + 2 frames.
+    static constexpr int kBatchRing = 8;
+    int T_max = 1;        // cfg.max_batch_frames
+    int lead = 6;         // batches
+    int hist_cap = 6;     // flows kept per object
+    int retain = ROFT_RETAIN_FRAMES;
+    DevBuf<FrameCtrl> dctrl[kBatchRing];
+    FrameCtrl* stage[kBatchRing] = {};     // pinned staging blocks
+    hipEvent_t ev_up[kBatchRing] = {};     // uploads of the batch on the device
+    hipEvent_t ev_ctrl[kBatchRing] = {};   // FrameCtrl blocks of the batch on the device (and the mask chain of the batch before)
+    hipEvent_t ev_mask[kBatchRing] = {};   // mask chain kernel of the batch complete
+    hipEvent_t ev_feat[kBatchRing] = {};   // features of the batch complete
+    hipEvent_t ev_vel[kBatchRing] = {};    // twists of the batch complete
+    hipEvent_t ev_done[kBatchRing] = {};   // pose chain of the batch complete
+    bool multi = false;
+    // ROFT_HOST_PROF=1: host time of the sections of the submit call / roft_step, printed by roft_engine_destroy
     bool host_prof = false;
     double hp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long hp_frames = 0;
+    long hp_batches = 0;
     std::vector<HostObject*> objs;
+    std::vector<Sched> backup;
     std::vector<ObjParams> h_params;
-    // pinned staging ring for FrameCtrl blocks
-    static constexpr int kStage = 16;
-    static_assert(kStage == kCtrlRing, "the staging event of a frame doubles as its FrameCtrl-ready event");
-    FrameCtrl* stage[kStage] = {};
+    std::vector<StageFrame> staging;       // [retain]
     ObjState* state_host = nullptr;   // pinned landing block of roft_get_state (velocity belief + corrected pose belief)
-    hipEvent_t stage_ev[kStage] = {};
-    int stage_idx = 0;
-    FrameCtrl* cur = nullptr;  // staging block of the submitted, not yet stepped frame
+    // the submitted, not yet stepped batch
     bool submitted = false;
-    int max_steps = 0;
-    bool any_new_mask = false, any_outlier = false, any_feat = false;
-    bool any_feat_now = false;   // some object's outlier test reads the feature set buffered in this same frame
-    int frame_counter = 0;
+    int cur_T = 0;
+    int n_segments = 1;
+    bool any_feat = false, any_feat_now = false, had_uploads = false;
+    int batch_counter = 0, frame_counter = 0;
+    int completed_batches = 0, completed_frames = 0;
+    int batch_end_frame[kBatchRing] = {};
+    roft_engine_stats stats{};
     // timing
     bool timing = false;
-    int timing_level = 2;   // 1: only flow_measure_kernel (two events per frame), 2: every launch group
+    int timing_level = 2;   // 1: only flow_measure_kernel (two events per batch), 2: every launch group
     std::vector<hipEvent_t> tev;
     std::vector<std::string> tnames_s;
     std::vector<const char*> tnames;
@@ -272,6 +308,16 @@ static inline double host_now_us()
     return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 #define HP_MARK(e, slot, t) do { if ((e)->host_prof) { const double _n = host_now_us(); (e)->hp_acc[slot] += _n - (t); (t) = _n; } } while (0)
+
+// blocks until batch b (and therefore every earlier one) has ended on the GPU
+static int wait_batch(roft_engine* e, int b)
+{
+    if (b < e->completed_batches || b >= e->batch_counter) return ROFT_OK;
+    HIP_TRY(hipEventSynchronize(e->ev_done[b % roft_engine::kBatchRing]));
+    e->completed_batches = b + 1;
+    e->completed_frames = e->batch_end_frame[b % roft_engine::kBatchRing];
+    return ROFT_OK;
+}
 
 extern "C" {
 
@@ -314,6 +360,7 @@ int roft_default_config(roft_config* c, int width, int height, int flow_type)
     c->ukf_cholesky_guard = 2e-4;
     c->ukf_cholesky_guard_bilinear = 4e-3;
     c->device = 0;
+    c->max_batch_frames = 1;
     return ROFT_OK;
 }
 
@@ -336,6 +383,56 @@ int roft_default_object(roft_object_desc* o)
     return ROFT_OK;
 }
 
+int roft_engine_destroy(roft_engine* e);
+
+static int engine_setup(roft_engine* e, const roft_config* cfg)
+{
+    constexpr int R = roft_engine::kBatchRing;
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    // The image chains of batch b+1 do not depend on the pose chain of batch b (only the other way round, through
+    // the twist ring and the mask planes), so the chains run on separate HIP streams, ordered by one event per batch
+    // and edge.  ROFT_ONE_STREAM=1 serialises everything on one stream (debugging).
+    const char* one = getenv("ROFT_ONE_STREAM");
+    e->multi = !(one && one[0] == '1');
+    if (e->multi) {
+        // the pose chain is the longest of the three: give its workgroups the dispatch priority
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const char* np = getenv("ROFT_NO_STREAM_PRIORITY");
+        if (np && np[0] == '1') greatest = least;
+        HIP_TRY(hipStreamCreateWithPriority(&e->pose_stream, hipStreamNonBlocking, greatest));
+        HIP_TRY(hipStreamCreateWithPriority(&e->vel_stream, hipStreamNonBlocking, (least + greatest) / 2));
+        HIP_TRY(hipStreamDestroy(e->stream));
+        e->stream = nullptr;
+        HIP_TRY(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, least));
+        HIP_TRY(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
+    } else {
+        e->pose_stream = e->vel_stream = e->up_stream = e->stream;
+    }
+    for (int i = 0; i < R; ++i) {
+        HIP_TRY(e->dctrl[i].ensure((size_t)cfg->max_objects * e->T_max, true));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects * e->T_max));
+        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i]})
+            HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    }
+    DevFlowFmt ff;
+    ff.type = cfg->flow_type;
+    ff.grid = cfg->flow_grid;
+    ff.cols = cfg->cam.width / cfg->flow_grid;
+    ff.rows = cfg->cam.height / cfg->flow_grid;
+    ff.scale = cfg->flow_scale;
+    const int radius = (int)(size_t)cfg->subsampling_radius;
+    if (int rc = e->arr.alloc(cfg->max_objects, e->T_max, make_cam(cfg->cam), ff, radius)) return rc;
+    e->arr.a.n_obj = 0;
+    e->arr.a.ukf_chol_guard = (cfg->ukf_cholesky_guard > 0.0) ? cfg->ukf_cholesky_guard : 0.0;
+    e->arr.a.ukf_chol_guard_bil = (cfg->ukf_cholesky_guard_bilinear > 0.0) ? cfg->ukf_cholesky_guard_bilinear : 0.0;
+    e->h_params.resize(cfg->max_objects);
+    e->staging.resize(e->retain);
+    const char* hpf = getenv("ROFT_HOST_PROF");
+    e->host_prof = hpf && hpf[0] == '1';
+    return ROFT_OK;
+}
+
 int roft_engine_create(const roft_config* cfg, roft_engine** out)
 {
     if (!cfg || !out) return fail(ROFT_ERR_INVALID, "null argument");
@@ -346,60 +443,34 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
         return fail(ROFT_ERR_INVALID, "flow_type must be ROFT_FLOW_S16C2 or ROFT_FLOW_F32C2");
     if (cfg->flow_grid <= 0 || cfg->cam.width % cfg->flow_grid) return fail(ROFT_ERR_INVALID, "bad flow grid");
     if (cfg->mask_frames_between > kMaxFlowHist)
-        return fail(ROFT_ERR_INVALID, "mask_frames_between > 6 is not supported");
-    if (cfg->pose_frames_between + 2 > kTwistRing) return fail(ROFT_ERR_INVALID, "pose_frames_between too large");
-    if (cfg->stamped_masks && (cfg->mask_frames_between < 1 || cfg->mask_frames_between > kMaxFlowHist))
-        return fail(ROFT_ERR_INVALID, "stamped_masks needs 1 <= mask_frames_between <= 6");
+        return fail(ROFT_ERR_INVALID, "mask_frames_between > 30 (ROFT_MAX_FLOW_CHASE) is not supported");
+    if (cfg->max_batch_frames < 0 || cfg->max_batch_frames > kMaxBatch)
+        return fail(ROFT_ERR_INVALID, "max_batch_frames must be 0 .. ROFT_MAX_BATCH_FRAMES");
+    if ((int)(size_t)cfg->subsampling_radius <= 0) return fail(ROFT_ERR_INVALID, "subsampling_radius must be >= 1");
+    const int T = std::max(cfg->max_batch_frames, 1);
+    const int lead = (T == 1) ? 6 : 3;
+    // the re-sync replays at most pose_frames_between + 1 buffered velocities (all of them when that number is unknown)
+    if (cfg->pose_frames_between + 2 > kMaxSteps)
+        return fail(ROFT_ERR_INVALID, "pose_frames_between too large (the re-sync replays pose_frames_between + 1 steps, at most 9)");
+    static_assert(roft_engine::kBatchRing > 6, "batch ring");
+    static_assert(3 * kMaxBatch + kMaxBatch + 1 < kPlaneSlots && 6 + 1 + 1 < kPlaneSlots, "plane ring");
+    static_assert(3 * kMaxBatch + kMaxSteps + 2 < kTwistRing, "twist ring");
+    static_assert(kFeatRing >= kMaxBatch + 2, "feature ring");
     HIP_TRY(hipSetDevice(cfg->device));
     roft_engine* e = new roft_engine();
     e->cfg = *cfg;
-    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    // The image chain of frame k+1 does not depend on the pose chain of frame k (only the other way round,
-    // through the twist ring and the mask planes), so the two run on separate HIP streams, ordered by one
-    // event per frame in each direction.  ROFT_ONE_STREAM=1 serialises everything on one stream (debugging).
-    const char* ku = getenv("ROFT_MEMCPY_UPLOAD");
-    e->kernel_upload = !(ku && ku[0] == '1');
-    const char* one = getenv("ROFT_ONE_STREAM");
-    e->two_streams = !(one && one[0] == '1');
-    if (e->two_streams) {
-        // the pose chain is the longest of the three: give its workgroups the dispatch priority
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const char* np = getenv("ROFT_NO_STREAM_PRIORITY");
-        if (np && np[0] == '1') greatest = least;
-        HIP_TRY(hipStreamCreateWithPriority(&e->pose_stream, hipStreamNonBlocking, greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&e->vel_stream, hipStreamNonBlocking, (least + greatest) / 2));
-        // ... and the mask chain (thousands of short workgroups per launch) the lowest
-        HIP_TRY(hipStreamDestroy(e->stream));
-        HIP_TRY(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, least));
-    } else {
-        e->pose_stream = e->vel_stream = e->stream;
+    e->cfg.max_batch_frames = T;
+    e->T_max = T;
+    e->lead = lead;
+    // flows kept per object: what one mask can be chased through
+    if (cfg->stamped_masks) e->hist_cap = (cfg->mask_frames_between > 0) ? std::min(cfg->mask_frames_between, 29) : 29;
+    else e->hist_cap = (cfg->mask_frames_between > 0) ? cfg->mask_frames_between : kMaxFlowHist;
+    e->retain = e->hist_cap + lead * T + 2;
+    if (const int rc = engine_setup(e, cfg)) {
+        const std::string msg = g_last_error;
+        (void)roft_engine_destroy(e);
+        return fail(rc, msg);
     }
-    for (int i = 0; i < roft_engine::kCtrlRing; ++i) {
-        HIP_TRY(e->dctrl[i].ensure(cfg->max_objects, true));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_mask[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_vel[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&e->ev_pose[i], hipEventDisableTiming));
-    }
-    DevFlowFmt ff;
-    ff.type = cfg->flow_type;
-    ff.grid = cfg->flow_grid;
-    ff.cols = cfg->cam.width / cfg->flow_grid;
-    ff.rows = cfg->cam.height / cfg->flow_grid;
-    ff.scale = cfg->flow_scale;
-    const int radius = (int)(size_t)cfg->subsampling_radius;
-    if (radius <= 0) { delete e; return fail(ROFT_ERR_INVALID, "subsampling_radius must be >= 1"); }
-    if (int rc = e->arr.alloc(cfg->max_objects, make_cam(cfg->cam), ff, radius)) { delete e; return rc; }
-    e->arr.a.n_obj = 0;
-    e->arr.a.ukf_chol_guard = (cfg->ukf_cholesky_guard > 0.0) ? cfg->ukf_cholesky_guard : 0.0;
-    e->arr.a.ukf_chol_guard_bil = (cfg->ukf_cholesky_guard_bilinear > 0.0) ? cfg->ukf_cholesky_guard_bilinear : 0.0;
-    for (int i = 0; i < roft_engine::kStage; ++i) {
-        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects));
-        HIP_TRY(hipEventCreateWithFlags(&e->stage_ev[i], hipEventDisableTiming));
-    }
-    e->h_params.resize(cfg->max_objects);
-    const char* hpf = getenv("ROFT_HOST_PROF");
-    e->host_prof = hpf && hpf[0] == '1';
     *out = e;
     return ROFT_OK;
 }
@@ -407,27 +478,26 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
 int roft_engine_destroy(roft_engine* e)
 {
     if (!e) return ROFT_OK;
+    constexpr int R = roft_engine::kBatchRing;
     (void)hipSetDevice(e->cfg.device);
-    if (e->host_prof && e->hp_frames > 0) {
-        static const char* names[7] = {"submit: wait staging/in-flight", "submit: frame programs", "step: throttle", "step: FrameCtrl upload",
-                                       "step: velocity chain", "step: mask chain", "step: pose chain"};
-        for (int i = 0; i < 7; ++i) std::fprintf(stderr, "[roft host] %-32s %7.2f us/frame\n", names[i], e->hp_acc[i] / e->hp_frames);
+    if (e->host_prof && e->hp_batches > 0) {
+        static const char* names[7] = {"submit: wait in-flight bound", "submit: frame programs + uploads", "submit: wait uploads",
+                                       "step: FrameCtrl upload", "step: mask chain", "step: velocity chain", "step: pose chain"};
+        for (int i = 0; i < 7; ++i) std::fprintf(stderr, "[roft host] %-36s %7.2f us/batch\n", names[i], e->hp_acc[i] / e->hp_batches);
     }
-    if (e->stream) (void)hipStreamSynchronize(e->stream);
-    if (e->vel_stream) (void)hipStreamSynchronize(e->vel_stream);
-    if (e->pose_stream) (void)hipStreamSynchronize(e->pose_stream);
-    for (int i = 0; i < roft_engine::kCtrlRing; ++i) {
-        if (e->ev_mask[i]) (void)hipEventDestroy(e->ev_mask[i]);
-        if (e->ev_vel[i]) (void)hipEventDestroy(e->ev_vel[i]);
-        if (e->ev_pose[i]) (void)hipEventDestroy(e->ev_pose[i]);
-    }
-    if (e->two_streams && e->pose_stream) (void)hipStreamDestroy(e->pose_stream);
-    if (e->two_streams && e->vel_stream) (void)hipStreamDestroy(e->vel_stream);
-    for (auto* o : e->objs) delete o;
-    for (int i = 0; i < roft_engine::kStage; ++i) {
+    for (hipStream_t s : {e->stream, e->vel_stream, e->pose_stream, e->up_stream})
+        if (s) (void)hipStreamSynchronize(s);
+    for (int i = 0; i < R; ++i) {
+        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i]})
+            if (ev) (void)hipEventDestroy(ev);
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
-        if (e->stage_ev[i]) (void)hipEventDestroy(e->stage_ev[i]);
     }
+    if (e->multi) {
+        if (e->pose_stream) (void)hipStreamDestroy(e->pose_stream);
+        if (e->vel_stream) (void)hipStreamDestroy(e->vel_stream);
+        if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
+    }
+    for (auto* o : e->objs) delete o;
     if (e->state_host) (void)hipHostFree(e->state_host);
     for (auto ev : e->tev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -435,11 +505,20 @@ int roft_engine_destroy(roft_engine* e)
     return ROFT_OK;
 }
 
+int roft_engine_retain_frames(const roft_engine* e) { return e ? e->retain : ROFT_RETAIN_FRAMES; }
+
+int roft_engine_get_stats(roft_engine* e, roft_engine_stats* out)
+{
+    if (!e || !out) return fail(ROFT_ERR_INVALID, "null argument");
+    *out = e->stats;
+    return ROFT_OK;
+}
+
 int roft_object_add(roft_engine* e, const roft_object_desc* d, int* obj_id)
 {
     if (!e || !d) return fail(ROFT_ERR_INVALID, "null argument");
     if ((int)e->objs.size() >= e->cfg.max_objects) return fail(ROFT_ERR_CAPACITY, "max_objects reached");
-    if (e->frame_counter > 0) return fail(ROFT_ERR_STATE, "objects must be added before the first frame");
+    if (e->frame_counter > 0 || e->submitted) return fail(ROFT_ERR_STATE, "objects must be added before the first frame");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int id = (int)e->objs.size();
     HostObject* o = new HostObject();
@@ -454,19 +533,18 @@ int roft_object_add(roft_engine* e, const roft_object_desc* d, int* obj_id)
     for (int i = 0; i < 6; ++i) p.v_q[i] = d->v_q_diag[i];
     p.r_flow[0] = d->v_meas_cov_flow[0];
     p.r_flow[1] = d->v_meas_cov_flow[1];
+    auto bail = [&](int code, const std::string& msg) { delete o; return fail(code, msg); };
     if (d->mesh.n_verts > 0 && d->mesh.n_tris > 0) {
-        HIP_TRY(o->verts.ensure((size_t)3 * d->mesh.n_verts));
-        HIP_TRY(o->tris.ensure((size_t)3 * d->mesh.n_tris));
-        HIP_TRY(hipMemcpy(o->verts.p, d->mesh.verts, sizeof(float) * 3 * d->mesh.n_verts, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(o->tris.p, d->mesh.tris, sizeof(int32_t) * 3 * d->mesh.n_tris, hipMemcpyHostToDevice));
+        hipError_t err = o->verts.ensure((size_t)3 * d->mesh.n_verts);
+        if (err == hipSuccess) err = o->tris.ensure((size_t)3 * d->mesh.n_tris);
+        if (err == hipSuccess) err = hipMemcpy(o->verts.p, d->mesh.verts, sizeof(float) * 3 * d->mesh.n_verts, hipMemcpyHostToDevice);
+        if (err == hipSuccess) err = hipMemcpy(o->tris.p, d->mesh.tris, sizeof(int32_t) * 3 * d->mesh.n_tris, hipMemcpyHostToDevice);
+        if (err != hipSuccess) return bail(ROFT_ERR_DEVICE, std::string("mesh upload: ") + hipGetErrorString(err));
         p.verts = o->verts.p; p.tris = o->tris.p;
         p.n_verts = d->mesh.n_verts; p.n_tris = d->mesh.n_tris;
-        e->arr.a.max_tris = std::max(e->arr.a.max_tris, d->mesh.n_tris);
     } else if (e->cfg.outlier_rejection && e->cfg.use_pose) {
-        delete o;
-        return fail(ROFT_ERR_INVALID, "outlier rejection needs a mesh");
+        return bail(ROFT_ERR_INVALID, "outlier rejection needs a mesh");
     }
-    HIP_TRY(hipMemcpy(e->arr.params.p + id, &p, sizeof(p), hipMemcpyHostToDevice));
     // initialization_step (ROFTFilter.cpp:216-237)
     ObjState* st = new ObjState();
     init_state(*st);
@@ -477,22 +555,27 @@ int roft_object_add(roft_engine* e, const roft_object_desc* d, int* obj_id)
     st->belief[B_CORR] = b;
     st->belief[B_PRED] = b;
     st->belief[B_BUF] = b;
-    hipError_t err = hipMemcpy(e->arr.state.p + id, st, sizeof(ObjState), hipMemcpyHostToDevice);
+    hipError_t err = hipMemcpy(e->arr.params.p + id, &p, sizeof(p), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(e->arr.state.p + id, st, sizeof(ObjState), hipMemcpyHostToDevice);
     delete st;
-    HIP_TRY(err);
+    if (err != hipSuccess) return bail(ROFT_ERR_DEVICE, std::string("state upload: ") + hipGetErrorString(err));
+    e->arr.a.max_tris = std::max(e->arr.a.max_tris, d->mesh.n_tris);
     e->objs.push_back(o);
     e->arr.a.n_obj = (int)e->objs.size();
     if (obj_id) *obj_id = id;
     return ROFT_OK;
 }
 
-static void build_pose_program(roft_engine* e, HostObject& o, const roft_frame_input& in, FrameCtrl& c)
+// The UKF steps of one frame (ROFTFilter.cpp:327-367 over CartesianQuaternionMeasurement::freeze, cpp:92-348).
+// Returns false when the frame needs more than kMaxSteps steps.
+static bool build_pose_program(const roft_config& cfg, Sched& o, const roft_frame_input& in, FrameCtrl& c)
 {
-    const roft_config& cfg = e->cfg;
     const int slot = o.frame_idx % kTwistRing;
     c.twist_slot = slot;
     int n = 0;
-    auto add = [&](StepDesc sd) { if (n < kMaxSteps) c.steps[n++] = sd; };
+    bool overflow = false;
+    auto add = [&](StepDesc sd) { if (n < kMaxSteps) c.steps[n++] = sd; else overflow = true; };
+    auto vel_pop_front = [&]() { std::memmove(o.vel_buf, o.vel_buf + 1, sizeof(int) * (size_t)(--o.n_vel)); };
 
     // CartesianQuaternionMeasurement::freeze(Standard)  (cpp:176-347)
     const bool has_vel = cfg.use_velocity != 0;
@@ -502,8 +585,10 @@ static void build_pose_program(roft_engine* e, HostObject& o, const roft_frame_i
     else if (has_vel) type = ROFT_MEAS_VELOCITY;
     else if (is_pose) type = ROFT_MEAS_POSE;
     if (has_vel) {
-        o.vel_buf.push_back(slot);
-        while ((int)o.vel_buf.size() > kTwistRing - 2) o.vel_buf.pop_front();  // only the last D+1 are ever used
+        // (only the last pose_frames_between + 1 entries are ever replayed; the ring bounds the rest)
+        if (o.n_vel == kTwistRing) vel_pop_front();
+        o.vel_buf[o.n_vel++] = slot;
+        while (o.n_vel > kMaxSteps + 2) vel_pop_front();
         o.last_meas_slot = slot;
     }
     for (int i = 0; i < 3; ++i) c.pose_x[i] = in.pose_x[i];
@@ -522,10 +607,10 @@ static void build_pose_program(roft_engine* e, HostObject& o, const roft_frame_i
             bool pose_pending = true;
             for (;;) {
                 if (cfg.pose_frames_between > 0)
-                    while ((int)o.vel_buf.size() > cfg.pose_frames_between + 1) o.vel_buf.pop_front();
-                if (o.vel_buf.empty()) { o.vel_buf.push_back(o.last_meas_slot); break; }
-                const int ts = o.vel_buf.front();
-                o.vel_buf.pop_front();
+                    while (o.n_vel > cfg.pose_frames_between + 1) vel_pop_front();
+                if (o.n_vel == 0) { o.vel_buf[o.n_vel++] = o.last_meas_slot; break; }
+                const int ts = o.vel_buf[0];
+                vel_pop_front();
                 o.last_meas_slot = ts;
                 StepDesc r{};
                 r.op = 1;
@@ -582,133 +667,215 @@ static void build_pose_program(roft_engine* e, HostObject& o, const roft_frame_i
         add(sd);
     }
     c.n_steps = n;
+    return !overflow;
+}
+
+// device copy of one HOST image of `frame` (uploads once per distinct host pointer and frame)
+static int stage_host(roft_engine* e, int frame, const void* host, size_t bytes, const void** dev)
+{
+    StageFrame& sf = e->staging[frame % e->retain];
+    for (auto& pr : sf.seen)
+        if (pr.first == host) { *dev = pr.second; return ROFT_OK; }
+    if (sf.used == sf.bufs.size()) sf.bufs.push_back(new DevBuf<unsigned char>());
+    DevBuf<unsigned char>& b = *sf.bufs[sf.used++];
+    HIP_TRY(b.ensure(bytes));
+    HIP_TRY(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, e->up_stream));
+    e->stats.h2d_bytes += (long long)bytes;
+    e->had_uploads = true;
+    sf.seen.emplace_back(host, b.p);
+    *dev = b.p;
+    return ROFT_OK;
+}
+
+static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_obj, int T)
+{
+    const roft_config& cfg = e->cfg;
+    const size_t npix = (size_t)cfg.cam.width * cfg.cam.height;
+    const size_t fbytes = flow_bytes(e->arr.a.ffmt);
+    const int b = e->batch_counter;
+    FrameCtrl* blk = e->stage[b % roft_engine::kBatchRing];
+    int max_outliers = 0;
+    std::vector<int> n_outliers(n_obj, 0);
+
+    for (int t = 0; t < T; ++t) {
+        const int frame = e->frame_counter + t;
+        {   // the staging slot of this frame is free again: every frame that could read it has ended (in-flight bound)
+            StageFrame& sf = e->staging[frame % e->retain];
+            sf.used = 0;
+            sf.seen.clear();
+        }
+        for (int id = 0; id < n_obj; ++id) {
+            HostObject& ho = *e->objs[id];
+            Sched& o = ho.s;
+            const roft_frame_input& in = inputs[(size_t)t * n_obj + id];
+            FrameCtrl& c = blk[(size_t)t * n_obj + id];
+            clear_ctrl(c);
+            if (!in.depth) return fail(ROFT_ERR_INVALID, "cannot continue without a continuous depth stream (ROFTFilter.cpp:261-266)");
+            c.dt = (in.dt > 0.0) ? in.dt : cfg.sample_time;
+
+            // ---- inputs to device memory
+            const float* d_depth;
+            const void* d_flow = nullptr;
+            const uint8_t* d_mask = nullptr;
+            if (in.mem_kind == ROFT_MEM_DEVICE) {
+                d_depth = in.depth;
+                d_flow = in.flow;
+                d_mask = in.mask;
+                if ((reinterpret_cast<uintptr_t>(d_mask) & 15) || (reinterpret_cast<uintptr_t>(d_flow) & 7) ||
+                    (reinterpret_cast<uintptr_t>(d_depth) & 3))
+                    return fail(ROFT_ERR_INVALID, "device buffers must be aligned: mask 16 B, flow 8 B, depth 4 B");
+            } else if (in.mem_kind == ROFT_MEM_HOST) {
+                const void* p = nullptr;
+                if (int rc = stage_host(e, frame, in.depth, npix * sizeof(float), &p)) return rc;
+                d_depth = static_cast<const float*>(p);
+                if (in.flow) { if (int rc = stage_host(e, frame, in.flow, fbytes, &d_flow)) return rc; }
+                if (in.mask) {
+                    if (int rc = stage_host(e, frame, in.mask, npix, &p)) return rc;
+                    d_mask = static_cast<const uint8_t*>(p);
+                }
+            } else {
+                return fail(ROFT_ERR_INVALID, "mem_kind must be ROFT_MEM_HOST or ROFT_MEM_DEVICE");
+            }
+
+            // ---- ImageSegmentationOFAidedSource::step_frame (hpp:127-231), schedule part
+            c.slot_prev = (o.frame_idx + kPlaneSlots - 1) % kPlaneSlots;
+            c.slot_cur = o.frame_idx % kPlaneSlots;
+            c.has_new_mask = d_mask ? 1 : 0;
+            c.new_mask = d_mask;
+            c.first_mask = 0;
+            if (d_mask && !o.seg_available) { o.seg_available = true; c.first_mask = 1; }
+            if (!o.seg_available)
+                return fail(ROFT_ERR_STATE, "no segmentation mask delivered yet: the first frame must carry one");
+            const bool valid_flow = d_flow && !o.of_first_frame;
+            o.of_first_frame = false;
+            if (valid_flow) {
+                const int keep = std::min(o.n_hist, e->hist_cap - 1);
+                std::memmove(o.hist + 1, o.hist, sizeof(FlowEntry) * (size_t)keep);
+                o.hist[0] = FlowEntry{d_flow, o.frame_idx, -1};
+                o.n_hist = keep + 1;
+                o.flows_since_mask++;
+            }
+            // Flows that later flows did not push out of the history in time (dropped flow frames): the caller may
+            // recycle the buffer once the retention window closes, the reference keeps a clone -- so does the engine.
+            for (int j = 0; j < o.n_hist; ++j) {
+                FlowEntry& fe = o.hist[j];
+                if (fe.owned >= 0 || o.frame_idx - fe.frame < e->hist_cap) continue;
+                int k = -1;
+                for (size_t q = 0; q < ho.owned.size(); ++q) {
+                    bool referenced = ho.owned[q]->last_ref_frame >= e->completed_frames;
+                    for (int j2 = 0; j2 < o.n_hist && !referenced; ++j2) referenced = o.hist[j2].owned == (int)q;
+                    if (!referenced) { k = (int)q; break; }
+                }
+                if (k < 0) { ho.owned.push_back(new OwnedFlow()); k = (int)ho.owned.size() - 1; }
+                HIP_TRY(ho.owned[k]->buf.ensure(fbytes));
+                HIP_TRY(hipMemcpyAsync(ho.owned[k]->buf.p, fe.ptr, fbytes, hipMemcpyDeviceToDevice, e->up_stream));
+                e->had_uploads = true;
+                fe.ptr = ho.owned[k]->buf.p;
+                fe.owned = k;
+            }
+            c.flow_valid = valid_flow ? 1 : 0;
+            if (cfg.stamped_masks) {
+                // OpticalFlowQueueHandler: window of 30 stamped flows; get_buffer_region(mask stamp) = the flows stored
+                // after the first entry within 1 ms of it (OpticalFlowQueueHandler.cpp:18-58)
+                c.stamped = 1;
+                if (valid_flow) {
+                    if (o.n_stamps == 30) std::memmove(o.stamps, o.stamps + 1, sizeof(double) * (size_t)(--o.n_stamps));
+                    o.stamps[o.n_stamps++] = in.stamp;
+                }
+                c.n_region = 0;
+                if (d_mask)
+                    for (int i = 0; i < o.n_stamps; ++i)
+                        if (std::fabs(o.stamps[i] - in.mask_stamp) < 1e-3) { c.n_region = o.n_stamps - (i + 1); break; }
+            } else if (d_mask && !c.first_mask) {
+                // a delivered mask consumes (or, when empty and the number of frames between masks is unknown, drops)
+                // the buffered flows; with that number unknown ALL of them are chased (hpp:239-245)
+                if (cfg.mask_frames_between <= 0 && o.flows_since_mask > kMaxFlowHist)
+                    return fail(ROFT_ERR_CAPACITY, "more than ROFT_MAX_FLOW_CHASE flows buffered since the last mask");
+                o.flows_since_mask = valid_flow ? 1 : 0;   // upper bound: 0 after a consumed mask, 1 after an empty one
+            }
+            c.n_hist = o.n_hist;
+            for (int j = 0; j < o.n_hist; ++j) {
+                c.flow[j] = o.hist[j].ptr;
+                if (o.hist[j].owned >= 0) ho.owned[o.hist[j].owned]->last_ref_frame = frame;
+            }
+
+            // ---- ImageOpticalFlowMeasurement::freeze state machine (hpp:217-229)
+            bool data_in = true;  // segmentation is available at this point
+            if (!d_flow || o.flow_first_frame) {
+                o.flow_first_frame = false;
+                data_in = false;
+            }
+            c.vel_stage = data_in ? 1 : 0;
+            c.depth_prev = o.depth_prev;
+            c.depth_cur = d_depth;
+            // (data_in implies valid_flow, so c.flow[0] is this frame's flow whenever the velocity stage runs)
+            o.depth_prev = d_depth;
+
+            // ---- outlier-rejection features on the first frame (ROFTFilter.cpp:313-322)
+            if (cfg.use_pose_resync && !o.features_initialized) {
+                c.feat_write = o.feat_next;
+                o.feat_next = (o.feat_next + 1) % kFeatRing;
+                o.feat_slot = c.feat_write;
+                o.features_initialized = true;
+            }
+            c.frame_idx = frame;
+            if (!build_pose_program(cfg, o, in, c))
+                return fail(ROFT_ERR_CAPACITY, "more buffered velocities to replay than one frame's program holds (kMaxSteps)");
+            if (c.outlier_step >= 0) max_outliers = std::max(max_outliers, ++n_outliers[id]);
+            if (c.feat_write >= 0) {
+                e->any_feat = true;
+                // a feature set is re-used only when the batch that read or wrote it last has ended
+                const int last = o.feat_use[c.feat_write];
+                if (last >= 0 && last < b) { if (int rc = wait_batch(e, last)) return rc; }
+                o.feat_use[c.feat_write] = b;
+            }
+            if (c.feat_read >= 0 && c.outlier_step >= 0) o.feat_use[c.feat_read] = b;
+            if (c.outlier_step >= 0 && c.feat_read == c.feat_write) e->any_feat_now = true;
+            o.frame_idx++;
+        }
+    }
+    e->n_segments = 1 + max_outliers;
+    return ROFT_OK;
+}
+
+int roft_frames_submit(roft_engine* e, const roft_frame_input* inputs, int n_objects, int n_frames)
+{
+    if (!e || !inputs) return fail(ROFT_ERR_INVALID, "null argument");
+    if (n_objects != (int)e->objs.size() || n_objects <= 0) return fail(ROFT_ERR_INVALID, "one input per object and frame required");
+    if (n_frames < 1 || n_frames > e->T_max) return fail(ROFT_ERR_INVALID, "n_frames must be 1 .. roft_config::max_batch_frames");
+    if (e->submitted) return fail(ROFT_ERR_STATE, "previous batch not stepped yet");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    double hp_t = e->host_prof ? host_now_us() : 0.0;
+    // bound the batches in flight (see roft_engine::lead); this also frees the batch ring slot
+    if (int rc = wait_batch(e, e->batch_counter - e->lead)) return rc;
+    HP_MARK(e, 0, hp_t);   // time blocked on the GPU
+    e->backup.resize(e->objs.size());
+    for (size_t i = 0; i < e->objs.size(); ++i) e->backup[i] = e->objs[i]->s;
+    e->any_feat = e->any_feat_now = e->had_uploads = false;
+    const int rc = submit_frames(e, inputs, n_objects, n_frames);
+    HP_MARK(e, 1, hp_t);
+    int rc2 = ROFT_OK;
+    if (e->had_uploads) {
+        // HOST buffers belong to the caller again when this call returns
+        const int slot = e->batch_counter % roft_engine::kBatchRing;
+        hipError_t err = hipEventRecord(e->ev_up[slot], e->up_stream);
+        if (err == hipSuccess) err = hipEventSynchronize(e->ev_up[slot]);
+        if (err != hipSuccess) rc2 = fail(ROFT_ERR_DEVICE, std::string("input upload: ") + hipGetErrorString(err));
+    }
+    HP_MARK(e, 2, hp_t);
+    if (rc != ROFT_OK || rc2 != ROFT_OK) {
+        const std::string msg = g_last_error;
+        for (size_t i = 0; i < e->objs.size(); ++i) e->objs[i]->s = e->backup[i];
+        return fail(rc != ROFT_OK ? rc : rc2, msg);
+    }
+    e->cur_T = n_frames;
+    e->submitted = true;
+    return ROFT_OK;
 }
 
 int roft_frame_submit(roft_engine* e, const roft_frame_input* inputs, int n_inputs)
 {
-    if (!e || !inputs) return fail(ROFT_ERR_INVALID, "null argument");
-    if (n_inputs != (int)e->objs.size()) return fail(ROFT_ERR_INVALID, "one input per object required");
-    if (e->submitted) return fail(ROFT_ERR_STATE, "previous frame not stepped yet");
-    HIP_TRY(hipSetDevice(e->cfg.device));
-    const roft_config& cfg = e->cfg;
-    const size_t npix = (size_t)cfg.cam.width * cfg.cam.height;
-    const size_t fbytes = flow_bytes(e->arr.a.ffmt);
-
-    const int si = e->stage_idx;
-    double hp_t = e->host_prof ? host_now_us() : 0.0;
-    HIP_TRY(hipEventSynchronize(e->stage_ev[si]));  // staging block free again?
-    // bound the frames in flight (see roft_engine::kMaxInFlight): frame j - kMaxInFlight must have ended
-    if (e->frame_counter >= roft_engine::kMaxInFlight) {
-        // (the pose chain records its completion event on even frames only, see roft_step: wait for the newest even
-        //  frame that keeps at most kMaxInFlight frames in flight)
-        const int f = (e->frame_counter - roft_engine::kMaxInFlight + 1) & ~1;
-        HIP_TRY(hipEventSynchronize(e->ev_pose[f % roft_engine::kCtrlRing]));
-    }
-    HP_MARK(e, 0, hp_t);   // time blocked on the GPU (staging block / in-flight bound)
-    FrameCtrl* blk = e->stage[si];
-    e->max_steps = 0;
-    e->any_new_mask = e->any_outlier = e->any_feat = false;
-    e->any_feat_now = false;
-
-    for (int id = 0; id < n_inputs; ++id) {
-        HostObject& o = *e->objs[id];
-        const roft_frame_input& in = inputs[id];
-        FrameCtrl& c = blk[id];
-        clear_ctrl(c);
-        if (!in.depth) return fail(ROFT_ERR_INVALID, "cannot continue without a continuous depth stream (ROFTFilter.cpp:261-266)");
-        c.dt = (in.dt > 0.0) ? in.dt : cfg.sample_time;
-        const int rs = o.frame_idx % kPlaneSlots;
-
-        // ---- inputs to device memory
-        const float* d_depth;
-        const void* d_flow = nullptr;
-        const uint8_t* d_mask = nullptr;
-        if (in.mem_kind == ROFT_MEM_DEVICE) {
-            d_depth = in.depth;
-            d_flow = in.flow;
-            d_mask = in.mask;
-            if ((reinterpret_cast<uintptr_t>(d_mask) & 15) || (reinterpret_cast<uintptr_t>(d_flow) & 7) ||
-                (reinterpret_cast<uintptr_t>(d_depth) & 3))
-                return fail(ROFT_ERR_INVALID, "device buffers must be aligned: mask 16 B, flow 8 B, depth 4 B");
-        } else {
-            HIP_TRY(o.depth_ring[rs].ensure(npix));
-            HIP_TRY(hipMemcpyAsync(o.depth_ring[rs].p, in.depth, npix * sizeof(float), hipMemcpyHostToDevice, e->stream));
-            d_depth = o.depth_ring[rs].p;
-            if (in.flow) {
-                HIP_TRY(o.flow_ring[rs].ensure(fbytes));
-                HIP_TRY(hipMemcpyAsync(o.flow_ring[rs].p, in.flow, fbytes, hipMemcpyHostToDevice, e->stream));
-                d_flow = o.flow_ring[rs].p;
-            }
-            if (in.mask) {
-                HIP_TRY(o.mask_stage.ensure(npix));
-                HIP_TRY(hipMemcpyAsync(o.mask_stage.p, in.mask, npix, hipMemcpyHostToDevice, e->stream));
-                d_mask = o.mask_stage.p;
-            }
-        }
-
-        // ---- ImageSegmentationOFAidedSource::step_frame (hpp:127-231), schedule part
-        c.slot_prev = (o.frame_idx + kPlaneSlots - 1) % kPlaneSlots;
-        c.slot_cur = rs;
-        c.has_new_mask = d_mask ? 1 : 0;
-        c.new_mask = d_mask;
-        c.first_mask = 0;
-        if (d_mask && !o.seg_available) { o.seg_available = true; c.first_mask = 1; }
-        if (!o.seg_available)
-            return fail(ROFT_ERR_STATE, "no segmentation mask delivered yet: the first frame must carry one");
-        const bool valid_flow = d_flow && !o.of_first_frame;
-        o.of_first_frame = false;
-        if (valid_flow) {
-            o.flow_hist.push_front(d_flow);
-            while ((int)o.flow_hist.size() > kMaxFlowHist) o.flow_hist.pop_back();
-        }
-        c.flow_valid = valid_flow ? 1 : 0;
-        if (cfg.stamped_masks) {
-            // OpticalFlowQueueHandler: window of 30 stamped flows; get_buffer_region(mask stamp) = the flows stored
-            // after the first entry within 1 ms of it (OpticalFlowQueueHandler.cpp:18-58)
-            c.stamped = 1;
-            if (valid_flow) {
-                o.flow_stamps.push_back(in.stamp);
-                while (o.flow_stamps.size() > 30) o.flow_stamps.pop_front();
-            }
-            c.n_region = 0;
-            if (d_mask)
-                for (size_t i = 0; i < o.flow_stamps.size(); ++i)
-                    if (std::fabs(o.flow_stamps[i] - in.mask_stamp) < 1e-3) { c.n_region = (int)(o.flow_stamps.size() - (i + 1)); break; }
-        }
-        for (int j = 0; j < kMaxFlowHist; ++j) c.flow[j] = j < (int)o.flow_hist.size() ? o.flow_hist[j] : nullptr;
-        if (c.has_new_mask) e->any_new_mask = true;
-
-        // ---- ImageOpticalFlowMeasurement::freeze state machine (hpp:217-229)
-        bool data_in = true;  // segmentation is available at this point
-        if (!d_flow || o.flow_first_frame) {
-            o.flow_first_frame = false;
-            data_in = false;
-        }
-        c.vel_stage = data_in ? 1 : 0;
-        c.depth_prev = o.depth_prev;
-        c.depth_cur = d_depth;
-        // (data_in implies valid_flow, so c.flow[0] is this frame's flow whenever the velocity stage runs)
-        o.depth_prev = d_depth;
-
-        // ---- outlier-rejection features on the first frame (ROFTFilter.cpp:313-322)
-        if (cfg.use_pose_resync && !o.features_initialized) {
-            c.feat_write = o.feat_next;
-            o.feat_next = (o.feat_next + 1) % kFeatRing;
-            o.feat_slot = c.feat_write;
-            o.features_initialized = true;
-        }
-        c.frame_idx = e->frame_counter;
-        build_pose_program(e, o, in, c);
-        e->max_steps = std::max(e->max_steps, c.n_steps);
-        if (c.outlier_step >= 0) e->any_outlier = true;
-        if (c.feat_write >= 0) e->any_feat = true;
-        if (c.outlier_step >= 0 && c.feat_read == c.feat_write) e->any_feat_now = true;
-        o.frame_idx++;
-    }
-    e->cur = blk;
-    e->submitted = true;
-    HP_MARK(e, 1, hp_t);
-    return ROFT_OK;
+    return roft_frames_submit(e, inputs, n_inputs, 1);
 }
 
 // Timing marks accumulate over any number of steps until roft_engine_get_timing() collects them:
@@ -758,104 +925,111 @@ static void tmark_kernel(roft_engine* e, const char* name, int which, hipEvent_t
     *stop = e->tev[idx + 1];
 }
 
-int roft_step(roft_engine* e)
+static int step_batch(roft_engine* e)
 {
-    if (!e) return fail(ROFT_ERR_INVALID, "null engine");
-    if (!e->submitted) return fail(ROFT_ERR_STATE, "roft_frame_submit must precede roft_step");
-    HIP_TRY(hipSetDevice(e->cfg.device));
+    constexpr int R = roft_engine::kBatchRing;
     EngineArrays a = e->arr.a;
     hipStream_t s = e->stream, sv = e->vel_stream, sp = e->pose_stream;
-    const int si = e->stage_idx;
-    constexpr int R = roft_engine::kCtrlRing;
-    const int ci = e->frame_counter % R;
-    const bool multi = e->two_streams;
+    const int slot = e->batch_counter % R;
+    const int T = e->cur_T;
+    const bool multi = e->multi;
+    const bool full = e->timing && e->timing_level > 1;   // markers between the launches carry the events' roles as well
+    long long& launches = e->stats.launches;
+    long long& evops = e->stats.event_ops;
     double hp_t = e->host_prof ? host_now_us() : 0.0;
-    // (How far the image chains lead the pose chain is bounded on the HOST: roft_frame_submit(k) returns only when the
-    //  pose chain of frame k - kMaxInFlight has ended.  Every event operation on the mask chain's stream costs ~8 us
-    //  of that chain -- it is the longest one -- so it gets exactly one per frame, below.)
-    HP_MARK(e, 2, hp_t);
-    a.ctrl = e->dctrl[ci].p;
+    a.T = T;
+    a.ctrl = e->dctrl[slot].p;
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
-    if (e->kernel_upload) {
-        const size_t n16 = sizeof(FrameCtrl) * a.n_obj / 16;
-        // (the previous frame's FrameCtrl block is still in the device ring)
-        const FrameCtrl* prev = (e->frame_counter > 0) ? e->dctrl[(e->frame_counter - 1) % R].p : nullptr;
-        // ONE event of the mask chain per frame, bound to this kernel's dispatch: "FrameCtrl (+ host input copies) of
-        // frame k on the device and the mask chain of frame k-1 complete" -- what the velocity chain of frame k needs,
-        // and what frees the pinned staging block.  (Events that complete with a kernel cost neither the barrier
-        // packet nor the host call of a hipEventRecord behind it.)
-        hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
-                              nullptr, e->stage_ev[si], 0, reinterpret_cast<const uint4*>(e->cur),
-                              reinterpret_cast<uint4*>(a.ctrl), n16, prev, a.state, a.n_obj);
-    } else {
-        HIP_TRY(hipMemcpyAsync(a.ctrl, e->cur, sizeof(FrameCtrl) * a.n_obj, hipMemcpyHostToDevice, s));
-        HIP_TRY(hipEventRecord(e->stage_ev[si], s));
-    }
-    e->stage_idx = (si + 1) % roft_engine::kStage;
-    HP_MARK(e, 3, hp_t);
 
-    // ---- velocity chain: needs FrameCtrl (+ host input copies) of this frame and the mask planes of the previous one
-    if (multi) HIP_TRY(hipStreamWaitEvent(sv, e->stage_ev[si], 0));
+    // ---- mask chain: control blocks of the batch, then every object's masks frame after frame
+    if (multi && e->had_uploads) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }
+    {
+        const size_t n16 = sizeof(FrameCtrl) * (size_t)a.n_obj * T / 16;
+        // Events that complete with a kernel (hipExtLaunchKernelGGL stop events) cost neither the barrier packet nor
+        // the host call of a hipEventRecord behind it.
+        hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
+                              nullptr, (multi && T == 1) ? e->ev_ctrl[slot] : nullptr, 0,
+                              reinterpret_cast<const uint4*>(e->stage[slot]), reinterpret_cast<uint4*>(a.ctrl), n16);
+        ++launches;
+    }
+    HP_MARK(e, 3, hp_t);
+    tmark(e, nullptr, 0);
+    launch_mask_chain(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, s, (multi && T > 1 && !full) ? e->ev_mask[slot] : nullptr);
+    ++launches;
+    tmark(e, "mask_chain", 0);
+    if (multi && T > 1 && full) { HIP_TRY(hipEventRecord(e->ev_mask[slot], s)); ++evops; }
+    // the pose chain waits for the features only when a test can read a set buffered in this very batch
+    const bool want_ev_feat = multi && e->any_feat && (T > 1 || e->any_feat_now);
+    if (e->any_feat) {
+        launch_features(a, s, (want_ev_feat && !full) ? e->ev_feat[slot] : nullptr);
+        ++launches;
+        tmark(e, "features", 0);
+        if (want_ev_feat && full) { HIP_TRY(hipEventRecord(e->ev_feat[slot], s)); ++evops; }
+    }
+    HP_MARK(e, 4, hp_t);
+
+    // ---- velocity chain: the measurement of frame k needs the control blocks and the mask planes of frame k-1 --
+    //      the previous batch's for a one-frame batch (ordered by the upload, which follows that batch's mask chain),
+    //      this batch's mask chain otherwise
+    if (multi) { HIP_TRY(hipStreamWaitEvent(sv, T == 1 ? e->ev_ctrl[slot] : e->ev_mask[slot], 0)); ++evops; }
     const int radius = (int)(size_t)e->cfg.subsampling_radius;
     {
         // the roofline kernel is timed by a start / stop event pair on its own dispatch: its duration as rocprofv3
         // reports it, with no marker packets around it
         hipEvent_t k1_start = nullptr, k1_stop = nullptr;
         tmark_kernel(e, "flow_measure", 2, &k1_start, &k1_stop);
-        launch_flow_measure(a, e->cfg.depth_maximum, radius, false, sv, k1_start, k1_stop);
+        launch_flow_measure(a, e->cfg.depth_maximum, radius, sv, k1_start, k1_stop);
+        ++launches;
     }
-    const bool time_skf = e->timing && e->timing_level > 1;   // a marker behind skf then carries ev_vel's role as well
-    launch_skf(a, e->cfg.flow_weighting, sv, (multi && !time_skf) ? e->ev_vel[ci] : nullptr);
-    tmark(e, "skf", 2);
-    if (multi && time_skf) HIP_TRY(hipEventRecord(e->ev_vel[ci], sv));
-
-    HP_MARK(e, 4, hp_t);
-    // ---- mask chain
-    tmark(e, nullptr, 0);
-    if (e->any_new_mask) { launch_mask_ingest(a, s); tmark(e, "mask_ingest", 0); }
-    launch_mask_propagate(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, !e->kernel_upload, s);
-    tmark(e, "mask_propagate", 0);
-    // ev_mask: only when the pose chain waits for this frame's features
-    const bool want_ev_mask = multi && e->any_feat_now;
-    if (e->any_feat) {
-        launch_features(a, s, want_ev_mask ? e->ev_mask[ci] : nullptr);
-        tmark(e, "features", 0);
-    } else if (want_ev_mask) {
-        HIP_TRY(hipEventRecord(e->ev_mask[ci], s));
-    }
-
+    launch_skf_chain(a, e->cfg.flow_weighting, sv, (multi && !full) ? e->ev_vel[slot] : nullptr);
+    ++launches;
+    tmark(e, "skf_chain", 2);
+    if (multi && full) { HIP_TRY(hipEventRecord(e->ev_vel[slot], sv)); ++evops; }
     HP_MARK(e, 5, hp_t);
-    // ---- pose chain (needs this frame's twist and mask planes; the next frames' image chains do not wait for it)
+
+    // ---- pose chain (needs the twists of the batch; the next batches' image chains do not wait for it)
     if (multi) {
-        HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[ci], 0));
-        // The pose chain reads mask-chain products only through the feature ring.  The set an outlier test reads was
-        // buffered at an earlier frame -- covered by ev_vel, since the velocity chain of frame k waited for the mask
-        // chain of frame k-1 -- unless it is this very frame's (outlier rejection without re-sync, or the first frame).
-        if (e->any_feat_now) HIP_TRY(hipStreamWaitEvent(sp, e->ev_mask[ci], 0));
+        HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[slot], 0));
+        ++evops;
+        // The pose chain reads mask-chain products only through the feature ring.  With one-frame batches the set an
+        // outlier test reads was buffered by an earlier batch -- covered by ev_vel, since the velocity chain waited for
+        // the mask chain of the batch before -- unless it is this very frame's.
+        if (want_ev_feat) { HIP_TRY(hipStreamWaitEvent(sp, e->ev_feat[slot], 0)); ++evops; }
     }
     tmark(e, nullptr, 1);
-    // step 0 (possibly followed by the outlier render + test), then all remaining steps in one launch
-    // Completion event of the pose chain: only the host reads it (bound on the frames in flight) -- every other frame
-    // is enough; it rides on the chain's last kernel of the frame.
-    hipEvent_t ev_pose = ((e->frame_counter & 1) == 0) ? e->ev_pose[ci] : nullptr;
-    if (e->max_steps > 0) {
-        const bool replay = e->max_steps > 1;
-        launch_ukf_step(a, 0, 1, e->cfg.ut, sp, (!e->any_outlier && !replay) ? ev_pose : nullptr);
-        tmark(e, "ukf_step", 1);
-        if (e->any_outlier) { launch_outlier(a, sp, !replay ? ev_pose : nullptr); tmark(e, "outlier_render_likelihood", 1); }
-        if (replay) {
-            launch_ukf_step(a, 1, e->max_steps, e->cfg.ut, sp, ev_pose);
-            tmark(e, "ukf_replay_steps", 1);
+    for (int seg = 0; seg < e->n_segments; ++seg) {
+        const bool last = seg == e->n_segments - 1;
+        launch_ukf_chain(a, e->cfg.ut, seg == 0, sp, (last && !full) ? e->ev_done[slot] : nullptr);
+        ++launches;
+        tmark(e, "ukf_chain", 1);
+        if (!last) {
+            launch_outlier(a, sp, nullptr);
+            launches += 3;
+            tmark(e, "outlier_render_likelihood", 1);
         }
-    } else if (ev_pose) {
-        HIP_TRY(hipEventRecord(ev_pose, sp));
     }
+    if (full) { HIP_TRY(hipEventRecord(e->ev_done[slot], sp)); ++evops; }
     HP_MARK(e, 6, hp_t);
-    if (e->host_prof) e->hp_frames++;
+    if (e->host_prof) e->hp_batches++;
     HIP_TRY(hipGetLastError());
-    e->frame_counter++;
-    e->submitted = false;
     return ROFT_OK;
+}
+
+int roft_step(roft_engine* e)
+{
+    if (!e) return fail(ROFT_ERR_INVALID, "null engine");
+    if (!e->submitted) return fail(ROFT_ERR_STATE, "roft_frame_submit must precede roft_step");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const int rc = step_batch(e);
+    // (a failed step leaves the engine consistent as far as the host can tell: the batch counts as enqueued)
+    const int slot = e->batch_counter % roft_engine::kBatchRing;
+    e->frame_counter += e->cur_T;
+    e->batch_end_frame[slot] = e->frame_counter;
+    e->batch_counter++;
+    e->stats.frames += e->cur_T;
+    e->stats.batches++;
+    e->submitted = false;
+    return rc;
 }
 
 int roft_sync(roft_engine* e)
@@ -863,10 +1037,13 @@ int roft_sync(roft_engine* e)
     if (!e) return fail(ROFT_ERR_INVALID, "null engine");
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->two_streams) {
+    if (e->multi) {
         HIP_TRY(hipStreamSynchronize(e->vel_stream));
         HIP_TRY(hipStreamSynchronize(e->pose_stream));
+        HIP_TRY(hipStreamSynchronize(e->up_stream));
     }
+    e->completed_batches = e->batch_counter;
+    e->completed_frames = e->frame_counter;
     return ROFT_OK;
 }
 
@@ -879,7 +1056,7 @@ int roft_get_state(roft_engine* e, int id, double pose13[13], double P12[144], d
     static_assert(B_CORR == 0 && offsetof(ObjState, v_mean) == 0, "roft_get_state copies the head of ObjState");
     constexpr size_t kHead = offsetof(ObjState, belief) + sizeof(PoseBelief);
     if (!e->state_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->state_host), sizeof(ObjState)));
-    hipStream_t last = e->two_streams ? e->pose_stream : e->stream;
+    hipStream_t last = e->multi ? e->pose_stream : e->stream;
     HIP_TRY(hipMemcpyAsync(e->state_host, e->arr.state.p + id, kHead, hipMemcpyDeviceToHost, last));
     if (int rc = roft_sync(e)) return rc;
     const ObjState* st = e->state_host;
@@ -933,8 +1110,8 @@ int roft_engine_get_log(roft_engine* e, int first_frame, int n_frames, roft_obje
 int roft_get_mask(roft_engine* e, int id, uint8_t* mask_out)
 {
     if (!e || !mask_out || id < 0 || id >= (int)e->objs.size()) return fail(ROFT_ERR_INVALID, "bad arguments");
-    HostObject& o = *e->objs[id];
-    if (o.frame_idx == 0) return fail(ROFT_ERR_STATE, "no frame processed yet");
+    const Sched& o = e->objs[id]->s;
+    if (o.frame_idx == 0 || e->submitted) return fail(ROFT_ERR_STATE, "no stepped frame to read the mask of");
     if (int rc = roft_sync(e)) return rc;
     const EngineArrays& a = e->arr.a;
     const int slot = (o.frame_idx - 1) % kPlaneSlots;
@@ -1015,13 +1192,14 @@ struct OpCtx {
         ff.rows = cam.height / ff.grid;
         ff.scale = fscale;
         if (!ready || W != cam.width || H != cam.height || radius != radius_) {
-            if (int rc = arr.alloc(1, make_cam(cam), ff, std::max(radius_, 1))) return rc;
+            if (int rc = arr.alloc(1, 1, make_cam(cam), ff, std::max(radius_, 1))) return rc;
             W = cam.width; H = cam.height; radius = radius_;
             ready = true;
         }
         arr.a.cam = make_cam(cam);
         arr.a.ffmt = ff;
         arr.a.n_obj = 1;
+        arr.a.T = 1;
         ObjState st;
         init_state(st);
         HIP_TRY(hipMemcpyAsync(arr.state.p, &st, sizeof(st), hipMemcpyHostToDevice, stream));
@@ -1081,9 +1259,9 @@ int roft_flow_measurement(const roft_camera* cam, const uint8_t* prev_mask, cons
     fc.vel_stage = 1;
     if (int rc = upload_ctrl(c, fc)) return rc;
     launch_mask_ingest(c.arr.a, c.stream);
-    launch_flow_measure(c.arr.a, depth_max, r, false, c.stream);
+    launch_flow_measure(c.arr.a, depth_max, r, c.stream);
     int n = 0;
-    HIP_TRY(hipMemcpyAsync(&n, &c.arr.state.p->n_flow_points, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipMemcpyAsync(&n, c.arr.a.npts, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     HIP_TRY(hipStreamSynchronize(c.stream));
     HIP_TRY(hipGetLastError());
     *n_out = n;
@@ -1092,7 +1270,7 @@ int roft_flow_measurement(const roft_camera* cam, const uint8_t* prev_mask, cons
         HIP_TRY(c.b3.ensure(sizeof(int32_t) * 2 * n));
         HIP_TRY(c.b4.ensure(sizeof(double) * 2 * n));
         HIP_TRY(c.b5.ensure(sizeof(double) * 12 * n));
-        launch_expand_yh(c.arr.a.recs, &c.arr.state.p->n_flow_points, c.arr.a.cam, dt, reinterpret_cast<int32_t*>(c.b3.p),
+        launch_expand_yh(c.arr.a.recs, c.arr.a.npts, c.arr.a.cam, dt, reinterpret_cast<int32_t*>(c.b3.p),
                          reinterpret_cast<double*>(c.b4.p), reinterpret_cast<double*>(c.b5.p), n, c.stream);
         HIP_TRY(hipMemcpyAsync(uv, c.b3.p, sizeof(int32_t) * 2 * n, hipMemcpyDeviceToHost, c.stream));
         HIP_TRY(hipMemcpyAsync(y, c.b4.p, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, c.stream));
@@ -1168,13 +1346,47 @@ int roft_skf_correct(const double x_pred[6], const double P_pred[36], int N, con
     return ROFT_OK;
 }
 
+int roft_skf_correct_points(const roft_camera* cam, double dt, const double x_pred[6], const double P_pred[36], int N,
+                            const int32_t* uv, const float* z, const float* flow_xy, const double Rdiag[2], int reweight,
+                            double x_out[6], double P_out[36], int* status_out)
+{
+    if (!cam || !x_pred || !P_pred || !Rdiag || !x_out || !P_out || (N > 0 && (!uv || !z || !flow_xy)))
+        return fail(ROFT_ERR_INVALID, "null argument");
+    OpCtx& c = op();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (int rc = op_simple_prepare(c)) return rc;
+    double in[44];
+    std::memcpy(in, x_pred, 48);
+    std::memcpy(in + 6, P_pred, 288);
+    in[42] = Rdiag[0]; in[43] = Rdiag[1];
+    if (int rc = to_dev(c.b0, in, 44, c.stream)) return rc;
+    const int n = std::max(N, 0);
+    std::vector<FlowRec> recs(n);
+    for (int i = 0; i < n; ++i) recs[i] = FlowRec{uv[2 * i], uv[2 * i + 1], z[i], flow_xy[2 * i], flow_xy[2 * i + 1]};
+    if (int rc = to_dev(c.b1, recs.data(), (size_t)n, c.stream)) return rc;
+    HIP_TRY(c.b3.ensure(sizeof(double) * 3 * std::max(n, 1)));
+    HIP_TRY(c.b4.ensure(sizeof(double) * 44));
+    double* d = reinterpret_cast<double*>(c.b0.p);
+    double* o = reinterpret_cast<double*>(c.b4.p);
+    launch_skf_records(d, d + 6, N, reinterpret_cast<const FlowRec*>(c.b1.p), make_cam(*cam), dt, d + 42, reweight,
+                       reinterpret_cast<double*>(c.b3.p), o, o + 6, reinterpret_cast<int*>(o + 42), c.stream);
+    double out[44];
+    HIP_TRY(hipMemcpyAsync(out, o, sizeof(out), hipMemcpyDeviceToHost, c.stream));
+    HIP_TRY(hipStreamSynchronize(c.stream));   // (also keeps `recs` alive until its upload has been read)
+    HIP_TRY(hipGetLastError());
+    std::memcpy(x_out, out, 48);
+    std::memcpy(P_out, out + 6, 288);
+    if (status_out) std::memcpy(status_out, out + 42, sizeof(int));
+    return ROFT_OK;
+}
+
 int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int n_flows, int frames_between)
 {
     if (!mask || (n_flows > 0 && !flows)) return fail(ROFT_ERR_INVALID, "null argument");
     int start = 0;
     if (frames_between > 0) start = std::max(0, n_flows - frames_between);
     const int used = n_flows - start;
-    if (used > kMaxFlowHist) return fail(ROFT_ERR_INVALID, "more than 6 flow frames per propagation are not supported");
+    if (used > kMaxFlowHist) return fail(ROFT_ERR_INVALID, "more than ROFT_MAX_FLOW_CHASE flow frames per propagation are not supported");
     OpCtx& c = op();
     std::lock_guard<std::mutex> lk(c.mu);
     roft_camera cam{W, H, 1.0, 1.0, 0.0, 0.0};
@@ -1196,6 +1408,7 @@ int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int
     fc.has_new_mask = 1;
     fc.new_mask = c.b0.p;
     fc.force_mode = 3;
+    fc.n_hist = used;
     fc.slot_prev = 1;
     fc.slot_cur = 0;
     fc.flow_valid = 0;
@@ -1205,8 +1418,7 @@ int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int
     st.fbuf_n = used;
     HIP_TRY(hipMemcpyAsync(c.arr.state.p, &st, sizeof(st), hipMemcpyHostToDevice, c.stream));
     if (int rc = upload_ctrl(c, fc)) return rc;
-    launch_mask_ingest(c.arr.a, c.stream);
-    launch_mask_propagate(c.arr.a, frames_between, 1, true, c.stream);
+    launch_mask_chain(c.arr.a, frames_between, 1, c.stream);
     HIP_TRY(c.b2.ensure(npix));
     launch_planes_to_mask(c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 0), c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 1),
                           (int)npix, c.b2.p, c.stream);
@@ -1286,7 +1498,7 @@ static int op_ukf(const double mean[13], const double P[144], const double* Q81,
     if (err != hipSuccess) { delete st; HIP_TRY(err); }
     c.arr.a.n_obj = 1;
     if (int rc = upload_ctrl(c, fc)) { delete st; return rc; }
-    launch_ukf_step(c.arr.a, 0, 1, *ut, c.stream);
+    launch_ukf_chain(c.arr.a, *ut, true, c.stream);
     err = hipMemcpyAsync(st, c.arr.state.p, sizeof(ObjState), hipMemcpyDeviceToHost, c.stream);
     if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
     if (err == hipSuccess) err = hipGetLastError();
@@ -1379,6 +1591,13 @@ int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint
     fc.feat_read = 0;
     fc.outlier_step = 0;
     if (int rc = upload_ctrl(c, fc)) return rc;
+    {
+        ObjState st0;
+        init_state(st0);
+        st0.pending_frame = 0;   // the test of frame 0 is pending
+        HIP_TRY(hipMemcpyAsync(c.arr.state.p, &st0, sizeof(st0), hipMemcpyHostToDevice, c.stream));
+        HIP_TRY(hipStreamSynchronize(c.stream));
+    }
     launch_mask_ingest(c.arr.a, c.stream);
     launch_features(c.arr.a, c.stream);
     // likelihood only (the z-buffers are already filled)
@@ -1425,15 +1644,13 @@ extern "C" int roft_debug_plan(const roft_config* cfg, const int* pose_valid, in
                                int* outlier, int* slots /* n_frames x kMaxSteps, -1 padded */)
 {
     if (!cfg || !pose_valid || n_frames < 0) return ROFT_ERR_INVALID;
-    roft_engine e;
-    e.cfg = *cfg;
-    HostObject o;
+    Sched o;
     roft_frame_input in{};
     for (int k = 0; k < n_frames; ++k) {
         FrameCtrl c;
         clear_ctrl(c);
         in.pose_valid = pose_valid[k];
-        build_pose_program(&e, o, in, c);
+        if (!build_pose_program(*cfg, o, in, c)) return ROFT_ERR_CAPACITY;
         o.frame_idx++;
         if (n_steps) n_steps[k] = c.n_steps;
         int nc = 0;

@@ -6,8 +6,9 @@
 //   keep   = flow finite and |.| < 1e9 (OpticalFlowUtilities.h:19-22) and 0 < Z < depth_maximum
 //   y_i    = flow / scale;  H_i = T * [interaction matrix rows]  (:272-282)
 //
-// MI355X design: one workgroup of 16 waves per object.  The previous frame's `obj` bit plane (W*H/8 bytes) is
-// staged in LDS once.  Plane words are in row-major order, so one block scan over per-thread popcounts of
+// MI355X design: one workgroup of 16 waves per (object, frame of the batch) -- the measurement of a frame needs only
+// the previous frame's mask plane, depth and the flow, none of the filter state, so all frames of a batch run in ONE
+// launch (grid n_obj x T).  The previous frame's `obj` bit plane (W*H/8 bytes) is held in registers (or staged in LDS).  Plane words are in row-major order, so one block scan over per-thread popcounts of
 // contiguous word chunks gives every word its starting rank; a word holds candidate c iff c*R falls into its rank
 // interval, and the pixel is the (c*R - start)-th set bit of the word.  The candidate pixels go through a small
 // list (LDS, or the global scratch for very large masks), then ONE thread per candidate gathers depth and flow --
@@ -83,11 +84,11 @@ __device__ __forceinline__ void emit_word(uint32_t bits, int w, int& rank, int& 
 
 // One thread per candidate: pixel of the work item, gather depth + flow, validity, ordered compaction (rank order is
 // thread order).
-__device__ __forceinline__ int gather_candidates(const EngineArrays& a, const float* depth, const void* flow, int obj,
+__device__ __forceinline__ int gather_candidates(const EngineArrays& a, const float* depth, const void* flow, int slot,
                                                  const uint2* list, int C, double depth_max, int* s_wave)
 {
     const int W = a.cam.W, wpr = a.cam.wpr;
-    FlowRec* recs = a.recs + (size_t)obj * a.cand_cap;
+    FlowRec* recs = a.recs + (size_t)slot * a.cand_cap;
     int base = 0;
     for (int c0 = 0; c0 < C; c0 += blockDim.x) {
         const int ci = c0 + threadIdx.x;
@@ -129,22 +130,21 @@ __device__ __forceinline__ FlowCtrl load_flow_ctrl(const FrameCtrl& c)
 // Plane words held in registers: thread t owns the PER4 consecutive 16-byte groups starting at t * PER4 (no LDS copy
 // of the plane at all).  Needs plane_words % 4 == 0 and plane_words / 4 <= PER4 * kFlowThreads.
 template <int PER4>
-__global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays a, double depth_max, int radius,
-                                                                   int mask_finish)
+__global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays a, double depth_max, int radius)
 {
     __shared__ int s_wave[16];
     __shared__ uint2 s_item[kCandLds];
-    const int obj = blockIdx.x;
-    const FrameCtrl& c = a.ctrl[obj];
+    const int obj = blockIdx.x, slot = blockIdx.y * a.n_obj + obj;   // slot = (frame of the batch, object)
+    const FrameCtrl& c = a.ctrl[slot];
+#ifdef ROFT_K1_PROFILE
     ObjState& st = a.state[obj];
+#endif
 #ifdef ROFT_K1_PROFILE
     long long k1_t0 = wall_clock64();
 #endif
     const FlowCtrl k = load_flow_ctrl(c);
-    // the mask stage's per-object bookkeeping rides along when asked to; this kernel reads none of the fields it touches
-    if (mask_finish && threadIdx.x == 0) mask_bookkeeping(c, st);
     if (!k.vel_stage) {
-        if (threadIdx.x == 0) st.n_flow_points = -1;
+        if (threadIdx.x == 0) a.npts[slot] = -1;
         return;
     }
     // 1. this thread's words of the previous frame's obj plane (unconditional loads, all in flight together)
@@ -181,26 +181,23 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays
         }
         __syncthreads();   // the list is written and read by this workgroup only
         K1TICK(3);
-        return gather_candidates(a, k.depth, k.flow, obj, list, C, depth_max, s_wave);
+        return gather_candidates(a, k.depth, k.flow, slot, list, C, depth_max, s_wave);
     };
-    const int n = (C <= kCandLds) ? tail(s_item) : tail(reinterpret_cast<uint2*>(a.cand + (size_t)obj * a.cand_cap));
+    const int n = (C <= kCandLds) ? tail(s_item) : tail(reinterpret_cast<uint2*>(a.cand + (size_t)slot * a.cand_cap));
     K1TICK(5);
-    if (threadIdx.x == 0) st.n_flow_points = n;
+    if (threadIdx.x == 0) a.npts[slot] = n;
 }
 
 // Any plane size: the plane is staged in dynamic LDS, every thread walks a contiguous chunk of its words.
-__global__ __launch_bounds__(kFlowThreads) void flow_measure_lds_kernel(EngineArrays a, double depth_max, int radius,
-                                                                       int mask_finish)
+__global__ __launch_bounds__(kFlowThreads) void flow_measure_lds_kernel(EngineArrays a, double depth_max, int radius)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_wave[16];
     __shared__ uint2 s_item[kCandLds];
-    const int obj = blockIdx.x;
-    const FrameCtrl& c = a.ctrl[obj];
-    ObjState& st = a.state[obj];
-    if (mask_finish && threadIdx.x == 0) mask_bookkeeping(c, st);
+    const int obj = blockIdx.x, slot = blockIdx.y * a.n_obj + obj;
+    const FrameCtrl& c = a.ctrl[slot];
     if (!c.vel_stage) {
-        if (threadIdx.x == 0) st.n_flow_points = -1;
+        if (threadIdx.x == 0) a.npts[slot] = -1;
         return;
     }
     uint32_t* s_plane = reinterpret_cast<uint32_t*>(smem);
@@ -217,38 +214,37 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_lds_kernel(EngineAr
     int M;
     int rank = block_exclusive_scan(cnt, s_wave, &M);
     const int C = (M + radius - 1) / radius;
-    uint2* list = (C <= kCandLds) ? s_item : reinterpret_cast<uint2*>(a.cand + (size_t)obj * a.cand_cap);
+    uint2* list = (C <= kCandLds) ? s_item : reinterpret_cast<uint2*>(a.cand + (size_t)slot * a.cand_cap);
     if (cnt) {
         int ci = (rank + radius - 1) / radius, next = ci * radius;
         for (int w = w0; w < w1; ++w) emit_word(s_plane[w], w, rank, next, ci, radius, list);
     }
     __syncthreads();
-    const int n = gather_candidates(a, c.depth_prev, c.flow[0], obj, list, C, depth_max, s_wave);
-    if (threadIdx.x == 0) st.n_flow_points = n;
+    const int n = gather_candidates(a, c.depth_prev, c.flow[0], slot, list, C, depth_max, s_wave);
+    if (threadIdx.x == 0) a.npts[slot] = n;
 }
 
 template <int PER4>
-static void launch_flow_reg(const EngineArrays& a, double depth_max, int radius, int mask_finish, hipStream_t s,
-                            hipEvent_t start, hipEvent_t stop)
+static void launch_flow_reg(const EngineArrays& a, double depth_max, int radius, hipStream_t s, hipEvent_t start,
+                            hipEvent_t stop)
 {
-    hipExtLaunchKernelGGL(flow_measure_kernel<PER4>, dim3(a.n_obj), dim3(kFlowThreads), 0, s, start, stop, 0, a, depth_max,
-                          radius, mask_finish);
+    hipExtLaunchKernelGGL(flow_measure_kernel<PER4>, dim3(a.n_obj, a.T), dim3(kFlowThreads), 0, s, start, stop, 0, a,
+                          depth_max, radius);
 }
 
-void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bool mask_finish, hipStream_t s,
-                         hipEvent_t start, hipEvent_t stop)
+void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, hipStream_t s, hipEvent_t start,
+                         hipEvent_t stop)
 {
-    const int mf = mask_finish ? 1 : 0;
     const size_t n4 = a.plane_words / 4;
     const int per4 = (int)((n4 + kFlowThreads - 1) / kFlowThreads);
     if (a.plane_words % 4 == 0 && per4 <= 10) {
-        if (per4 <= 1) launch_flow_reg<1>(a, depth_max, radius, mf, s, start, stop);
-        else if (per4 <= 2) launch_flow_reg<2>(a, depth_max, radius, mf, s, start, stop);
-        else if (per4 <= 3) launch_flow_reg<3>(a, depth_max, radius, mf, s, start, stop);
-        else if (per4 <= 4) launch_flow_reg<4>(a, depth_max, radius, mf, s, start, stop);
-        else if (per4 <= 6) launch_flow_reg<6>(a, depth_max, radius, mf, s, start, stop);
-        else if (per4 <= 8) launch_flow_reg<8>(a, depth_max, radius, mf, s, start, stop);
-        else launch_flow_reg<10>(a, depth_max, radius, mf, s, start, stop);
+        if (per4 <= 1) launch_flow_reg<1>(a, depth_max, radius, s, start, stop);
+        else if (per4 <= 2) launch_flow_reg<2>(a, depth_max, radius, s, start, stop);
+        else if (per4 <= 3) launch_flow_reg<3>(a, depth_max, radius, s, start, stop);
+        else if (per4 <= 4) launch_flow_reg<4>(a, depth_max, radius, s, start, stop);
+        else if (per4 <= 6) launch_flow_reg<6>(a, depth_max, radius, s, start, stop);
+        else if (per4 <= 8) launch_flow_reg<8>(a, depth_max, radius, s, start, stop);
+        else launch_flow_reg<10>(a, depth_max, radius, s, start, stop);
         return;
     }
     const size_t lds = (a.plane_words * 4 + 15) & ~(size_t)15;
@@ -259,8 +255,8 @@ void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bo
                                   160 * 1024 - 256 - kCandLds * (int)sizeof(uint2) - 128);
         attr_set = true;
     }
-    hipExtLaunchKernelGGL(flow_measure_lds_kernel, dim3(a.n_obj), dim3(kFlowThreads), lds, s, start, stop, 0, a, depth_max,
-                          radius, mf);
+    hipExtLaunchKernelGGL(flow_measure_lds_kernel, dim3(a.n_obj, a.T), dim3(kFlowThreads), lds, s, start, stop, 0, a,
+                          depth_max, radius);
 }
 
 // ---- records -> (uv, y, H) exactly as the reference assembles them (hpp:258-283) -------------

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
     __shared__ int s_wave[16];
     __shared__ int s_chunk[kFeatThreads];
     const int obj = blockIdx.x;
-    const FrameCtrl& c = a.ctrl[obj];
+    const FrameCtrl& c = frame_ctrl(a, blockIdx.y, obj);   // grid: (n_obj, frames of the batch)
 #ifdef ROFT_FEAT_PROFILE
     long long f_t0 = wall_clock64();
 #endif
@@ -124,7 +124,7 @@ void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop)
                                   160 * 1024 - 256 - kFeatThreads * (int)sizeof(int) - 128);
         attr_set = true;
     }
-    hipExtLaunchKernelGGL(features_kernel, dim3(a.n_obj), dim3(kFeatThreads), (uint32_t)((a.plane_words * 4 + 15) & ~(size_t)15), s,
+    hipExtLaunchKernelGGL(features_kernel, dim3(a.n_obj, a.T), dim3(kFeatThreads), (uint32_t)((a.plane_words * 4 + 15) & ~(size_t)15), s,
                           nullptr, stop, 0, a);
 }
 
@@ -203,8 +203,7 @@ __device__ void raster_triangle(const float* verts, const int32_t* tri, const Re
 __global__ __launch_bounds__(256) void raster_engine_kernel(EngineArrays a)
 {
     const int obj = blockIdx.z, alt = blockIdx.y;
-    const FrameCtrl& c = a.ctrl[obj];
-    if (c.outlier_step < 0) return;
+    if (a.state[obj].pending_frame < 0) return;   // no outlier test pending between the pose chain segments
     const ObjParams& prm = a.params[obj];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= prm.n_tris) return;
@@ -227,9 +226,9 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
     __shared__ double s_cnt[2][kOutlierThreads / 64];
     __shared__ int s_sel;
     const int obj = blockIdx.x;
-    const FrameCtrl& c = a.ctrl[obj];
-    if (c.outlier_step < 0) return;
     ObjState& st = a.state[obj];
+    if (st.pending_frame < 0) return;
+    const FrameCtrl& c = frame_ctrl(a, st.pending_frame, obj);
     const int W = a.cam.W, d = a.cam.divider, tw = a.tile_w;
     const int fslot = (c.feat_read >= 0) ? c.feat_read : 0;
     const uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
     PoseBelief& dst = st.belief[B_CORR];
     for (int i = threadIdx.x; i < 144; i += blockDim.x) dst.cov[i] = src.cov[i];
     if (threadIdx.x < 13) dst.mean[threadIdx.x] = src.mean[threadIdx.x];
-    if (roft_object_output* row = log_row(a, obj)) {
+    if (roft_object_output* row = log_row(a, c, obj)) {
         if (threadIdx.x < 13) row->pose[threadIdx.x] = src.mean[threadIdx.x];
         if (threadIdx.x == 0) {
             row->outlier_selected = s_sel;

@@ -460,69 +460,76 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
     return S.sel[0];
 }
 
-__global__ __launch_bounds__(kSkfThreads) void skf_kernel(EngineArrays a, int reweight)
+// One workgroup per object walks the frames of the batch: the velocity belief of frame k is the prior of frame k+1,
+// so the recursion is sequential per object; the flow records of all frames are already there (flow_measure_kernel).
+__global__ __launch_bounds__(kSkfThreads) void skf_chain_kernel(EngineArrays a, int reweight)
 {
     __shared__ SkfShared S;
     __shared__ double s_x[6];
     __shared__ double s_P[36];
 
     const int obj = blockIdx.x;
-    const FrameCtrl& c = a.ctrl[obj];
     ObjState& st = a.state[obj];
     const ObjParams& prm = a.params[obj];
-    const int N = c.vel_stage ? st.n_flow_points : -1;
+    for (int t = 0; t < a.T; ++t) {
+        const int slot = t * a.n_obj + obj;
+        const FrameCtrl& c = a.ctrl[slot];
+        const int n_pts = c.vel_stage ? a.npts[slot] : -1;
+        const int N = n_pts;
+        roft_object_output* row = log_row(a, c, obj);
+        if (threadIdx.x == 0) st.n_flow_points = n_pts;
 
-    // unobservable / no data: the belief is left exactly as it was (ROFTFilter.cpp:291-301)
-    if (N < 3) {
-        if (threadIdx.x < 6) st.twist_hist[c.twist_slot][threadIdx.x] = st.v_mean[threadIdx.x];
-        if (threadIdx.x == 0) {
-            st.skf_status = (N <= 0) ? 1 : 2;
-            if (roft_object_output* row = log_row(a, obj)) {
-                for (int i = 0; i < 6; ++i) row->twist[i] = st.v_mean[i];
-                row->n_flow_points = st.n_flow_points;
-                row->outlier_selected = -1;
+        // unobservable / no data: the belief is left exactly as it was (ROFTFilter.cpp:291-301)
+        if (N < 3) {
+            if (threadIdx.x < 6) {
+                const double v = st.v_mean[threadIdx.x];
+                st.twist_hist[c.twist_slot][threadIdx.x] = v;
+                if (row) row->twist[threadIdx.x] = v;
             }
+            if (threadIdx.x == 0) {
+                st.skf_status = (N <= 0) ? 1 : 2;
+                if (row) { row->n_flow_points = n_pts; row->outlier_selected = -1; }
+            }
+            __syncthreads();
+            continue;
         }
-        return;
-    }
 #ifdef ROFT_SKF_PROFILE
-    if (threadIdx.x == 0) S.t0 = wall_clock64();
+        if (threadIdx.x == 0) S.t0 = wall_clock64();
 #endif
-    if (threadIdx.x < 6) s_x[threadIdx.x] = st.v_mean[threadIdx.x];  // s^- = s (F = I)
-    if (threadIdx.x < 36) {
-        const int i = threadIdx.x;
-        s_P[i] = st.v_cov[i] + ((i / 6 == i % 6) ? prm.v_q[i / 6] : 0.0);  // P^- = P + Q
-    }
-    __syncthreads();
-    double x[6];
-    for (int i = 0; i < 6; ++i) x[i] = s_x[i];
-    SKFTICK(0);
+        if (threadIdx.x < 6) s_x[threadIdx.x] = st.v_mean[threadIdx.x];  // s^- = s (F = I)
+        if (threadIdx.x < 36) {
+            const int i = threadIdx.x;
+            s_P[i] = st.v_cov[i] + ((i / 6 == i % 6) ? prm.v_q[i / 6] : 0.0);  // P^- = P + Q
+        }
+        __syncthreads();
+        double x[6];
+        for (int i = 0; i < 6; ++i) x[i] = s_x[i];
+        SKFTICK(0);
 
-    RecAccessor acc{a.recs + (size_t)obj * a.cand_cap, a.cam, c.dt};
-    const int rc = skf_core(acc, N, x, s_P, prm.r_flow, reweight, a.norms + (size_t)obj * 3 * a.cand_cap, S);
-    // rc 3: numerically singular, belief left unchanged
-    if (rc == 0 && threadIdx.x < 36) st.v_cov[threadIdx.x] = S.Lm[threadIdx.x];
-    if (threadIdx.x < 6) {
-        const double v = (rc == 0) ? S.xo[threadIdx.x] : s_x[threadIdx.x];
-        if (rc == 0) st.v_mean[threadIdx.x] = v;
-        st.twist_hist[c.twist_slot][threadIdx.x] = v;
-        if (roft_object_output* row = log_row(a, obj)) row->twist[threadIdx.x] = v;
-    }
-    if (threadIdx.x == 0) {
-        st.skf_status = rc;
-#ifdef ROFT_SKF_PROFILE
-        for (int i = 0; i < 9; ++i) st.dbg[i] = S.dbg[i];
-#endif
-        if (roft_object_output* row = log_row(a, obj)) {
-            row->n_flow_points = st.n_flow_points;
-            row->outlier_selected = -1;
+        RecAccessor acc{a.recs + (size_t)slot * a.cand_cap, a.cam, c.dt};
+        const int rc = skf_core(acc, N, x, s_P, prm.r_flow, reweight, a.norms + (size_t)obj * 3 * a.cand_cap, S);
+        // rc 3: numerically singular, belief left unchanged
+        if (rc == 0 && threadIdx.x < 36) st.v_cov[threadIdx.x] = S.Lm[threadIdx.x];
+        if (threadIdx.x < 6) {
+            const double v = (rc == 0) ? S.xo[threadIdx.x] : s_x[threadIdx.x];
+            if (rc == 0) st.v_mean[threadIdx.x] = v;
+            st.twist_hist[c.twist_slot][threadIdx.x] = v;
+            if (row) row->twist[threadIdx.x] = v;
         }
+        if (threadIdx.x == 0) {
+            st.skf_status = rc;
+#ifdef ROFT_SKF_PROFILE
+            for (int i = 0; i < 9; ++i) st.dbg[i] = S.dbg[i];
+#endif
+            if (row) { row->n_flow_points = n_pts; row->outlier_selected = -1; }
+        }
+        __syncthreads();   // the belief written here is the next frame's prior (same workgroup)
     }
 }
 
-void launch_skf(const EngineArrays& a, int reweight, hipStream_t s, hipEvent_t stop)
+void launch_skf_chain(const EngineArrays& a, int reweight, hipStream_t s, hipEvent_t stop)
 {
-    hipExtLaunchKernelGGL(skf_kernel, dim3(a.n_obj), dim3(kSkfThreads), 0, s, nullptr, stop, 0, a, reweight);
+    hipExtLaunchKernelGGL(skf_chain_kernel, dim3(a.n_obj), dim3(kSkfThreads), 0, s, nullptr, stop, 0, a, reweight);
 }
 
 // ---- operator level ---------------------------------------------------------------------------
@@ -545,6 +552,36 @@ __global__ __launch_bounds__(kSkfThreads) void skf_arrays_kernel(const double* x
     if (threadIdx.x < 6) x_out[threadIdx.x] = (rc == 0) ? S.xo[threadIdx.x] : x_pred[threadIdx.x];
     if (threadIdx.x < 36) P_out[threadIdx.x] = (rc == 0) ? S.Lm[threadIdx.x] : P_pred[threadIdx.x];
     if (threadIdx.x == 0) *status = rc;
+}
+
+// operator level through the accessor the engine uses: compact flow records, H rows rebuilt on the fly
+__global__ __launch_bounds__(kSkfThreads) void skf_records_kernel(const double* x_pred, const double* P_pred, int N,
+                                                                  const FlowRec* recs, DevCamera cam, double dt,
+                                                                  const double* Rdiag, int reweight, double* norms,
+                                                                  double* x_out, double* P_out, int* status)
+{
+    __shared__ SkfShared S;
+    if (N <= 0) {
+        if (threadIdx.x < 6) x_out[threadIdx.x] = x_pred[threadIdx.x];
+        if (threadIdx.x < 36) P_out[threadIdx.x] = P_pred[threadIdx.x];
+        if (threadIdx.x == 0) *status = 1;
+        return;
+    }
+    double x[6], r[2] = {Rdiag[0], Rdiag[1]};
+    for (int i = 0; i < 6; ++i) x[i] = x_pred[i];
+    RecAccessor acc{recs, cam, dt};
+    const int rc = skf_core(acc, N, x, P_pred, r, reweight, norms, S);
+    if (threadIdx.x < 6) x_out[threadIdx.x] = (rc == 0) ? S.xo[threadIdx.x] : x_pred[threadIdx.x];
+    if (threadIdx.x < 36) P_out[threadIdx.x] = (rc == 0) ? S.Lm[threadIdx.x] : P_pred[threadIdx.x];
+    if (threadIdx.x == 0) *status = rc;
+}
+
+void launch_skf_records(const double* x_pred, const double* P_pred, int N, const FlowRec* recs, DevCamera cam, double dt,
+                        const double* Rdiag, int reweight, double* norms, double* x_out, double* P_out, int* status,
+                        hipStream_t s)
+{
+    hipLaunchKernelGGL(skf_records_kernel, dim3(1), dim3(kSkfThreads), 0, s, x_pred, P_pred, N, recs, cam, dt, Rdiag,
+                       reweight, norms, x_out, P_out, status);
 }
 
 void launch_skf_arrays(const double* x_pred, const double* P_pred, int N, const double* y, const double* H,

@@ -997,12 +997,9 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
 }
 
 // One launch = one StepDesc per object: optional prediction, then 0, 1 or 2 corrections of it.
-__device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const UtTable& ut, UkfLds& L)
+__device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj, int step, const UtTable& ut, UkfLds& L)
 {
-    const FrameCtrl& c = a.ctrl[obj];
     ObjState& st = a.state[obj];
-    if (step == 0 && threadIdx.x == 0) st.outlier_selected = -1;  // set again by outlier_kernel if it runs
-    if (step >= c.n_steps) return;
     const StepDesc sd = c.steps[step];
     if (!sd.op) return;
     const ObjParams& prm = a.params[obj];
@@ -1041,7 +1038,7 @@ __device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const UtT
         PoseBelief& d = st.belief[sd.dst[0]];
         for (int i = lane; i < 144; i += kUkfThreads) d.cov[i] = L.cov[i];
         if (lane < 13) d.mean[lane] = L.mean[lane];
-        if (roft_object_output* row = log_row(a, obj))
+        if (roft_object_output* row = log_row(a, c, obj))
             if (lane < 13 && sd.dst[0] == B_CORR) row->pose[lane] = L.mean[lane];
         return;
     }
@@ -1058,7 +1055,7 @@ __device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const UtT
     }
     if (lane == 0) st.ukf_status = status;
     // output log: the corrected belief after this frame's last step is what ROFTFilter logs
-    if (roft_object_output* row = log_row(a, obj)) {
+    if (roft_object_output* row = log_row(a, c, obj)) {
         __syncthreads();
         if (lane < 13) row->pose[lane] = st.belief[B_CORR].mean[lane];
     }
@@ -1068,28 +1065,46 @@ __device__ void ukf_one_step(const EngineArrays& a, int obj, int step, const UtT
 #endif
 }
 
-// One launch runs the StepDescs [step0, step1) of every object back to back (the velocity-only replays of a
-// pose re-sync need no other kernel in between, so they share one launch).
-__global__ __launch_bounds__(kUkfThreads) void ukf_step_kernel(EngineArrays a, int step0, int step1, UtTable ut)
+// Pose chain of a batch: one workgroup per object runs its UKF steps frame after frame.  A step followed by the
+// depth-render outlier test ends the segment -- the host enqueues launch_outlier and another segment behind it, which
+// resumes at the object's cursor (ObjState::pc_frame / pc_step) -- otherwise the segment runs to the end of the batch.
+__global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, UtTable ut, int first_segment)
 {
     // static LDS on purpose: with `extern __shared__` the compiler re-reads the dynamic-LDS base address from a
     // table in global memory inside every Jacobi round (two dependent global loads per round)
     __shared__ UkfLds L;
+    const int obj = blockIdx.x;
+    ObjState& st = a.state[obj];
+    int t = first_segment ? 0 : st.pc_frame, step = first_segment ? 0 : st.pc_step;
+    if (t >= a.T) return;   // (this object's chain of the batch ended in an earlier segment)
     jacobi12_table(L);
     for (int i = threadIdx.x; i < 100; i += kUkfThreads) L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0;   // see ukf_predict
     if (threadIdx.x < 10) L.wQ[threadIdx.x] = 0.0;
     __syncthreads();
-    for (int step = step0; step < step1; ++step) {
-        ukf_one_step(a, blockIdx.x, step, ut, L);
+    bool pending = false;
+    while (t < a.T) {
+        const FrameCtrl& c = frame_ctrl(a, t, obj);
+        if (step == 0 && threadIdx.x == 0) st.outlier_selected = -1;  // set again by outlier_kernel if it runs
+        if (step >= c.n_steps) { ++t; step = 0; continue; }
+        if (c.steps[step].op) ukf_one_step(a, c, obj, step, ut, L);
         __syncthreads();   // beliefs written by this step are read by the next one (same workgroup)
+        pending = (step == c.outlier_step);
+        ++step;
+        if (pending) break;
+    }
+    if (threadIdx.x == 0) {
+        st.pending_frame = pending ? t : -1;
+        st.pc_frame = t;     // == a.T when the chain of this batch is complete
+        st.pc_step = step;
     }
 }
 
-void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s, hipEvent_t stop)
+void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, hipStream_t s, hipEvent_t stop)
 {
     UtTable tab;
     for (int k = 0; k < 3; ++k) tab.w[k] = ut_weights(18 + 3 * k, ut);
-    hipExtLaunchKernelGGL(ukf_step_kernel, dim3(a.n_obj), dim3(kUkfThreads), 0, s, nullptr, stop, 0, a, step0, step1, tab);
+    hipExtLaunchKernelGGL(ukf_chain_kernel, dim3(a.n_obj), dim3(kUkfThreads), 0, s, nullptr, stop, 0, a, tab,
+                          first_segment ? 1 : 0);
 }
 
 }  // namespace roft

@@ -1,8 +1,9 @@
 // roft_device.h -- device-visible data layout of the MI355X ROFT engine (gfx950 only).
 //
 // Everything the per-frame hot path touches lives in HBM in these structures; the host only
-// uploads one small FrameCtrl block per frame and enqueues a fixed sequence of batched kernels
-// (one workgroup per object), so a frame needs no device->host round trip.
+// uploads one small FrameCtrl block per object and frame and enqueues a fixed sequence of kernels per BATCH of
+// frames (roft_frames_submit: 1 .. kMaxBatch frames; per-object chain kernels loop over the frames of the batch),
+// so a frame needs no device->host round trip and a batch needs ~8 launches whatever its length.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -15,12 +16,14 @@ namespace roft {
 
 constexpr int kWave = 64;              // CDNA wavefront
 constexpr int kNumBelief = 6;          // pose belief slots per object
-constexpr int kTwistRing = 32;         // twist history ring (velocity deque of the measurement model + frames in flight)
-constexpr int kMaxFlowHist = 6;        // flows a new mask can be chased through (frames between masks)
-constexpr int kMaxSteps = 10;          // UKF launches per frame (re-sync replays <= 7)
-constexpr int kPlaneSlots = ROFT_RETAIN_FRAMES;  // mask bit-plane ring per object
-constexpr int kFeatRing = 8;           // buffered outlier-rejection feature sets per object (> frames in flight between
-                                       // the mask chain that writes them and the pose chain that reads them)
+constexpr int kMaxBatch = ROFT_MAX_BATCH_FRAMES;   // frames per roft_frames_submit
+constexpr int kTwistRing = 64;         // twist history ring (velocity deque of the measurement model + frames in flight)
+constexpr int kMaxFlowHist = ROFT_MAX_FLOW_CHASE;  // flows a new mask can be chased through (30-entry queue of the
+                                       // time-stamped source, OpticalFlowQueueHandler.cpp:18-26; "all buffered" otherwise)
+constexpr int kMaxSteps = 10;          // UKF steps per frame (re-sync replays <= pose_frames_between + 1 <= 9)
+constexpr int kPlaneSlots = 48;        // mask bit-plane ring per object (> frames in flight + one batch + 1)
+constexpr int kFeatRing = 12;          // buffered outlier-rejection feature sets per object (>= kMaxBatch + 2; the host
+                                       // waits before it re-uses a set an unfinished batch still reads)
 
 enum BeliefSlot { B_CORR = 0, B_PRED = 1, B_BUF = 2, B_ALT0 = 3, B_ALT1 = 4, B_SPARE = 5 };
 
@@ -66,10 +69,12 @@ struct ObjState {
     PoseBelief belief[kNumBelief];
     double twist_hist[kTwistRing][6];
     int fbuf_n;            // flows buffered since the last consumed mask (OF-aided source)
-    int new_mask_count;    // non-zero pixels of the newly ingested mask
-    int mask_mode;         // decided by the scatter kernel: 0 copy, 1 propagate, 2 new mask
-    int bbox[4];           // target bounding box of the scatter: xmin, ymin, xmax, ymax
-    int n_flow_points;     // N of the velocity stage (-1: did not run)
+    int mask_binary;       // the current propagated mask has no pixel of value 1 (nz plane == obj plane): its
+                           // propagation is an order-free OR-scatter (k_mask.hip)
+    int mask_mode;         // mode of the last frame: 0 copy, 1 propagate, 2 new mask
+    int pc_frame, pc_step; // pose chain cursor inside the current batch (ukf_chain_kernel)
+    int pending_frame;     // frame of the batch whose outlier test is pending between two pose chain segments, -1 none
+    int n_flow_points;     // N of the velocity stage of the last frame (-1: did not run)
     int n_feat[kFeatRing]; // buffered outlier-rejection samples (rank-even mask pixels) per feature ring slot
     int outlier_selected;
     double outlier_L[2];
@@ -107,6 +112,7 @@ struct alignas(16) FrameCtrl {
     int first_mask;                  // first mask ever: initialisation, not "new" (hpp:169-178)
     int stamped;                     // time-stamped source (…Stamped.hpp): n_region replaces the device-side flow count
     int n_region;                    // flows stored after the flow whose stamp matches the new mask's (0: none / no match)
+    int n_hist;                      // valid entries of flow[]
     int slot_prev, slot_cur;         // bit-plane ring slots
     int vel_stage;                   // run the velocity stage this frame
     int twist_slot;                  // twist_hist slot written this frame
@@ -131,11 +137,13 @@ struct EngineArrays {
     DevFlowFmt ffmt;
     ObjParams* params;       // [n_obj]
     ObjState* state;         // [n_obj]
-    FrameCtrl* ctrl;         // [n_obj] (current frame)
+    int T;                   // frames of the current batch
+    FrameCtrl* ctrl;         // [T][n_obj] (current batch)
     uint32_t* planes;        // [n_obj][kPlaneSlots + 2][2][wpr*H]   (nz plane, obj plane)
-    int32_t* map;            // [n_obj][W*H] scatter map (kept all-zero between frames)
-    FlowRec* cand;           // [n_obj][cand_cap] candidate scratch
-    FlowRec* recs;           // [n_obj][cand_cap] kept flow records
+    int32_t* map;            // [n_obj][W*H] scatter map of the general (non-binary) mask path, all-zero between frames
+    FlowRec* cand;           // [T][n_obj][cand_cap] candidate scratch
+    FlowRec* recs;           // [T][n_obj][cand_cap] kept flow records
+    int* npts;               // [T][n_obj] N of the velocity stage (-1: did not run)
     double* norms;           // [n_obj][3 * cand_cap] SKF scratch (innovations + norms when N > LDS capacity)
     uint32_t* feat_pix;      // [n_obj][kFeatRing][feat_cap] buffered feature pixel (linear index)
     float* feat_depth;       // [n_obj][kFeatRing][feat_cap]
@@ -150,29 +158,37 @@ struct EngineArrays {
     int log_cap;
 };
 
-// row of the device-side output log this frame writes (null when logging is off)
-__device__ inline roft_object_output* log_row(const EngineArrays& a, int obj)
+// control block of frame t of the batch
+__device__ inline const FrameCtrl& frame_ctrl(const EngineArrays& a, int t, int obj)
+{
+    return a.ctrl[(size_t)t * a.n_obj + obj];
+}
+
+// row of the device-side output log a frame writes (null when logging is off)
+__device__ inline roft_object_output* log_row(const EngineArrays& a, const FrameCtrl& c, int obj)
 {
     if (!a.out_log) return nullptr;
-    return a.out_log + (size_t)(a.ctrl[obj].frame_idx % a.log_cap) * a.n_obj + obj;
+    return a.out_log + (size_t)(c.frame_idx % a.log_cap) * a.n_obj + obj;
 }
 
 constexpr int kSlotNew = kPlaneSlots;       // plane slot receiving an ingested mask
 constexpr int kSlotFeat = kPlaneSlots + 1;  // plane slot holding the buffered features' mask
 
-// Mask mode of this frame (ImageSegmentationOFAidedSource::step_frame, hpp:169-226), decided on the device
+// Mask mode of a frame (ImageSegmentationOFAidedSource::step_frame, hpp:169-226), decided on the device
 // because it depends on whether the newly delivered mask is empty:
 // 0 copy (no flow, no usable new mask); 1 propagate the last mask through this frame's flow with
-// mask(0,0) forced to 0 (hpp:221-226); 2 new mask chased through the buffered flows (hpp:211-219)
-__device__ inline int decide_mode(const FrameCtrl& c, const ObjState& st, int& src_slot, int& n_flows)
+// mask(0,0) forced to 0 (hpp:221-226); 2 new mask chased through the buffered flows (hpp:211-219).
+// fbuf_n = flows buffered before this frame, new_count = non-zero pixels of the mask delivered with it.
+__device__ inline int decide_mode(const FrameCtrl& c, int fbuf_n, int new_count, int frames_between, int& src_slot,
+                                  int& n_flows)
 {
-    const int n_avail = st.fbuf_n + (c.flow_valid ? 1 : 0);
+    const int n_avail = fbuf_n + (c.flow_valid ? 1 : 0);
+    int mode;
     if (c.force_mode == 3) {  // operator level: map() + remap() of the given mask through n flows
         src_slot = kSlotNew;
-        n_flows = n_avail < kMaxFlowHist ? n_avail : kMaxFlowHist;
-        return 2;
-    }
-    if (c.has_new_mask && !c.first_mask && st.new_mask_count > 0) {
+        n_flows = n_avail;
+        mode = 2;
+    } else if (c.has_new_mask && !c.first_mask && new_count > 0) {
         src_slot = kSlotNew;
         if (c.stamped && c.n_region <= 0) {
             // …Stamped.hpp:229-236: no flow after the mask's stamp in the queue -> the NEW mask through this frame's
@@ -180,26 +196,27 @@ __device__ inline int decide_mode(const FrameCtrl& c, const ObjState& st, int& s
             n_flows = 1;
             return c.flow_valid ? 1 : 0;
         }
-        const int n_use = c.stamped ? c.n_region : n_avail;
-        n_flows = n_use < kMaxFlowHist ? n_use : kMaxFlowHist;
-        return 2;
+        n_flows = c.stamped ? c.n_region : n_avail;
+        mode = 2;
+    } else {
+        src_slot = (c.has_new_mask && c.first_mask) ? kSlotNew : c.slot_prev;
+        n_flows = 1;
+        return c.flow_valid ? 1 : 0;
     }
-    src_slot = (c.has_new_mask && c.first_mask) ? kSlotNew : c.slot_prev;
-    n_flows = 1;
-    return c.flow_valid ? 1 : 0;
+    // map(): only the last frames_between flows of the region when that number is known (hpp:239-245)
+    if (frames_between > 0 && n_flows > frames_between) n_flows = frames_between;
+    if (n_flows > c.n_hist) n_flows = c.n_hist;   // (the host refuses frames whose history it cannot supply)
+    return mode;
 }
 
-// bookkeeping after the gather (one thread per object): flow buffer count, per-frame scratch reset
-__device__ inline void mask_bookkeeping(const FrameCtrl& c, ObjState& st)
+// flows buffered after a frame (flow_buffer_ of the OF-aided source): a consumed new mask clears the buffer
+// (hpp:218), an EMPTY new mask clears it only when the number of frames between masks is unknown (hpp:192-196)
+__device__ inline int next_fbuf(const FrameCtrl& c, int fbuf_n, int new_count, int mode, int frames_between)
 {
-    int src_slot, n_flows;
-    const int mode = decide_mode(c, st, src_slot, n_flows);
-    int n_avail = st.fbuf_n + (c.flow_valid ? 1 : 0);
-    if (n_avail > kMaxFlowHist) n_avail = kMaxFlowHist;
-    st.fbuf_n = (mode == 2) ? 0 : n_avail;
-    st.mask_mode = mode;
-    st.new_mask_count = 0;
-    st.bbox[0] = INT32_MAX; st.bbox[1] = INT32_MAX; st.bbox[2] = -1; st.bbox[3] = -1;
+    if (c.has_new_mask && !c.first_mask && new_count == 0 && frames_between <= 0) fbuf_n = 0;
+    int n = fbuf_n + (c.flow_valid ? 1 : 0);
+    if (n > kMaxFlowHist) n = kMaxFlowHist;
+    return (mode == 2) ? 0 : n;
 }
 
 __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, int slot, int which)
@@ -207,24 +224,31 @@ __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, i
     return (((size_t)obj * (kPlaneSlots + 2) + slot) * 2 + which) * a.plane_words;
 }
 
-void launch_mask_ingest(const EngineArrays& a, hipStream_t s);
-// finish = false: the caller guarantees that flow_measure_kernel (which then does the bookkeeping) follows
-void launch_mask_propagate(const EngineArrays& a, int frames_between, int flow_aided, bool finish, hipStream_t s);
+void launch_mask_ingest(const EngineArrays& a, hipStream_t s);   // operator level: frame 0's new mask -> plane slot kSlotNew
+// Mask chain of the batch: one workgroup per object walks the frames (ingest, mode decision, propagation).
+void launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s, hipEvent_t stop = nullptr);
 void launch_planes_to_mask(const uint32_t* nz, const uint32_t* ob, int npix, uint8_t* mask, hipStream_t s);
 // `stop` / `start` (optional): HIP events bound to the kernel's own dispatch (hipExtLaunchKernelGGL) -- they complete
 // with the kernel, without the extra barrier packet and host call of a hipEventRecord behind it.
-void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, bool mask_finish, hipStream_t s,
+// Flow measurement of every (frame, object) of the batch in one launch.
+void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, hipStream_t s,
                          hipEvent_t start = nullptr, hipEvent_t stop = nullptr);
-void launch_skf(const EngineArrays& a, int reweight, hipStream_t s, hipEvent_t stop = nullptr);
+// Velocity filter: one workgroup per object walks the frames of the batch.
+void launch_skf_chain(const EngineArrays& a, int reweight, hipStream_t s, hipEvent_t stop = nullptr);
 // operator level: explicit (y, H) arrays, x_pred/P_pred in, x/P out (all device pointers)
 void launch_skf_arrays(const double* x_pred, const double* P_pred, int N, const double* y, const double* H,
                        const double* Rdiag, int reweight, double* norms, double* x_out, double* P_out, int* status,
                        hipStream_t s);
+// same, fed with compact flow records through the accessor the engine uses (parity tests)
+void launch_skf_records(const double* x_pred, const double* P_pred, int N, const FlowRec* recs, DevCamera cam, double dt,
+                        const double* Rdiag, int reweight, double* norms, double* x_out, double* P_out, int* status,
+                        hipStream_t s);
 void launch_kf_predict(const double* x, const double* P, const double* qdiag, double* xo, double* Po, hipStream_t s);
-void launch_ukf_step(const EngineArrays& a, int step0, int step1, roft_ut_params ut, hipStream_t s,
-                     hipEvent_t stop = nullptr);  // steps [step0, step1)
-void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // after the mask stage of the frame
-void launch_outlier(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // z-buffer clear + render + likelihood + decision
+// Pose chain segment: every object runs its UKF steps from its cursor up to and including its next outlier-rejection
+// step (then launch_outlier and another segment follow) or to the end of the batch.
+void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, hipStream_t s, hipEvent_t stop = nullptr);
+void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // after the mask chain of the batch
+void launch_outlier(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // render + likelihood + decision of the pending tests
 void launch_outlier_only(const EngineArrays& a, hipStream_t s);  // likelihood + decision on filled z-buffers
 
 // operator-level helpers on raw device buffers (used by the C ABI operator entry points)

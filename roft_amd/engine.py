@@ -12,11 +12,12 @@ import numpy as np
 from . import _lib as L
 
 
-def default_config(width, height, flow_type=L.FLOW_F32C2, max_objects=64, device=0):
+def default_config(width, height, flow_type=L.FLOW_F32C2, max_objects=64, device=0, max_batch_frames=1):
     cfg = L.Config()
     L.check(L.lib().roft_default_config(C.byref(cfg), width, height, flow_type))
     cfg.max_objects = max_objects
     cfg.device = device
+    cfg.max_batch_frames = max_batch_frames
     return cfg
 
 
@@ -93,6 +94,38 @@ class ROFTFilterBatch:
 
     def submit_raw(self, inputs):
         L.check(L.lib().roft_frame_submit(self._h, inputs, self.n_objects))
+
+    def build_batch(self, frames_list):
+        """ctypes input array of a batch: frames_list[t] = one dict per object (see submit), t = 0 .. T-1."""
+        T = len(frames_list)
+        arr = (L.FrameInput * (self.n_objects * T))()
+        keep = []
+        saved = self._inputs
+        for t, frames in enumerate(frames_list):
+            self._inputs = (L.FrameInput * self.n_objects)()
+            self._fill(frames)
+            for i in range(self.n_objects):
+                arr[t * self.n_objects + i] = self._inputs[i]
+            keep.append(self._keep)
+        self._inputs = saved
+        return arr, keep, T
+
+    def submit_batch(self, frames_list):
+        """A batch of consecutive frames (at most cfg.max_batch_frames), roft_frames_submit."""
+        arr, keep, T = self.build_batch(frames_list)
+        self._keep = keep
+        L.check(L.lib().roft_frames_submit(self._h, arr, self.n_objects, T))
+
+    def submit_batch_raw(self, arr, T):
+        L.check(L.lib().roft_frames_submit(self._h, arr, self.n_objects, T))
+
+    def retain_frames(self):
+        return L.lib().roft_engine_retain_frames(self._h)
+
+    def stats(self):
+        st = L.EngineStats()
+        L.check(L.lib().roft_engine_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in L.EngineStats._fields_}
 
     def step(self):
         L.check(L.lib().roft_step(self._h))

@@ -72,6 +72,20 @@ def skf_correct(x, P, y, Hm, rdiag=(1.0, 1.0), reweight=True):
     return st.value, xo, Po
 
 
+def skf_correct_points(cam, dt, x, P, uv, z, flow_xy, rdiag=(1.0, 1.0), reweight=True):
+    """SKFCorrection::correctStep fed with the kept flow points (the engine's form: H rows rebuilt on the device)."""
+    x, P, rd = _f64(x), _f64(P), _f64(rdiag)
+    uv = np.ascontiguousarray(uv, np.int32)
+    z = np.ascontiguousarray(z, np.float32)
+    fxy = np.ascontiguousarray(flow_xy, np.float32)
+    n = z.size
+    xo, Po = np.zeros(6), np.zeros((6, 6))
+    st = C.c_int(0)
+    L.check(L.lib().roft_skf_correct_points(C.byref(cam), dt, _p(x), _p(P), n, _p(uv), _p(z), _p(fxy), _p(rd),
+                                            int(reweight), _p(xo), _p(Po), C.byref(st)))
+    return st.value, xo, Po
+
+
 def mask_propagate(mask, flow_arrs, frames_between=6):
     mask = np.ascontiguousarray(mask, np.uint8).copy()
     H, W = mask.shape

@@ -1,0 +1,190 @@
+"""Frame batches (roft_frames_submit): the three per-object chains of the engine walk a batch of frames in one
+persistent kernel each.  A batch must give bit for bit what the same frames give one at a time -- same kernels, same
+arithmetic, only the launch structure differs -- for every split of the sequence into batches, and both must match
+the oracle's ROFTFilter restatement (ROFTFilter::filtering_step, src/roft-lib/src/ROFTFilter.cpp:255-452)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from roft_amd import _lib as L
+from roft_amd import synth
+
+import util
+from test_engine_gpu import POS_TOL, make_engine, rot_err
+
+pytestmark = pytest.mark.gpu
+
+
+def clone(st):
+    c = copy.copy(st)
+    c.depth, c.flow, c.mask_gt = st.depth.clone(), st.flow.clone(), st.mask_gt.clone()
+    c.mask_delivery, c.pose_valid, c.pose_meas, c.flow_valid = (st.mask_delivery.copy(), st.pose_valid.copy(),
+                                                                st.pose_meas.copy(), st.flow_valid.copy())
+    return c
+
+
+def awkward_streams(n):
+    """Three objects that exercise every branch of the chains: (0) the default schedule, (1) dropped poses, a missing
+    flow frame and an empty delivered mask, (2) a three-valued mask {0, 1, 255} (the general, map-based propagation)
+    and a pose on every frame (an outlier test per frame: several pose chain segments per batch)."""
+    a = clone(util.stream(700, n, scale=2, device="cuda"))
+    b = clone(util.stream(701, n, scale=2, pose_drop_prob=0.4, device="cuda"))
+    b.flow_valid[[7, 8]] = False
+    b.mask_gt[6] = 0
+    c = clone(util.stream(702, n, scale=2, device="cuda"))
+    m = c.mask_gt.numpy()
+    for k in range(m.shape[0]):
+        vs, us = np.nonzero(m[k])
+        m[k, vs[::3], us[::3]] = 1
+    c.pose_valid[:] = True
+    for k in range(n):
+        c.pose_meas[k, :3] = c.gt.x[k] + 0.002
+        c.pose_meas[k, 3:] = c.gt.q[k]
+    return [a, b, c]
+
+
+def check_against_oracle(streams, n, log, masks, **over):
+    from oracle import binding as ob
+    pose, twist, npts, sel = log
+    for o, st in enumerate(streams):
+        ref = util.run_oracle_tracker(ob, st, n, **over)
+        assert np.array_equal(npts[:, o], np.array([r["n"] for r in ref])), o
+        assert np.array_equal(sel[:, o], np.array([r["sel"] for r in ref])), o
+        want = np.array([r["pose"] for r in ref])
+        assert np.abs(pose[:, o, :9] - want[:, :9]).max() < POS_TOL, o
+        assert max(rot_err(pose[k, o, 9:], want[k, 9:]) for k in range(n)) < 1e-6, o
+        assert np.abs(twist[:, o] - np.array([r["twist"] for r in ref])).max() < 1e-6, o
+        assert np.array_equal(masks[o], ref[n - 1]["mask"]), o
+
+
+def test_batches_equal_single_frames_bit_for_bit():
+    n = 40
+    streams = awkward_streams(n)
+    dev = [util.to_device(st) for st in streams]
+    one, masks1, stats1 = util.run_engine_logged(make_engine, dev, n, T=1)
+    check_against_oracle(streams, n, one, masks1)
+    assert (one[3][:, 2] >= 0).sum() >= n - 2            # the every-frame pose object tests (nearly) every frame
+    for kw in (dict(T=2), dict(T=6), dict(T=8), dict(splits=[3, 1, 8, 5])):
+        got, masks, stats = util.run_engine_logged(make_engine, dev, n, **kw)
+        for x, y in zip(one, got):
+            assert np.array_equal(x, y), kw
+        for x, y in zip(masks1, masks):
+            assert np.array_equal(x, y), kw
+        assert stats["launches"] < stats1["launches"]
+    # launches per frame fall with the batch length
+    assert stats1["launches"] / n > 5.0
+
+
+def test_batches_one_stream_equals_three_streams(monkeypatch):
+    n = 30
+    dev = [util.to_device(st) for st in awkward_streams(n)]
+    a, ma, _ = util.run_engine_logged(make_engine, dev, n, T=6)
+    monkeypatch.setenv("ROFT_ONE_STREAM", "1")
+    b, mb, _ = util.run_engine_logged(make_engine, dev, n, T=6)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    for x, y in zip(ma, mb):
+        assert np.array_equal(x, y)
+
+
+def test_batch_ablations_match_oracle():
+    """No re-sync (the outlier test reads the features buffered in the same frame) and no flow-aided segmentation,
+    in batches."""
+    n = 26
+    streams = [util.stream(710, n, scale=2, device="cuda")]
+    dev = [util.to_device(st) for st in streams]
+    for over in (dict(use_pose_resync=0), dict(flow_aided_segmentation=0), dict(outlier_rejection=0, flow_weighting=0)):
+        log, masks, _ = util.run_engine_logged(make_engine, dev, n, T=5, **over)
+        check_against_oracle(streams, n, log, masks, **over)
+
+
+def test_batch_size_is_checked_and_a_failed_submit_consumes_nothing():
+    n = 12
+    st = util.stream(720, n, scale=2, device="cuda")
+    dev = util.to_device(st)
+    ref, masks_ref, _ = util.run_engine_logged(make_engine, [dev], n, T=4)
+    eng = make_engine([dev], max_batch_frames=4)
+    eng.enable_log(n)
+    with pytest.raises(L.RoftError):
+        eng.submit_batch([[util.device_frame(dev, k)] for k in range(5)])      # longer than max_batch_frames
+    for k0 in range(0, n, 4):
+        frames = [[util.device_frame(dev, k0 + j)] for j in range(4)]
+        bad = [[dict(f[0])] for f in frames]
+        bad[2][0]["depth"] = None                                               # third frame lacks its depth image
+        with pytest.raises(L.RoftError):
+            eng.submit_batch(bad)
+        with pytest.raises(L.RoftError):
+            eng.step()                                                          # nothing was submitted
+        eng.submit_batch(frames)                                                # the same frames, corrected
+        eng.step()
+    got = eng.get_log(0, n)
+    assert np.array_equal(eng.mask(0), masks_ref[0])
+    eng.close()
+    for x, y in zip(ref, got):
+        assert np.array_equal(x, y)
+
+
+def test_host_buffers_may_be_reused_when_submit_returns():
+    """roft_frame_input: HOST buffers are copied before the submit call returns -- a live caller that refills its one
+    pinned capture buffer right after the call must get the same trajectory."""
+    n = 20
+    st = util.stream(730, n, scale=2, device="cuda")
+    dev = util.to_device(st)
+    ref, masks_ref, _ = util.run_engine_logged(make_engine, [dev], n, T=1)
+    depth = torch.zeros_like(st.depth[0]).pin_memory()
+    flow = torch.zeros_like(st.flow[0]).pin_memory()
+    mask = torch.zeros_like(st.mask_gt[0]).pin_memory()
+    for T in (1, 4):
+        eng = make_engine([st], max_batch_frames=T)
+        eng.enable_log(n)
+        for k0 in range(0, n, T):
+            bufs = []
+            frames = []
+            for k in range(k0, min(k0 + T, n)):
+                # one set of pinned buffers per frame of the batch, overwritten with garbage right after the call
+                d, f, m = (depth, flow, mask) if T == 1 else (depth.clone().pin_memory(), flow.clone().pin_memory(), mask.clone().pin_memory())
+                d.copy_(st.depth[k]); f.copy_(st.flow[k])
+                mi = st.mask_delivery[k]
+                if mi >= 0:
+                    m.copy_(st.mask_gt[mi])
+                pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
+                frames.append([dict(depth=d.data_ptr(), flow=f.data_ptr() if st.flow_valid[k] else None,
+                                    mask=m.data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=L.MEM_HOST)])
+                bufs.append((d, f, m))
+            eng.submit_batch(frames)
+            for d, f, m in bufs:
+                d.fill_(float("nan")); f.fill_(1e10); m.fill_(255)
+            eng.step()
+        got = eng.get_log(0, n)
+        assert np.array_equal(eng.mask(0), masks_ref[0])
+        eng.close()
+        for x, y in zip(ref, got):
+            assert np.array_equal(x, y), T
+
+
+def test_shared_scene_host_inputs_are_uploaded_once():
+    """Config #4's shared-scene form: every object points at the same HOST depth and flow image; the engine uploads
+    each distinct buffer once per frame."""
+    n, n_obj = 6, 4
+    st = util.stream(740, n, scale=2, device="cuda")
+    eng = make_engine([st] * n_obj)
+    depth, flow, masks = st.depth.numpy(), st.flow.numpy(), st.mask_gt.numpy()
+    for k in range(n):
+        mi = st.mask_delivery[k]
+        pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
+        f = dict(depth=depth[k].ctypes.data, flow=flow[k].ctypes.data if st.flow_valid[k] else None,
+                 mask=masks[mi].ctypes.data if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=L.MEM_HOST)
+        eng.submit([f] * n_obj)
+        eng.step()
+    s = eng.stats()
+    poses = [eng.state(o)[0] for o in range(n_obj)]
+    eng.close()
+    per_frame = depth[0].nbytes + flow[0].nbytes
+    n_masks = int((st.mask_delivery[:n] >= 0).sum())
+    n_flows = int(st.flow_valid[:n].sum())
+    assert s["h2d_bytes"] == n * depth[0].nbytes + n_flows * flow[0].nbytes + n_masks * masks[0].nbytes
+    assert s["h2d_bytes"] < 0.5 * n_obj * n * per_frame
+    for p in poses[1:]:
+        assert np.array_equal(p, poses[0])

@@ -95,11 +95,12 @@ def test_device_buffers_recycled_after_retain_frames():
     n = 70
     st = util.stream(540, n, scale=2, device="cuda")
     ref = util.run_oracle_tracker(ob, st, n)
-    R = L.RETAIN_FRAMES
+    eng = make_engine([st])
+    R = eng.retain_frames()
+    assert R <= L.RETAIN_FRAMES       # ROFT_RETAIN_FRAMES covers the default configuration
     depth = torch.zeros((R,) + tuple(st.depth.shape[1:]), dtype=st.depth.dtype, device="cuda")
     flow = torch.zeros((R,) + tuple(st.flow.shape[1:]), dtype=st.flow.dtype, device="cuda")
     mask = torch.zeros((R,) + tuple(st.mask_gt.shape[1:]), dtype=st.mask_gt.dtype, device="cuda")
-    eng = make_engine([st])
     eng.enable_log(n)
     for k in range(n):
         s = k % R
@@ -120,6 +121,61 @@ def test_device_buffers_recycled_after_retain_frames():
     assert np.abs(pose_log[:, 0] - want).max() < 1e-8
     assert np.array_equal(npts[:, 0], np.array([r["n"] for r in ref]))
     assert np.array_equal(sel[:, 0], np.array([r["sel"] for r in ref]))
+
+
+def test_unknown_frames_between_masks_chases_all_buffered_flows():
+    """mask_frames_between <= 0 (`segm_frames_between_iterations_` unknown): a new mask is chased through ALL flows
+    buffered since the last one -- 12 after a skipped delivery -- and an EMPTY delivered mask drops the buffer before
+    that frame's flow is stored, so the next mask goes through 7 flows, not 6 (hpp:186-198, 239-245)."""
+    st = clone(util.stream(525, 34, scale=2, device="cuda"))
+    assert st.mask_delivery[12] == 6 and st.mask_delivery[18] == 12
+    st.mask_delivery[12] = -1     # no delivery at frame 12: frame 18's mask goes through the 12 flows 7..18
+    st.mask_gt[18] = 0            # delivered (empty) at frame 24: buffer dropped, frame 30's mask goes through 7 flows
+    compare([st], 34, mask_frames_between=0)
+    compare([st], 34, mask_frames_between=-1)
+    compare([st], 34, mask_frames_between=9)
+
+
+def test_sparse_flows_and_a_mask_outage_over_recycled_buffers():
+    """Two of three flow frames are missing and no mask arrives for 36 frames: the six flows the next mask is chased
+    through span 18 frames, more than the retention window of the caller's recycled DEVICE buffers.  The reference
+    clones every buffered flow; the engine copies a flow into its own memory before the window closes."""
+    from oracle import binding as ob
+    from roft_amd import _lib as L
+    from test_engine_gpu import make_engine
+    n = 64
+    st = clone(util.stream(545, n, scale=2, device="cuda"))
+    st.flow_valid[:] = False
+    st.flow_valid[1::3] = True
+    st.mask_delivery[12:48] = -1
+    ref = util.run_oracle_tracker(ob, st, n)
+    eng = make_engine([st])
+    R = eng.retain_frames()
+    assert R <= L.RETAIN_FRAMES
+    depth = torch.zeros((R,) + tuple(st.depth.shape[1:]), dtype=st.depth.dtype, device="cuda")
+    flow = torch.zeros((R,) + tuple(st.flow.shape[1:]), dtype=st.flow.dtype, device="cuda")
+    mask = torch.zeros((R,) + tuple(st.mask_gt.shape[1:]), dtype=st.mask_gt.dtype, device="cuda")
+    eng.enable_log(n)
+    for k in range(n):
+        s = k % R
+        depth[s].copy_(st.depth[k])
+        flow[s].fill_(float("nan"))          # a recycled slot never keeps an old flow
+        if st.flow_valid[k]:
+            flow[s].copy_(st.flow[k])
+        mi = st.mask_delivery[k]
+        if mi >= 0:
+            mask[s].copy_(st.mask_gt[mi])
+        torch.cuda.synchronize()
+        pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
+        eng.submit([dict(depth=depth[s].data_ptr(), flow=flow[s].data_ptr() if st.flow_valid[k] else None,
+                         mask=mask[s].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE)])
+        eng.step()
+        if k in (47, 48, 49, n - 1):
+            assert np.array_equal(eng.mask(0), ref[k]["mask"]), k
+    pose_log, twist_log, npts, sel = eng.get_log(0, n)
+    eng.close()
+    assert np.abs(pose_log[:, 0] - np.array([r["pose"] for r in ref])).max() < 1e-8
+    assert np.array_equal(npts[:, 0], np.array([r["n"] for r in ref]))
 
 
 def test_width_not_a_multiple_of_64():

@@ -96,11 +96,30 @@ def test_engine_stamped_source_matches_oracle():
     eng.close()
 
 
-def test_stamped_mode_needs_a_frames_between_window():
-    from roft_amd import _lib as L
-    from roft_amd import engine as E
-    cfg = E.default_config(320, 240, L.FLOW_F32C2, max_objects=1)
-    cfg.stamped_masks = 1
-    cfg.mask_frames_between = 0
-    with pytest.raises(L.RoftError):
-        E.ROFTFilterBatch(cfg)
+@pytest.mark.gpu
+@pytest.mark.parametrize("fb", [0, 12])
+def test_engine_stamped_source_long_latency(fb):
+    """Masks that arrive 20 and 29 frames late are chased through every flow stored after their stamp (up to the 29
+    that follow the matching entry of the 30-flow queue, OpticalFlowQueueHandler.cpp:18-57) -- or through the last
+    mask_frames_between of them when that number is known; a mask older than the queue takes the fall-back path."""
+    from oracle import binding as ob
+    from test_engine_gpu import make_engine
+    n = 46
+    st = util.stream(92, n, 2)
+    deliver = {0: (0, 0.0), 25: (5, 5 / 30.0), 33: (4, 4 / 30.0), 41: (9, 9 / 30.0)}
+    cfg = util.oracle_config(ob, st, stamped_masks=1, mask_frames_between=fb)
+    trk = ob.Tracker(cfg, *st.mesh)
+    eng = make_engine([st], stamped_masks=1, mask_frames_between=fb)
+    for k in range(n):
+        depth, flow, _, pose = util.frame_inputs(st, k)
+        mask, mstamp = None, 0.0
+        if k in deliver:
+            mask, mstamp = st.mask_gt[deliver[k][0]].cpu().numpy(), deliver[k][1]
+        r = trk.step(st.dt, depth, flow, mask, pose, stamp=k / 30.0, mask_stamp=mstamp)
+        eng.submit([dict(depth=depth, flow=flow, mask=mask, pose=pose, dt=st.dt, stamp=k / 30.0, mask_stamp=mstamp)])
+        eng.step()
+        assert np.array_equal(eng.mask(0), trk.mask()), k
+        assert eng.outputs()[0].n_flow_points == r.n_flow_points, k
+        assert np.abs(eng.state(0)[0] - np.array(r.pose)).max() < 1e-8, k
+    trk.close()
+    eng.close()

@@ -59,3 +59,43 @@ def run_oracle_tracker(ob, st, n_frames=None, **over):
                         sel=r.outlier_selected, L=np.array(r.outlier_L), mask=trk.mask()))
     trk.close()
     return out
+
+
+def to_device(st):
+    """Copy of a stream whose image tensors live in HBM (zero-copy DEVICE inputs of the engine)."""
+    import copy
+    c = copy.copy(st)
+    c.depth, c.flow, c.mask_gt = st.depth.cuda(), st.flow.cuda(), st.mask_gt.cuda()
+    return c
+
+
+def device_frame(st, k):
+    """roft_frame_input of frame k for a stream returned by to_device()."""
+    from roft_amd import _lib as L
+    mi = st.mask_delivery[k]
+    pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
+    return dict(depth=st.depth[k].data_ptr(), flow=st.flow[k].data_ptr() if st.flow_valid[k] else None,
+                mask=st.mask_gt[mi].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE)
+
+
+def run_engine_logged(make_engine, streams, n, T=1, splits=None, **over):
+    """Runs device-resident streams through the engine in batches of T frames (or the explicit list `splits` of batch
+    sizes) and returns (pose, twist, n_points, outlier decision) logs plus the final masks."""
+    eng = make_engine(streams, max_batch_frames=max(T, max(splits) if splits else 1), **over)
+    eng.enable_log(n)
+    k = 0
+    i = 0
+    while k < n:
+        t = min(splits[i % len(splits)] if splits else T, n - k)
+        i += 1
+        if t == 1 and not splits:
+            eng.submit([device_frame(st, k) for st in streams])
+        else:
+            eng.submit_batch([[device_frame(st, k + j) for st in streams] for j in range(t)])
+        eng.step()
+        k += t
+    log = eng.get_log(0, n)
+    masks = [eng.mask(o) for o in range(len(streams))]
+    stats = eng.stats()
+    eng.close()
+    return log, masks, stats
