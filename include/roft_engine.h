@@ -271,6 +271,9 @@ int roft_get_mask(roft_engine* e, int obj_id, uint8_t* mask_out);
  * a ring of n_frames x n_objects records written by the step itself, read back in one copy. */
 int roft_engine_enable_log(roft_engine* e, int n_frames);
 int roft_engine_get_log(roft_engine* e, int first_frame, int n_frames, roft_object_output* outs);
+/* the same log as the reference writes it: rows[(f * n_objects + obj) * 19 ..] = pose(13: v w x q) | twist(6)
+ * (`pose_estimate` + `velocity_estimate`, ROFTFilter.cpp:386-394) -- the per-object records a multi-GPU job gathers */
+int roft_engine_get_log_rows(roft_engine* e, int first_frame, int n_frames, double* rows);
 
 /* work enqueued since roft_engine_create */
 typedef struct {

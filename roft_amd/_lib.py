@@ -90,7 +90,7 @@ ABI_SYMBOLS = [
     "roft_ukf_correct", "roft_render_depth", "roft_depth_likelihood", "roft_default_config",
     "roft_default_object", "roft_engine_create", "roft_engine_destroy", "roft_object_add",
     "roft_frame_submit", "roft_frames_submit", "roft_engine_retain_frames", "roft_engine_get_stats", "roft_step", "roft_sync", "roft_get_state", "roft_get_outputs", "roft_get_mask",
-    "roft_engine_enable_log", "roft_engine_get_log", "roft_engine_stream", "roft_engine_enable_timing",
+    "roft_engine_enable_log", "roft_engine_get_log", "roft_engine_get_log_rows", "roft_engine_stream", "roft_engine_enable_timing",
     "roft_engine_get_timing", "roft_default_of_params", "roft_optical_flow", "roft_flow_producer_create",
     "roft_flow_producer_destroy", "roft_flow_producer_run", "roft_flow_producer_sync", "roft_flow_producer_stream",
 ]
@@ -149,6 +149,7 @@ def lib():
     L.roft_get_mask.argtypes = [vp, C.c_int, vp]
     L.roft_engine_enable_log.argtypes = [vp, C.c_int]
     L.roft_engine_get_log.argtypes = [vp, C.c_int, C.c_int, C.POINTER(ObjectOutput)]
+    L.roft_engine_get_log_rows.argtypes = [vp, C.c_int, C.c_int, vp]
     L.roft_engine_stream.restype = vp
     L.roft_engine_stream.argtypes = [vp]
     L.roft_engine_enable_timing.argtypes = [vp, C.c_int]

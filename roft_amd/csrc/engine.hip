@@ -118,6 +118,7 @@ struct Arrays {
     DevBuf<FlowRec> cand, recs;
     DevBuf<double> norms;
     DevBuf<int> npts;
+    DevBuf<MaskRec> mrec;
     DevBuf<uint32_t> feat_pix;
     DevBuf<float> feat_depth;
     DevBuf<uint32_t> zbuf;
@@ -138,7 +139,8 @@ struct Arrays {
         HIP_TRY(params.ensure(n_obj, true));
         HIP_TRY(state.ensure(n_obj, true));
         HIP_TRY(ctrl.ensure((size_t)n_obj * T, true));
-        HIP_TRY(planes.ensure((size_t)n_obj * (kPlaneSlots + 2) * 2 * a.plane_words, true));
+        HIP_TRY(planes.ensure((size_t)n_obj * (kPlaneSlots + kMaxBatch) * 2 * a.plane_words, true));
+        HIP_TRY(mrec.ensure((size_t)n_obj * (kMaxBatch + 1), true));
         HIP_TRY(map.ensure((size_t)n_obj * npix, true));
         HIP_TRY(cand.ensure((size_t)n_obj * T * a.cand_cap));
         HIP_TRY(recs.ensure((size_t)n_obj * T * a.cand_cap));
@@ -148,7 +150,8 @@ struct Arrays {
         HIP_TRY(feat_depth.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
         HIP_TRY(zbuf.ensure((size_t)n_obj * 2 * a.tile_w * a.tile_h));
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
-        a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
+        a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.mrec = mrec.p;
+        a.T_prev = 0; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
         a.zbuf = zbuf.p;
         a.out_log = nullptr;
         a.log_cap = 0;
@@ -233,13 +236,12 @@ struct HostObject {
     ~HostObject() { for (auto* o : owned) delete o; }
 };
 
-// Device copies of HOST inputs: one list of buffers per frame of the retention window, handed out in order; identical
-// host pointers within a frame (a scene shared by several objects) share one upload.
+// Device copies of HOST inputs: one slab for the whole retention window (allocated at the first HOST upload), a
+// bump allocator per frame slot; identical host pointers within a frame (a scene shared by several objects) share one
+// upload.
 struct StageFrame {
-    std::vector<DevBuf<unsigned char>*> bufs;
     size_t used = 0;
     std::vector<std::pair<const void*, void*>> seen;
-    ~StageFrame() { for (auto* b : bufs) delete b; }
 };
 
 }  // namespace
@@ -281,12 +283,16 @@ struct roft_engine {
     std::vector<Sched> backup;
     std::vector<ObjParams> h_params;
     std::vector<StageFrame> staging;       // [retain]
+    DevBuf<unsigned char> host_slab;       // retain x slot_bytes
+    size_t slot_bytes = 0;
     ObjState* state_host = nullptr;   // pinned landing block of roft_get_state (velocity belief + corrected pose belief)
     // the submitted, not yet stepped batch
     bool submitted = false;
     int cur_T = 0;
     int n_segments = 1;
     bool any_feat = false, any_feat_now = false, had_uploads = false;
+    unsigned new_mask_frames = 0;   // bit t: some object receives a mask in frame t of the batch
+    int prev_T = 0;                 // frames of the batch stepped before
     int batch_counter = 0, frame_counter = 0;
     int completed_batches = 0, completed_frames = 0;
     int batch_end_frame[kBatchRing] = {};
@@ -676,14 +682,21 @@ static int stage_host(roft_engine* e, int frame, const void* host, size_t bytes,
     StageFrame& sf = e->staging[frame % e->retain];
     for (auto& pr : sf.seen)
         if (pr.first == host) { *dev = pr.second; return ROFT_OK; }
-    if (sf.used == sf.bufs.size()) sf.bufs.push_back(new DevBuf<unsigned char>());
-    DevBuf<unsigned char>& b = *sf.bufs[sf.used++];
-    HIP_TRY(b.ensure(bytes));
-    HIP_TRY(hipMemcpyAsync(b.p, host, bytes, hipMemcpyHostToDevice, e->up_stream));
+    if (!e->host_slab.p) {
+        const size_t npix = (size_t)e->cfg.cam.width * e->cfg.cam.height;
+        const size_t per_obj = ((npix * 4 + 255) & ~(size_t)255) + ((flow_bytes(e->arr.a.ffmt) + 255) & ~(size_t)255) + ((npix + 255) & ~(size_t)255);
+        e->slot_bytes = per_obj * (size_t)e->cfg.max_objects;
+        HIP_TRY(e->host_slab.ensure(e->slot_bytes * (size_t)e->retain));
+    }
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (sf.used + need > e->slot_bytes) return fail(ROFT_ERR_CAPACITY, "HOST staging slot exhausted");
+    unsigned char* d = e->host_slab.p + (size_t)(frame % e->retain) * e->slot_bytes + sf.used;
+    sf.used += need;
+    HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, e->up_stream));
     e->stats.h2d_bytes += (long long)bytes;
     e->had_uploads = true;
-    sf.seen.emplace_back(host, b.p);
-    *dev = b.p;
+    sf.seen.emplace_back(host, d);
+    *dev = d;
     return ROFT_OK;
 }
 
@@ -742,6 +755,7 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
             c.slot_cur = o.frame_idx % kPlaneSlots;
             c.has_new_mask = d_mask ? 1 : 0;
             c.new_mask = d_mask;
+            if (d_mask) e->new_mask_frames |= 1u << t;
             c.first_mask = 0;
             if (d_mask && !o.seg_available) { o.seg_available = true; c.first_mask = 1; }
             if (!o.seg_available)
@@ -852,6 +866,7 @@ int roft_frames_submit(roft_engine* e, const roft_frame_input* inputs, int n_obj
     e->backup.resize(e->objs.size());
     for (size_t i = 0; i < e->objs.size(); ++i) e->backup[i] = e->objs[i]->s;
     e->any_feat = e->any_feat_now = e->had_uploads = false;
+    e->new_mask_frames = 0;
     const int rc = submit_frames(e, inputs, n_objects, n_frames);
     HP_MARK(e, 1, hp_t);
     int rc2 = ROFT_OK;
@@ -925,6 +940,12 @@ static void tmark_kernel(roft_engine* e, const char* name, int which, hipEvent_t
     *stop = e->tev[idx + 1];
 }
 
+#define CHECK_LAUNCH(what)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = hipGetLastError();                                                              \
+        if (_e != hipSuccess) return fail(ROFT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
 static int step_batch(roft_engine* e)
 {
     constexpr int R = roft_engine::kBatchRing;
@@ -937,7 +958,9 @@ static int step_batch(roft_engine* e)
     long long& launches = e->stats.launches;
     long long& evops = e->stats.event_ops;
     double hp_t = e->host_prof ? host_now_us() : 0.0;
+    (void)hipGetLastError();   // a stale error of another library on this thread is not this step's
     a.T = T;
+    a.T_prev = e->prev_T;
     a.ctrl = e->dctrl[slot].p;
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
 
@@ -952,10 +975,12 @@ static int step_batch(roft_engine* e)
                               reinterpret_cast<const uint4*>(e->stage[slot]), reinterpret_cast<uint4*>(a.ctrl), n16);
         ++launches;
     }
+    CHECK_LAUNCH("FrameCtrl upload");
     HP_MARK(e, 3, hp_t);
     tmark(e, nullptr, 0);
-    launch_mask_chain(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, s, (multi && T > 1 && !full) ? e->ev_mask[slot] : nullptr);
-    ++launches;
+    launches += launch_mask_chain(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, e->new_mask_frames, s,
+                                  (multi && T > 1 && !full) ? e->ev_mask[slot] : nullptr);
+    CHECK_LAUNCH("mask chain");
     tmark(e, "mask_chain", 0);
     if (multi && T > 1 && full) { HIP_TRY(hipEventRecord(e->ev_mask[slot], s)); ++evops; }
     // the pose chain waits for the features only when a test can read a set buffered in this very batch
@@ -963,6 +988,7 @@ static int step_batch(roft_engine* e)
     if (e->any_feat) {
         launch_features(a, s, (want_ev_feat && !full) ? e->ev_feat[slot] : nullptr);
         ++launches;
+        CHECK_LAUNCH("features");
         tmark(e, "features", 0);
         if (want_ev_feat && full) { HIP_TRY(hipEventRecord(e->ev_feat[slot], s)); ++evops; }
     }
@@ -980,9 +1006,11 @@ static int step_batch(roft_engine* e)
         tmark_kernel(e, "flow_measure", 2, &k1_start, &k1_stop);
         launch_flow_measure(a, e->cfg.depth_maximum, radius, sv, k1_start, k1_stop);
         ++launches;
+        CHECK_LAUNCH("flow measurement");
     }
     launch_skf_chain(a, e->cfg.flow_weighting, sv, (multi && !full) ? e->ev_vel[slot] : nullptr);
     ++launches;
+    CHECK_LAUNCH("velocity filter chain");
     tmark(e, "skf_chain", 2);
     if (multi && full) { HIP_TRY(hipEventRecord(e->ev_vel[slot], sv)); ++evops; }
     HP_MARK(e, 5, hp_t);
@@ -1001,10 +1029,12 @@ static int step_batch(roft_engine* e)
         const bool last = seg == e->n_segments - 1;
         launch_ukf_chain(a, e->cfg.ut, seg == 0, sp, (last && !full) ? e->ev_done[slot] : nullptr);
         ++launches;
+        CHECK_LAUNCH("pose chain segment");
         tmark(e, "ukf_chain", 1);
         if (!last) {
             launch_outlier(a, sp, nullptr);
             launches += 3;
+            CHECK_LAUNCH("outlier rejection");
             tmark(e, "outlier_render_likelihood", 1);
         }
     }
@@ -1024,6 +1054,7 @@ int roft_step(roft_engine* e)
     // (a failed step leaves the engine consistent as far as the host can tell: the batch counts as enqueued)
     const int slot = e->batch_counter % roft_engine::kBatchRing;
     e->frame_counter += e->cur_T;
+    e->prev_T = e->cur_T;
     e->batch_end_frame[slot] = e->frame_counter;
     e->batch_counter++;
     e->stats.frames += e->cur_T;
@@ -1099,10 +1130,26 @@ int roft_engine_get_log(roft_engine* e, int first_frame, int n_frames, roft_obje
     if (!e || !outs || !e->arr.a.out_log) return fail(ROFT_ERR_INVALID, "log not enabled");
     if (int rc = roft_sync(e)) return rc;
     const int n_obj = e->arr.a.n_obj;
-    for (int f = 0; f < n_frames; ++f) {
+    for (int f = 0; f < n_frames;) {   // one copy per contiguous run of ring rows
         const int slot = (first_frame + f) % e->arr.a.log_cap;
+        const int run = std::min(n_frames - f, e->arr.a.log_cap - slot);
         HIP_TRY(hipMemcpy(outs + (size_t)f * n_obj, e->arr.a.out_log + (size_t)slot * n_obj,
-                          sizeof(roft_object_output) * n_obj, hipMemcpyDeviceToHost));
+                          sizeof(roft_object_output) * n_obj * run, hipMemcpyDeviceToHost));
+        f += run;
+    }
+    return ROFT_OK;
+}
+
+int roft_engine_get_log_rows(roft_engine* e, int first_frame, int n_frames, double* rows)
+{
+    if (!e || !rows || !e->arr.a.out_log || n_frames < 0) return fail(ROFT_ERR_INVALID, "log not enabled");
+    const int n_obj = e->arr.a.n_obj;
+    std::vector<roft_object_output> outs((size_t)n_frames * n_obj);
+    if (n_frames == 0) return ROFT_OK;
+    if (int rc = roft_engine_get_log(e, first_frame, n_frames, outs.data())) return rc;
+    for (size_t i = 0; i < outs.size(); ++i) {
+        std::memcpy(rows + 19 * i, outs[i].pose, sizeof(double) * 13);
+        std::memcpy(rows + 19 * i + 13, outs[i].twist, sizeof(double) * 6);
     }
     return ROFT_OK;
 }
@@ -1184,6 +1231,7 @@ struct OpCtx {
         if (roft_device_count() <= 0) return fail(ROFT_ERR_DEVICE, "no HIP device (libroft_hip has no CPU path)");
         if (int rc = check_geometry(cam.width, cam.height)) return rc;
         HIP_TRY(hipSetDevice(0));
+        (void)hipGetLastError();   // a stale error of another library on this thread is not this call's
         if (!stream) HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         DevFlowFmt ff;
         ff.type = ftype_;
@@ -1258,7 +1306,7 @@ int roft_flow_measurement(const roft_camera* cam, const uint8_t* prev_mask, cons
     fc.flow[0] = c.b2.p;
     fc.vel_stage = 1;
     if (int rc = upload_ctrl(c, fc)) return rc;
-    launch_mask_ingest(c.arr.a, c.stream);
+    launch_mask_ingest(c.arr.a, 0, c.stream);
     launch_flow_measure(c.arr.a, depth_max, r, c.stream);
     int n = 0;
     HIP_TRY(hipMemcpyAsync(&n, c.arr.a.npts, sizeof(int), hipMemcpyDeviceToHost, c.stream));
@@ -1288,6 +1336,7 @@ static int op_simple_prepare(OpCtx& c)
 {
     if (roft_device_count() <= 0) return fail(ROFT_ERR_DEVICE, "no HIP device (libroft_hip has no CPU path)");
     HIP_TRY(hipSetDevice(0));
+    (void)hipGetLastError();   // a stale error of another library on this thread is not this call's
     if (!c.stream) HIP_TRY(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     return ROFT_OK;
 }
@@ -1412,13 +1461,16 @@ int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int
     fc.slot_prev = 1;
     fc.slot_cur = 0;
     fc.flow_valid = 0;
-    // decide_mode() uses fbuf_n + flow_valid as the number of buffered flows
-    ObjState st;
-    init_state(st);
-    st.fbuf_n = used;
-    HIP_TRY(hipMemcpyAsync(c.arr.state.p, &st, sizeof(st), hipMemcpyHostToDevice, c.stream));
+    // decide_mode() uses fbuf_n + flow_valid as the number of buffered flows: state carried in = `used` buffered flows
+    MaskRec rec0[2];
+    std::memset(rec0, 0, sizeof(rec0));
+    rec0[0].fbuf_n = used;
+    HIP_TRY(hipMemcpyAsync(c.arr.mrec.p, rec0, sizeof(rec0), hipMemcpyHostToDevice, c.stream));
+    // the step kernel ORs into a zeroed destination (inside the engine the frame before leaves it zeroed)
+    HIP_TRY(hipMemsetAsync(c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 0), 0, sizeof(uint32_t) * 2 * c.arr.a.plane_words, c.stream));
     if (int rc = upload_ctrl(c, fc)) return rc;
-    launch_mask_chain(c.arr.a, frames_between, 1, c.stream);
+    c.arr.a.T_prev = 0;
+    launch_mask_chain(c.arr.a, frames_between, 1, 1u, c.stream);
     HIP_TRY(c.b2.ensure(npix));
     launch_planes_to_mask(c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 0), c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 1),
                           (int)npix, c.b2.p, c.stream);
@@ -1598,7 +1650,7 @@ int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint
         HIP_TRY(hipMemcpyAsync(c.arr.state.p, &st0, sizeof(st0), hipMemcpyHostToDevice, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
     }
-    launch_mask_ingest(c.arr.a, c.stream);
+    launch_mask_ingest(c.arr.a, 0, c.stream);
     launch_features(c.arr.a, c.stream);
     // likelihood only (the z-buffers are already filled)
     launch_outlier_only(c.arr.a, c.stream);

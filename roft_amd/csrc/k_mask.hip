@@ -8,17 +8,21 @@
 // MI355X design: a mask lives in HBM as two 1-bit planes (W*H/8 bytes each instead of W*H):
 //   nz  = raw value != 0  (what cv::findNonZero sees inside the OF-aided source)
 //   obj = raw value  > 1  (what every consumer sees after the threshold)
-// One workgroup of 16 waves per object walks the frames of a batch (mask_chain_kernel): the mask of frame k is the
-// source of frame k+1, so the recursion is sequential per object and a launch per frame only adds dispatch
-// gaps.  Per frame: ingest of a newly delivered mask (u8 -> planes, counts), the mode decision of step_frame,
-// and the propagation:
-//  * binary masks (no pixel of value 1, i.e. nz == obj -- decided on the device at ingest): every source pixel
-//    carries the same value, so the reference's "later writer wins" map + remap is an order-free OR of the target
-//    bits.  The target plane lives in LDS (W*H/8 bytes), LDS atomicOr, one coalesced write-out; no map, no gather.
-//  * general masks ({0, 1, 255}): the winner among the sources of a target is the one with the LARGEST linear
-//    index = an atomicMax on a W*H int32 map whose zero value doubles as "unmapped -> sample mask(0,0)" exactly like
-//    the zero-initialised cv::Mat map (:237); the gather reads every entry inside the targets' bounding box with an
-//    atomic exchange (read + clear), so the map is never memset and never read through a stale L1 line.
+// The mask of frame k is the source of frame k+1: the recursion is sequential per object and frame.  Per frame of a
+// batch the chain is [mask_ingest_kernel on frames that deliver masks: u8 -> planes, counts] + mask_step_kernel:
+//  * binary masks (no pixel of value 1, i.e. nz == obj -- decided on the device at ingest): every source pixel carries
+//    the same value, so the reference's "later writer wins" map + remap is an order-free OR of the target bits.  S
+//    workgroups per object (grid S x n_obj, S * n_obj ~ the CU count) each walk a share of the source's 64-pixel groups,
+//    OR into an LDS plane of their own (W*H/8 bytes, LDS atomics) and flush its non-zero words with global atomicOr into
+//    the destination, which the step kernel of the frame before left zeroed.  No map, no gather; only the obj plane of a
+//    binary mask is written and read.
+//  * general masks ({0, 1, 255}): mask_general_kernel, one persistent workgroup per object at the end of the batch,
+//    handles the frames whose source is not binary: the winner among the sources of a target is the one with the LARGEST
+//    linear index = an atomicMax on a W*H int32 map whose zero value doubles as "unmapped -> sample mask(0,0)" exactly
+//    like the zero-initialised cv::Mat map (:237); the gather reads every entry inside the targets' bounding box with
+//    an atomic exchange (read + clear), so the map is never memset and never read through a stale L1 line.
+// The per-frame decisions (mode, source, flow count, binary or not) are made once, by the step kernel, and recorded in
+// MaskRec rows that carry the state from frame to frame and from batch to batch.
 #include "roft_device.h"
 
 namespace roft {
@@ -98,26 +102,31 @@ __device__ __forceinline__ void ingest_group(const uint4* src, int g, uint2* nz,
     ones += __popcll(bnz & ~bob);
 }
 
-// operator level (roft_flow_measurement, roft_depth_likelihood): frame 0's mask -> plane slot kSlotNew.
-// grid: (ceil(W*H/64/256), n_obj)
-__global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a)
+// grid: (ceil(W*H/64/256), n_obj); frame t of the batch
+__global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a, int t)
 {
     const int obj = blockIdx.y;
-    const FrameCtrl& c = a.ctrl[obj];
+    const FrameCtrl& c = frame_ctrl(a, t, obj);
     if (!c.has_new_mask) return;
     const int n_grp = (a.cam.W * a.cam.H) >> 6;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     int count = 0, ones = 0;
     if (g < n_grp)
         ingest_group(reinterpret_cast<const uint4*>(c.new_mask), g,
-                     reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, kSlotNew, 0)),
-                     reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, kSlotNew, 1)), count, ones);
+                     reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, kSlotNew + t, 0)),
+                     reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, kSlotNew + t, 1)), count, ones);
+    for (int off = 32; off > 0; off >>= 1) { count += __shfl_xor(count, off, 64); ones += __shfl_xor(ones, off, 64); }
+    if ((threadIdx.x & 63) == 0 && count) {
+        MaskRec& r = a.mrec[(size_t)(t + 1) * a.n_obj + obj];
+        atomicAdd(&r.new_count, count);
+        if (ones) atomicAdd(&r.new_ones, ones);
+    }
 }
 
-void launch_mask_ingest(const EngineArrays& a, hipStream_t s)
+void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s)
 {
     const int n_grp = a.cam.W * a.cam.H / 64;
-    hipLaunchKernelGGL(mask_ingest_kernel, dim3((n_grp + 255) / 256, a.n_obj), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(mask_ingest_kernel, dim3((n_grp + 255) / 256, a.n_obj), dim3(256), 0, s, a, t);
 }
 
 // ---- mask chain ------------------------------------------------------------------------------------
@@ -127,94 +136,140 @@ constexpr int kMaskWaves = kMaskThreads / 64;
 //  walk is a chain of dependent loads, the chains of different groups are independent)
 
 struct MaskShared {
-    int red[2][kMaskWaves];
     int bbox[4];
     int n_list;
     const void* flows[kMaxFlowHist];
 };
 
-__device__ __forceinline__ int2 block_sum2(int a0, int a1, MaskShared& S)
-{
-    for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); }
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) { S.red[0][threadIdx.x >> 6] = a0; S.red[1][threadIdx.x >> 6] = a1; }
-    __syncthreads();
-    int t0 = 0, t1 = 0;
-    for (int w = 0; w < kMaskWaves; ++w) { t0 += S.red[0][w]; t1 += S.red[1][w]; }
-    return make_int2(t0, t1);
-}
-
 // Geometry the walks need (a handful of scalars instead of the whole EngineArrays block)
 struct ChaseGeo {
-    int W, H, cols;
+    int W, H, cols, grid;
     float grid_f, scale;
+    float inv_grid, inv_scale;   // exact reciprocals when grid and scale are powers of two (they are: 1 | 4, 1 | 32)
+    int mode;                    // 2: grid 1 and scale 1; 1: multiply by the reciprocals (bit-identical to the divisions); 0: divide
 };
+
+__host__ __device__ inline ChaseGeo make_chase_geo(const DevCamera& cam, const DevFlowFmt& f)
+{
+    ChaseGeo g;
+    g.W = cam.W; g.H = cam.H; g.cols = f.cols; g.grid = f.grid;
+    g.grid_f = (float)f.grid; g.scale = f.scale;
+    g.inv_grid = 1.0f / g.grid_f; g.inv_scale = 1.0f / f.scale;
+    int e = 0;
+    const bool p2g = (f.grid & (f.grid - 1)) == 0;
+    const bool p2s = f.scale > 0.0f && frexpf(f.scale, &e) == 0.5f;
+    g.mode = (p2g && p2s) ? ((f.grid == 1 && f.scale == 1.0f) ? 2 : 1) : 0;
+    return g;
+}
+
+// (int)x of the reference's x86-64 build as far as the bounds tests and indices can tell: NaN and |x| >= 2^31 give
+// INT_MIN there (cvttss2si), i.e. "out of the image"; here NaN -> -2 and the value is clamped to [-2, 2^24] before the
+// conversion, which is out of the image as well (W*H < 2^24) and exact in between, (-1, 0) -> 0 included.
+// (v_med3_f32 returns min3 of its operands when one of them is a NaN, and v_min_f32 returns the other operand: a NaN
+//  becomes -2 without a separate test; the NaN-flow cases of tests/test_parity_gpu.py pin this.)
+__device__ __forceinline__ int trunc_clamped(float x)
+{
+    return (int)__builtin_amdgcn_fmed3f(x, -2.0f, 16777216.0f);
+}
+
+#define ROFT_GLOBAL __attribute__((address_space(1)))
 
 // Walks of the source pixels of one frame.  `list` (LDS) holds the indices of the non-empty 64-pixel groups of the
 // source plane; wave w owns entries w, w + 16, ... (the object's rows spread over all waves), prefetches the plane
 // words of up to 64 of them with one load (lane i <-> the wave's i-th entry) and chases them NCH at a time: the
 // flow reads of a wave are row-contiguous (64 x 8 B).  A surviving pixel is handed to `hit(target, x, y, source)`.
-template <int FT, int NCH, class Hit>
-__device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plane2, const uint16_t* list, int n_list,
+// One CU walks a whole object, so the instruction count per pixel and flow matters as much as the load latency:
+//  * per-group work (row / column of the group) is wave-uniform;
+//  * a pixel that is not set, or left the image, carries t_x = NaN from then on -- NaN survives every flow addition and
+//    converts to "out of the image", so there is no per-walk activity flag to keep (and a NaN flow drops the pixel the
+//    same way, as cvttss2si does in the reference);
+//  * the float -> int conversions are clamps; MODE 2: grid 1 and scale 1 (CV_32FC2), the flow element of a pixel is
+//    the pixel itself; MODE 1: grid and scale are powers of two, the divisions are exact reciprocal multiplies;
+//    MODE 0: true divisions.
+template <int FT, int NCH, int MODE, class Hit>
+__device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plane2_, const uint16_t* list, int n_list,
                                              int n_flows, bool clear00, const void* const* flows, Hit hit)
 {
     const int W = g.W, H = g.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const ROFT_GLOBAL uint2* plane2 = (const ROFT_GLOBAL uint2*)plane2_;
+    const float nan = __uint_as_float(0x7FC00000u);
     for (int e0 = wave; e0 < n_list; e0 += kMaskWaves * 64) {
         const int my_e = e0 + lane * kMaskWaves;
         int my_grp = -1;
         uint2 mine = make_uint2(0u, 0u);
-        if (my_e < n_list) { my_grp = list[my_e]; mine = plane2[my_grp]; }
+        if (my_e < n_list) {
+            my_grp = list[my_e];
+            const unsigned long long w = *(const ROFT_GLOBAL unsigned long long*)(plane2 + my_grp);
+            mine = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+        }
         unsigned long long pending = __ballot(my_grp >= 0);
         while (pending) {
             float t_x[NCH], t_y[NCH];
-            int grp[NCH];
-            bool act[NCH];
+            int src[NCH];
 #pragma unroll
             for (int u = 0; u < NCH; ++u) {
-                act[u] = false;
-                grp[u] = 0;
-                t_x[u] = t_y[u] = 0.0f;
+                t_x[u] = nan;
+                t_y[u] = 0.0f;
+                src[u] = 0;
                 if (pending) {
                     const int it = __builtin_ctzll(pending);
                     pending &= pending - 1;
-                    grp[u] = __builtin_amdgcn_readlane(my_grp, it);
+                    const int grp = __builtin_amdgcn_readlane(my_grp, it);
                     unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine.y, it) << 32) |
                                               (uint32_t)__builtin_amdgcn_readlane((int)mine.x, it);
-                    if (clear00 && grp[u] == 0) bits &= ~1ull;                 // mask_.at<uchar>(0,0) = 0
-                    act[u] = (bits >> lane) & 1ull;
-                    const int p = grp[u] * 64 + lane;
-                    const int py = p / W, px = p - py * W;
-                    t_x[u] = (float)px;
+                    if (clear00 && grp == 0) bits &= ~1ull;                 // mask_.at<uchar>(0,0) = 0
+                    // row / column of the group's first pixel: wave-uniform; a group may straddle rows when W % 64 != 0
+                    const int p0 = grp * 64, y0 = p0 / W;
+                    int px = p0 - y0 * W + lane, py = y0;
+                    if (px >= W) { px -= W; ++py; }
+                    if (px >= W) { px -= W; ++py; }
+                    src[u] = p0 + lane;
+                    t_x[u] = ((bits >> lane) & 1ull) ? (float)px : nan;
                     t_y[u] = (float)py;
                 }
             }
             // flows in chronological order: oldest buffered first (flows[n_flows-1]) ... current (flows[0])
             for (int j = n_flows - 1; j >= 0; --j) {
-                const void* fl = flows[j];
+                // (wave-uniform base pointer in scalar registers: the loads need only a 32-bit offset per lane)
+                const unsigned long long fl_bits = (unsigned long long)flows[j];
+                const ROFT_GLOBAL unsigned char* fl = (const ROFT_GLOBAL unsigned char*)(
+                    ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fl_bits >> 32)) << 32) |
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fl_bits));
                 uint2 raw[NCH];
 #pragma unroll
                 for (int u = 0; u < NCH; ++u) {
-                    const int ix = trunc_int_x86(t_x[u]), iy = trunc_int_x86(t_y[u]);
-                    if (ix < 0 || ix >= W || iy < 0 || iy >= H) act[u] = false;   // left the image: the pixel is dropped
-                    // inactive lanes read element (0, 0): the loads stay unconditional and in flight together
-                    const int fr = act[u] ? trunc_int_x86(t_y[u] / g.grid_f) : 0;
-                    const int fc = act[u] ? trunc_int_x86(t_x[u] / g.grid_f) : 0;
-                    raw[u] = flow_raw<FT>(fl, (size_t)(fr * g.cols + fc));
+                    const int ix = trunc_clamped(t_x[u]), iy = trunc_clamped(t_y[u]);
+                    const bool in = (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
+                    t_x[u] = in ? t_x[u] : nan;   // left the image: the pixel is dropped (hpp:262-266)
+                    int fr, fc;
+                    if (MODE == 2) { fr = iy; fc = ix; }
+                    else if (MODE == 1) { fr = trunc_clamped(t_y[u] * g.inv_grid); fc = trunc_clamped(t_x[u] * g.inv_grid); }
+                    else { fr = trunc_clamped(t_y[u] / g.grid_f); fc = trunc_clamped(t_x[u] / g.grid_f); }
+                    // dropped pixels read element (0, 0): the loads stay unconditional and in flight together
+                    const uint32_t off = in ? (uint32_t)(fr * g.cols + fc) * (FT == ROFT_FLOW_S16C2 ? 4u : 8u) : 0u;
+                    if (FT == ROFT_FLOW_S16C2) {
+                        raw[u] = make_uint2(*(const ROFT_GLOBAL uint32_t*)(fl + off), 0u);
+                    } else {
+                        const unsigned long long w = *(const ROFT_GLOBAL unsigned long long*)(fl + off);
+                        raw[u] = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < NCH; ++u) {
                     float dx, dy;
-                    flow_decode<FT>(raw[u], g.scale, dx, dy);
+                    if (FT == ROFT_FLOW_S16C2) { dx = (float)(short)(raw[u].x & 0xFFFFu); dy = (float)(short)(raw[u].x >> 16); }
+                    else { dx = __uint_as_float(raw[u].x); dy = __uint_as_float(raw[u].y); }
+                    if (MODE == 1) { dx *= g.inv_scale; dy *= g.inv_scale; }
+                    else if (MODE == 0) { dx /= g.scale; dy /= g.scale; }
                     t_x[u] += dx;
                     t_y[u] += dy;
                 }
             }
 #pragma unroll
             for (int u = 0; u < NCH; ++u) {
-                const int ix = trunc_int_x86(t_x[u]), iy = trunc_int_x86(t_y[u]);
-                if (!act[u] || ix < 0 || ix >= W || iy < 0 || iy >= H) continue;
-                hit(iy * W + ix, ix, iy, grp[u] * 64 + lane);
+                const int ix = trunc_clamped(t_x[u]), iy = trunc_clamped(t_y[u]);
+                if ((unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) hit(iy * W + ix, ix, iy, src[u]);
             }
         }
     }
@@ -225,8 +280,10 @@ template <int FT>
 __device__ __noinline__ void propagate_binary(ChaseGeo g, const uint2* plane2, const uint16_t* list, int n_list, int n_flows,
                                               bool clear00, const void* const* flows, uint32_t* s_tgt)
 {
-    chase_groups<FT, 8>(g, plane2, list, n_list, n_flows, clear00, flows,
-                        [&](int tp, int, int, int) { atomicOr(&s_tgt[tp >> 5], 1u << (tp & 31)); });
+    auto hit = [s_tgt](int tp, int, int, int) { atomicOr(&s_tgt[tp >> 5], 1u << (tp & 31)); };   // (by value: no reload per hit)
+    if (g.mode == 2) chase_groups<FT, 8, 2>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
+    else if (g.mode == 1) chase_groups<FT, 8, 1>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
+    else chase_groups<FT, 4, 0>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
 }
 
 // general source: map of the winning (largest) source index per target + the targets' bounding box (LDS bbox[4])
@@ -235,11 +292,14 @@ __device__ __noinline__ void propagate_general(ChaseGeo g, const uint2* plane2, 
                                                bool clear00, const void* const* flows, int32_t* map, int* s_bbox)
 {
     int bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = -1, by1 = -1;
-    chase_groups<FT, 4>(g, plane2, list, n_list, n_flows, clear00, flows, [&](int tp, int ix, int iy, int p) {
+    auto hit = [map, &bx0, &by0, &bx1, &by1](int tp, int ix, int iy, int p) {
         atomicMax(&map[tp], p);
         bx0 = min(bx0, ix); bx1 = max(bx1, ix);
         by0 = min(by0, iy); by1 = max(by1, iy);
-    });
+    };
+    if (g.mode == 2) chase_groups<FT, 4, 2>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
+    else if (g.mode == 1) chase_groups<FT, 4, 1>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
+    else chase_groups<FT, 4, 0>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
     for (int off = 32; off > 0; off >>= 1) {
         bx0 = min(bx0, __shfl_xor(bx0, off, 64)); by0 = min(by0, __shfl_xor(by0, off, 64));
         bx1 = max(bx1, __shfl_xor(bx1, off, 64)); by1 = max(by1, __shfl_xor(by1, off, 64));
@@ -250,85 +310,162 @@ __device__ __noinline__ void propagate_general(ChaseGeo g, const uint2* plane2, 
     }
 }
 
-// plane-wide copies / fills by the whole workgroup: 16-byte accesses when the planes are 16-byte aligned
-// (plane_words % 4 == 0), 8-byte ones otherwise (plane_words is always even: W*H % 64 == 0)
-__device__ __forceinline__ void plane_copy2(uint32_t* d0, uint32_t* d1, const uint32_t* s0, const uint32_t* s1, size_t n_words)
+// copies / fills of plane words by the whole workgroup: 16-byte accesses when pointers and length allow, 8-byte ones
+// otherwise (plane offsets and shares are multiples of two words: W*H % 64 == 0)
+__device__ __forceinline__ void plane_copy(uint32_t* d, const uint32_t* s, size_t n_words)
 {
-    if ((n_words & 3) == 0) {
-        for (size_t i = threadIdx.x; i < n_words / 4; i += blockDim.x) {
-            reinterpret_cast<uint4*>(d0)[i] = reinterpret_cast<const uint4*>(s0)[i];
-            reinterpret_cast<uint4*>(d1)[i] = reinterpret_cast<const uint4*>(s1)[i];
-        }
-    } else {
-        for (size_t i = threadIdx.x; i < n_words / 2; i += blockDim.x) {
-            reinterpret_cast<uint2*>(d0)[i] = reinterpret_cast<const uint2*>(s0)[i];
-            reinterpret_cast<uint2*>(d1)[i] = reinterpret_cast<const uint2*>(s1)[i];
-        }
-    }
+    if (((n_words & 3) | ((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15)) == 0)
+        for (size_t i = threadIdx.x; i < n_words / 4; i += blockDim.x) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    else
+        for (size_t i = threadIdx.x; i < n_words / 2; i += blockDim.x) reinterpret_cast<uint2*>(d)[i] = reinterpret_cast<const uint2*>(s)[i];
 }
 
 __device__ __forceinline__ void plane_fill(uint32_t* d, uint32_t v, size_t n_words)
 {
-    if ((n_words & 3) == 0)
+    if (((n_words & 3) | (reinterpret_cast<uintptr_t>(d) & 15)) == 0)
         for (size_t i = threadIdx.x; i < n_words / 4; i += blockDim.x) reinterpret_cast<uint4*>(d)[i] = make_uint4(v, v, v, v);
     else
         for (size_t i = threadIdx.x; i < n_words / 2; i += blockDim.x) reinterpret_cast<uint2*>(d)[i] = make_uint2(v, v);
 }
 
-// dynamic LDS: [plane_words] OR target | [W*H/64] uint16 list of non-empty groups
+// State carried into the batch + reset of the per-frame counters the ingest kernels accumulate into.
+__global__ void mask_carry_kernel(EngineArrays a)
+{
+    const int obj = blockIdx.x * blockDim.x + threadIdx.x;
+    if (obj >= a.n_obj) return;
+    if (a.T_prev > 0) {
+        const MaskRec last = a.mrec[(size_t)a.T_prev * a.n_obj + obj];
+        MaskRec& r0 = a.mrec[obj];
+        r0.fbuf_n = last.fbuf_n;
+        r0.binary = last.binary;
+    }
+    for (int t = 1; t <= a.T; ++t) {
+        MaskRec& r = a.mrec[(size_t)t * a.n_obj + obj];
+        r.new_count = 0;
+        r.new_ones = 0;
+    }
+}
+
+// The decisions of frame t (ImageSegmentationOFAidedSource::step_frame, hpp:169-226) from the state after frame t-1.
+__device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskRec& cur, int t, const FrameCtrl& c,
+                                                int frames_between, int flow_aided)
+{
+    MaskRec r = cur;   // new_count / new_ones of this frame
+    const int new_count = c.has_new_mask ? r.new_count : 0;
+    const int new_binary = r.new_ones == 0;
+    if (flow_aided) {
+        r.mode = decide_mode(c, kSlotNew + t, prev.fbuf_n, new_count, frames_between, r.src_slot, r.n_flows);
+        r.fbuf_n = next_fbuf(c, prev.fbuf_n, new_count, r.mode, frames_between);
+    } else {  // no flow-aided segmentation: the delivered mask is used as is, otherwise the last one persists
+        r.mode = 0;
+        r.src_slot = c.has_new_mask ? kSlotNew + t : c.slot_prev;
+        r.n_flows = 0;
+        r.fbuf_n = 0;
+    }
+    r.src_binary = (r.src_slot >= kSlotNew) ? new_binary : prev.binary;
+    r.binary = r.src_binary;
+    return r;
+}
+
+// dynamic LDS: [plane_words] OR target | uint16 list of this workgroup's non-empty groups
+// grid: (S, n_obj); frame t of the batch.  Workgroup q of an object owns the 64-pixel groups q, q + S, ... of the
+// source and the words [q, q+1) * plane_words / S of the planes it copies / fills / zeroes.
 template <int FT>
-__global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a, int frames_between, int flow_aided)
+__global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a, int t, int frames_between, int flow_aided)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ MaskShared S;
     uint32_t* s_tgt = reinterpret_cast<uint32_t*>(smem);
     uint16_t* s_list = reinterpret_cast<uint16_t*>(smem + ((a.plane_words * 4 + 15) & ~(size_t)15));
+    const int obj = blockIdx.y, q = blockIdx.x, nq = gridDim.x;
+    const int W = a.cam.W, H = a.cam.H, n_grp = (W * H) >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // control block and the two state records -> LDS with one load per thread
+    __shared__ FrameCtrl s_c;
+    __shared__ MaskRec s_rec[2];
+    stage_ctrl(&s_c, frame_ctrl(a, t, obj));
+    static_assert(sizeof(MaskRec) == 32, "two 16-byte loads per record");
+    if (tid >= 128 && tid < 132) {
+        const int k = tid - 128;   // 0, 1: record of frame t-1 (or the carry); 2, 3: this frame's
+        reinterpret_cast<uint4*>(s_rec)[k] = reinterpret_cast<const uint4*>(a.mrec + (size_t)(t + (k >> 1)) * a.n_obj + obj)[k & 1];
+    }
+    __syncthreads();
+    const FrameCtrl& c = s_c;
+    const MaskRec r = decide_frame(s_rec[0], s_rec[1], t, c, frames_between, flow_aided);
+    if (q == 0 && tid == 0) a.mrec[(size_t)(t + 1) * a.n_obj + obj] = r;   // (every workgroup computes the same record)
+    // share of the plane words of this workgroup, in 16-byte units when the planes are 16-byte aligned
+    const int unit = (a.plane_words & 3) ? 2 : 4;
+    const int n_units = (int)(a.plane_words / unit);
+    const int u0 = (int)((long long)n_units * q / nq) * unit, u1 = (int)((long long)n_units * (q + 1) / nq) * unit;
+    // the obj plane of the NEXT frame's slot is left zeroed for that frame's OR flush (nobody reads that slot any more:
+    // its last user is kPlaneSlots frames back)
+    plane_fill(a.planes + plane_offset(a, obj, (c.slot_cur + 1) % kPlaneSlots, 1) + u0, 0u, (size_t)(u1 - u0));
+    if (!r.src_binary) return;   // three-valued source: mask_general_kernel
+    const uint32_t* src = a.planes + plane_offset(a, obj, r.src_slot, 1);
+    uint32_t* dst = a.planes + plane_offset(a, obj, c.slot_cur, 1);
+    if (r.mode == 0) {
+        plane_copy(dst + u0, src + u0, (size_t)(u1 - u0));
+        return;
+    }
+    if (r.mode == 2 && (src[0] & 1u)) {
+        // mask(0,0) set in a new-mask frame: every target, mapped or not, samples a set pixel
+        plane_fill(dst + u0, ~0u, (size_t)(u1 - u0));
+        return;
+    }
+    if (tid < kMaxFlowHist) S.flows[tid] = (tid < r.n_flows) ? c.flow[tid] : nullptr;
+    if (tid == 0) S.n_list = 0;
+    plane_fill(s_tgt, 0u, a.plane_words);
+    __syncthreads();
+    // this workgroup's non-empty 64-pixel groups of the source -> list (any order: the scatter is order-free)
+    const uint2* plane2 = reinterpret_cast<const uint2*>(src);
+    for (int i0 = 0; q + nq * i0 < n_grp; i0 += kMaskThreads) {
+        const int g = q + nq * (i0 + tid);
+        bool ne = false;
+        if (g < n_grp) { const uint2 w = plane2[g]; ne = (w.x | w.y) != 0u; }
+        const unsigned long long b = __ballot(ne);
+        int base = 0;
+        if (lane == 0 && b) base = atomicAdd(&S.n_list, __popcll(b));
+        base = __shfl(base, 0, 64);
+        if (ne) s_list[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)g;
+    }
+    __syncthreads();
+    propagate_binary<FT>(make_chase_geo(a.cam, a.ffmt), plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, s_tgt);
+    __syncthreads();
+    // flush: the non-zero words of this workgroup's plane into the (zeroed) destination
+    for (int i = tid; i < (int)a.plane_words; i += kMaskThreads) {
+        const uint32_t v = s_tgt[i];
+        if (v) atomicOr(&dst[i], v);
+    }
+}
+
+// One persistent workgroup per object at the end of the batch's mask chain: the frames whose source is three-valued.
+// dynamic LDS: uint16 list of the non-empty groups
+template <int FT>
+__global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ MaskShared S;
+    uint16_t* s_list = reinterpret_cast<uint16_t*>(smem);
     const int obj = blockIdx.x;
-    ObjState& st = a.state[obj];
     const int W = a.cam.W, H = a.cam.H, npix = W * H, n_grp = npix >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
-    int fbuf_n = st.fbuf_n, cur_binary = st.mask_binary, mode = 0;
-
     for (int t = 0; t < a.T; ++t) {
+        const MaskRec r = a.mrec[(size_t)(t + 1) * a.n_obj + obj];
+        if (r.src_binary) continue;
         const FrameCtrl& c = frame_ctrl(a, t, obj);
-        const int has_new = c.has_new_mask;
-        // ---- a newly delivered mask -> plane slot kSlotNew, its non-zero count and whether it is binary
-        int new_count = 0, new_binary = 1;
-        if (has_new) {
-            const uint4* src = reinterpret_cast<const uint4*>(c.new_mask);
-            uint2* nz = reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, kSlotNew, 0));
-            uint2* ob = reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, kSlotNew, 1));
-            int count = 0, ones = 0;
-            for (int g = tid; g < n_grp; g += kMaskThreads) ingest_group(src, g, nz, ob, count, ones);
-            const int2 tot = block_sum2(count, ones, S);   // (its barriers also order the plane stores before the reads below)
-            new_count = tot.x;
-            new_binary = tot.y == 0;
-        }
+        const uint32_t* snz = a.planes + plane_offset(a, obj, r.src_slot, 0);
+        const uint32_t* sob = a.planes + plane_offset(a, obj, r.src_slot, 1);
         uint32_t* dnz = a.planes + plane_offset(a, obj, c.slot_cur, 0);
         uint32_t* dob = a.planes + plane_offset(a, obj, c.slot_cur, 1);
-        int src_slot, n_flows;
-        if (flow_aided) {
-            mode = decide_mode(c, fbuf_n, new_count, frames_between, src_slot, n_flows);
-        } else {  // no flow-aided segmentation: the delivered mask is used as is, otherwise the last one persists
-            mode = 0;
-            src_slot = has_new ? kSlotNew : c.slot_prev;
-            n_flows = 0;
-        }
-        const int src_binary = (src_slot == kSlotNew) ? new_binary : cur_binary;
-        const uint32_t* snz = a.planes + plane_offset(a, obj, src_slot, 0);
-        const uint32_t* sob = a.planes + plane_offset(a, obj, src_slot, 1);
-
-        if (mode == 0) {
-            plane_copy2(dnz, dob, snz, sob, a.plane_words);
+        if (r.mode == 0) {
+            plane_copy(dnz, snz, a.plane_words);
+            plane_copy(dob, sob, a.plane_words);
         } else {
             // background = mask(0,0) of the source: unmapped targets sample it; forced to 0 in mode 1
-            const bool bg_nz = (mode == 2) && (snz[0] & 1u), bg_ob = (mode == 2) && (sob[0] & 1u);
-            if (tid < kMaxFlowHist) S.flows[tid] = (tid < n_flows) ? c.flow[tid] : nullptr;
+            const bool bg_nz = (r.mode == 2) && (snz[0] & 1u), bg_ob = (r.mode == 2) && (sob[0] & 1u);
+            if (tid < kMaxFlowHist) S.flows[tid] = (tid < r.n_flows) ? c.flow[tid] : nullptr;
             if (tid == 0) { S.n_list = 0; S.bbox[0] = INT32_MAX; S.bbox[1] = INT32_MAX; S.bbox[2] = -1; S.bbox[3] = -1; }
-            const bool fast = src_binary && !bg_nz;
-            if (fast) plane_fill(s_tgt, 0u, a.plane_words);
             __syncthreads();
-            // non-empty 64-pixel groups of the source -> list (any order: both scatters are order-free)
             const uint2* plane2 = reinterpret_cast<const uint2*>(snz);
             for (int g0 = 0; g0 < n_grp; g0 += kMaskThreads) {
                 const int g = g0 + tid;
@@ -341,67 +478,71 @@ __global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a
                 if (ne) s_list[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)g;
             }
             __syncthreads();
-            const int n_list = S.n_list;
-            const ChaseGeo geo{W, H, a.ffmt.cols, (float)a.ffmt.grid, a.ffmt.scale};
-            if (fast) {
-                // ---- binary source: OR-scatter into the LDS plane
-                propagate_binary<FT>(geo, plane2, s_list, n_list, n_flows, mode == 1, S.flows, s_tgt);
-                __syncthreads();
-                plane_copy2(dnz, dob, s_tgt, s_tgt, a.plane_words);
-            } else if (src_binary) {
-                // binary source with mask(0,0) set in a new-mask frame: every target, mapped or not, samples a set pixel
-                plane_fill(dnz, ~0u, a.plane_words);
-                plane_fill(dob, ~0u, a.plane_words);
-            } else {
-                // ---- general source: map of the winning (largest) source index per target, then the gather
-                int32_t* map = a.map + (size_t)obj * npix;
-                propagate_general<FT>(geo, plane2, s_list, n_list, n_flows, mode == 1, S.flows, map, S.bbox);
-                __syncthreads();
-                const int bx0 = S.bbox[0], by0 = S.bbox[1], bx1 = S.bbox[2], by1 = S.bbox[3];
-                // every 64-pixel output group: constant background outside the box, map samples inside
-                const int wave = tid >> 6;
-                for (int g = wave; g < n_grp; g += kMaskWaves) {
-                    const int p = g * 64 + lane;
-                    const int y = p / W, x = p - y * W;
-                    bool nzb = bg_nz, obb = bg_ob;
-                    if (y >= by0 && y <= by1 && x >= bx0 && x <= bx1) {
-                        const int m = atomicExch(&map[p], 0);   // read + clear at the L2, never a stale L1 line
-                        if (m != 0) {
-                            nzb = (snz[m >> 5] >> (m & 31)) & 1u;
-                            obb = (sob[m >> 5] >> (m & 31)) & 1u;
-                        }
+            int32_t* map = a.map + (size_t)obj * npix;
+            propagate_general<FT>(make_chase_geo(a.cam, a.ffmt), plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, map, S.bbox);
+            __syncthreads();
+            const int bx0 = S.bbox[0], by0 = S.bbox[1], bx1 = S.bbox[2], by1 = S.bbox[3];
+            // every 64-pixel output group: constant background outside the box, map samples inside
+            const int wave = tid >> 6;
+            for (int g = wave; g < n_grp; g += kMaskWaves) {
+                const int p = g * 64 + lane;
+                const int y = p / W, x = p - y * W;
+                bool nzb = bg_nz, obb = bg_ob;
+                if (y >= by0 && y <= by1 && x >= bx0 && x <= bx1) {
+                    const int m = atomicExch(&map[p], 0);   // read + clear at the L2, never a stale L1 line
+                    if (m != 0) {
+                        nzb = (snz[m >> 5] >> (m & 31)) & 1u;
+                        obb = (sob[m >> 5] >> (m & 31)) & 1u;
                     }
-                    const unsigned long long b1 = __ballot(nzb), b2 = __ballot(obb);
-                    if (lane == 0) {
-                        reinterpret_cast<uint2*>(dnz)[g] = make_uint2((uint32_t)b1, (uint32_t)(b1 >> 32));
-                        reinterpret_cast<uint2*>(dob)[g] = make_uint2((uint32_t)b2, (uint32_t)(b2 >> 32));
-                    }
+                }
+                const unsigned long long b1 = __ballot(nzb), b2 = __ballot(obb);
+                if (lane == 0) {
+                    reinterpret_cast<uint2*>(dnz)[g] = make_uint2((uint32_t)b1, (uint32_t)(b1 >> 32));
+                    reinterpret_cast<uint2*>(dob)[g] = make_uint2((uint32_t)b2, (uint32_t)(b2 >> 32));
                 }
             }
         }
-        fbuf_n = flow_aided ? next_fbuf(c, fbuf_n, new_count, mode, frames_between) : 0;
-        cur_binary = src_binary;
         __syncthreads();   // this frame's planes are the next frame's source (same workgroup)
     }
-    if (tid == 0) { st.fbuf_n = fbuf_n; st.mask_binary = cur_binary; st.mask_mode = mode; }
 }
 
-void launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s, hipEvent_t stop)
+int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s,
+                      hipEvent_t stop)
 {
-    const size_t lds = ((a.plane_words * 4 + 15) & ~(size_t)15) + (((size_t)a.cam.W * a.cam.H / 64) * 2 + 15 & ~(size_t)15);
+    const size_t n_grp = (size_t)a.cam.W * a.cam.H / 64;
+    // workgroups per object: the step kernel's walks are instruction-bound on one CU, so an object is spread over as
+    // many CUs as the chip has to spare (256 CUs; at most 8 per object)
+    int S = 256 / (a.n_obj > 0 ? a.n_obj : 1);
+    S = S < 1 ? 1 : (S > 8 ? 8 : S);
+    const size_t lds_plane = (a.plane_words * 4 + 15) & ~(size_t)15;
+    const size_t lds_step = lds_plane + (((n_grp + S - 1) / S) * 2 + 15 & ~(size_t)15);
+    const size_t lds_gen = (n_grp * 2 + 15) & ~(size_t)15;
     static bool attr_set = false;
     if (!attr_set) {
-        const int cap = 160 * 1024 - 256 - (int)sizeof(MaskShared) - 128;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_chain_kernel<ROFT_FLOW_S16C2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_chain_kernel<ROFT_FLOW_F32C2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        const int cap = 160 * 1024 - 4096;   // (the kernel's static LDS -- control block, records, flow pointers -- is ~1.2 KB)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_step_kernel<ROFT_FLOW_S16C2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_step_kernel<ROFT_FLOW_F32C2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         attr_set = true;
     }
-    if (a.ffmt.type == ROFT_FLOW_S16C2)
-        hipExtLaunchKernelGGL(mask_chain_kernel<ROFT_FLOW_S16C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds, s, nullptr, stop, 0,
-                              a, frames_between, flow_aided);
+    int launches = 0;
+    hipLaunchKernelGGL(mask_carry_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a);
+    ++launches;
+    const bool s16 = a.ffmt.type == ROFT_FLOW_S16C2;
+    for (int t = 0; t < a.T; ++t) {
+        if (new_mask_frames & (1u << t)) { launch_mask_ingest(a, t, s); ++launches; }
+        if (s16)
+            hipLaunchKernelGGL(mask_step_kernel<ROFT_FLOW_S16C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a, t,
+                               frames_between, flow_aided);
+        else
+            hipLaunchKernelGGL(mask_step_kernel<ROFT_FLOW_F32C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a, t,
+                               frames_between, flow_aided);
+        ++launches;
+    }
+    if (s16)
+        hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_S16C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, stop, 0, a);
     else
-        hipExtLaunchKernelGGL(mask_chain_kernel<ROFT_FLOW_F32C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds, s, nullptr, stop, 0,
-                              a, frames_between, flow_aided);
+        hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_F32C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, stop, 0, a);
+    return launches + 1;
 }
 
 // ---- plane -> u8 mask (operator-level output / roft_get_mask) --------------------------------

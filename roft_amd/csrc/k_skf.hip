@@ -468,13 +468,18 @@ __global__ __launch_bounds__(kSkfThreads) void skf_chain_kernel(EngineArrays a, 
     __shared__ double s_x[6];
     __shared__ double s_P[36];
 
+    __shared__ FrameCtrl s_c;
+    __shared__ int s_npts;
     const int obj = blockIdx.x;
     ObjState& st = a.state[obj];
     const ObjParams& prm = a.params[obj];
     for (int t = 0; t < a.T; ++t) {
         const int slot = t * a.n_obj + obj;
-        const FrameCtrl& c = a.ctrl[slot];
-        const int n_pts = c.vel_stage ? a.npts[slot] : -1;
+        stage_ctrl(&s_c, a.ctrl[slot]);   // (the barrier at the end of the previous frame precedes this overwrite)
+        if (threadIdx.x == 255) s_npts = a.npts[slot];
+        __syncthreads();
+        const FrameCtrl& c = s_c;
+        const int n_pts = c.vel_stage ? s_npts : -1;
         const int N = n_pts;
         roft_object_output* row = log_row(a, c, obj);
         if (threadIdx.x == 0) st.n_flow_points = n_pts;

@@ -1082,8 +1082,16 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
     if (threadIdx.x < 10) L.wQ[threadIdx.x] = 0.0;
     __syncthreads();
     bool pending = false;
+    __shared__ FrameCtrl s_c;
+    int staged = -1;
     while (t < a.T) {
-        const FrameCtrl& c = frame_ctrl(a, t, obj);
+        if (staged != t) {   // this frame's control block -> LDS
+            __syncthreads();     // (nobody still reads the previous frame's)
+            stage_ctrl(&s_c, frame_ctrl(a, t, obj));
+            staged = t;
+            __syncthreads();
+        }
+        const FrameCtrl& c = s_c;
         if (step == 0 && threadIdx.x == 0) st.outlier_selected = -1;  // set again by outlier_kernel if it runs
         if (step >= c.n_steps) { ++t; step = 0; continue; }
         if (c.steps[step].op) ukf_one_step(a, c, obj, step, ut, L);

@@ -68,10 +68,6 @@ struct ObjState {
     double v_cov[36];
     PoseBelief belief[kNumBelief];
     double twist_hist[kTwistRing][6];
-    int fbuf_n;            // flows buffered since the last consumed mask (OF-aided source)
-    int mask_binary;       // the current propagated mask has no pixel of value 1 (nz plane == obj plane): its
-                           // propagation is an order-free OR-scatter (k_mask.hip)
-    int mask_mode;         // mode of the last frame: 0 copy, 1 propagate, 2 new mask
     int pc_frame, pc_step; // pose chain cursor inside the current batch (ukf_chain_kernel)
     int pending_frame;     // frame of the batch whose outlier test is pending between two pose chain segments, -1 none
     int n_flow_points;     // N of the velocity stage of the last frame (-1: did not run)
@@ -129,6 +125,20 @@ struct alignas(16) FrameCtrl {
     int frame_idx;                   // engine frame counter (row of the output log)
 };
 
+// Mask chain record of one frame of the batch and one object (k_mask.hip).  Row t + 1 of EngineArrays::mrec belongs to
+// frame t; row 0 carries the state in from the batch before.
+struct MaskRec {
+    int mode;        // 0 copy, 1 propagate the last mask through this frame's flow, 2 new mask through the buffered flows
+    int src_slot;    // plane slot of the source mask
+    int n_flows;     // flows the source is chased through
+    int src_binary;  // the source has no pixel of value 1 (nz plane == obj plane): order-free OR-scatter, only the obj
+                     // plane of the result is written; otherwise the general, map-based path writes both planes
+    int fbuf_n;      // flows buffered AFTER this frame (OF-aided source)
+    int binary;      // == src_binary: the propagated mask after this frame is binary
+    int new_count;   // non-zero pixels of the mask delivered with this frame (mask_ingest_kernel)
+    int new_ones;    // ... of value 1 among them
+};
+
 // ---- launch wrappers (defined in the k_*.hip files) -------------------------------------------
 
 struct EngineArrays {
@@ -139,7 +149,9 @@ struct EngineArrays {
     ObjState* state;         // [n_obj]
     int T;                   // frames of the current batch
     FrameCtrl* ctrl;         // [T][n_obj] (current batch)
-    uint32_t* planes;        // [n_obj][kPlaneSlots + 2][2][wpr*H]   (nz plane, obj plane)
+    uint32_t* planes;        // [n_obj][kPlaneSlots + kMaxBatch][2][wpr*H]   (nz plane, obj plane)
+    MaskRec* mrec;           // [kMaxBatch + 1][n_obj]
+    int T_prev;              // frames of the batch before (row of mrec that carries the state in), 0: none
     int32_t* map;            // [n_obj][W*H] scatter map of the general (non-binary) mask path, all-zero between frames
     FlowRec* cand;           // [T][n_obj][cand_cap] candidate scratch
     FlowRec* recs;           // [T][n_obj][cand_cap] kept flow records
@@ -158,6 +170,16 @@ struct EngineArrays {
     int log_cap;
 };
 
+// Control block -> LDS with one 16-byte load per thread (threads 0 .. sizeof(FrameCtrl)/16 - 1; the caller's barrier
+// follows): read field by field from global memory, the compiler sinks every load to its first use and the kernel pays
+// one memory latency per field.
+__device__ inline void stage_ctrl(FrameCtrl* s_c, const FrameCtrl& g)
+{
+    constexpr int n16 = (int)(sizeof(FrameCtrl) / 16);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x)
+        reinterpret_cast<uint4*>(s_c)[i] = reinterpret_cast<const uint4*>(&g)[i];
+}
+
 // control block of frame t of the batch
 __device__ inline const FrameCtrl& frame_ctrl(const EngineArrays& a, int t, int obj)
 {
@@ -171,25 +193,24 @@ __device__ inline roft_object_output* log_row(const EngineArrays& a, const Frame
     return a.out_log + (size_t)(c.frame_idx % a.log_cap) * a.n_obj + obj;
 }
 
-constexpr int kSlotNew = kPlaneSlots;       // plane slot receiving an ingested mask
-constexpr int kSlotFeat = kPlaneSlots + 1;  // plane slot holding the buffered features' mask
+constexpr int kSlotNew = kPlaneSlots;       // plane slots receiving the ingested masks: kSlotNew + frame of the batch
 
 // Mask mode of a frame (ImageSegmentationOFAidedSource::step_frame, hpp:169-226), decided on the device
 // because it depends on whether the newly delivered mask is empty:
 // 0 copy (no flow, no usable new mask); 1 propagate the last mask through this frame's flow with
 // mask(0,0) forced to 0 (hpp:221-226); 2 new mask chased through the buffered flows (hpp:211-219).
 // fbuf_n = flows buffered before this frame, new_count = non-zero pixels of the mask delivered with it.
-__device__ inline int decide_mode(const FrameCtrl& c, int fbuf_n, int new_count, int frames_between, int& src_slot,
-                                  int& n_flows)
+__device__ inline int decide_mode(const FrameCtrl& c, int new_slot, int fbuf_n, int new_count, int frames_between,
+                                  int& src_slot, int& n_flows)
 {
     const int n_avail = fbuf_n + (c.flow_valid ? 1 : 0);
     int mode;
     if (c.force_mode == 3) {  // operator level: map() + remap() of the given mask through n flows
-        src_slot = kSlotNew;
+        src_slot = new_slot;
         n_flows = n_avail;
         mode = 2;
     } else if (c.has_new_mask && !c.first_mask && new_count > 0) {
-        src_slot = kSlotNew;
+        src_slot = new_slot;
         if (c.stamped && c.n_region <= 0) {
             // …Stamped.hpp:229-236: no flow after the mask's stamp in the queue -> the NEW mask through this frame's
             // flow only, mask(0,0) forced to 0 (mode 1 semantics on the new mask)
@@ -199,7 +220,7 @@ __device__ inline int decide_mode(const FrameCtrl& c, int fbuf_n, int new_count,
         n_flows = c.stamped ? c.n_region : n_avail;
         mode = 2;
     } else {
-        src_slot = (c.has_new_mask && c.first_mask) ? kSlotNew : c.slot_prev;
+        src_slot = (c.has_new_mask && c.first_mask) ? new_slot : c.slot_prev;
         n_flows = 1;
         return c.flow_valid ? 1 : 0;
     }
@@ -221,12 +242,15 @@ __device__ inline int next_fbuf(const FrameCtrl& c, int fbuf_n, int new_count, i
 
 __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, int slot, int which)
 {
-    return (((size_t)obj * (kPlaneSlots + 2) + slot) * 2 + which) * a.plane_words;
+    return (((size_t)obj * (kPlaneSlots + kMaxBatch) + slot) * 2 + which) * a.plane_words;
 }
 
-void launch_mask_ingest(const EngineArrays& a, hipStream_t s);   // operator level: frame 0's new mask -> plane slot kSlotNew
-// Mask chain of the batch: one workgroup per object walks the frames (ingest, mode decision, propagation).
-void launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s, hipEvent_t stop = nullptr);
+void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s);   // frame t's new masks -> plane slot kSlotNew + t
+// Mask chain of the batch: carry of the state, then per frame [ingest of new masks +] one step kernel (binary masks),
+// and one persistent kernel for the frames of objects with three-valued masks.  new_mask_frames: bit t set when some
+// object receives a mask in frame t.  Returns the number of launches.
+int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s,
+                      hipEvent_t stop = nullptr);
 void launch_planes_to_mask(const uint32_t* nz, const uint32_t* ob, int npix, uint8_t* mask, hipStream_t s);
 // `stop` / `start` (optional): HIP events bound to the kernel's own dispatch (hipExtLaunchKernelGGL) -- they complete
 // with the kernel, without the extra barrier packet and host call of a hipEventRecord behind it.

@@ -167,6 +167,12 @@ class ROFTFilterBatch:
                 sel[f, o] = r.outlier_selected
         return pose, twist, npts, sel
 
+    def get_log_rows(self, first, n):
+        """[n, n_objects, 19] float64: pose(13) | twist(6) per object-frame, as the reference logs them."""
+        rows = np.zeros((n, self.n_objects, 19))
+        L.check(L.lib().roft_engine_get_log_rows(self._h, first, n, rows.ctypes.data))
+        return rows
+
     def stream(self):
         return L.lib().roft_engine_stream(self._h)
 

@@ -54,11 +54,19 @@ def max_over_ranks(value, device="cpu"):
 
 
 def gather_records(records, device="cpu"):
-    """All-gather a [n_local, k] float64 tensor of per-object records (19 doubles per object-frame in
-    the reference's logs); every rank must contribute the same n_local."""
+    """All-gather [n_local, ...] float64 records (19 doubles per object-frame in the reference's logs) along the first
+    axis; the shards may differ in n_local (block partition of an object count the ranks do not divide)."""
     records = records.to(device=device, dtype=torch.float64).contiguous()
     if not dist.is_initialized():
         return records
-    out = [torch.empty_like(records) for _ in range(dist.get_world_size())]
-    dist.all_gather(out, records)
-    return torch.cat(out, 0)
+    world = dist.get_world_size()
+    n = torch.tensor([records.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    pad = max(counts)
+    buf = torch.zeros((pad,) + tuple(records.shape[1:]), dtype=torch.float64, device=device)
+    buf[:records.shape[0]] = records
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf)
+    return torch.cat([o[:c] for o, c in zip(out, counts)], 0)

@@ -79,6 +79,16 @@ assert t == float(world), t
 rec = torch.full((3, 19), float(rank))
 allrec = parallel.gather_records(rec)
 assert allrec.shape == (3 * world, 19) and float(allrec[:, 0].sum()) == 3.0 * sum(range(world))
+# uneven shards of engine-log-shaped records ([object, frame, 19]: pose 13 | twist 6), as bench.py gathers them:
+# 5 objects over 2 ranks = 3 + 2; the gathered block is in global object order
+n_frames = 4
+rows = torch.zeros((len(mine), n_frames, 19), dtype=torch.float64)
+for i, gid in enumerate(mine):
+    rows[i] = gid * 100.0 + torch.arange(n_frames, dtype=torch.float64)[:, None] + torch.arange(19, dtype=torch.float64)[None, :] / 100.0
+allrows = parallel.gather_records(rows)
+assert allrows.shape == (5, n_frames, 19)
+for gid in range(5):
+    assert float(allrows[gid, 2, 7]) == gid * 100.0 + 2 + 0.07
 # every object is owned by exactly one rank
 own = torch.zeros(5)
 own[mine] = 1
