@@ -21,6 +21,10 @@ FLOW_S16C2 = 11  # OpenCV type codes stored in the reference's .float flow files
 FLOW_F32C2 = 13
 
 CRACKER_BOX_HALF_EXTENTS = (0.082, 0.1065, 0.036)  # 003_cracker_box.obj extents / 2
+# extents (m) in the spirit of the five Fast-YCB objects of the reference (cracker box, sugar box, mustard bottle,
+# tomato soup can, potted meat can; src/roft-lib/meshes/DOPE/*.obj); boxes stand in for the meshes (BASELINE config #3)
+FAST_YCB_HALF_EXTENTS = [CRACKER_BOX_HALF_EXTENTS, (0.046, 0.088, 0.019), (0.048, 0.096, 0.033), (0.034, 0.051, 0.034),
+                         (0.051, 0.042, 0.029)]
 
 
 @dataclass
@@ -98,6 +102,49 @@ class Trajectory:
     twist: np.ndarray
 
 
+def loop_index(k, period):
+    """Image index of frame k of a stream whose images repeat with `period` (make_stream(..., period=P) holds frames
+    0 .. P, frame P showing the pose of frame 0 again): k for k <= P, then 1 .. P over and over."""
+    return k if k <= period else ((k - 1) % period) + 1
+
+
+def make_periodic_trajectory(seed, period, dt=1.0 / 30.0, speed=1.0):
+    """period + 1 poses of a closed motion (pose[period] == pose[0]): sinusoids whose frequencies are multiples of
+    1 / (period dt) for the position, a product of two oscillating rotations for the orientation.  A stream built on it
+    can be tracked for any number of frames by cycling through its images (loop_index)."""
+    rng = np.random.default_rng(seed)
+    Tp = period * dt
+    x0 = np.array([rng.uniform(-0.12, 0.12), rng.uniform(-0.08, 0.08), rng.uniform(0.6, 0.85)])
+    A = rng.uniform(0.03, 0.08, 3) * speed
+    m = rng.integers(1, 3, 3)
+    ph = rng.uniform(0, 2 * math.pi, 3)
+    ax1 = rng.normal(size=3)
+    ax1 /= np.linalg.norm(ax1)
+    ax2 = rng.normal(size=3)
+    ax2 /= np.linalg.norm(ax2)
+    a1, a2 = rng.uniform(0.3, 0.6) * speed, rng.uniform(0.2, 0.4) * speed
+    ph2 = rng.uniform(0, 2 * math.pi)
+    q0 = quat_exp(rng.normal(0, 0.6, 3))
+
+    def pose(t):
+        x = x0 + A * np.sin(2 * math.pi * m * t / Tp + ph)
+        q = quat_mul(quat_exp(a1 * math.sin(2 * math.pi * t / Tp) * ax1),
+                     quat_mul(quat_exp(a2 * math.sin(4 * math.pi * t / Tp + ph2) * ax2), q0))
+        return x, q / np.linalg.norm(q)
+
+    xs, qs, tw = [], [], []
+    for k in range(period + 1):
+        x, q = pose((k % period) * dt)
+        xn, qn = pose(((k % period) + 1e-4) * dt)
+        dq = quat_mul(qn, q * np.array([1.0, -1.0, -1.0, -1.0]))
+        w = 2.0 * dq[1:] / (1e-4 * dt)
+        xd = (xn - x) / (1e-4 * dt)
+        xs.append(x)
+        qs.append(q)
+        tw.append(np.concatenate([xd - np.cross(w, x), w]))
+    return Trajectory(np.array(xs), np.array(qs), np.array(tw))
+
+
 def make_trajectory(seed, n_frames, dt=1.0 / 30.0, speed=1.0):
     rng = np.random.default_rng(seed)
     x0 = np.array([rng.uniform(-0.12, 0.12), rng.uniform(-0.08, 0.08), rng.uniform(0.6, 0.85)])
@@ -143,10 +190,16 @@ class Stream:
     dt: float = 1.0 / 30.0
     mesh: tuple = field(default=None, repr=False)
     gray: torch.Tensor = None  # [F, H, W] u8 textured intensity image (only with with_gray=True)
+    period: int = None         # looping stream (make_stream(..., period=P)): images 0 .. P, image P shows pose 0 again
 
     @property
     def n_frames(self):
         return self.depth.shape[0]
+
+    def image(self, k):
+        """Index into depth / flow / gt of the image shown at frame k of the sequence (k itself unless the stream
+        loops; the schedules mask_delivery / pose_valid / pose_meas / flow_valid are indexed by k)."""
+        return loop_index(k, self.period) if self.period else k
 
 
 def _render_box(cam, half, x, R, device):
@@ -187,10 +240,19 @@ def make_stream(seed, n_frames, camera=None, flow_type=FLOW_F32C2, half_extents=
                 device="cpu", background_z=1.5, mask_period=6, pose_period=6, depth_noise=1e-3,
                 depth_dropout=0.02, flow_invalid=0.005, pose_noise_x=0.005, pose_noise_rot=math.radians(2.0),
                 pose_outlier_prob=0.10, pose_drop_prob=0.03, mask_dilate=1, speed=1.0, mesh_n=36, chunk=8,
-                with_gray=False):
+                with_gray=False, period=None, n_schedule=None):
+    """period = P: a looping stream -- P + 1 image frames of a closed motion (n_frames is ignored) whose delivery
+    schedules (mask_delivery, pose_valid, pose_meas) cover n_schedule frames; frame k of the sequence shows image
+    loop_index(k, P), mask_delivery already holds image indices."""
     cam = camera or Camera.shape_a()
     dt = 1.0 / 30.0
-    gt = make_trajectory(seed, n_frames, dt, speed)
+    if period:
+        n_frames = period + 1
+        gt = make_periodic_trajectory(seed, period, dt, speed)
+    else:
+        gt = make_trajectory(seed, n_frames, dt, speed)
+    n_sched = n_schedule if (period and n_schedule) else n_frames
+    li = (lambda k: loop_index(k, period)) if period else (lambda k: k)
     rng = np.random.default_rng(seed + 7919)
     device = torch.device(device)
     g = torch.Generator(device=device).manual_seed(seed)   # seeded per (seed, device type)
@@ -258,15 +320,15 @@ def make_stream(seed, n_frames, camera=None, flow_type=FLOW_F32C2, half_extents=
             mask_gt[k0:k0 + 32] = torch.nn.functional.max_pool2d(m[:, None].float(), k, 1, mask_dilate)[:, 0].to(torch.uint8)
 
     # delivery schedules: frame h delivers the content of frame max(h - D, 0) iff (h - D) % D == 0
-    mask_delivery = np.full(n_frames, -1, np.int64)
-    pose_valid = np.zeros(n_frames, bool)
-    pose_meas = np.zeros((n_frames, 7))
+    mask_delivery = np.full(n_sched, -1, np.int64)
+    pose_valid = np.zeros(n_sched, bool)
+    pose_meas = np.zeros((n_sched, 7))
     pose_meas[:, 3] = 1.0
-    for h in range(n_frames):
+    for h in range(n_sched):
         if mask_period > 0 and (h - mask_period) % mask_period == 0:
-            mask_delivery[h] = max(h - mask_period, 0)
+            mask_delivery[h] = li(max(h - mask_period, 0))
         if pose_period > 0 and (h - pose_period) % pose_period == 0:
-            src = max(h - pose_period, 0)
+            src = li(max(h - pose_period, 0))
             if h > 0 and rng.uniform() < pose_drop_prob:
                 continue  # dropped detection (all-zero row in poses.txt = invalid)
             outlier = h > 0 and rng.uniform() < pose_outlier_prob
@@ -278,10 +340,10 @@ def make_stream(seed, n_frames, camera=None, flow_type=FLOW_F32C2, half_extents=
             pose_meas[h, :3] = xm
             pose_meas[h, 3:] = qm / np.linalg.norm(qm)
 
-    flow_valid = np.ones(n_frames, bool)
+    flow_valid = np.ones(n_sched, bool)
     flow_valid[0] = False
     return Stream(cam, flow_type, grid, scale, tuple(half_extents), depth, flow, flow_valid, mask_gt, mask_delivery,
-                  pose_valid, pose_meas, gt, dt, box_mesh(half_extents, mesh_n), gray)
+                  pose_valid, pose_meas, gt, dt, box_mesh(half_extents, mesh_n), gray, period)
 
 
 def initial_pose_from_stream(stream):

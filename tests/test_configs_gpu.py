@@ -1,0 +1,114 @@
+"""BASELINE.json configs #3 and #5 at their full size, through the C ABI on the GPU:
+
+ #3  the five Fast-YCB-sized objects -- five different extents, five different meshes -- batched in one engine at
+     1280x720 with CV_16SC2 grid-4 flow (config_fast_ycb.cfg + nvof_1_slow), against the oracle's ROFTFilter;
+ #5  16 objects at 1280x720 with pose re-sync and outlier rejection (the branches of ROFTFilter.cpp:313-367),
+     against the oracle over the first frames and over the full 3 000 frames through size-independent properties:
+     the run is deterministic, one stream gives what three streams give, every estimate is finite, stays on the
+     ground truth, and the outlier test fires at every pose arrival.
+
+The long run cycles through the images of a closed motion (synth.make_stream(period=...)), so 3 000 frames of 16
+objects need 61 images per object in HBM, used in place (zero copy)."""
+import numpy as np
+import pytest
+import torch
+
+from roft_amd import synth
+
+import util
+from test_engine_gpu import POS_TOL, make_engine, rot_err
+
+pytestmark = pytest.mark.gpu
+
+MESH_N = [36, 30, 33, 24, 27]    # box_mesh subdivisions: five meshes of different sizes (6.5 k ... 15.5 k triangles)
+
+
+def shape_b_stream(seed, obj, n_frames=None, **kw):
+    return synth.make_stream(seed, n_frames or 1, synth.Camera.shape_b(), flow_type=synth.FLOW_S16C2,
+                             half_extents=synth.FAST_YCB_HALF_EXTENTS[obj % 5], mesh_n=MESH_N[obj % 5], device="cuda", **kw)
+
+
+def host_copy(st):
+    import copy
+    c = copy.copy(st)
+    c.depth, c.flow, c.mask_gt = st.depth.cpu(), st.flow.cpu(), st.mask_gt.cpu()
+    return c
+
+
+def check(log, masks, o, ref, n):
+    pose, twist, npts, sel = log
+    assert np.array_equal(npts[:n, o], np.array([r["n"] for r in ref])), o
+    assert np.array_equal(sel[:n, o], np.array([r["sel"] for r in ref])), o
+    want = np.array([r["pose"] for r in ref])
+    assert np.abs(pose[:n, o, :9] - want[:, :9]).max() < POS_TOL, o
+    assert max(rot_err(pose[k, o, 9:], want[k, 9:]) for k in range(n)) < 1e-6, o
+    assert np.abs(twist[:n, o] - np.array([r["twist"] for r in ref])).max() < 1e-6, o
+    if masks is not None:
+        assert np.array_equal(masks[o], ref[n - 1]["mask"]), o
+
+
+def test_config3_five_different_objects_batched_1280x720_s16():
+    """Identical flow point counts, masks and outlier decisions; pose / twist within 1e-6 of the oracle, frame by
+    frame (single frames, HOST inputs) and in batches of 6 over DEVICE inputs."""
+    from oracle import binding as ob
+    from test_engine_gpu import compare
+    n = 26
+    dev = [shape_b_stream(3000 + i, i, n) for i in range(5)]
+    assert len({st.mesh[1].shape[0] for st in dev}) == 5 and len({st.half_extents for st in dev}) == 5
+    host = [host_copy(st) for st in dev]
+    n_tests = compare(host, n)                      # per-frame masks, N, decisions, likelihoods, poses
+    assert n_tests >= 5 * 3
+    log, masks, stats = util.run_engine_logged(make_engine, dev, n, T=6)
+    for o, st in enumerate(host):
+        check(log, masks, o, util.run_oracle_tracker(ob, st, n), n)
+    assert stats["launches"] / n < 6.0
+
+
+N5_OBJECTS, N5_FRAMES, N5_PERIOD, N5_ORACLE = 16, 3000, 60, 66
+
+
+@pytest.fixture(scope="module")
+def config5_streams():
+    return [shape_b_stream(5000 + i, i, period=N5_PERIOD, n_schedule=N5_FRAMES) for i in range(N5_OBJECTS)]
+
+
+def test_config5_16_objects_1280x720_resync_outlier_vs_oracle(config5_streams):
+    """The first 66 frames (past the point where the image loop closes) of all 16 objects against the oracle."""
+    from oracle import binding as ob
+    n = N5_ORACLE
+    log, masks, _ = util.run_engine_logged(make_engine, config5_streams, n, T=6)
+    n_tests = 0
+    for o, st in enumerate(config5_streams):
+        ref = util.run_oracle_tracker(ob, host_copy(st), n)
+        check(log, masks, o, ref, n)
+        n_tests += sum(r["sel"] >= 0 for r in ref)
+    assert n_tests >= 16 * 8
+
+
+def test_config5_full_length_properties(config5_streams, monkeypatch):
+    n = N5_FRAMES
+    a, ma, stats = util.run_engine_logged(make_engine, config5_streams, n, T=8)
+    b, mb, _ = util.run_engine_logged(make_engine, config5_streams, n, T=8)
+    for x, y in zip(a, b):                            # deterministic
+        assert np.array_equal(x, y)
+    monkeypatch.setenv("ROFT_ONE_STREAM", "1")
+    c, mc, _ = util.run_engine_logged(make_engine, config5_streams, n, T=8)
+    monkeypatch.delenv("ROFT_ONE_STREAM")
+    for x, y in zip(a, c):                            # one stream == three streams
+        assert np.array_equal(x, y)
+    for x, y in zip(ma, mc):
+        assert np.array_equal(x, y)
+    pose, twist, npts, sel = a
+    assert np.isfinite(pose).all() and np.isfinite(twist).all()
+    assert np.abs(np.linalg.norm(pose[:, :, 9:], axis=2) - 1.0).max() < 1e-9
+    # an outlier test at every valid pose arrival after the first, for every object
+    for o, st in enumerate(config5_streams):
+        assert np.array_equal(sel[1:, o] >= 0, st.pose_valid[1:n]), o
+    assert (sel == 1).sum() > 0 and (sel == 0).sum() > (sel == 1).sum()
+    assert (npts[1:] >= 3).mean() > 0.99
+    # the tracker stays on the ground truth over the whole sequence
+    img = np.array([synth.loop_index(k, N5_PERIOD) for k in range(n)])
+    err = np.stack([np.linalg.norm(pose[:, o, 6:9] - st.gt.x[img], axis=1) for o, st in enumerate(config5_streams)], 1)
+    print('config5 position error vs GT: median %.4f p99 %.4f max %.4f; outlier tests %d rejected %d' % (np.median(err), np.quantile(err, 0.99), err.max(), (sel >= 0).sum(), (sel == 1).sum()))
+    assert np.median(err) < 0.02 and np.quantile(err, 0.99) < 0.10
+    assert stats["frames"] == n and stats["launches"] / n < 4.0

@@ -27,8 +27,9 @@ def frame_inputs(st, k):
     """What the Dataset* sources would hand to the tracker at frame k."""
     mask = st.mask_gt[st.mask_delivery[k]].cpu().numpy() if st.mask_delivery[k] >= 0 else None
     pose = (st.pose_meas[k, :3].copy(), st.pose_meas[k, 3:].copy()) if st.pose_valid[k] else None
-    flow = st.flow[k].cpu().numpy() if st.flow_valid[k] else None
-    depth = st.depth[k].cpu().numpy()
+    i = st.image(k)
+    flow = st.flow[i].cpu().numpy() if st.flow_valid[k] else None
+    depth = st.depth[i].cpu().numpy()
     return depth, flow, mask, pose
 
 
@@ -74,7 +75,8 @@ def device_frame(st, k):
     from roft_amd import _lib as L
     mi = st.mask_delivery[k]
     pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
-    return dict(depth=st.depth[k].data_ptr(), flow=st.flow[k].data_ptr() if st.flow_valid[k] else None,
+    i = st.image(k)
+    return dict(depth=st.depth[i].data_ptr(), flow=st.flow[i].data_ptr() if st.flow_valid[k] else None,
                 mask=st.mask_gt[mi].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE)
 
 

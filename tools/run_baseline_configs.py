@@ -30,10 +30,7 @@ from roft_amd import metrics, synth
 import util
 from oracle import binding as ob
 
-# extents (m) in the spirit of the five Fast-YCB objects of the reference (cracker box, sugar box, mustard bottle,
-# tomato soup can, potted meat can); boxes stand in for the meshes
-FAST_YCB_HALF_EXTENTS = [(0.082, 0.1065, 0.036), (0.046, 0.088, 0.019), (0.048, 0.096, 0.033), (0.034, 0.051, 0.034),
-                         (0.051, 0.042, 0.029)]
+FAST_YCB_HALF_EXTENTS = synth.FAST_YCB_HALF_EXTENTS
 
 
 def make_engine(streams):
