@@ -148,7 +148,7 @@ struct Arrays {
         HIP_TRY(norms.ensure((size_t)n_obj * 3 * a.cand_cap));
         HIP_TRY(feat_pix.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
         HIP_TRY(feat_depth.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
-        HIP_TRY(zbuf.ensure((size_t)n_obj * 2 * a.tile_w * a.tile_h));
+        HIP_TRY(zbuf.ensure((size_t)kNumLin * n_obj * 2 * a.tile_w * a.tile_h));
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
         a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.mrec = mrec.p;
         a.T_prev = 0; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
@@ -165,9 +165,8 @@ struct Arrays {
 void init_state(ObjState& st)
 {
     std::memset(&st, 0, sizeof(st));
-    st.pending_frame = -1;
+    for (PoseLane& pl : st.lane) { pl.pending_frame = -1; pl.outlier_selected = -1; }
     st.n_flow_points = -1;
-    st.outlier_selected = -1;
 }
 
 void clear_ctrl(FrameCtrl& c)
@@ -218,6 +217,9 @@ struct Sched {
     int n_vel = 0;
     int vel_buf[kTwistRing];           // twist_hist slots (CartesianQuaternionMeasurement::buffer_velocities_), oldest first
     int last_meas_slot = 0;            // slot of measurement_.head<6>()
+    int cur_slot = 0;                  // B_LIN0 / B_LIN1: slot holding p_corr_belief_ (the other one holds buffered_belief_)
+    int own[kNumLin] = {0, 1};         // pose chain lane that walks each of the two slots (always different lanes)
+    int last_touch[kNumLin] = {-1, -1};   // last batch whose pose chain reads or writes each slot
     int flows_since_mask = 0;          // upper bound of the flows buffered since the last delivered mask
     const float* depth_prev = nullptr;
     Sched() { for (int& u : feat_use) u = -1; }
@@ -230,6 +232,7 @@ struct OwnedFlow {
 
 struct HostObject {
     Sched s;
+    int stepped_slot = 0, stepped_lane = 0;   // slot holding p_corr_belief_ after the last stepped frame, and its lane
     std::vector<OwnedFlow*> owned;   // engine copies of flows that outlived the zero-copy retention window
     DevBuf<float> verts;
     DevBuf<int32_t> tris;
@@ -252,7 +255,7 @@ struct roft_engine {
     // Three in-order chains per batch, one HIP stream each (ROFT_ONE_STREAM=1 puts them on one stream):
     hipStream_t stream = nullptr;       // mask chain: FrameCtrl upload, mask chain kernel, features
     hipStream_t vel_stream = nullptr;   // velocity chain: flow measurement, velocity filter
-    hipStream_t pose_stream = nullptr;  // pose chain: UKF segments, outlier rejection
+    hipStream_t pose_stream[kNumLin] = {nullptr, nullptr};  // pose chain, one stream per lane (BeliefSlot): UKF segments, outlier rejection
     hipStream_t up_stream = nullptr;    // uploads of HOST inputs and the copies of aged-out flows
     // Batches in flight.  The image chains of batch b+1 do not depend on the pose chain of batch b, so they run ahead
     // of it.  The lead is bounded on the host: the submit call of batch b returns only when batch b - lead has ended
@@ -273,7 +276,8 @@ struct roft_engine {
     hipEvent_t ev_mask[kBatchRing] = {};   // mask chain kernel of the batch complete
     hipEvent_t ev_feat[kBatchRing] = {};   // features of the batch complete
     hipEvent_t ev_vel[kBatchRing] = {};    // twists of the batch complete
-    hipEvent_t ev_done[kBatchRing] = {};   // pose chain of the batch complete
+    hipEvent_t ev_done[kBatchRing][kNumLin] = {};   // pose chain of the batch complete (per lane)
+    bool done_used[kBatchRing][kNumLin] = {};       // ... the lane had work in that batch
     bool multi = false;
     // ROFT_HOST_PROF=1: host time of the sections of the submit call / roft_step, printed by roft_engine_destroy
     bool host_prof = false;
@@ -289,7 +293,9 @@ struct roft_engine {
     // the submitted, not yet stepped batch
     bool submitted = false;
     int cur_T = 0;
-    int n_segments = 1;
+    int n_segments[kNumLin] = {1, 1};     // pose chain segments per lane (1 + outlier tests of the busiest object)
+    bool lin_any[kNumLin] = {false, false};   // some object has a frame on the lane in the batch
+    int relabel_wait[kNumLin] = {-1, -1};     // batch of the OTHER lane this lane's launches must follow (slots that changed lanes)
     bool any_feat = false, any_feat_now = false, had_uploads = false;
     unsigned new_mask_frames = 0;   // bit t: some object receives a mask in frame t of the batch
     int prev_T = 0;                 // frames of the batch stepped before
@@ -319,7 +325,8 @@ static inline double host_now_us()
 static int wait_batch(roft_engine* e, int b)
 {
     if (b < e->completed_batches || b >= e->batch_counter) return ROFT_OK;
-    HIP_TRY(hipEventSynchronize(e->ev_done[b % roft_engine::kBatchRing]));
+    for (int l = 0; l < kNumLin; ++l)
+        if (e->done_used[b % roft_engine::kBatchRing][l]) HIP_TRY(hipEventSynchronize(e->ev_done[b % roft_engine::kBatchRing][l]));
     e->completed_batches = b + 1;
     e->completed_frames = e->batch_end_frame[b % roft_engine::kBatchRing];
     return ROFT_OK;
@@ -406,19 +413,19 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
         const char* np = getenv("ROFT_NO_STREAM_PRIORITY");
         if (np && np[0] == '1') greatest = least;
-        HIP_TRY(hipStreamCreateWithPriority(&e->pose_stream, hipStreamNonBlocking, greatest));
+        for (int l = 0; l < kNumLin; ++l) HIP_TRY(hipStreamCreateWithPriority(&e->pose_stream[l], hipStreamNonBlocking, greatest));
         HIP_TRY(hipStreamCreateWithPriority(&e->vel_stream, hipStreamNonBlocking, (least + greatest) / 2));
         HIP_TRY(hipStreamDestroy(e->stream));
         e->stream = nullptr;
         HIP_TRY(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, least));
         HIP_TRY(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
     } else {
-        e->pose_stream = e->vel_stream = e->up_stream = e->stream;
+        e->pose_stream[0] = e->pose_stream[1] = e->vel_stream = e->up_stream = e->stream;
     }
     for (int i = 0; i < R; ++i) {
         HIP_TRY(e->dctrl[i].ensure((size_t)cfg->max_objects * e->T_max, true));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects * e->T_max));
-        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i]})
+        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
             HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
     DevFlowFmt ff;
@@ -491,15 +498,15 @@ int roft_engine_destroy(roft_engine* e)
                                        "step: FrameCtrl upload", "step: mask chain", "step: velocity chain", "step: pose chain"};
         for (int i = 0; i < 7; ++i) std::fprintf(stderr, "[roft host] %-36s %7.2f us/batch\n", names[i], e->hp_acc[i] / e->hp_batches);
     }
-    for (hipStream_t s : {e->stream, e->vel_stream, e->pose_stream, e->up_stream})
+    for (hipStream_t s : {e->stream, e->vel_stream, e->pose_stream[0], e->pose_stream[1], e->up_stream})
         if (s) (void)hipStreamSynchronize(s);
     for (int i = 0; i < R; ++i) {
-        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i]})
+        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
             if (ev) (void)hipEventDestroy(ev);
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
     }
     if (e->multi) {
-        if (e->pose_stream) (void)hipStreamDestroy(e->pose_stream);
+        for (int l = 0; l < kNumLin; ++l) if (e->pose_stream[l]) (void)hipStreamDestroy(e->pose_stream[l]);
         if (e->vel_stream) (void)hipStreamDestroy(e->vel_stream);
         if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
     }
@@ -558,9 +565,9 @@ int roft_object_add(roft_engine* e, const roft_object_desc* d, int* obj_id)
     PoseBelief b{};
     for (int i = 0; i < 13; ++i) b.mean[i] = d->p_mean0[i];
     for (int i = 0; i < 12; ++i) b.cov[i * 12 + i] = d->p_cov0_diag[i];
-    st->belief[B_CORR] = b;
-    st->belief[B_PRED] = b;
-    st->belief[B_BUF] = b;
+    st->belief[B_LIN0] = b;       // p_corr_belief_
+    st->belief[B_LIN1] = b;       // buffered_belief_ = p_corr_belief_ at initialization (ROFTFilter.cpp:231)
+    st->belief[B_PRED] = st->belief[B_PRED + 1] = b;
     hipError_t err = hipMemcpy(e->arr.params.p + id, &p, sizeof(p), hipMemcpyHostToDevice);
     if (err == hipSuccess) err = hipMemcpy(e->arr.state.p + id, st, sizeof(ObjState), hipMemcpyHostToDevice);
     delete st;
@@ -600,16 +607,24 @@ static bool build_pose_program(const roft_config& cfg, Sched& o, const roft_fram
     for (int i = 0; i < 3; ++i) c.pose_x[i] = in.pose_x[i];
     for (int i = 0; i < 4; ++i) c.pose_q[i] = in.pose_q[i];
 
+    if (type == ROFT_MEAS_POSE_VELOCITY && cfg.use_pose_resync) {
+        // ROFTFilter.cpp:333-340: buffered_belief_ <- p_corr_belief_, p_corr_belief_ <- the old buffered_belief_.
+        // The two Gaussians swap roles; nothing is copied (see BeliefSlot in roft_device.h).
+        o.cur_slot ^= 1;
+    }
+    const int cur = B_LIN0 + o.cur_slot;
+    const int lin = o.own[o.cur_slot];
+    c.lane = lin;
+    c.cur_slot = cur;
     StepDesc sd{};
     sd.op = 1;
-    sd.src = B_CORR;
+    sd.src = cur;
     sd.do_predict = 1;
     sd.twist_slot = slot;
     if (type == ROFT_MEAS_POSE_VELOCITY) {
         if (cfg.use_pose_resync) {
-            // ROFTFilter.cpp:331-354: roll back to the belief buffered at the previous pose arrival and
+            // ROFTFilter.cpp:331-354: continue from the belief buffered at the previous pose arrival and
             // replay the buffered velocities (PopBufferedMeasurement, cpp:97-154)
-            bool first = true;
             bool pose_pending = true;
             for (;;) {
                 if (cfg.pose_frames_between > 0)
@@ -622,25 +637,23 @@ static bool build_pose_program(const roft_config& cfg, Sched& o, const roft_fram
                 r.op = 1;
                 r.do_predict = 1;
                 r.twist_slot = ts;
-                r.src = first ? B_BUF : B_CORR;
-                r.save_corr_to_buf = first ? 1 : 0;
+                r.src = cur;
                 if (pose_pending) {
                     pose_pending = false;
                     if (cfg.outlier_rejection) {
                         r.n_corr = 2;
-                        r.type[0] = ROFT_MEAS_POSE_VELOCITY; r.dst[0] = B_ALT0;
-                        r.type[1] = ROFT_MEAS_VELOCITY;      r.dst[1] = B_ALT1;
+                        r.type[0] = ROFT_MEAS_POSE_VELOCITY; r.dst[0] = b_alt(lin, 0);
+                        r.type[1] = ROFT_MEAS_VELOCITY;      r.dst[1] = b_alt(lin, 1);
                         c.outlier_step = n;
                     } else {
                         r.n_corr = 1;
-                        r.type[0] = ROFT_MEAS_POSE_VELOCITY; r.dst[0] = B_CORR;
+                        r.type[0] = ROFT_MEAS_POSE_VELOCITY; r.dst[0] = cur;
                     }
                 } else {
                     r.n_corr = 1;
-                    r.type[0] = ROFT_MEAS_VELOCITY; r.dst[0] = B_CORR;
+                    r.type[0] = ROFT_MEAS_VELOCITY; r.dst[0] = cur;
                 }
                 add(r);
-                first = false;
             }
             // the test reads the features buffered at the previous pose arrival; this frame's are buffered for
             // the next one (ROFTFilter.cpp:353)
@@ -650,8 +663,8 @@ static bool build_pose_program(const roft_config& cfg, Sched& o, const roft_fram
         } else {
             if (cfg.outlier_rejection) {
                 sd.n_corr = 2;
-                sd.type[0] = ROFT_MEAS_POSE_VELOCITY; sd.dst[0] = B_ALT0;
-                sd.type[1] = ROFT_MEAS_VELOCITY;      sd.dst[1] = B_ALT1;
+                sd.type[0] = ROFT_MEAS_POSE_VELOCITY; sd.dst[0] = b_alt(lin, 0);
+                sd.type[1] = ROFT_MEAS_VELOCITY;      sd.dst[1] = b_alt(lin, 1);
                 c.outlier_step = n;
                 // without re-sync the test uses the current frame's depth and mask
                 if (c.feat_write < 0) { c.feat_write = o.feat_next; o.feat_next = (o.feat_next + 1) % kFeatRing; }
@@ -659,17 +672,17 @@ static bool build_pose_program(const roft_config& cfg, Sched& o, const roft_fram
                 o.feat_slot = c.feat_write;
             } else {
                 sd.n_corr = 1;
-                sd.type[0] = ROFT_MEAS_POSE_VELOCITY; sd.dst[0] = B_CORR;
+                sd.type[0] = ROFT_MEAS_POSE_VELOCITY; sd.dst[0] = cur;
             }
             add(sd);
         }
     } else if (type != ROFT_MEAS_NONE) {
         sd.n_corr = 1;
-        sd.type[0] = type; sd.dst[0] = B_CORR;
+        sd.type[0] = type; sd.dst[0] = cur;
         add(sd);
     } else {
         sd.n_corr = 0;  // p_corr = p_pred (ROFTFilter.cpp:366-367)
-        sd.dst[0] = B_CORR;
+        sd.dst[0] = cur;
         add(sd);
     }
     c.n_steps = n;
@@ -707,8 +720,28 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
     const size_t fbytes = flow_bytes(e->arr.a.ffmt);
     const int b = e->batch_counter;
     FrameCtrl* blk = e->stage[b % roft_engine::kBatchRing];
-    int max_outliers = 0;
-    std::vector<int> n_outliers(n_obj, 0);
+    int max_outliers[kNumLin] = {0, 0};
+    std::vector<int> n_outliers((size_t)n_obj * kNumLin, 0);
+    e->lin_any[0] = e->lin_any[1] = false;
+    {
+        // Balance of the two pose chain lanes.  A lane's launch lasts as long as its busiest object, so the lanes only
+        // overlap if, in every batch, the re-sync replays of all objects are on ONE lane and the ordinary steps in
+        // front of them on the other.  An object that missed a pose (or received an extra one) has its lineages on the
+        // opposite lanes from then on: hand its two slots over to the other lanes at the batch boundary.  The new lane
+        // of a slot must run behind the last batch in which the old lane touched it (relabel_wait; in the steady state
+        // that launch was a short one of the previous batch and has long ended).
+        int cnt[kNumLin] = {0, 0};
+        for (int id = 0; id < n_obj; ++id) cnt[e->objs[id]->s.own[e->objs[id]->s.cur_slot]]++;
+        const int c = cnt[1] > cnt[0] ? 1 : 0;
+        e->relabel_wait[0] = e->relabel_wait[1] = -1;
+        for (int id = 0; id < n_obj; ++id) {
+            Sched& o = e->objs[id]->s;
+            if (o.own[o.cur_slot] == c) continue;
+            e->relabel_wait[c] = std::max(e->relabel_wait[c], o.last_touch[o.cur_slot]);
+            e->relabel_wait[1 - c] = std::max(e->relabel_wait[1 - c], o.last_touch[1 - o.cur_slot]);
+            std::swap(o.own[0], o.own[1]);
+        }
+    }
 
     for (int t = 0; t < T; ++t) {
         const int frame = e->frame_counter + t;
@@ -835,7 +868,10 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
             c.frame_idx = frame;
             if (!build_pose_program(cfg, o, in, c))
                 return fail(ROFT_ERR_CAPACITY, "more buffered velocities to replay than one frame's program holds (kMaxSteps)");
-            if (c.outlier_step >= 0) max_outliers = std::max(max_outliers, ++n_outliers[id]);
+            e->lin_any[c.lane] = true;
+            o.last_touch[o.cur_slot] = b;
+            if (c.outlier_step >= 0)
+                max_outliers[c.lane] = std::max(max_outliers[c.lane], ++n_outliers[(size_t)id * kNumLin + c.lane]);
             if (c.feat_write >= 0) {
                 e->any_feat = true;
                 // a feature set is re-used only when the batch that read or wrote it last has ended
@@ -848,7 +884,7 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
             o.frame_idx++;
         }
     }
-    e->n_segments = 1 + max_outliers;
+    for (int l = 0; l < kNumLin; ++l) e->n_segments[l] = 1 + max_outliers[l];
     return ROFT_OK;
 }
 
@@ -914,7 +950,7 @@ static void tmark(roft_engine* e, const char* name, int which = 0)
     }
     e->tmark.push_back(id);
     e->tstream.push_back(which);
-    (void)hipEventRecord(e->tev[idx], which == 1 ? e->pose_stream : (which == 2 ? e->vel_stream : e->stream));
+    (void)hipEventRecord(e->tev[idx], which == 1 ? e->pose_stream[0] : (which == 3 ? e->pose_stream[1] : (which == 2 ? e->vel_stream : e->stream)));
 }
 
 // Timing of ONE kernel by a start / stop event pair bound to its dispatch (two consecutive marks: the first opens the
@@ -950,7 +986,7 @@ static int step_batch(roft_engine* e)
 {
     constexpr int R = roft_engine::kBatchRing;
     EngineArrays a = e->arr.a;
-    hipStream_t s = e->stream, sv = e->vel_stream, sp = e->pose_stream;
+    hipStream_t s = e->stream, sv = e->vel_stream;
     const int slot = e->batch_counter % R;
     const int T = e->cur_T;
     const bool multi = e->multi;
@@ -1015,30 +1051,45 @@ static int step_batch(roft_engine* e)
     if (multi && full) { HIP_TRY(hipEventRecord(e->ev_vel[slot], sv)); ++evops; }
     HP_MARK(e, 5, hp_t);
 
-    // ---- pose chain (needs the twists of the batch; the next batches' image chains do not wait for it)
-    if (multi) {
-        HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[slot], 0));
-        ++evops;
-        // The pose chain reads mask-chain products only through the feature ring.  With one-frame batches the set an
-        // outlier test reads was buffered by an earlier batch -- covered by ev_vel, since the velocity chain waited for
-        // the mask chain of the batch before -- unless it is this very frame's.
-        if (want_ev_feat) { HIP_TRY(hipStreamWaitEvent(sp, e->ev_feat[slot], 0)); ++evops; }
-    }
-    tmark(e, nullptr, 1);
-    for (int seg = 0; seg < e->n_segments; ++seg) {
-        const bool last = seg == e->n_segments - 1;
-        launch_ukf_chain(a, e->cfg.ut, seg == 0, sp, (last && !full) ? e->ev_done[slot] : nullptr);
-        ++launches;
-        CHECK_LAUNCH("pose chain segment");
-        tmark(e, "ukf_chain", 1);
-        if (!last) {
-            launch_outlier(a, sp, nullptr);
-            launches += 3;
-            CHECK_LAUNCH("outlier rejection");
-            tmark(e, "outlier_render_likelihood", 1);
+    // ---- pose chain (needs the twists of the batch; the next batches' image chains do not wait for it), one stream per
+    //      lane: the frames before a pose arrival and the frames from it on belong to different belief lineages and
+    //      do not depend on each other (BeliefSlot in roft_device.h), so the re-sync replay of this batch runs next to
+    //      the ordinary steps of the other lineage -- of this batch and of the neighbouring ones
+    for (int lin = 0; lin < kNumLin; ++lin) {
+        hipStream_t sp = e->pose_stream[lin];
+        e->done_used[slot][lin] = e->lin_any[lin];
+        // slots handed over to this lane (submit_frames): behind the other lane's last launch that touched them
+        const int wb = e->relabel_wait[lin];
+        if (multi && wb >= e->completed_batches && wb < e->batch_counter && e->done_used[wb % R][1 - lin]) {
+            HIP_TRY(hipStreamWaitEvent(sp, e->ev_done[wb % R][1 - lin], 0));
+            ++evops;
         }
+        if (!e->lin_any[lin]) continue;
+        const int which = lin == 0 ? 1 : 3;
+        if (multi) {
+            HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[slot], 0));
+            ++evops;
+            // The pose chain reads mask-chain products only through the feature ring.  With one-frame batches the set an
+            // outlier test reads was buffered by an earlier batch -- covered by ev_vel, since the velocity chain waited for
+            // the mask chain of the batch before -- unless it is this very frame's.
+            if (want_ev_feat && e->n_segments[lin] > 1) { HIP_TRY(hipStreamWaitEvent(sp, e->ev_feat[slot], 0)); ++evops; }
+        }
+        tmark(e, nullptr, which);
+        for (int seg = 0; seg < e->n_segments[lin]; ++seg) {
+            const bool last = seg == e->n_segments[lin] - 1;
+            launch_ukf_chain(a, e->cfg.ut, seg == 0, lin, sp, (last && !full) ? e->ev_done[slot][lin] : nullptr);
+            ++launches;
+            CHECK_LAUNCH("pose chain segment");
+            tmark(e, "ukf_chain", which);
+            if (!last) {
+                launch_outlier(a, lin, sp, nullptr);
+                launches += 3;
+                CHECK_LAUNCH("outlier rejection");
+                tmark(e, "outlier_render_likelihood", which);
+            }
+        }
+        if (full) { HIP_TRY(hipEventRecord(e->ev_done[slot][lin], sp)); ++evops; }
     }
-    if (full) { HIP_TRY(hipEventRecord(e->ev_done[slot], sp)); ++evops; }
     HP_MARK(e, 6, hp_t);
     if (e->host_prof) e->hp_batches++;
     HIP_TRY(hipGetLastError());
@@ -1051,6 +1102,7 @@ int roft_step(roft_engine* e)
     if (!e->submitted) return fail(ROFT_ERR_STATE, "roft_frame_submit must precede roft_step");
     HIP_TRY(hipSetDevice(e->cfg.device));
     const int rc = step_batch(e);
+    for (HostObject* ho : e->objs) { ho->stepped_slot = ho->s.cur_slot; ho->stepped_lane = ho->s.own[ho->s.cur_slot]; }
     // (a failed step leaves the engine consistent as far as the host can tell: the batch counts as enqueued)
     const int slot = e->batch_counter % roft_engine::kBatchRing;
     e->frame_counter += e->cur_T;
@@ -1070,7 +1122,7 @@ int roft_sync(roft_engine* e)
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (e->multi) {
         HIP_TRY(hipStreamSynchronize(e->vel_stream));
-        HIP_TRY(hipStreamSynchronize(e->pose_stream));
+        for (int l = 0; l < kNumLin; ++l) HIP_TRY(hipStreamSynchronize(e->pose_stream[l]));
         HIP_TRY(hipStreamSynchronize(e->up_stream));
     }
     e->completed_batches = e->batch_counter;
@@ -1082,17 +1134,19 @@ int roft_get_state(roft_engine* e, int id, double pose13[13], double P12[144], d
 {
     if (!e || id < 0 || id >= (int)e->objs.size()) return fail(ROFT_ERR_INVALID, "bad object id");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    // v_mean, v_cov and belief[B_CORR] are the leading bytes of ObjState: one small copy into pinned memory, queued
-    // behind the pose chain (the last writer of all three), then the other chains are waited for as roft_sync does
-    static_assert(B_CORR == 0 && offsetof(ObjState, v_mean) == 0, "roft_get_state copies the head of ObjState");
-    constexpr size_t kHead = offsetof(ObjState, belief) + sizeof(PoseBelief);
+    // v_mean, v_cov and the beliefs of the two lineages are the leading bytes of ObjState: one small copy into pinned
+    // memory, queued behind the pose chain of the lineage that holds p_corr_belief_ after the last stepped frame (the
+    // last writer of what is returned), then the other chains are waited for as roft_sync does
+    static_assert(B_LIN0 == 0 && B_LIN1 == 1 && offsetof(ObjState, v_mean) == 0, "roft_get_state copies the head of ObjState");
+    constexpr size_t kHead = offsetof(ObjState, belief) + kNumLin * sizeof(PoseBelief);
     if (!e->state_host) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->state_host), sizeof(ObjState)));
-    hipStream_t last = e->multi ? e->pose_stream : e->stream;
+    const int lin = e->objs[id]->stepped_slot;
+    hipStream_t last = e->multi ? e->pose_stream[e->objs[id]->stepped_lane] : e->stream;
     HIP_TRY(hipMemcpyAsync(e->state_host, e->arr.state.p + id, kHead, hipMemcpyDeviceToHost, last));
     if (int rc = roft_sync(e)) return rc;
     const ObjState* st = e->state_host;
-    if (pose13) std::memcpy(pose13, st->belief[B_CORR].mean, sizeof(double) * 13);
-    if (P12) std::memcpy(P12, st->belief[B_CORR].cov, sizeof(double) * 144);
+    if (pose13) std::memcpy(pose13, st->belief[B_LIN0 + lin].mean, sizeof(double) * 13);
+    if (P12) std::memcpy(P12, st->belief[B_LIN0 + lin].cov, sizeof(double) * 144);
     if (twist6) std::memcpy(twist6, st->v_mean, sizeof(double) * 6);
     if (Pv) std::memcpy(Pv, st->v_cov, sizeof(double) * 36);
     return ROFT_OK;
@@ -1105,12 +1159,13 @@ int roft_get_outputs(roft_engine* e, roft_object_output* outs, int n_outs)
     std::vector<ObjState> st(n_outs);
     HIP_TRY(hipMemcpy(st.data(), e->arr.state.p, sizeof(ObjState) * n_outs, hipMemcpyDeviceToHost));
     for (int i = 0; i < n_outs; ++i) {
-        std::memcpy(outs[i].pose, st[i].belief[B_CORR].mean, sizeof(double) * 13);
+        const int lin = e->objs[i]->stepped_lane;
+        std::memcpy(outs[i].pose, st[i].belief[B_LIN0 + e->objs[i]->stepped_slot].mean, sizeof(double) * 13);
         std::memcpy(outs[i].twist, st[i].v_mean, sizeof(double) * 6);
         outs[i].n_flow_points = st[i].n_flow_points;
-        outs[i].outlier_selected = st[i].outlier_selected;
-        outs[i].outlier_L[0] = st[i].outlier_L[0];
-        outs[i].outlier_L[1] = st[i].outlier_L[1];
+        outs[i].outlier_selected = st[i].lane[lin].outlier_selected;
+        outs[i].outlier_L[0] = st[i].lane[lin].outlier_L[0];
+        outs[i].outlier_L[1] = st[i].lane[lin].outlier_L[1];
     }
     return ROFT_OK;
 }
@@ -1189,7 +1244,7 @@ int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, 
     const size_t nk = e->tnames_s.size();
     e->tms.assign(nk, 0.f);
     e->tlaunches.assign(nk, 0);
-    long prev[3] = {-1, -1, -1};
+    long prev[4] = {-1, -1, -1, -1};
     for (size_t i = 0; i < e->tmark.size(); ++i) {
         const int w = e->tstream[i];
         if (e->tmark[i] >= 0 && prev[w] >= 0) {
@@ -1550,14 +1605,14 @@ static int op_ukf(const double mean[13], const double P[144], const double* Q81,
     if (err != hipSuccess) { delete st; HIP_TRY(err); }
     c.arr.a.n_obj = 1;
     if (int rc = upload_ctrl(c, fc)) { delete st; return rc; }
-    launch_ukf_chain(c.arr.a, *ut, true, c.stream);
+    launch_ukf_chain(c.arr.a, *ut, true, 0, c.stream);
     err = hipMemcpyAsync(st, c.arr.state.p, sizeof(ObjState), hipMemcpyDeviceToHost, c.stream);
     if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
     if (err == hipSuccess) err = hipGetLastError();
     if (err == hipSuccess) {
         std::memcpy(mean_out, st->belief[B_SPARE].mean, sizeof(double) * 13);
         std::memcpy(P_out, st->belief[B_SPARE].cov, sizeof(double) * 144);
-        if (status) *status = st->ukf_status & 0xF;
+        if (status) *status = st->lane[0].ukf_status & 0xF;
     }
     delete st;
     HIP_TRY(err);
@@ -1646,7 +1701,7 @@ int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint
     {
         ObjState st0;
         init_state(st0);
-        st0.pending_frame = 0;   // the test of frame 0 is pending
+        st0.lane[0].pending_frame = 0;   // the test of frame 0 is pending
         HIP_TRY(hipMemcpyAsync(c.arr.state.p, &st0, sizeof(st0), hipMemcpyHostToDevice, c.stream));
         HIP_TRY(hipStreamSynchronize(c.stream));
     }
@@ -1659,8 +1714,8 @@ int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint
     if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
     if (err == hipSuccess) err = hipGetLastError();
     if (err == hipSuccess) {
-        *L_out = st->outlier_L[0];
-        if (samples_out) *samples_out = (long)st->outlier_cnt[0];
+        *L_out = st->lane[0].outlier_L[0];
+        if (samples_out) *samples_out = (long)st->lane[0].outlier_cnt[0];
     }
     delete st;
     // restore the default tile geometry of this context

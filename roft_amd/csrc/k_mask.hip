@@ -370,9 +370,18 @@ __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskR
 // dynamic LDS: [plane_words] OR target | uint16 list of this workgroup's non-empty groups
 // grid: (S, n_obj); frame t of the batch.  Workgroup q of an object owns the 64-pixel groups q, q + S, ... of the
 // source and the words [q, q+1) * plane_words / S of the planes it copies / fills / zeroes.
+#ifdef ROFT_MASK_PROFILE
+#define MTICK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { long long _t = wall_clock64(); a.state[blockIdx.y].dbg[i] = _t - m_t0; m_t0 = _t; } } while (0)
+#else
+#define MTICK(i) do {} while (0)
+#endif
+
 template <int FT>
 __global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a, int t, int frames_between, int flow_aided)
 {
+#ifdef ROFT_MASK_PROFILE
+    long long m_t0 = wall_clock64();
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ MaskShared S;
     uint32_t* s_tgt = reinterpret_cast<uint32_t*>(smem);
@@ -392,6 +401,7 @@ __global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a,
     __syncthreads();
     const FrameCtrl& c = s_c;
     const MaskRec r = decide_frame(s_rec[0], s_rec[1], t, c, frames_between, flow_aided);
+    MTICK(0);
     if (q == 0 && tid == 0) a.mrec[(size_t)(t + 1) * a.n_obj + obj] = r;   // (every workgroup computes the same record)
     // share of the plane words of this workgroup, in 16-byte units when the planes are 16-byte aligned
     const int unit = (a.plane_words & 3) ? 2 : 4;
@@ -416,6 +426,7 @@ __global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a,
     if (tid == 0) S.n_list = 0;
     plane_fill(s_tgt, 0u, a.plane_words);
     __syncthreads();
+    MTICK(1);
     // this workgroup's non-empty 64-pixel groups of the source -> list (any order: the scatter is order-free)
     const uint2* plane2 = reinterpret_cast<const uint2*>(src);
     for (int i0 = 0; q + nq * i0 < n_grp; i0 += kMaskThreads) {
@@ -429,13 +440,16 @@ __global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a,
         if (ne) s_list[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)g;
     }
     __syncthreads();
+    MTICK(2);
     propagate_binary<FT>(make_chase_geo(a.cam, a.ffmt), plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, s_tgt);
     __syncthreads();
+    MTICK(3);
     // flush: the non-zero words of this workgroup's plane into the (zeroed) destination
     for (int i = tid; i < (int)a.plane_words; i += kMaskThreads) {
         const uint32_t v = s_tgt[i];
         if (v) atomicOr(&dst[i], v);
     }
+    MTICK(4);
 }
 
 // One persistent workgroup per object at the end of the batch's mask chain: the frames whose source is three-valued.

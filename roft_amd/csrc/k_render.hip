@@ -200,19 +200,19 @@ __device__ void raster_triangle(const float* verts, const int32_t* tri, const Re
 }
 
 // grid: (ceil(n_tris_max/256), 2 alternatives, n_obj)
-__global__ __launch_bounds__(256) void raster_engine_kernel(EngineArrays a)
+__global__ __launch_bounds__(256) void raster_engine_kernel(EngineArrays a, int lin)
 {
     const int obj = blockIdx.z, alt = blockIdx.y;
-    if (a.state[obj].pending_frame < 0) return;   // no outlier test pending between the pose chain segments
+    if (a.state[obj].lane[lin].pending_frame < 0) return;   // no outlier test pending between the pose chain segments
     const ObjParams& prm = a.params[obj];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= prm.n_tris) return;
-    const PoseBelief& bl = a.state[obj].belief[alt == 0 ? B_ALT0 : B_ALT1];
+    const PoseBelief& bl = a.state[obj].belief[b_alt(lin, alt)];
     const RenderPose P = make_pose(bl.mean + 6, bl.mean + 9);
     const int d = a.cam.divider;
     const float fx = (float)(a.cam.fx / d), fy = (float)(a.cam.fy / d), cx = (float)(a.cam.cx / d),
                 cy = (float)(a.cam.cy / d);
-    uint32_t* zb = a.zbuf + ((size_t)obj * 2 + alt) * a.tile_w * a.tile_h;
+    uint32_t* zb = a.zbuf + (((size_t)lin * a.n_obj + obj) * 2 + alt) * a.tile_w * a.tile_h;
     raster_triangle(prm.verts, prm.tris + (size_t)3 * t, P, fx, fy, cx, cy, a.tile_w, a.tile_h, zb);
 }
 
@@ -220,20 +220,21 @@ __global__ __launch_bounds__(256) void raster_engine_kernel(EngineArrays a)
 // and the selected belief becomes the corrected belief (ROFTFilter.cpp:581-583, 670-675)
 constexpr int kOutlierThreads = 1024;
 
-__global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a)
+__global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a, int lin)
 {
     __shared__ double s_err[2][kOutlierThreads / 64];
     __shared__ double s_cnt[2][kOutlierThreads / 64];
     __shared__ int s_sel;
     const int obj = blockIdx.x;
     ObjState& st = a.state[obj];
-    if (st.pending_frame < 0) return;
-    const FrameCtrl& c = frame_ctrl(a, st.pending_frame, obj);
+    PoseLane& pl = st.lane[lin];
+    if (pl.pending_frame < 0) return;
+    const FrameCtrl& c = frame_ctrl(a, pl.pending_frame, obj);
     const int W = a.cam.W, d = a.cam.divider, tw = a.tile_w;
     const int fslot = (c.feat_read >= 0) ? c.feat_read : 0;
     const uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
     const float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
-    const uint32_t* z0 = a.zbuf + ((size_t)obj * 2) * a.tile_w * a.tile_h;
+    const uint32_t* z0 = a.zbuf + (((size_t)lin * a.n_obj + obj) * 2) * a.tile_w * a.tile_h;
     const uint32_t* z1 = z0 + (size_t)a.tile_w * a.tile_h;
     double err[2] = {0.0, 0.0}, cnt[2] = {0.0, 0.0};
     const int n = st.n_feat[fslot];
@@ -278,42 +279,43 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
             L[k] = (n2 == 0.0) ? 1.7976931348623157e308 : (e / n2) / 1.0;  // gain is a bool -> 1.0 (ROFTFilter.h:64)
         }
         const int sel = (L[0] > 2.0 * L[1]) ? 1 : 0;
-        st.outlier_selected = sel;
-        st.outlier_L[0] = L[0];
-        st.outlier_L[1] = L[1];
+        pl.outlier_selected = sel;
+        pl.outlier_L[0] = L[0];
+        pl.outlier_L[1] = L[1];
         for (int k = 0; k < 2; ++k) {
             double n2 = 0.0;
             for (int w = 0; w < kOutlierThreads / 64; ++w) n2 += s_cnt[k][w];
-            st.outlier_cnt[k] = n2;
+            pl.outlier_cnt[k] = n2;
         }
         s_sel = sel;
     }
     __syncthreads();
-    const PoseBelief& src = st.belief[s_sel ? B_ALT1 : B_ALT0];
-    PoseBelief& dst = st.belief[B_CORR];
+    const PoseBelief& src = st.belief[b_alt(lin, s_sel ? 1 : 0)];
+    PoseBelief& dst = st.belief[c.cur_slot];
     for (int i = threadIdx.x; i < 144; i += blockDim.x) dst.cov[i] = src.cov[i];
     if (threadIdx.x < 13) dst.mean[threadIdx.x] = src.mean[threadIdx.x];
     if (roft_object_output* row = log_row(a, c, obj)) {
         if (threadIdx.x < 13) row->pose[threadIdx.x] = src.mean[threadIdx.x];
         if (threadIdx.x == 0) {
             row->outlier_selected = s_sel;
-            row->outlier_L[0] = st.outlier_L[0];
-            row->outlier_L[1] = st.outlier_L[1];
+            row->outlier_L[0] = pl.outlier_L[0];
+            row->outlier_L[1] = pl.outlier_L[1];
         }
     }
 }
 
-void launch_outlier(const EngineArrays& a, hipStream_t s, hipEvent_t stop)
+void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t stop)
 {
     // objects that do not test this frame return immediately
-    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.zbuf), 0x7F800000, (size_t)a.n_obj * 2 * a.tile_w * a.tile_h, s);
-    hipLaunchKernelGGL(raster_engine_kernel, dim3((a.max_tris + 255) / 256, 2, a.n_obj), dim3(256), 0, s, a);
-    hipExtLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(kOutlierThreads), 0, s, nullptr, stop, 0, a);
+    const size_t n = (size_t)a.n_obj * 2 * a.tile_w * a.tile_h;
+    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.zbuf + (size_t)lin * n), 0x7F800000, n, s);
+    hipLaunchKernelGGL(raster_engine_kernel, dim3((a.max_tris + 255) / 256, 2, a.n_obj), dim3(256), 0, s, a, lin);
+    hipExtLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(kOutlierThreads), 0, s, nullptr, stop, 0, a, lin);
 }
 
 void launch_outlier_only(const EngineArrays& a, hipStream_t s)
 {
-    hipLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(kOutlierThreads), 0, s, a);
+    hipLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(kOutlierThreads), 0, s, a, 0);
 }
 
 // ---- operator level: render one pose into a float tile ------------------------------------------

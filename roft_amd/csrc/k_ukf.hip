@@ -1004,6 +1004,7 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
     if (!sd.op) return;
     const ObjParams& prm = a.params[obj];
     const int lane = threadIdx.x;
+    const int lin = c.lane, cur = c.cur_slot;
 
 #ifdef ROFT_UKF_PROFILE
     if (lane < 32) L.dbg[lane] = 0;
@@ -1020,17 +1021,11 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
         L.meas[i] = (i < 6) ? st.twist_hist[sd.twist_slot][i] : ((i < 9) ? c.pose_x[i - 6] : c.pose_q[i - 9]);
     }
     __syncthreads();
-    if (sd.save_corr_to_buf) {
-        const PoseBelief& cr = st.belief[B_CORR];
-        PoseBelief& bf = st.belief[B_BUF];
-        for (int i = lane; i < 144; i += kUkfThreads) bf.cov[i] = cr.cov[i];
-        if (lane < 13) bf.mean[lane] = cr.mean[lane];
-    }
 
     TICK(L, 0);
     if (sd.do_predict) {
-        ukf_predict(L, prm, c.dt, ut, st.warm_V[0], &st.warm_age[0], a.ukf_chol_guard);
-        PoseBelief& pr = st.belief[B_PRED];
+        ukf_predict(L, prm, c.dt, ut, st.warm_V[cur][0], &st.warm_age[cur][0], a.ukf_chol_guard);
+        PoseBelief& pr = st.belief[B_PRED + lin];
         for (int i = lane; i < 144; i += kUkfThreads) pr.cov[i] = L.cov[i];
         if (lane < 13) pr.mean[lane] = L.mean[lane];
     }
@@ -1039,13 +1034,13 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
         for (int i = lane; i < 144; i += kUkfThreads) d.cov[i] = L.cov[i];
         if (lane < 13) d.mean[lane] = L.mean[lane];
         if (roft_object_output* row = log_row(a, c, obj))
-            if (lane < 13 && sd.dst[0] == B_CORR) row->pose[lane] = L.mean[lane];
+            if (lane < 13 && sd.dst[0] == cur) row->pose[lane] = L.mean[lane];
         return;
     }
     TICK(L, 6);
     // square root of the predicted covariance, shared by both corrections of an outlier-rejection step
     if (!cholesky_state_sqrt(L, true, c.dt, a.ukf_chol_guard, a.ukf_chol_guard_bil))
-        decompose_state_cov(L, st.warm_V[1], &st.warm_age[1]);
+        decompose_state_cov(L, st.warm_V[cur][1], &st.warm_age[cur][1]);
     TICK(L, 7);
     int status = 0;
     for (int k = 0; k < sd.n_corr; ++k) {
@@ -1053,11 +1048,11 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
         status |= rc << (4 * k);
         __syncthreads();
     }
-    if (lane == 0) st.ukf_status = status;
+    if (lane == 0) st.lane[lin].ukf_status = status;
     // output log: the corrected belief after this frame's last step is what ROFTFilter logs
     if (roft_object_output* row = log_row(a, c, obj)) {
         __syncthreads();
-        if (lane < 13) row->pose[lane] = st.belief[B_CORR].mean[lane];
+        if (lane < 13) row->pose[lane] = st.belief[cur].mean[lane];
     }
 #ifdef ROFT_UKF_PROFILE
     __syncthreads();
@@ -1065,18 +1060,31 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
 #endif
 }
 
-// Pose chain of a batch: one workgroup per object runs its UKF steps frame after frame.  A step followed by the
-// depth-render outlier test ends the segment -- the host enqueues launch_outlier and another segment behind it, which
-// resumes at the object's cursor (ObjState::pc_frame / pc_step) -- otherwise the segment runs to the end of the batch.
-__global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, UtTable ut, int first_segment)
+// Pose chain of a batch, one lane (BeliefSlot) per launch: one workgroup per object runs the UKF steps of the frames
+// that belong to lane `lin`, frame after frame.  A step followed by the depth-render outlier test ends
+// the segment -- the host enqueues launch_outlier and another segment behind it, which resumes at the lane's cursor
+// (PoseLane::pc_frame / pc_step) -- otherwise the segment runs to the end of the batch.
+__global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, UtTable ut, int first_segment, int lin)
 {
     // static LDS on purpose: with `extern __shared__` the compiler re-reads the dynamic-LDS base address from a
     // table in global memory inside every Jacobi round (two dependent global loads per round)
     __shared__ UkfLds L;
+    __shared__ unsigned s_mine;
     const int obj = blockIdx.x;
     ObjState& st = a.state[obj];
-    int t = first_segment ? 0 : st.pc_frame, step = first_segment ? 0 : st.pc_step;
-    if (t >= a.T) return;   // (this object's chain of the batch ended in an earlier segment)
+    PoseLane& pl = st.lane[lin];
+    int t = first_segment ? 0 : pl.pc_frame, step = first_segment ? 0 : pl.pc_step;
+    if (t >= a.T) return;   // (this lane's chain of the batch ended in an earlier segment)
+    // frames of the batch that belong to this lane (one load per frame, all in flight together)
+    if (threadIdx.x == 0) s_mine = 0u;
+    __syncthreads();
+    if ((int)threadIdx.x < a.T && frame_ctrl(a, threadIdx.x, obj).lane == lin) atomicOr(&s_mine, 1u << threadIdx.x);
+    __syncthreads();
+    const unsigned mine = s_mine;
+    if ((mine >> t) == 0u) {   // nothing (left) to do for this lane in this batch
+        if (threadIdx.x == 0) { pl.pending_frame = -1; pl.pc_frame = a.T; pl.pc_step = 0; }
+        return;
+    }
     jacobi12_table(L);
     for (int i = threadIdx.x; i < 100; i += kUkfThreads) L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0;   // see ukf_predict
     if (threadIdx.x < 10) L.wQ[threadIdx.x] = 0.0;
@@ -1085,6 +1093,7 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
     __shared__ FrameCtrl s_c;
     int staged = -1;
     while (t < a.T) {
+        if (!((mine >> t) & 1u)) { ++t; step = 0; continue; }
         if (staged != t) {   // this frame's control block -> LDS
             __syncthreads();     // (nobody still reads the previous frame's)
             stage_ctrl(&s_c, frame_ctrl(a, t, obj));
@@ -1092,7 +1101,7 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
             __syncthreads();
         }
         const FrameCtrl& c = s_c;
-        if (step == 0 && threadIdx.x == 0) st.outlier_selected = -1;  // set again by outlier_kernel if it runs
+        if (step == 0 && threadIdx.x == 0) pl.outlier_selected = -1;  // set again by outlier_kernel if it runs
         if (step >= c.n_steps) { ++t; step = 0; continue; }
         if (c.steps[step].op) ukf_one_step(a, c, obj, step, ut, L);
         __syncthreads();   // beliefs written by this step are read by the next one (same workgroup)
@@ -1101,18 +1110,18 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
         if (pending) break;
     }
     if (threadIdx.x == 0) {
-        st.pending_frame = pending ? t : -1;
-        st.pc_frame = t;     // == a.T when the chain of this batch is complete
-        st.pc_step = step;
+        pl.pending_frame = pending ? t : -1;
+        pl.pc_frame = t;     // == a.T when the chain of this batch is complete
+        pl.pc_step = step;
     }
 }
 
-void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, hipStream_t s, hipEvent_t stop)
+void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, int lin, hipStream_t s, hipEvent_t stop)
 {
     UtTable tab;
     for (int k = 0; k < 3; ++k) tab.w[k] = ut_weights(18 + 3 * k, ut);
     hipExtLaunchKernelGGL(ukf_chain_kernel, dim3(a.n_obj), dim3(kUkfThreads), 0, s, nullptr, stop, 0, a, tab,
-                          first_segment ? 1 : 0);
+                          first_segment ? 1 : 0, lin);
 }
 
 }  // namespace roft

@@ -15,7 +15,8 @@
 namespace roft {
 
 constexpr int kWave = 64;              // CDNA wavefront
-constexpr int kNumBelief = 6;          // pose belief slots per object
+constexpr int kNumLin = 2;             // belief lineages per object = lanes of the pose chain (see BeliefSlot)
+constexpr int kNumBelief = 9;          // pose belief slots per object
 constexpr int kMaxBatch = ROFT_MAX_BATCH_FRAMES;   // frames per roft_frames_submit
 constexpr int kTwistRing = 64;         // twist history ring (velocity deque of the measurement model + frames in flight)
 constexpr int kMaxFlowHist = ROFT_MAX_FLOW_CHASE;  // flows a new mask can be chased through (30-entry queue of the
@@ -25,7 +26,18 @@ constexpr int kPlaneSlots = 48;        // mask bit-plane ring per object (> fram
 constexpr int kFeatRing = 12;          // buffered outlier-rejection feature sets per object (>= kMaxBatch + 2; the host
                                        // waits before it re-uses a set an unfinished batch still reads)
 
-enum BeliefSlot { B_CORR = 0, B_PRED = 1, B_BUF = 2, B_ALT0 = 3, B_ALT1 = 4, B_SPARE = 5 };
+// Pose belief slots.  The reference's re-sync swaps two Gaussians at every pose arrival -- `buffered_belief_ <-
+// p_corr_belief_`, `p_corr_belief_ <- old buffered_belief_`, then replays the buffered velocities on the latter
+// (ROFTFilter.cpp:331-350) -- so a filter with re-sync carries TWO interleaved belief lineages that never read each
+// other: the one that is p_corr_belief_ between pose arrivals 2j and 2j+1, and the one that is between 2j+1 and 2j+2
+// (it sits in buffered_belief_ meanwhile).  Here each lineage lives in one of the slots B_LIN0 / B_LIN1; the swap is a
+// role change decided on the host (FrameCtrl::cur_slot), never a copy.  The pose chain has two LANES (HIP streams,
+// FrameCtrl::lane) with their own scratch slots, cursors and z-buffers; a lineage is walked by the lane that owns its
+// slot, so the re-sync replay of one lineage runs next to the ordinary steps of the other -- of the same batch and of
+// the neighbouring ones -- which halves the serial UKF work per frame on the pose chain.
+enum BeliefSlot { B_LIN0 = 0, B_LIN1 = 1, B_PRED = 2 /* + lane */, B_ALT0 = 4 /* + 2 lane */, B_ALT1 = 5 /* + 2 lane */,
+                  B_SPARE = 8, B_CORR = B_LIN0 /* operator level: one lineage */ };
+__host__ __device__ inline int b_alt(int lane, int k) { return B_ALT0 + 2 * lane + k; }
 
 struct DevCamera {
     int W, H;
@@ -63,23 +75,29 @@ struct FlowRec {
     float z, dx, dy;
 };
 
+// pose chain state of one lane of one object
+struct PoseLane {
+    int pc_frame, pc_step; // cursor inside the current batch (ukf_chain_kernel)
+    int pending_frame;     // frame of the batch whose outlier test is pending between two pose chain segments, -1 none
+    int outlier_selected;  // of the lane's last frame
+    double outlier_L[2];
+    double outlier_cnt[2];
+    int ukf_status;
+    int pad_;
+};
+
 struct ObjState {
     double v_mean[6];
     double v_cov[36];
     PoseBelief belief[kNumBelief];
     double twist_hist[kTwistRing][6];
-    int pc_frame, pc_step; // pose chain cursor inside the current batch (ukf_chain_kernel)
-    int pending_frame;     // frame of the batch whose outlier test is pending between two pose chain segments, -1 none
+    PoseLane lane[kNumLin];
     int n_flow_points;     // N of the velocity stage of the last frame (-1: did not run)
     int n_feat[kFeatRing]; // buffered outlier-rejection samples (rank-even mask pixels) per feature ring slot
-    int outlier_selected;
-    double outlier_L[2];
-    double outlier_cnt[2];
     int skf_status;
-    int ukf_status;
-    // warm start of the covariance eigen-decomposition: [0] prediction input, [1] correction input
-    double warm_V[2][144];
-    int warm_age[2];       // 0 = no basis yet; a cold start is forced every kWarmRefresh uses
+    // warm start of the covariance eigen-decomposition per lineage slot: [0] prediction input, [1] correction input
+    double warm_V[kNumLin][2][144];
+    int warm_age[kNumLin][2];  // 0 = no basis yet; a cold start is forced every kWarmRefresh uses
     long long dbg[32];     // phase cycle counters of the last ukf_step (ROFT_UKF_PROFILE builds only)
 };
 
@@ -94,7 +112,7 @@ struct StepDesc {
     int type[2];     // ROFT_MEAS_*
     int dst[2];      // belief slots written
     int twist_slot;  // twist_hist index used as the velocity measurement
-    int save_corr_to_buf;  // re-sync: after reading src, B_BUF <- B_CORR (ROFTFilter.cpp:333-340)
+    int pad_;
 };
 
 struct alignas(16) FrameCtrl {
@@ -123,6 +141,9 @@ struct alignas(16) FrameCtrl {
     int outlier_step;                // index of the step followed by render + likelihood (-1 none)
     int force_mode;                  // operator level: force the mask mode (0 = decide on device)
     int frame_idx;                   // engine frame counter (row of the output log)
+    int lane;                        // pose chain lane (stream) that walks this frame's steps (see BeliefSlot)
+    int cur_slot;                    // B_LIN0 / B_LIN1: slot of p_corr_belief_ during this frame
+    int pad_[2];
 };
 
 // Mask chain record of one frame of the batch and one object (k_mask.hip).  Row t + 1 of EngineArrays::mrec belongs to
@@ -159,7 +180,7 @@ struct EngineArrays {
     double* norms;           // [n_obj][3 * cand_cap] SKF scratch (innovations + norms when N > LDS capacity)
     uint32_t* feat_pix;      // [n_obj][kFeatRing][feat_cap] buffered feature pixel (linear index)
     float* feat_depth;       // [n_obj][kFeatRing][feat_cap]
-    uint32_t* zbuf;          // [n_obj][2][tile_h*tile_w] float bits, +inf = empty
+    uint32_t* zbuf;          // [kNumLin][n_obj][2][tile_h*tile_w] float bits, +inf = empty
     int cand_cap, feat_cap;
     size_t plane_words;      // wpr*H
     int tile_w, tile_h;
@@ -270,9 +291,10 @@ void launch_skf_records(const double* x_pred, const double* P_pred, int N, const
 void launch_kf_predict(const double* x, const double* P, const double* qdiag, double* xo, double* Po, hipStream_t s);
 // Pose chain segment: every object runs its UKF steps from its cursor up to and including its next outlier-rejection
 // step (then launch_outlier and another segment follow) or to the end of the batch.
-void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, hipStream_t s, hipEvent_t stop = nullptr);
+// Of every object only the frames of lane `lin` are walked.
+void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, int lin, hipStream_t s, hipEvent_t stop = nullptr);
 void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // after the mask chain of the batch
-void launch_outlier(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // render + likelihood + decision of the pending tests
+void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t stop = nullptr);   // render + likelihood + decision of the pending tests of a lineage
 void launch_outlier_only(const EngineArrays& a, hipStream_t s);  // likelihood + decision on filled z-buffers
 
 // operator-level helpers on raw device buffers (used by the C ABI operator entry points)

@@ -27,7 +27,7 @@ def frame_inputs(st, k):
     """What the Dataset* sources would hand to the tracker at frame k."""
     mask = st.mask_gt[st.mask_delivery[k]].cpu().numpy() if st.mask_delivery[k] >= 0 else None
     pose = (st.pose_meas[k, :3].copy(), st.pose_meas[k, 3:].copy()) if st.pose_valid[k] else None
-    i = st.image(k)
+    i = st.image(k) if hasattr(st, "image") else k
     flow = st.flow[i].cpu().numpy() if st.flow_valid[k] else None
     depth = st.depth[i].cpu().numpy()
     return depth, flow, mask, pose

@@ -24,6 +24,8 @@ eng = rb.make_engine(streams)
 names = ["ctrl", "plane->LDS", "popc+scan", "cand list", "gathers", "scan+write"]
 if os.environ.get("PHASES") == "feat":
     names = ["count", "scan+ranks", "expand", "gathers"]
+if os.environ.get("PHASES") == "mask":   # -DROFT_MASK_PROFILE: workgroup 0 of each object, mask_step_kernel
+    names = ["ctrl + decide", "zero next + LDS plane", "group list", "walks", "flush"]
 if os.environ.get("PHASES") == "skf":
     names = ["load", "innovations", "norms", "median", "mean abs dev", "max weight", "accumulate", "reduce", "solve"]
 for k in range(n):
