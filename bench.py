@@ -147,6 +147,7 @@ def parse():
                    help="hand the engine HOST buffers in the main run (PCIe-inclusive rate; never the headline value)")
     p.add_argument("--pcie-frames", type=int, default=12, help="timed frames of the two PCIe-inclusive legs (0: skip them)")
     p.add_argument("--no-ramp", action="store_true", help="equal batches from the first timed frame on (no short first batches)")
+    p.add_argument("--splits", default="", help="explicit batch sizes of the timed frames, e.g. 2,6,6,6 (must sum to --steps)")
     p.add_argument("--no-kernel-timing", action="store_true",
                    help="do not record HIP events in the timed region and skip the per-kernel breakdown")
     return p.parse_args()
@@ -264,7 +265,15 @@ def main():
         return eng.build_batch(frames_list)
 
     warm_batches = [build(k0, t) for k0, t in split_batches(0, args.warmup, T)]
-    timed_batches = [build(k0, t) for k0, t in split_batches(args.warmup, n_timed_end, T, ramp=not args.no_ramp)]
+    if args.splits:
+        sizes = [int(x) for x in args.splits.split(",")]
+        if sum(sizes) != args.steps or max(sizes) > T or min(sizes) < 1:
+            raise SystemExit("bench.py: --splits must sum to --steps with entries in 1..--batch")
+        starts = np.cumsum([args.warmup] + sizes[:-1])
+        timed_splits = list(zip([int(x) for x in starts], sizes))
+    else:
+        timed_splits = split_batches(args.warmup, n_timed_end, T, ramp=not args.no_ramp)
+    timed_batches = [build(k0, t) for k0, t in timed_splits]
     extra_batches = [build(k0, t) for k0, t in split_batches(n_timed_end, n_frames, T)]
 
     def run(batches):
@@ -528,7 +537,7 @@ def main():
                                if adds_cpu is not None else None),
         "rmse_vs_gt": rmse,
         "pipeline": "three HIP streams per engine (mask / velocity / pose chains), one persistent per-object kernel per chain "
-                    "and batch, up to 3 batches in flight",
+                    "and batch, up to 5 batches in flight",
         "kernels_post_run_breakdown": kernels,
         "dominant_kernel": dominant,
         "stream_generation_s": t_gen,

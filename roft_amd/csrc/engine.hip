@@ -99,10 +99,10 @@ int check_geometry(int W, int H)
         return fail(ROFT_ERR_INVALID, "image width must be a multiple of 32 and width*height a multiple of 64");
     if ((size_t)W * H >= (1u << 24))
         return fail(ROFT_ERR_INVALID, "width*height must be < 2^24 (float-accumulated sampling index, hpp:237)");
-    // LDS of the mask chain kernel: the OR target plane + the list of non-empty 64-pixel groups (2 B each); of the flow
+    // LDS of the mask step kernel: the OR target plane + a list of non-empty 64-pixel groups (any length); of the flow
     // measurement / feature kernels: the plane + their work lists
     const size_t plane = (size_t)(W / 32) * H * 4;
-    if (plane + std::max<size_t>((size_t)W * H / 64 * 2 + 1024, 16384 + 128) > 160 * 1024 - 256)
+    if (plane + 16384 + 128 > 160 * 1024 - 4096)
         return fail(ROFT_ERR_INVALID, "mask bit plane does not fit the 160 KiB LDS of a CU");
     return ROFT_OK;
 }
@@ -461,13 +461,15 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
         return fail(ROFT_ERR_INVALID, "max_batch_frames must be 0 .. ROFT_MAX_BATCH_FRAMES");
     if ((int)(size_t)cfg->subsampling_radius <= 0) return fail(ROFT_ERR_INVALID, "subsampling_radius must be >= 1");
     const int T = std::max(cfg->max_batch_frames, 1);
-    const int lead = (T == 1) ? 6 : 3;
+    // batches in flight: enough that the host never runs out of enqueued work while it waits for the oldest one -- a
+    // batch takes about three batch periods from its mask chain to the end of its pose chain
+    const int lead = (T == 1) ? 6 : 5;
     // the re-sync replays at most pose_frames_between + 1 buffered velocities (all of them when that number is unknown)
     if (cfg->pose_frames_between + 2 > kMaxSteps)
         return fail(ROFT_ERR_INVALID, "pose_frames_between too large (the re-sync replays pose_frames_between + 1 steps, at most 9)");
     static_assert(roft_engine::kBatchRing > 6, "batch ring");
-    static_assert(3 * kMaxBatch + kMaxBatch + 1 < kPlaneSlots && 6 + 1 + 1 < kPlaneSlots, "plane ring");
-    static_assert(3 * kMaxBatch + kMaxSteps + 2 < kTwistRing, "twist ring");
+    static_assert(5 * kMaxBatch + kMaxBatch + 1 < kPlaneSlots && 6 + 1 + 1 < kPlaneSlots, "plane ring");
+    static_assert(5 * kMaxBatch + kMaxSteps + 2 < kTwistRing, "twist ring");
     static_assert(kFeatRing >= kMaxBatch + 2, "feature ring");
     HIP_TRY(hipSetDevice(cfg->device));
     roft_engine* e = new roft_engine();

@@ -173,9 +173,21 @@ __device__ __forceinline__ int trunc_clamped(float x)
 }
 
 #define ROFT_GLOBAL __attribute__((address_space(1)))
+#define ROFT_LDS __attribute__((address_space(3)))
 
-// Walks of the source pixels of one frame.  `list` (LDS) holds the indices of the non-empty 64-pixel groups of the
-// source plane; wave w owns entries w, w + 16, ... (the object's rows spread over all waves), prefetches the plane
+// LDS address of an object in DYNAMIC LDS, pinned in a scalar register.  The base of `extern __shared__` memory is not
+// a link-time constant: left to itself the compiler re-reads it from a table in memory wherever it is used -- a scalar
+// load and an s_waitcnt in front of every LDS atomic of the scatter loops.
+__device__ __forceinline__ ROFT_LDS uint32_t* pin_lds(uint32_t* p)
+{
+    uint32_t off = (uint32_t)(uintptr_t)(ROFT_LDS uint32_t*)p;
+    asm volatile("" : "+s"(off));
+    return (ROFT_LDS uint32_t*)(uintptr_t)off;
+}
+
+// Walks of the source pixels of one frame.  `list` (LDS) holds the non-empty 64-pixel groups of the source plane as
+// (row << 16 | column) of their first pixel -- the division by the image width is done once per group by the list
+// pass, one group per thread, instead of by every wave that walks the group; wave w owns entries w, w + 16, ... (the object's rows spread over all waves), prefetches the plane
 // words of up to 64 of them with one load (lane i <-> the wave's i-th entry) and chases them NCH at a time: the
 // flow reads of a wave are row-contiguous (64 x 8 B).  A surviving pixel is handed to `hit(target, x, y, source)`.
 // One CU walks a whole object, so the instruction count per pixel and flow matters as much as the load latency:
@@ -187,8 +199,9 @@ __device__ __forceinline__ int trunc_clamped(float x)
 //    the pixel itself; MODE 1: grid and scale are powers of two, the divisions are exact reciprocal multiplies;
 //    MODE 0: true divisions.
 template <int FT, int NCH, int MODE, class Hit>
-__device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plane2_, const uint16_t* list, int n_list,
-                                             int n_flows, bool clear00, const void* const* flows, Hit hit)
+__device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plane2_, const uint32_t* list, int n_list,
+                                             int n_flows, bool clear00, const void* const* flows, Hit hit,
+                                             const uint2* words = nullptr)
 {
     const int W = g.W, H = g.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -196,14 +209,19 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
     const float nan = __uint_as_float(0x7FC00000u);
     for (int e0 = wave; e0 < n_list; e0 += kMaskWaves * 64) {
         const int my_e = e0 + lane * kMaskWaves;
-        int my_grp = -1;
+        uint32_t my_yx = 0u;
         uint2 mine = make_uint2(0u, 0u);
         if (my_e < n_list) {
-            my_grp = list[my_e];
-            const unsigned long long w = *(const ROFT_GLOBAL unsigned long long*)(plane2 + my_grp);
-            mine = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+            my_yx = list[my_e];
+            if (words) {   // (LDS copy kept by the list pass: no second trip to memory)
+                mine = words[my_e];
+            } else {
+                const int my_grp = (int)(((my_yx >> 16) * (uint32_t)W + (my_yx & 0xFFFFu)) >> 6);
+                const unsigned long long w = *(const ROFT_GLOBAL unsigned long long*)(plane2 + my_grp);
+                mine = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+            }
         }
-        unsigned long long pending = __ballot(my_grp >= 0);
+        unsigned long long pending = __ballot(my_e < n_list);
         while (pending) {
             float t_x[NCH], t_y[NCH];
             int src[NCH];
@@ -215,16 +233,18 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
                 if (pending) {
                     const int it = __builtin_ctzll(pending);
                     pending &= pending - 1;
-                    const int grp = __builtin_amdgcn_readlane(my_grp, it);
+                    const uint32_t yx = (uint32_t)__builtin_amdgcn_readlane((int)my_yx, it);
                     unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)mine.y, it) << 32) |
                                               (uint32_t)__builtin_amdgcn_readlane((int)mine.x, it);
-                    if (clear00 && grp == 0) bits &= ~1ull;                 // mask_.at<uchar>(0,0) = 0
+                    if (clear00 && yx == 0u) bits &= ~1ull;                 // mask_.at<uchar>(0,0) = 0
                     // row / column of the group's first pixel: wave-uniform; a group may straddle rows when W % 64 != 0
-                    const int p0 = grp * 64, y0 = p0 / W;
-                    int px = p0 - y0 * W + lane, py = y0;
-                    if (px >= W) { px -= W; ++py; }
-                    if (px >= W) { px -= W; ++py; }
-                    src[u] = p0 + lane;
+                    const int y0 = (int)(yx >> 16), x0 = (int)(yx & 0xFFFFu);
+                    int px = x0 + lane, py = y0;
+                    if (W & 63) {
+                        if (px >= W) { px -= W; ++py; }
+                        if (px >= W) { px -= W; ++py; }
+                    }
+                    src[u] = y0 * W + x0 + lane;
                     t_x[u] = ((bits >> lane) & 1ull) ? (float)px : nan;
                     t_y[u] = (float)py;
                 }
@@ -275,20 +295,29 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
     }
 }
 
-// binary source: OR-scatter into the LDS plane (eight walks in flight per wave)
+// binary source: OR-scatter into the LDS plane.  kBinaryWalks walks in flight per wave: a workgroup's share of an object
+// is about a dozen groups per wave, so all their flow reads go out together and the frame pays ONE memory latency per
+// flow instead of one per eight groups.
+#ifndef ROFT_BINARY_WALKS
+#define ROFT_BINARY_WALKS 8
+#endif
+constexpr int kBinaryWalks = ROFT_BINARY_WALKS;
 template <int FT>
-__device__ __noinline__ void propagate_binary(ChaseGeo g, const uint2* plane2, const uint16_t* list, int n_list, int n_flows,
-                                              bool clear00, const void* const* flows, uint32_t* s_tgt)
+__device__ __noinline__ void propagate_binary(ChaseGeo g, const uint2* plane2, const uint32_t* list, int n_list, int n_flows,
+                                              bool clear00, const void* const* flows, uint32_t* s_tgt, const uint2* words)
 {
-    auto hit = [s_tgt](int tp, int, int, int) { atomicOr(&s_tgt[tp >> 5], 1u << (tp & 31)); };   // (by value: no reload per hit)
-    if (g.mode == 2) chase_groups<FT, 8, 2>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
-    else if (g.mode == 1) chase_groups<FT, 8, 1>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
-    else chase_groups<FT, 4, 0>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
+    ROFT_LDS uint32_t* const tgt = pin_lds(s_tgt);
+    auto hit = [tgt](int tp, int, int, int) {
+        (void)__hip_atomic_fetch_or(tgt + (tp >> 5), 1u << (tp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    if (g.mode == 2) chase_groups<FT, kBinaryWalks, 2>(g, plane2, list, n_list, n_flows, clear00, flows, hit, words);
+    else if (g.mode == 1) chase_groups<FT, kBinaryWalks, 1>(g, plane2, list, n_list, n_flows, clear00, flows, hit, words);
+    else chase_groups<FT, 4, 0>(g, plane2, list, n_list, n_flows, clear00, flows, hit, words);
 }
 
 // general source: map of the winning (largest) source index per target + the targets' bounding box (LDS bbox[4])
 template <int FT>
-__device__ __noinline__ void propagate_general(ChaseGeo g, const uint2* plane2, const uint16_t* list, int n_list, int n_flows,
+__device__ __noinline__ void propagate_general(ChaseGeo g, const uint2* plane2, const uint32_t* list, int n_list, int n_flows,
                                                bool clear00, const void* const* flows, int32_t* map, int* s_bbox)
 {
     int bx0 = INT32_MAX, by0 = INT32_MAX, bx1 = -1, by1 = -1;
@@ -367,17 +396,18 @@ __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskR
     return r;
 }
 
-// dynamic LDS: [plane_words] OR target | uint16 list of this workgroup's non-empty groups
+// dynamic LDS: [plane_words] OR target | list of this workgroup's non-empty groups [| their plane words]
 // grid: (S, n_obj); frame t of the batch.  Workgroup q of an object owns the 64-pixel groups q, q + S, ... of the
 // source and the words [q, q+1) * plane_words / S of the planes it copies / fills / zeroes.
 #ifdef ROFT_MASK_PROFILE
-#define MTICK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x == 0) { long long _t = wall_clock64(); a.state[blockIdx.y].dbg[i] = _t - m_t0; m_t0 = _t; } } while (0)
+#define MTICK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4) { long long _t = wall_clock64(); a.state[blockIdx.y].dbg[blockIdx.x * 8 + (i)] = _t - m_t0; m_t0 = _t; } } while (0)
 #else
 #define MTICK(i) do {} while (0)
 #endif
 
 template <int FT>
-__global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a, int t, int frames_between, int flow_aided)
+__global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a, int t, int frames_between, int flow_aided,
+                                                                 int list_cap, int keep_words)
 {
 #ifdef ROFT_MASK_PROFILE
     long long m_t0 = wall_clock64();
@@ -385,8 +415,11 @@ __global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ MaskShared S;
     uint32_t* s_tgt = reinterpret_cast<uint32_t*>(smem);
-    uint16_t* s_list = reinterpret_cast<uint16_t*>(smem + ((a.plane_words * 4 + 15) & ~(size_t)15));
+    uint32_t* s_list = reinterpret_cast<uint32_t*>(smem + ((a.plane_words * 4 + 15) & ~(size_t)15));
     const int obj = blockIdx.y, q = blockIdx.x, nq = gridDim.x;
+    // plane words of the listed groups (behind the list, when the launch reserved the room)
+    uint2* s_words = keep_words ? reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(s_list) + (((size_t)list_cap * 4 + 15) & ~(size_t)15))
+                                : nullptr;
     const int W = a.cam.W, H = a.cam.H, n_grp = (W * H) >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
     // control block and the two state records -> LDS with one load per thread
@@ -427,21 +460,38 @@ __global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a,
     plane_fill(s_tgt, 0u, a.plane_words);
     __syncthreads();
     MTICK(1);
-    // this workgroup's non-empty 64-pixel groups of the source -> list (any order: the scatter is order-free)
+    // This workgroup's non-empty 64-pixel groups of the source (g = q + nq i) -> list (any order: the scatter is
+    // order-free), then their walks; in chunks of list_cap groups when the LDS next to the plane cannot list the whole
+    // share at once (a 1280x720 plane with one workgroup per object).
     const uint2* plane2 = reinterpret_cast<const uint2*>(src);
-    for (int i0 = 0; q + nq * i0 < n_grp; i0 += kMaskThreads) {
-        const int g = q + nq * (i0 + tid);
-        bool ne = false;
-        if (g < n_grp) { const uint2 w = plane2[g]; ne = (w.x | w.y) != 0u; }
-        const unsigned long long b = __ballot(ne);
-        int base = 0;
-        if (lane == 0 && b) base = atomicAdd(&S.n_list, __popcll(b));
-        base = __shfl(base, 0, 64);
-        if (ne) s_list[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)g;
+    const int share = (n_grp - q + nq - 1) / nq;
+    for (int c0 = 0; c0 < share; c0 += list_cap) {
+        if (c0 > 0) {
+            __syncthreads();   // the walks of the chunk before have read the list
+            if (tid == 0) S.n_list = 0;
+            __syncthreads();
+        }
+        const int c1 = min(share, c0 + list_cap);
+        for (int i0 = c0; i0 < c1; i0 += kMaskThreads) {
+            const int i = i0 + tid, g = q + nq * i;
+            bool ne = false;
+            uint2 w = make_uint2(0u, 0u);
+            if (i < c1) { w = plane2[g]; ne = (w.x | w.y) != 0u; }
+            const unsigned long long b = __ballot(ne);
+            int base = 0;
+            if (lane == 0 && b) base = atomicAdd(&S.n_list, __popcll(b));
+            base = __shfl(base, 0, 64);
+            if (ne) {
+                const int e = base + __popcll(b & ((1ull << lane) - 1ull));
+                const int p0 = g * 64, y0 = p0 / W;
+                s_list[e] = ((uint32_t)y0 << 16) | (uint32_t)(p0 - y0 * W);
+                if (s_words) s_words[e] = w;
+            }
+        }
+        __syncthreads();
+        MTICK(2);
+        propagate_binary<FT>(make_chase_geo(a.cam, a.ffmt), plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, s_tgt, s_words);
     }
-    __syncthreads();
-    MTICK(2);
-    propagate_binary<FT>(make_chase_geo(a.cam, a.ffmt), plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, s_tgt);
     __syncthreads();
     MTICK(3);
     // flush: the non-zero words of this workgroup's plane into the (zeroed) destination
@@ -453,13 +503,13 @@ __global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a,
 }
 
 // One persistent workgroup per object at the end of the batch's mask chain: the frames whose source is three-valued.
-// dynamic LDS: uint16 list of the non-empty groups
+// dynamic LDS: list of the non-empty groups
 template <int FT>
 __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ MaskShared S;
-    uint16_t* s_list = reinterpret_cast<uint16_t*>(smem);
+    uint32_t* s_list = reinterpret_cast<uint32_t*>(smem);
     const int obj = blockIdx.x;
     const int W = a.cam.W, H = a.cam.H, npix = W * H, n_grp = npix >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -489,7 +539,10 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
                 int base = 0;
                 if (lane == 0 && b) base = atomicAdd(&S.n_list, __popcll(b));
                 base = __shfl(base, 0, 64);
-                if (ne) s_list[base + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)g;
+                if (ne) {
+                    const int p0 = g * 64, y0 = p0 / W;
+                    s_list[base + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)y0 << 16) | (uint32_t)(p0 - y0 * W);
+                }
             }
             __syncthreads();
             int32_t* map = a.map + (size_t)obj * npix;
@@ -529,8 +582,14 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
     int S = 256 / (a.n_obj > 0 ? a.n_obj : 1);
     S = S < 1 ? 1 : (S > 8 ? 8 : S);
     const size_t lds_plane = (a.plane_words * 4 + 15) & ~(size_t)15;
-    const size_t lds_step = lds_plane + (((n_grp + S - 1) / S) * 2 + 15 & ~(size_t)15);
-    const size_t lds_gen = (n_grp * 2 + 15) & ~(size_t)15;
+    // list of a workgroup's groups next to its plane (4 B per group), their plane words behind it (8 B) if the CU's LDS
+    // has the room; a share that does not fit even the list is walked in chunks
+    const size_t lds_cap = 160 * 1024 - 4096;
+    size_t list_cap = (n_grp + S - 1) / S;
+    const int keep_words = lds_plane + ((list_cap * 4 + 15) & ~(size_t)15) + list_cap * 8 <= lds_cap ? 1 : 0;
+    if (lds_plane + ((list_cap * 4 + 15) & ~(size_t)15) > lds_cap) list_cap = ((lds_cap - lds_plane) / 4) & ~(size_t)3;
+    const size_t lds_step = lds_plane + ((list_cap * 4 + 15) & ~(size_t)15) + (keep_words ? list_cap * 8 : 0);
+    const size_t lds_gen = (n_grp * 4 + 15) & ~(size_t)15;
     static bool attr_set = false;
     if (!attr_set) {
         const int cap = 160 * 1024 - 4096;   // (the kernel's static LDS -- control block, records, flow pointers -- is ~1.2 KB)
@@ -546,10 +605,10 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
         if (new_mask_frames & (1u << t)) { launch_mask_ingest(a, t, s); ++launches; }
         if (s16)
             hipLaunchKernelGGL(mask_step_kernel<ROFT_FLOW_S16C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a, t,
-                               frames_between, flow_aided);
+                               frames_between, flow_aided, (int)list_cap, keep_words);
         else
             hipLaunchKernelGGL(mask_step_kernel<ROFT_FLOW_F32C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a, t,
-                               frames_between, flow_aided);
+                               frames_between, flow_aided, (int)list_cap, keep_words);
         ++launches;
     }
     if (s16)

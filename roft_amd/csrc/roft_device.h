@@ -22,7 +22,7 @@ constexpr int kTwistRing = 64;         // twist history ring (velocity deque of 
 constexpr int kMaxFlowHist = ROFT_MAX_FLOW_CHASE;  // flows a new mask can be chased through (30-entry queue of the
                                        // time-stamped source, OpticalFlowQueueHandler.cpp:18-26; "all buffered" otherwise)
 constexpr int kMaxSteps = 10;          // UKF steps per frame (re-sync replays <= pose_frames_between + 1 <= 9)
-constexpr int kPlaneSlots = 48;        // mask bit-plane ring per object (> frames in flight + one batch + 1)
+constexpr int kPlaneSlots = 64;        // mask bit-plane ring per object (> frames in flight + one batch + 1)
 constexpr int kFeatRing = 12;          // buffered outlier-rejection feature sets per object (>= kMaxBatch + 2; the host
                                        // waits before it re-uses a set an unfinished batch still reads)
 

@@ -43,7 +43,10 @@ for k in range(n):
         for o in range(n_obj):
             buf = (C.c_longlong * 32)()
             L.lib().roft_debug_get_dbg(eng._h, o, buf)
-            rows.append([buf[i] / 100.0 for i in range(len(names))])
+            if os.environ.get("PHASES") == "mask":   # slowest of the object's first four workgroups, phase by phase
+                rows.append([max(buf[q * 8 + i] for q in range(4)) / 100.0 for i in range(len(names))])
+            else:
+                rows.append([buf[i] / 100.0 for i in range(len(names))])
         r = np.array(rows)
         print("frame %d  mean us per phase: " % k + ", ".join("%s %.2f" % (nm, v) for nm, v in zip(names, r.mean(0))) +
               "  | sum %.2f (max over objects %.2f)" % (r.sum(1).mean(), r.sum(1).max()))
