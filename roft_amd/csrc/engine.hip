@@ -148,7 +148,7 @@ struct Arrays {
         HIP_TRY(norms.ensure((size_t)n_obj * 3 * a.cand_cap));
         HIP_TRY(feat_pix.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
         HIP_TRY(feat_depth.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
-        HIP_TRY(zbuf.ensure((size_t)kNumLin * n_obj * 2 * a.tile_w * a.tile_h));
+        HIP_TRY(zbuf.ensure((size_t)2 * a.tile_w * a.tile_h));   // operator level only (roft_depth_likelihood)
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
         a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.mrec = mrec.p;
         a.T_prev = 0; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
@@ -156,6 +156,7 @@ struct Arrays {
         a.out_log = nullptr;
         a.log_cap = 0;
         a.max_tris = 0;
+        a.max_verts = 0;
         a.ukf_chol_guard = 0.0;
         a.ukf_chol_guard_bil = 0.0;
         return ROFT_OK;
@@ -575,6 +576,7 @@ int roft_object_add(roft_engine* e, const roft_object_desc* d, int* obj_id)
     delete st;
     if (err != hipSuccess) return bail(ROFT_ERR_DEVICE, std::string("state upload: ") + hipGetErrorString(err));
     e->arr.a.max_tris = std::max(e->arr.a.max_tris, d->mesh.n_tris);
+    e->arr.a.max_verts = std::max(e->arr.a.max_verts, d->mesh.n_verts);
     e->objs.push_back(o);
     e->arr.a.n_obj = (int)e->objs.size();
     if (obj_id) *obj_id = id;
@@ -1085,7 +1087,7 @@ static int step_batch(roft_engine* e)
             tmark(e, "ukf_chain", which);
             if (!last) {
                 launch_outlier(a, lin, sp, nullptr);
-                launches += 3;
+                ++launches;
                 CHECK_LAUNCH("outlier rejection");
                 tmark(e, "outlier_render_likelihood", which);
             }

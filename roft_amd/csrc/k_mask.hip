@@ -173,18 +173,6 @@ __device__ __forceinline__ int trunc_clamped(float x)
 }
 
 #define ROFT_GLOBAL __attribute__((address_space(1)))
-#define ROFT_LDS __attribute__((address_space(3)))
-
-// LDS address of an object in DYNAMIC LDS, pinned in a scalar register.  The base of `extern __shared__` memory is not
-// a link-time constant: left to itself the compiler re-reads it from a table in memory wherever it is used -- a scalar
-// load and an s_waitcnt in front of every LDS atomic of the scatter loops.
-__device__ __forceinline__ ROFT_LDS uint32_t* pin_lds(uint32_t* p)
-{
-    uint32_t off = (uint32_t)(uintptr_t)(ROFT_LDS uint32_t*)p;
-    asm volatile("" : "+s"(off));
-    return (ROFT_LDS uint32_t*)(uintptr_t)off;
-}
-
 // Walks of the source pixels of one frame.  `list` (LDS) holds the non-empty 64-pixel groups of the source plane as
 // (row << 16 | column) of their first pixel -- the division by the image width is done once per group by the list
 // pass, one group per thread, instead of by every wave that walks the group; wave w owns entries w, w + 16, ... (the object's rows spread over all waves), prefetches the plane

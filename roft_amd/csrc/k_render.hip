@@ -16,6 +16,8 @@
 //    frames later (findNonZero, every second pixel).  Here the "features" are extracted once into
 //    a compact (pixel, depth) list indexed by rank/2, so the likelihood is a dense reduction over
 //    ~N_mask/2 samples and the frame itself need not be retained.
+#include <algorithm>
+
 #include "plane_rank.h"
 
 namespace roft {
@@ -159,13 +161,13 @@ __device__ __forceinline__ void project_vertex(const float* v, const RenderPose&
     }
 }
 
-__device__ void raster_triangle(const float* verts, const int32_t* tri, const RenderPose& P, float fx, float fy,
-                                float cx, float cy, int w, int h, uint32_t* zbuf)
+// Scan conversion of one projected triangle on a w x h target: `store(i, j, z)` receives every covered pixel with its
+// eye-space depth (the render contract of oracle/ro_render.c, operation by operation); rows outside [j_lo, j_hi] are
+// skipped (a strip of the target).
+template <class Store>
+__device__ __forceinline__ void raster_projected(float x0, float y0, float z0, float x1, float y1, float z1, float x2, float y2,
+                                                 float z2, int w, int h, int j_lo, int j_hi, Store store)
 {
-    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
-    project_vertex(verts + (size_t)3 * tri[0], P, fx, fy, cx, cy, x0, y0, z0);
-    project_vertex(verts + (size_t)3 * tri[1], P, fx, fy, cx, cy, x1, y1, z1);
-    project_vertex(verts + (size_t)3 * tri[2], P, fx, fy, cx, cy, x2, y2, z2);
     if (!(z0 > 0.001f && z1 > 0.001f && z2 > 0.001f)) return;
     const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
     if (area == 0.0f || !(area == area)) return;
@@ -178,8 +180,11 @@ __device__ void raster_triangle(const float* verts, const int32_t* tri, const Re
     if (fi1 > (float)(w - 1)) fi1 = (float)(w - 1);
     if (fj1 > (float)(h - 1)) fj1 = (float)(h - 1);
     if (!(fi0 <= fi1) || !(fj0 <= fj1)) return;
-    const int ia = (int)fi0, ib = (int)fi1, ja = (int)fj0, jb = (int)fj1;
-    const float iz0 = 1.0f / z0, iz1 = 1.0f / z1, iz2 = 1.0f / z2;
+    const int ia = (int)fi0, ib = (int)fi1, ja = max((int)fj0, j_lo), jb = min((int)fj1, j_hi);
+    // (the three reciprocals are only needed once a pixel centre is inside: most triangles of a fine mesh are smaller
+    //  than a pixel and cover none -- the quotients are the same wherever they are evaluated)
+    float iz0 = 0.0f, iz1 = 0.0f, iz2 = 0.0f;
+    bool have_iz = false;
     for (int j = ja; j <= jb; ++j) {
         const float py = (float)j + 0.5f;
         for (int i = ia; i <= ib; ++i) {
@@ -190,34 +195,30 @@ __device__ void raster_triangle(const float* verts, const int32_t* tri, const Re
             const bool inside = (area > 0.0f) ? (w0 >= 0.0f && w1 >= 0.0f && w2 >= 0.0f)
                                               : (w0 <= 0.0f && w1 <= 0.0f && w2 <= 0.0f);
             if (!inside) continue;
+            if (!have_iz) { iz0 = 1.0f / z0; iz1 = 1.0f / z1; iz2 = 1.0f / z2; have_iz = true; }
             const float b0 = w0 / area, b1 = w1 / area, b2 = w2 / area;
             const float iz = (b0 * iz0 + b1 * iz1) + b2 * iz2;
             const float z = 1.0f / iz;
             if (!(z > 0.0f)) continue;
-            atomicMin(&zbuf[(size_t)j * w + i], __float_as_uint(z));
+            store(i, j, z);
         }
     }
 }
 
-// grid: (ceil(n_tris_max/256), 2 alternatives, n_obj)
-__global__ __launch_bounds__(256) void raster_engine_kernel(EngineArrays a, int lin)
+__device__ void raster_triangle(const float* verts, const int32_t* tri, const RenderPose& P, float fx, float fy,
+                                float cx, float cy, int w, int h, uint32_t* zbuf)
 {
-    const int obj = blockIdx.z, alt = blockIdx.y;
-    if (a.state[obj].lane[lin].pending_frame < 0) return;   // no outlier test pending between the pose chain segments
-    const ObjParams& prm = a.params[obj];
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= prm.n_tris) return;
-    const PoseBelief& bl = a.state[obj].belief[b_alt(lin, alt)];
-    const RenderPose P = make_pose(bl.mean + 6, bl.mean + 9);
-    const int d = a.cam.divider;
-    const float fx = (float)(a.cam.fx / d), fy = (float)(a.cam.fy / d), cx = (float)(a.cam.cx / d),
-                cy = (float)(a.cam.cy / d);
-    uint32_t* zb = a.zbuf + (((size_t)lin * a.n_obj + obj) * 2 + alt) * a.tile_w * a.tile_h;
-    raster_triangle(prm.verts, prm.tris + (size_t)3 * t, P, fx, fy, cx, cy, a.tile_w, a.tile_h, zb);
+    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+    project_vertex(verts + (size_t)3 * tri[0], P, fx, fy, cx, cy, x0, y0, z0);
+    project_vertex(verts + (size_t)3 * tri[1], P, fx, fy, cx, cy, x1, y1, z1);
+    project_vertex(verts + (size_t)3 * tri[2], P, fx, fy, cx, cy, x2, y2, z2);
+    raster_projected(x0, y0, z0, x1, y1, z1, x2, y2, z2, w, h, 0, h - 1,
+                     [zbuf, w](int i, int j, float z) { atomicMin(&zbuf[(size_t)j * w + i], __float_as_uint(z)); });
 }
 
-// one workgroup per object: likelihood of both alternatives over the buffered features, decision,
-// and the selected belief becomes the corrected belief (ROFTFilter.cpp:581-583, 670-675)
+// Operator level (roft_depth_likelihood): likelihood of both alternatives over the buffered features from z-buffers in
+// HBM (EngineArrays::zbuf), decision, and the selected belief becomes the corrected belief (ROFTFilter.cpp:581-583,
+// 670-675).  One workgroup per object.  The engine's own test is outlier_fused_kernel below.
 constexpr int kOutlierThreads = 1024;
 
 __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a, int lin)
@@ -304,13 +305,199 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
     }
 }
 
+// ---- the engine's outlier test: depth render + likelihood of ONE alternative per workgroup, all in LDS ------------------
+// The render is only ever sampled at the buffered feature pixels, and the object covers a small window of the render
+// target (about 70 x 90 of 320 x 240 pixels at the metric shape).  So: the mesh vertices are projected once per
+// alternative into LDS (a vertex is shared by six triangles), their pixel bounding box is the z window -- also in LDS,
+// resolved with LDS atomicMin, +inf = empty --, and the likelihood reads it in place.  No z-buffer in HBM, no clear
+// pass, no global atomics, one launch instead of three.  A window that does not fit the LDS next to the vertices is
+// rendered in horizontal strips (every strip walks all triangles and all features); a mesh whose vertices do not fit is
+// projected per triangle.  Same per-pixel arithmetic as raster_triangle: the depths are bit-identical.
+// grid: (2 alternatives, n_obj).  dynamic LDS: [3 * vcache_cap floats] | [win_cap z values]
+constexpr int kFusedThreads = 1024;
+// phase stamps (-DROFT_FUSED_PROFILE; PHASES=fused tools/k1_phase_profile.py): 100 MHz ticks -> ObjState::dbg[alt * 8 + phase]
+#ifdef ROFT_FUSED_PROFILE
+#define UTICK(i) do { __syncthreads(); if (threadIdx.x == 0) { long long _t = wall_clock64(); st.dbg[blockIdx.x * 8 + (i)] += _t - u_t0; u_t0 = _t; } } while (0)
+#else
+#define UTICK(i) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArrays a, int lin, int vcache_cap, int win_cap)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double s_err[kFusedThreads / 64], s_cnt[kFusedThreads / 64];
+    __shared__ int s_box[4];
+    const int obj = blockIdx.y, alt = blockIdx.x, tid = threadIdx.x;
+    ObjState& st = a.state[obj];
+    PoseLane& pl = st.lane[lin];
+    if (pl.pending_frame < 0) return;   // no outlier test pending between the pose chain segments
+    const FrameCtrl& c = frame_ctrl(a, pl.pending_frame, obj);
+    const ObjParams& prm = a.params[obj];
+    const PoseBelief& bl = st.belief[b_alt(lin, alt)];
+    const RenderPose P = make_pose(bl.mean + 6, bl.mean + 9);
+    const int d = a.cam.divider, W = a.cam.W, tw = a.tile_w, th = a.tile_h;
+    const float fx = (float)(a.cam.fx / d), fy = (float)(a.cam.fy / d), cx = (float)(a.cam.cx / d), cy = (float)(a.cam.cy / d);
+    const int nv = prm.n_verts, nt = prm.n_tris;
+    const bool cached = nv <= vcache_cap;
+    float* s_v = reinterpret_cast<float*>(smem);
+    uint32_t* s_z = reinterpret_cast<uint32_t*>(smem + (((size_t)vcache_cap * 12 + 15) & ~(size_t)15));
+    if (tid < 4) s_box[tid] = (tid < 2) ? INT32_MAX : -1;
+#ifdef ROFT_FUSED_PROFILE
+    long long u_t0 = wall_clock64();
+    if (tid < 8) st.dbg[blockIdx.x * 8 + tid] = 0;
+#endif
+    __syncthreads();
+    // vertices -> screen; pixel bounding box of the triangles that can be drawn (pixel ranges as raster_projected clips
+    // them: ceil(min - 0.5) .. floor(max - 0.5) are monotone, so the box of the vertices covers every triangle)
+    {
+        int bi0 = INT32_MAX, bj0 = INT32_MAX, bi1 = -1, bj1 = -1;
+        constexpr int kVB = 4;   // vertices per thread whose coordinates are fetched together
+        for (int vb = tid; vb < nv; vb += kVB * kFusedThreads) {
+          float vc[kVB][3];
+#pragma unroll
+          for (int k = 0; k < kVB; ++k) {
+              const int v = min(vb + k * kFusedThreads, nv - 1);
+#pragma unroll
+              for (int q = 0; q < 3; ++q) vc[k][q] = prm.verts[(size_t)3 * v + q];
+          }
+#pragma unroll
+          for (int k = 0; k < kVB; ++k) {
+            const int v = vb + k * kFusedThreads;
+            if (v >= nv) break;
+            float sx, sy, z;
+            project_vertex(vc[k], P, fx, fy, cx, cy, sx, sy, z);
+            if (cached) { s_v[3 * v] = sx; s_v[3 * v + 1] = sy; s_v[3 * v + 2] = z; }
+            if (z > 0.001f) {
+                // (a vertex far outside the target clamps to an empty or full range; float -> int saturates)
+                const float lo_i = fminf(fmaxf(ceilf(sx - 0.5f), 0.0f), (float)tw), hi_i = fminf(fmaxf(floorf(sx - 0.5f), -1.0f), (float)(tw - 1));
+                const float lo_j = fminf(fmaxf(ceilf(sy - 0.5f), 0.0f), (float)th), hi_j = fminf(fmaxf(floorf(sy - 0.5f), -1.0f), (float)(th - 1));
+                bi0 = min(bi0, (int)lo_i); bi1 = max(bi1, (int)hi_i);
+                bj0 = min(bj0, (int)lo_j); bj1 = max(bj1, (int)hi_j);
+            }
+          }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            bi0 = min(bi0, __shfl_xor(bi0, off, 64)); bj0 = min(bj0, __shfl_xor(bj0, off, 64));
+            bi1 = max(bi1, __shfl_xor(bi1, off, 64)); bj1 = max(bj1, __shfl_xor(bj1, off, 64));
+        }
+        if ((tid & 63) == 0) {
+            atomicMin(&s_box[0], bi0); atomicMin(&s_box[1], bj0);
+            atomicMax(&s_box[2], bi1); atomicMax(&s_box[3], bj1);
+        }
+    }
+    __syncthreads();
+    // (a triangle's pixels lie between the smallest lower bound and the largest upper bound of its vertices; vertices
+    //  left or above the target contribute lower bound 0, vertices right or below it the upper bound w - 1 / h - 1)
+    UTICK(0);
+    const int i0 = min(s_box[0], tw - 1), j0 = min(s_box[1], th - 1), i1 = s_box[2], j1 = s_box[3];
+    const int win_w = i1 - i0 + 1;
+    const int fslot = (c.feat_read >= 0) ? c.feat_read : 0;
+    const uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
+    const float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
+    const int n = st.n_feat[fslot];
+    double err = 0.0, cnt = 0.0;
+    if (win_w > 0 && j1 >= j0 && i0 >= 0 && j0 >= 0) {
+        const int rows = max(1, win_cap / win_w);   // (win_cap >= the target's width: a strip holds at least one row)
+        for (int js = j0; js <= j1; js += rows) {
+            const int je = min(j1, js + rows - 1), npx = win_w * (je - js + 1);
+            for (int i = tid; i < npx; i += kFusedThreads) s_z[i] = 0x7F800000u;
+            __syncthreads();
+            UTICK(1);
+            ROFT_LDS uint32_t* const zw = pin_lds(s_z);
+            auto store = [zw, i0, js, win_w](int i, int j, float z) {
+                (void)__hip_atomic_fetch_min(zw + ((j - js) * win_w + (i - i0)), __float_as_uint(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            constexpr int kTB = 8;   // triangles per thread whose vertex indices are fetched together
+            for (int tb = tid; tb < nt; tb += kTB * kFusedThreads) {
+              int idx[kTB][3];
+#pragma unroll
+              for (int k = 0; k < kTB; ++k) {
+                  const int32_t* tri = prm.tris + (size_t)3 * min(tb + k * kFusedThreads, nt - 1);
+                  idx[k][0] = tri[0]; idx[k][1] = tri[1]; idx[k][2] = tri[2];
+              }
+#pragma unroll
+              for (int k = 0; k < kTB; ++k) {
+                if (tb + k * kFusedThreads >= nt) break;
+                const int v0 = idx[k][0], v1 = idx[k][1], v2 = idx[k][2];
+                float x0, y0, z0, x1, y1, z1, x2, y2, z2;
+                if (cached) {
+                    x0 = s_v[3 * v0]; y0 = s_v[3 * v0 + 1]; z0 = s_v[3 * v0 + 2];
+                    x1 = s_v[3 * v1]; y1 = s_v[3 * v1 + 1]; z1 = s_v[3 * v1 + 2];
+                    x2 = s_v[3 * v2]; y2 = s_v[3 * v2 + 1]; z2 = s_v[3 * v2 + 2];
+                } else {
+                    project_vertex(prm.verts + (size_t)3 * v0, P, fx, fy, cx, cy, x0, y0, z0);
+                    project_vertex(prm.verts + (size_t)3 * v1, P, fx, fy, cx, cy, x1, y1, z1);
+                    project_vertex(prm.verts + (size_t)3 * v2, P, fx, fy, cx, cy, x2, y2, z2);
+                }
+                raster_projected(x0, y0, z0, x1, y1, z1, x2, y2, z2, tw, th, js, je, store);
+              }
+            }
+            __syncthreads();
+            UTICK(2);
+            // likelihood samples of this strip (feature slots in ascending order per thread, as outlier_kernel adds them)
+            constexpr int kBatch = 16;
+            for (int f0 = tid; f0 < n; f0 += kBatch * kFusedThreads) {
+                float dep[kBatch];
+                uint32_t pix[kBatch];
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    const int i = f0 + k * kFusedThreads;
+                    dep[k] = (i < n) ? fdep[i] : 0.0f;
+                    pix[k] = (i < n) ? fpix[i] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < kBatch; ++k) {
+                    if (!((dep[k] > 0) && ((double)dep[k] < 2.0))) continue;  // hard-coded 2.0 (ROFTFilter.cpp:561)
+                    const int v = (int)(pix[k] / W), u = (int)(pix[k] - v * W);
+                    const int tj = v / d, ti = u / d;
+                    if (tj < js || tj > je || ti < i0 || ti > i1) continue;
+                    const uint32_t b = s_z[(tj - js) * win_w + (ti - i0)];
+                    if (b != 0x7F800000u) { err += (double)fabsf(dep[k] - __uint_as_float(b)); cnt += 1.0; }
+                }
+            }
+            __syncthreads();   // the next strip clears the window
+            UTICK(3);
+#ifdef ROFT_FUSED_PROFILE
+            if (tid == 0) st.dbg[blockIdx.x * 8 + 4] += 1;
+            if (tid == 0) st.dbg[blockIdx.x * 8 + 5] = (long long)win_w * 100 ;
+            if (tid == 0) st.dbg[blockIdx.x * 8 + 6] = (long long)(j1 - j0 + 1) * 100;
+#endif
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) { err += __shfl_down(err, off, 64); cnt += __shfl_down(cnt, off, 64); }
+    if ((tid & 63) == 0) { s_err[tid >> 6] = err; s_cnt[tid >> 6] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        double e = 0.0, n2 = 0.0;
+        for (int w = 0; w < kFusedThreads / 64; ++w) { e += s_err[w]; n2 += s_cnt[w]; }
+        pl.outlier_L[alt] = (n2 == 0.0) ? 1.7976931348623157e308 : (e / n2) / 1.0;   // gain is a bool -> 1.0 (ROFTFilter.h:64)
+        pl.outlier_cnt[alt] = n2;
+    }
+}
+
 void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t stop)
 {
-    // objects that do not test this frame return immediately
-    const size_t n = (size_t)a.n_obj * 2 * a.tile_w * a.tile_h;
-    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(a.zbuf + (size_t)lin * n), 0x7F800000, n, s);
-    hipLaunchKernelGGL(raster_engine_kernel, dim3((a.max_tris + 255) / 256, 2, a.n_obj), dim3(256), 0, s, a, lin);
-    hipExtLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(kOutlierThreads), 0, s, nullptr, stop, 0, a, lin);
+    // objects that do not test this frame return immediately; the decision (ROFTFilter.cpp:581-583) is taken by the
+    // pose chain segment that follows (ukf_chain_kernel)
+    const size_t lds_total = 160 * 1024 - 4096;
+    const size_t vbytes = ((size_t)a.max_verts * 12 + 15) & ~(size_t)15;
+    // cache the projected vertices when they leave room for a window of 8 k pixels (a window that large or larger is
+    // rendered in strips) and for the widest row of the target
+    const size_t min_win = (size_t)4 * std::max(8192, a.tile_w);
+#ifdef ROFT_EXP_NO_VCACHE
+    const bool cache = false;
+#else
+    const bool cache = vbytes + min_win <= lds_total;
+#endif
+    const int vcache_cap = cache ? a.max_verts : 0;
+    const int win_cap = (int)((lds_total - (cache ? vbytes : 0)) / 4);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(outlier_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
+        attr_set = true;
+    }
+    hipExtLaunchKernelGGL(outlier_fused_kernel, dim3(2, a.n_obj), dim3(kFusedThreads), (uint32_t)lds_total, s, nullptr, stop, 0, a, lin,
+                          vcache_cap, win_cap);
 }
 
 void launch_outlier_only(const EngineArrays& a, hipStream_t s)

@@ -1085,6 +1085,24 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
         if (threadIdx.x == 0) { pl.pending_frame = -1; pl.pc_frame = a.T; pl.pc_step = 0; }
         return;
     }
+    if (!first_segment && pl.pending_frame >= 0) {
+        // The outlier test between the segments (outlier_fused_kernel) left the likelihood of both alternatives:
+        // pick_best_alternative's decision (ROFTFilter.cpp:581-583) and the chosen belief -> p_corr_belief_ (:670-675)
+        const FrameCtrl& pc = frame_ctrl(a, pl.pending_frame, obj);
+        const double L0 = pl.outlier_L[0], L1 = pl.outlier_L[1];
+        const int sel = (L0 > 2.0 * L1) ? 1 : 0;
+        const PoseBelief& src = st.belief[b_alt(lin, sel)];
+        PoseBelief& dst = st.belief[pc.cur_slot];
+        for (int i = threadIdx.x; i < 144; i += kUkfThreads) dst.cov[i] = src.cov[i];
+        if (threadIdx.x < 13) dst.mean[threadIdx.x] = src.mean[threadIdx.x];
+        roft_object_output* row = log_row(a, pc, obj);
+        if (row && threadIdx.x < 13) row->pose[threadIdx.x] = src.mean[threadIdx.x];
+        if (threadIdx.x == 0) {
+            pl.outlier_selected = sel;
+            if (row) { row->outlier_selected = sel; row->outlier_L[0] = L0; row->outlier_L[1] = L1; }
+        }
+        __syncthreads();   // the next step of this workgroup reads the chosen belief
+    }
     jacobi12_table(L);
     for (int i = threadIdx.x; i < 100; i += kUkfThreads) L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0;   // see ukf_predict
     if (threadIdx.x < 10) L.wQ[threadIdx.x] = 0.0;

@@ -180,16 +180,28 @@ struct EngineArrays {
     double* norms;           // [n_obj][3 * cand_cap] SKF scratch (innovations + norms when N > LDS capacity)
     uint32_t* feat_pix;      // [n_obj][kFeatRing][feat_cap] buffered feature pixel (linear index)
     float* feat_depth;       // [n_obj][kFeatRing][feat_cap]
-    uint32_t* zbuf;          // [kNumLin][n_obj][2][tile_h*tile_w] float bits, +inf = empty
+    uint32_t* zbuf;          // [2][tile_h*tile_w] float bits, +inf = empty: z-buffers of the operator-level likelihood
     int cand_cap, feat_cap;
     size_t plane_words;      // wpr*H
     int tile_w, tile_h;
-    int max_tris;            // largest mesh among the objects
+    int max_tris, max_verts; // largest mesh among the objects
     double ukf_chol_guard;      // roft_config::ukf_cholesky_guard (0: always the eigen-decomposition)
     double ukf_chol_guard_bil;  // roft_config::ukf_cholesky_guard_bilinear
     roft_object_output* out_log;  // [log_cap][n_obj] per-frame outputs, or null
     int log_cap;
 };
+
+#define ROFT_LDS __attribute__((address_space(3)))
+
+// LDS address of an object in DYNAMIC LDS, pinned in a scalar register.  The base of `extern __shared__` memory is not
+// a link-time constant: left to itself the compiler re-reads it from a table in memory wherever it is used -- a scalar
+// load and an s_waitcnt in front of every LDS atomic of the scatter loops.
+__device__ __forceinline__ ROFT_LDS uint32_t* pin_lds(uint32_t* p)
+{
+    uint32_t off = (uint32_t)(uintptr_t)(ROFT_LDS uint32_t*)p;
+    asm volatile("" : "+s"(off));
+    return (ROFT_LDS uint32_t*)(uintptr_t)off;
+}
 
 // Control block -> LDS with one 16-byte load per thread (threads 0 .. sizeof(FrameCtrl)/16 - 1; the caller's barrier
 // follows): read field by field from global memory, the compiler sinks every load to its first use and the kernel pays

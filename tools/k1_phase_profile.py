@@ -17,7 +17,7 @@ from roft_amd import _lib as L, synth
 import run_baseline_configs as rb
 
 n_obj = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-n = 12
+n = 14 if os.environ.get("PHASES") == "fused" else 12
 dev = torch.device("cuda", 0)
 streams = [synth.make_stream(4000 + i, n, synth.Camera.shape_a(), device=dev) for i in range(n_obj)]
 eng = rb.make_engine(streams)
@@ -26,6 +26,8 @@ if os.environ.get("PHASES") == "feat":
     names = ["count", "scan+ranks", "expand", "gathers"]
 if os.environ.get("PHASES") == "mask":   # -DROFT_MASK_PROFILE: workgroup 0 of each object, mask_step_kernel
     names = ["ctrl + decide", "zero next + LDS plane", "group list", "walks", "flush"]
+if os.environ.get("PHASES") == "fused":   # -DROFT_FUSED_PROFILE: alternative 0 of each object, outlier_fused_kernel
+    names = ["vertices + box", "clear", "triangles", "features", "strips", "window w", "window h"]
 if os.environ.get("PHASES") == "skf":
     names = ["load", "innovations", "norms", "median", "mean abs dev", "max weight", "accumulate", "reduce", "solve"]
 for k in range(n):
@@ -38,7 +40,7 @@ for k in range(n):
     eng.submit_raw(eng.build_inputs(frames)[0])
     eng.step()
     eng.sync()
-    if k >= 8:
+    if k >= 8 and (os.environ.get("PHASES") != "fused" or k in (6, 12)):
         rows = []
         for o in range(n_obj):
             buf = (C.c_longlong * 32)()
