@@ -1,80 +1,416 @@
-// Compat.h -- minimal stand-ins for the bfl / Eigen types the reference's filter classes mention
-// (bfl::Gaussian, Eigen::MatrixXd / VectorXd), so that the facade classes in this directory can keep
-// the reference's class names and method signatures without Eigen or BayesFilters being installed.
-// A maintainer integrating into the real ROFT tree would drop this file and use the real types: the
-// facades only need `.data()`, `.rows()`, `.cols()` of row-major double storage.
+// Compat.h -- stand-ins for the third-party types the reference's filter classes are written against: Eigen (dense
+// matrices, Ref, Transform), BayesFilters (bfl::Data, VectorDescription, Gaussian, the model / prediction / correction
+// base classes, KFPrediction, UKFPrediction, FilteringAlgorithm), OpenCV (cv::Mat as an image buffer) and RobotsIO (camera
+// parameters, the Segmentation / Transform / SpatialVelocity source interfaces).  None of them is installed where this
+// repository is built; the facade classes of include/ROFT/ keep the reference's class names, constructor signatures and
+// virtuals over these types, and a maintainer integrating into the real ROFT tree drops this file (define
+// ROFT_HAVE_REAL_DEPENDENCIES and include the real headers first): the facades only use the members declared here.
+//
+// Only the surface the reference's headers mention is provided -- these are not general-purpose replacements.
+// Matrices are dense, ROW-major double / float storage.
 #pragma once
 
+#include <any>
+#include <cmath>
 #include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <utility>
 #include <vector>
 
-namespace ROFT {
-namespace compat {
+#include "../roft_engine.h"
 
-// dense row-major double matrix
-class MatrixXd {
+#ifndef ROFT_HAVE_REAL_DEPENDENCIES
+
+// ---- Eigen ---------------------------------------------------------------------------------------------------
+namespace Eigen {
+
+template <class S>
+class DenseMatrix {
 public:
-    MatrixXd() = default;
-    MatrixXd(std::size_t r, std::size_t c) : r_(r), c_(c), d_(r * c, 0.0) {}
-    static MatrixXd Zero(std::size_t r, std::size_t c) { return MatrixXd(r, c); }
-    static MatrixXd Identity(std::size_t n)
+    DenseMatrix() = default;
+    DenseMatrix(std::size_t r, std::size_t c) : r_(r), c_(c), d_(r * c, S(0)) {}
+    explicit DenseMatrix(std::size_t n) : r_(n), c_(1), d_(n, S(0)) {}
+    static DenseMatrix Zero(std::size_t r, std::size_t c = 1) { return DenseMatrix(r, c); }
+    static DenseMatrix Identity(std::size_t r, std::size_t c)
     {
-        MatrixXd m(n, n);
-        for (std::size_t i = 0; i < n; ++i) m(i, i) = 1.0;
+        DenseMatrix m(r, c);
+        for (std::size_t i = 0; i < r && i < c; ++i) m(i, i) = S(1);
         return m;
     }
-    void resize(std::size_t r, std::size_t c) { r_ = r; c_ = c; d_.assign(r * c, 0.0); }
+    void resize(std::size_t r, std::size_t c = 1) { r_ = r; c_ = c; d_.assign(r * c, S(0)); }
     std::size_t rows() const { return r_; }
     std::size_t cols() const { return c_; }
     std::size_t size() const { return d_.size(); }
-    double& operator()(std::size_t i, std::size_t j = 0) { return d_[i * c_ + j]; }
-    double operator()(std::size_t i, std::size_t j = 0) const { return d_[i * c_ + j]; }
-    double* data() { return d_.data(); }
-    const double* data() const { return d_.data(); }
+    S& operator()(std::size_t i, std::size_t j = 0) { return d_[i * c_ + j]; }
+    const S& operator()(std::size_t i, std::size_t j = 0) const { return d_[i * c_ + j]; }
+    S* data() { return d_.data(); }
+    const S* data() const { return d_.data(); }
+    // diag(v) of a vector, as `v.asDiagonal()` is used in the reference's constructors
+    DenseMatrix asDiagonal() const
+    {
+        DenseMatrix m(d_.size(), d_.size());
+        for (std::size_t i = 0; i < d_.size(); ++i) m(i, i) = d_[i];
+        return m;
+    }
 
 private:
     std::size_t r_ = 0, c_ = 0;
-    std::vector<double> d_;
+    std::vector<S> d_;
 };
-using VectorXd = MatrixXd;  // n x 1
+using MatrixXd = DenseMatrix<double>;
+using VectorXd = DenseMatrix<double>;   // n x 1
+using MatrixXf = DenseMatrix<float>;    // depth images: (v, u)
 
-// bfl::Gaussian(dim_linear, dim_circular, use_quaternion): mean size lin + 4 circ, covariance lin + 3 circ
-// (the sizes ROFTFilter relies on: Gaussian(9, 1, true) -> 13 / 12x12, Gaussian(6, 0, false) -> 6 / 6x6,
-// src/roft-lib/src/ROFTFilter.cpp:64-67)
+// `Eigen::Ref<const Eigen::MatrixXd>` in a signature accepts a matrix by reference
+template <class T>
+using Ref = T&;
+
+enum TransformTraits { Affine = 1 };
+// rigid transform as the pose sources deliver it: translation + unit quaternion (w, x, y, z)
+template <class S, int Dim, int Mode>
+class Transform {
+public:
+    Transform() { t_[0] = t_[1] = t_[2] = S(0); q_[0] = S(1); q_[1] = q_[2] = q_[3] = S(0); }
+    S* translation() { return t_; }
+    const S* translation() const { return t_; }
+    S* quaternion() { return q_; }
+    const S* quaternion() const { return q_; }
+
+private:
+    S t_[3], q_[4];
+};
+
+}  // namespace Eigen
+
+// ---- OpenCV ---------------------------------------------------------------------------------------------------
+#ifndef CV_8UC1
+#define CV_8UC1 0
+#define CV_16SC2 11
+#define CV_32FC2 13
+#endif
+
+namespace cv {
+
+struct Vec2f { float v[2]; float operator()(int i) const { return v[i]; } };
+struct Vec2s { short v[2]; short operator()(int i) const { return v[i]; } };
+
+// an image buffer: rows x cols elements of `type`, row-major, reference counted like cv::Mat
+class Mat {
+public:
+    Mat() = default;
+    Mat(int rows, int cols, int type) : rows(rows), cols(cols), type_(type), buf_(std::make_shared<std::vector<unsigned char>>((std::size_t)rows * cols * elem(type), 0)) { data = buf_->data(); }
+    // wraps caller memory (no ownership), like cv::Mat(rows, cols, type, void*)
+    Mat(int rows, int cols, int type, void* external) : rows(rows), cols(cols), data(static_cast<unsigned char*>(external)), type_(type) {}
+    int type() const { return type_; }
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    std::size_t total() const { return (std::size_t)rows * cols; }
+    std::size_t elemSize() const { return elem(type_); }
+    Mat clone() const
+    {
+        Mat m(rows, cols, type_);
+        if (!empty()) std::memcpy(m.data, data, total() * elemSize());
+        return m;
+    }
+    template <class T> T& at(int r, int c) { return reinterpret_cast<T*>(data)[(std::size_t)r * cols + c]; }
+    template <class T> const T& at(int r, int c) const { return reinterpret_cast<const T*>(data)[(std::size_t)r * cols + c]; }
+    int rows = 0, cols = 0;
+    unsigned char* data = nullptr;
+
+private:
+    static std::size_t elem(int type) { return type == CV_32FC2 ? 8 : (type == CV_16SC2 ? 4 : 1); }
+    int type_ = CV_8UC1;
+    std::shared_ptr<std::vector<unsigned char>> buf_;
+};
+
+}  // namespace cv
+
+// ---- RobotsIO ---------------------------------------------------------------------------------------------------
+namespace RobotsIO {
+namespace Camera {
+
+class CameraParameters {
+public:
+    std::size_t width() const { return width_; }
+    std::size_t height() const { return height_; }
+    double fx() const { return fx_; }
+    double fy() const { return fy_; }
+    double cx() const { return cx_; }
+    double cy() const { return cy_; }
+    void width(std::size_t v) { width_ = v; }
+    void height(std::size_t v) { height_ = v; }
+    void fx(double v) { fx_ = v; }
+    void fy(double v) { fy_ = v; }
+    void cx(double v) { cx_ = v; }
+    void cy(double v) { cy_ = v; }
+    bool initialized() const { return width_ > 0 && height_ > 0; }
+
+private:
+    std::size_t width_ = 0, height_ = 0;
+    double fx_ = 0, fy_ = 0, cx_ = 0, cy_ = 0;
+};
+
+// RGB-D source: what ROFT::CameraMeasurement polls (RobotsIO::Camera::Camera)
+class Camera {
+public:
+    virtual ~Camera() = default;
+    virtual bool status() const { return true; }
+    virtual bool step_frame() { return true; }
+    virtual bool reset() { return true; }
+    virtual std::pair<bool, CameraParameters> parameters() const = 0;
+    virtual std::pair<bool, Eigen::MatrixXf> depth(const bool& blocking) = 0;      // metres, (v, u)
+    virtual std::pair<bool, cv::Mat> rgb(const bool& /*blocking*/) { return {false, cv::Mat()}; }
+    virtual std::pair<bool, Eigen::Transform<double, 3, Eigen::Affine>> pose(const bool&) { return {true, {}}; }
+    virtual std::pair<bool, double> time_stamp_rgb() const { return {false, 0.0}; }
+    virtual std::pair<bool, double> time_stamp_depth() const { return {false, 0.0}; }
+    virtual std::int32_t frame_index() const { return -1; }
+};
+
+}  // namespace Camera
+
+namespace Utils {
+
+// key/value parameter bag with the accessor shape of RobotsIO's `robots_io_declare_*_field` macros: p.name() / p.name(v)
+class Parameters {
+public:
+    virtual ~Parameters() = default;
+};
+
+class Segmentation {
+public:
+    virtual ~Segmentation() = default;
+    virtual bool reset() { return true; }
+    virtual bool step_frame() { return true; }
+    virtual bool is_stepping_required() const = 0;
+    virtual void reset_data_loading_time() {}
+    virtual double get_data_loading_time() const { return 0.0; }
+    virtual int get_frames_between_iterations() const { return -1; }
+    // (valid, mask): valid == a NEW mask arrived with this frame
+    virtual std::pair<bool, cv::Mat> segmentation(const bool& blocking) = 0;
+    virtual std::pair<bool, cv::Mat> latest_segmentation() { return {false, cv::Mat()}; }
+    virtual std::pair<bool, double> get_time_stamp() { return {false, 0.0}; }
+    virtual void set_rgb_image(const cv::Mat& /*image*/, const double& /*timestamp*/) {}
+};
+
+class Transform {
+public:
+    virtual ~Transform() = default;
+    virtual Eigen::Transform<double, 3, Eigen::Affine> transform() = 0;
+    virtual bool freeze(const bool blocking = false) = 0;     // true: a new pose was received
+    virtual int get_frames_between_iterations() const { return -1; }
+    virtual bool transform_received() { return false; }
+};
+
+class SpatialVelocity {
+public:
+    virtual ~SpatialVelocity() = default;
+    virtual bool freeze(const bool blocking = false) = 0;
+    // twist expressed at the camera origin: v_O (3), omega (3)
+    virtual const double* linear_velocity_origin() = 0;
+    virtual const double* angular_velocity() = 0;
+    virtual bool is_screw_degenerate() { return false; }
+};
+
+class SpatialVelocityBuffer : public SpatialVelocity {
+public:
+    void set_twist(const double linear[3], const double angular[3], const double elapsed_time = 0.0)
+    {
+        (void)elapsed_time;
+        for (int i = 0; i < 3; ++i) { v_[i] = linear[i]; w_[i] = angular[i]; }
+    }
+    bool freeze(const bool = false) override { return true; }
+    const double* linear_velocity_origin() override { return v_; }
+    const double* angular_velocity() override { return w_; }
+
+private:
+    double v_[3] = {0, 0, 0}, w_[3] = {0, 0, 0};
+};
+
+}  // namespace Utils
+}  // namespace RobotsIO
+
+// ---- BayesFilters ---------------------------------------------------------------------------------------------------
+namespace bfl {
+
+namespace any {
+using std::any_cast;
+using any = std::any;
+}  // namespace any
+using Data = std::any;
+
+// sizes of a state / measurement / noise vector: `circular` components are unit quaternions (4 numbers, 3 degrees of
+// freedom), as ROFT uses them (VectorDescription(lin, circ, noise, CircularType::Quaternion))
+class VectorDescription {
+public:
+    enum class CircularType { Euler, Quaternion };
+    VectorDescription(std::size_t linear = 0, std::size_t circular = 0, std::size_t noise = 0,
+                      CircularType type = CircularType::Quaternion)
+        : lin_(linear), circ_(circular), noise_(noise), type_(type) {}
+    std::size_t linear_size() const { return lin_; }
+    std::size_t circular_size() const { return circ_; }
+    std::size_t noise_size() const { return noise_; }
+    std::size_t total_size() const { return lin_ + (type_ == CircularType::Quaternion ? 4 : 1) * circ_ + noise_; }
+    std::size_t dof_size() const { return lin_ + (type_ == CircularType::Quaternion ? 3 : 1) * circ_ + noise_; }
+
+private:
+    std::size_t lin_, circ_, noise_;
+    CircularType type_;
+};
+
+// Gaussian(dim_linear, dim_circular, use_quaternion): mean size lin + 4 circ, covariance lin + 3 circ -- the sizes
+// ROFTFilter relies on: Gaussian(9, 1, true) -> 13 / 12 x 12, Gaussian(6) -> 6 / 6 x 6 (ROFTFilter.cpp:64-67)
 class Gaussian {
 public:
     Gaussian() : Gaussian(1, 0, false) {}
-    Gaussian(std::size_t dim_linear, std::size_t dim_circular = 0, bool use_quaternion = false)
+    explicit Gaussian(std::size_t dim_linear, std::size_t dim_circular = 0, bool use_quaternion = false)
         : dim_linear(dim_linear), dim_circular(dim_circular), use_quaternion(use_quaternion),
           mean_(dim_linear + (use_quaternion ? 4 : 1) * dim_circular, 1),
           cov_(dim_linear + (use_quaternion ? 3 : 1) * dim_circular, dim_linear + (use_quaternion ? 3 : 1) * dim_circular)
     {}
-    VectorXd& mean() { return mean_; }
-    const VectorXd& mean() const { return mean_; }
+    Eigen::VectorXd& mean() { return mean_; }
+    const Eigen::VectorXd& mean() const { return mean_; }
     double& mean(std::size_t i) { return mean_(i); }
-    MatrixXd& covariance() { return cov_; }
-    const MatrixXd& covariance() const { return cov_; }
+    Eigen::MatrixXd& covariance() { return cov_; }
+    const Eigen::MatrixXd& covariance() const { return cov_; }
     std::size_t dim_linear, dim_circular;
     bool use_quaternion;
 
 private:
-    VectorXd mean_;
-    MatrixXd cov_;
+    Eigen::VectorXd mean_;
+    Eigen::MatrixXd cov_;
 };
 using GaussianMixture = Gaussian;  // the reference only ever uses one component (SKFCorrection.cpp:39)
 
+class MeasurementModel {
+public:
+    virtual ~MeasurementModel() = default;
+    virtual bool freeze(const Data& data = Data()) = 0;
+    virtual std::pair<bool, Data> measure(const Data& data = Data()) const = 0;
+    virtual std::pair<bool, Data> predictedMeasure(const Eigen::Ref<const Eigen::MatrixXd>& cur_states) const = 0;
+    virtual std::pair<bool, Data> innovation(const Data& predicted_measurements, const Data& measurements) const = 0;
+    virtual std::pair<bool, Eigen::MatrixXd> getNoiseCovarianceMatrix() const { return {false, Eigen::MatrixXd()}; }
+    virtual VectorDescription getInputDescription() const { return VectorDescription(); }
+    virtual VectorDescription getMeasurementDescription() const { return VectorDescription(); }
+    virtual bool setProperty(const std::string& /*property*/) { return false; }
+};
+
+class LinearMeasurementModel : public MeasurementModel {
+public:
+    virtual Eigen::MatrixXd getMeasurementMatrix() const = 0;
+};
+
+class StateModel {
+public:
+    virtual ~StateModel() = default;
+    virtual void propagate(const Eigen::Ref<const Eigen::MatrixXd>& cur_states, Eigen::Ref<Eigen::MatrixXd> mot_states) = 0;
+    virtual void motion(const Eigen::Ref<const Eigen::MatrixXd>& cur_states, Eigen::Ref<Eigen::MatrixXd> mot_states) = 0;
+    virtual Eigen::MatrixXd getNoiseCovarianceMatrix() = 0;
+    virtual bool setSamplingTime(const double& /*sample_time*/) { return false; }
+    virtual bool setProperty(const std::string& /*property*/) { return false; }
+    virtual VectorDescription getInputDescription() = 0;
+    virtual VectorDescription getStateDescription() = 0;
+};
+
+class LinearStateModel : public StateModel {
+public:
+    virtual Eigen::MatrixXd getStateTransitionMatrix() = 0;
+    void propagate(const Eigen::Ref<const Eigen::MatrixXd>& cur, Eigen::Ref<Eigen::MatrixXd> mot) override
+    {
+        const Eigen::MatrixXd F = getStateTransitionMatrix();
+        mot.resize(F.rows(), cur.cols());
+        for (std::size_t i = 0; i < F.rows(); ++i)
+            for (std::size_t c = 0; c < cur.cols(); ++c) {
+                double s = 0.0;
+                for (std::size_t k = 0; k < F.cols(); ++k) s += F(i, k) * cur(k, c);
+                mot(i, c) = s;
+            }
+    }
+    void motion(const Eigen::Ref<const Eigen::MatrixXd>& cur, Eigen::Ref<Eigen::MatrixXd> mot) override { propagate(cur, mot); }
+};
+
+class GaussianPrediction {
+public:
+    virtual ~GaussianPrediction() = default;
+    void predict(const GaussianMixture& prev_state, GaussianMixture& pred_state) { predictStep(prev_state, pred_state); }
+    virtual StateModel& getStateModel() = 0;
+
+protected:
+    virtual void predictStep(const GaussianMixture& prev_state, GaussianMixture& pred_state) = 0;
+};
+
+class GaussianCorrection {
+public:
+    virtual ~GaussianCorrection() = default;
+    void correct(const GaussianMixture& pred_state, GaussianMixture& corr_state) { correctStep(pred_state, corr_state); }
+    virtual MeasurementModel& getMeasurementModel() = 0;
+    virtual std::pair<bool, Eigen::VectorXd> getLikelihood() { return {false, Eigen::VectorXd()}; }
+
+protected:
+    virtual void correctStep(const GaussianMixture& pred_state, GaussianMixture& corr_state) = 0;
+};
+
+// the filter loop of bfl::FilteringAlgorithm, run on the calling thread: boot() arms it, run() executes
+// initialization_step() and then filtering_step() while run_condition() holds, wait() returns when it is over
+class FilteringAlgorithm {
+public:
+    virtual ~FilteringAlgorithm() = default;
+    bool boot() { booted_ = true; return true; }
+    void run()
+    {
+        if (!booted_) boot();
+        teardown_ = false;
+        if (!initialization_step()) return;
+        step_ = 0;
+        while (run_condition() && !teardown_) {
+            filtering_step();
+            ++step_;
+        }
+    }
+    bool wait() { return true; }
+    bool teardown() { teardown_ = true; return true; }
+    unsigned int step_number() const { return step_; }
+    virtual bool skip(const std::string& /*what_step*/, const bool /*status*/) { return false; }
+
+protected:
+    virtual bool initialization_step() = 0;
+    virtual void filtering_step() = 0;
+    virtual bool run_condition() = 0;
+
+private:
+    bool booted_ = false, teardown_ = false;
+    unsigned int step_ = 0;
+};
+
+}  // namespace bfl
+
+#endif  // ROFT_HAVE_REAL_DEPENDENCIES
+
+namespace ROFT {
+namespace compat {
+
 // thrown where the reference throws std::runtime_error; carries roft_last_error_string()
-inline void throw_if(int rc, const char* what);
-
-}  // namespace compat
-}  // namespace ROFT
-
-extern "C" const char* roft_last_error_string(void);
-
-inline void ROFT::compat::throw_if(int rc, const char* what)
+inline void throw_if(int rc, const char* what)
 {
     if (rc != 0) throw std::runtime_error(std::string(what) + ": " + roft_last_error_string());
 }
+
+// diagonal of a covariance given either as an n x n matrix or as an n-vector (the reference passes `v.asDiagonal()`)
+inline void diagonal_of(const Eigen::MatrixXd& m, double* out, std::size_t n)
+{
+    if (m.rows() == n && m.cols() == n) for (std::size_t i = 0; i < n; ++i) out[i] = m(i, i);
+    else if (m.size() == n) for (std::size_t i = 0; i < n; ++i) out[i] = m.data()[i];
+    else throw std::runtime_error("covariance of unexpected size");
+}
+
+// names kept from the first version of the facade
+using Gaussian = bfl::Gaussian;
+using MatrixXd = Eigen::MatrixXd;
+using VectorXd = Eigen::VectorXd;
+
+}  // namespace compat
+}  // namespace ROFT

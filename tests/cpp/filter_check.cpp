@@ -1,69 +1,72 @@
-// Drives the whole-filter facade ROFT::ROFTFilter (include/ROFT/Filters.h) the way ROFT-tracker drives
-// ROFT::ROFTFilter: one filtering_step() per frame with that frame's depth / flow / mask / pose, then the estimate.
-// Input: a small binary stream written by tests/test_facade.py; output: pose (13) + twist (6) per frame.
+// Drives ROFT::ROFTFilter (include/ROFT/ROFTFilter.h) the way ROFT-tracker drives the reference's class: construct it with
+// the reference's constructor signature (sources + parameter vectors, src/roft-lib/include/ROFT/ROFTFilter.h:42-73), boot(),
+// run().  Input: a recorded stream written by tests/test_facade.py; output: pose (13) + twist (6) per frame.
 #include <cstdio>
-#include <cstdint>
-#include <vector>
+#include <fstream>
 
-#include "ROFT/Filters.h"
+#include "mem_sources.h"
 
-template <class T>
-static bool rd(FILE* f, T* p, size_t n) { return std::fread(p, sizeof(T), n, f) == n; }
+// a filter that records its estimate after every step (the reference logs the same quantities, ROFTFilter.cpp:386-394)
+class RecordingFilter : public ROFT::ROFTFilter {
+public:
+    using ROFT::ROFTFilter::ROFTFilter;
+    std::vector<double> rows;
+
+protected:
+    void filtering_step() override
+    {
+        const long before = frames();
+        ROFT::ROFTFilter::filtering_step();
+        if (frames() == before) return;
+        for (int i = 0; i < 13; ++i) rows.push_back(pose_belief().mean()(i));
+        for (int i = 0; i < 6; ++i) rows.push_back(velocity_belief().mean()(i));
+    }
+};
 
 int main(int argc, char** argv)
 {
     if (argc < 3) return 2;
-    FILE* f = std::fopen(argv[1], "rb");
-    if (!f) return 2;
-    int32_t hdr[5];   // W, H, n_frames, n_verts, n_tris
-    double cam[4], init[13];
-    if (!rd(f, hdr, 5) || !rd(f, cam, 4) || !rd(f, init, 13)) return 2;
-    const int W = hdr[0], H = hdr[1], n = hdr[2], nv = hdr[3], nt = hdr[4];
-    std::vector<float> verts(3 * (size_t)nv);
-    std::vector<int32_t> tris(3 * (size_t)nt);
-    if (!rd(f, verts.data(), verts.size()) || !rd(f, tris.data(), tris.size())) return 2;
+    RecordedStream s;
+    if (!s.load(argv[1])) return 2;
     try {
-        roft_config cfg;
-        if (roft_default_config(&cfg, W, H, ROFT_FLOW_F32C2) != ROFT_OK) throw std::runtime_error(roft_last_error_string());
-        cfg.cam.fx = cam[0]; cfg.cam.fy = cam[1]; cfg.cam.cx = cam[2]; cfg.cam.cy = cam[3];
-        cfg.max_objects = 1;
-        ROFT::ROFTFilter filter(cfg);
-        roft_object_desc obj;
-        roft_default_object(&obj);
-        for (int i = 0; i < 13; ++i) obj.p_mean0[i] = init[i];
-        obj.mesh.verts = verts.data(); obj.mesh.n_verts = nv;
-        obj.mesh.tris = tris.data(); obj.mesh.n_tris = nt;
-        const int id = filter.add_object(obj);
-        FILE* o = std::fopen(argv[2], "wb");
-        std::vector<float> depth((size_t)W * H), flow(2 * (size_t)W * H);
-        std::vector<uint8_t> mask((size_t)W * H);
-        for (int k = 0; k < n; ++k) {
-            double dt, pose[7];
-            int32_t flags[3];   // has_flow, has_mask, has_pose
-            if (!rd(f, &dt, 1) || !rd(f, flags, 3) || !rd(f, depth.data(), depth.size())) return 2;
-            if (flags[0] && !rd(f, flow.data(), flow.size())) return 2;
-            if (flags[1] && !rd(f, mask.data(), mask.size())) return 2;
-            if (flags[2] && !rd(f, pose, 7)) return 2;
-            roft_frame_input in{};
-            in.dt = dt;
-            in.depth = depth.data();
-            in.flow = flags[0] ? flow.data() : nullptr;
-            in.mask = flags[1] ? mask.data() : nullptr;
-            in.pose_valid = flags[2];
-            for (int i = 0; i < 3; ++i) in.pose_x[i] = pose[i];
-            for (int i = 0; i < 4; ++i) in.pose_q[i] = pose[3 + i];
-            in.mem_kind = ROFT_MEM_HOST;
-            filter.filtering_step({in});
-            double p13[13], tw[6];
-            filter.state(id, p13, tw);
-            std::fwrite(p13, 8, 13, o);
-            std::fwrite(tw, 8, 6, o);
+        // the mesh goes through a Wavefront OBJ file, as the reference's ModelParameters name one
+        const std::string obj_path = std::string(argv[2]) + ".obj";
+        {
+            std::ofstream o(obj_path);
+            o.precision(9);
+            for (std::size_t i = 0; i < s.verts.size() / 3; ++i) o << "v " << s.verts[3 * i] << " " << s.verts[3 * i + 1] << " " << s.verts[3 * i + 2] << "\n";
+            for (std::size_t i = 0; i < s.tris.size() / 3; ++i)
+                o << "f " << s.tris[3 * i] + 1 << "//" << s.tris[3 * i] + 1 << " " << s.tris[3 * i + 1] + 1 << "//" << s.tris[3 * i + 1] + 1 << " "
+                  << s.tris[3 * i + 2] + 1 << "//" << s.tris[3 * i + 2] + 1 << "\n";
         }
+        ROFT::ModelParameters model;
+        model.name("object");
+        model.mesh_external_path(obj_path);
+        auto camera = std::make_shared<ROFT::CameraMeasurement>(std::make_shared<MemCamera>(s));
+        auto segmentation = std::make_shared<MemSegmentation>(s, 6);
+        auto flow = std::make_shared<MemFlow>(s);
+        auto pose = std::make_shared<MemPose>(s, 6);
+        // parameter vectors as src/roft/src/main.cpp:286-325 packs the keys of config_fast_ycb.cfg
+        Eigen::VectorXd p0(13), p_cov0(12), p_model(6), p_meas(12), v0(6), v_cov0(6), v_model(6), v_meas(2);
+        for (int i = 0; i < 13; ++i) p0(i) = s.init[i];
+        for (int i = 0; i < 12; ++i) p_cov0(i) = 1e-3;
+        for (int i = 0; i < 6; ++i) { p_model(i) = 1.0; v_cov0(i) = 1e-3; v_model(i) = 0.1; }
+        for (int i = 0; i < 3; ++i) { p_meas(i) = 0.1; p_meas(3 + i) = 1e-4; p_meas(6 + i) = 1e-3; p_meas(9 + i) = 1e-4; }
+        v_meas(0) = v_meas(1) = 1.0;
+        RecordingFilter filter(camera, segmentation, flow, pose, model, p0, p_cov0, p_model, p_meas, v0, v_cov0, v_model, v_meas,
+                               /* ut */ 1.0, 2.0, 0.0, /* sample_time */ s.frames[0].dt, /* pose_meas */ true, /* pose_resync */ true,
+                               /* outlier rejection, gain */ true, true, /* velocity_meas */ true, /* flow_weighting */ true,
+                               /* flow_aided_segmentation */ true, /* maximum_depth */ 2.0, /* subsampling_radius */ 35.0,
+                               /* enable_log */ false, "", "");
+        filter.boot();
+        filter.run();     // until the camera runs out of frames
+        filter.wait();
+        FILE* o = std::fopen(argv[2], "wb");
+        std::fwrite(filter.rows.data(), 8, filter.rows.size(), o);
         std::fclose(o);
     } catch (const std::runtime_error& e) {
         std::printf("runtime_error: %s\n", e.what());
         return 3;
     }
-    std::fclose(f);
     return 0;
 }

@@ -1,23 +1,27 @@
-"""C++ facade (include/ROFT/Filters.h): compiles against the C ABI, fails loudly without a device,
-and on the GPU returns what the operator-level ABI returns."""
+"""C++ facade (include/ROFT/): every class of the reference's filter API -- SpatialVelocityModel, CartesianQuaternionModel,
+ImageOpticalFlowMeasurement<T>, CartesianQuaternionMeasurement, SKFCorrection, UKFCorrection,
+ImageSegmentationOFAidedSource<T>, ROFTFilter with the constructor of ROFTFilter.h:42-73 -- compiles against the C ABI,
+fails loudly without a device, and on the GPU returns bit for bit what the operator-level ABI / the engine return."""
 import os
 import struct
 import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "roft_amd", "csrc")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def build_exe(tmp_path):
+def build(tmp_path, name):
     from roft_amd import _lib
     _lib.build()
-    exe = str(tmp_path / "facade_check")
-    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "facade_check.cpp"), "-o", exe, "-L", CSRC, "-lroft_hip",
-                           "-Wl,-rpath," + CSRC, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    exe = str(tmp_path / name)
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "tests", "cpp"), os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
+                           "-L", CSRC, "-lroft_hip", "-Wl,-rpath," + CSRC, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     return exe
 
 
@@ -34,62 +38,18 @@ def problem(tmp_path):
     pm[9] = 1.0
     pm[3:6] = [0.2, -0.1, 0.3]
     pP = np.eye(12) * 1e-3
+    # measurement of the pose filter: twist (v_O, w) and pose (x, q) near the state
+    qm = np.array([0.999, 0.02, -0.03, 0.01])
+    meas = np.concatenate([[0.01, -0.02, 0.03, 0.19, -0.12, 0.31], [0.004, 0.103, 0.702], qm / np.linalg.norm(qm)])
     path = str(tmp_path / "in.bin")
     with open(path, "wb") as f:
         f.write(struct.pack("i", n))
-        for a in (x, P, q, y, H, pm, pP):
+        for a in (x, P, q, y, H, pm, pP, meas):
             f.write(np.ascontiguousarray(a, np.float64).tobytes())
-    return path, (x, P, q, y, H, pm, pP)
-
-
-def test_facade_compiles_and_fails_loudly_without_device(tmp_path):
-    from roft_amd import _lib
-    exe = build_exe(tmp_path)
-    if _lib.lib().roft_device_count() > 0:
-        pytest.skip("a HIP device is present")
-    inp, _ = problem(tmp_path)
-    r = subprocess.run([exe, inp, str(tmp_path / "out.bin")], capture_output=True, text=True)
-    assert r.returncode == 3 and "runtime_error" in r.stdout
-
-
-@pytest.mark.gpu
-def test_facade_matches_operator_abi(tmp_path):
-    from roft_amd import ops
-    exe = build_exe(tmp_path)
-    inp, (x, P, q, y, H, pm, pP) = problem(tmp_path)
-    out = str(tmp_path / "out.bin")
-    subprocess.check_call([exe, inp, out])
-    raw = open(out, "rb").read()
-    got = np.frombuffer(raw[:8 * (6 + 36 + 13 + 144)], np.float64)
-    flow = np.frombuffer(raw[8 * (6 + 36 + 13 + 144):], np.float32).reshape(48, 64, 2)
-    xp, Pp = ops.kf_predict(x, P, q)
-    rc, xc, Pc = ops.skf_correct(xp, Pp, y, H, (1.0, 1.0), True)
-    Q = ops.process_noise([1.0] * 3, [1.0] * 3, 1.0 / 30.0)
-    m1, P1 = ops.ukf_predict(pm, pP, Q, 1.0 / 30.0)
-    assert np.array_equal(got[:6], xc) and np.array_equal(got[6:42].reshape(6, 6), Pc)
-    assert np.array_equal(got[42:55], m1) and np.array_equal(got[55:].reshape(12, 12), P1)
-    # optical-flow source facade == operator ABI on the same pattern, and it sees the (2, 1) shift
-    yy, xx = np.mgrid[0:48, 0:64]
-    g0 = (128 + (60.0 * np.sin(0.35 * xx) * np.cos(0.27 * yy)).astype(np.int64)).astype(np.uint8)
-    g1 = (128 + (60.0 * np.sin(0.35 * (xx - 2)) * np.cos(0.27 * (yy - 1))).astype(np.int64)).astype(np.uint8)
-    assert np.array_equal(flow, ops.optical_flow(g0, g1, levels=2, det_min=1.0))
-    inner = flow[12:36, 16:48]
-    assert abs(np.median(inner[..., 0]) - 2.0) < 0.3 and abs(np.median(inner[..., 1]) - 1.0) < 0.3
-
-
-def build_filter_exe(tmp_path):
-    from roft_amd import _lib
-    _lib.build()
-    exe = str(tmp_path / "filter_check")
-    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"),
-                           os.path.join(ROOT, "tests", "cpp", "filter_check.cpp"), "-o", exe, "-L", CSRC, "-lroft_hip",
-                           "-Wl,-rpath," + CSRC, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
-    return exe
+    return path, (x, P, q, y, H, pm, pP, meas)
 
 
 def dump_stream(path, st, n):
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
     import util
     from roft_amd import synth
     verts, tris = st.mesh
@@ -112,12 +72,119 @@ def dump_stream(path, st, n):
                 f.write(np.concatenate([pose[0], pose[1]]).astype(np.float64).tobytes())
 
 
-def test_whole_filter_facade_compiles_and_fails_loudly_without_device(tmp_path):
-    from roft_amd import _lib
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def test_facade_classes_compile_and_fail_loudly_without_device(tmp_path):
     import util
-    exe = build_filter_exe(tmp_path)
+    from roft_amd import _lib
+    exe = build(tmp_path, "facade_check")
+    if _lib.lib().roft_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    inp, _ = problem(tmp_path)
+    st = util.stream(33, 3, 4)
+    dump_stream(str(tmp_path / "s.bin"), st, 3)
+    r = subprocess.run([exe, inp, str(tmp_path / "out.bin"), str(tmp_path / "s.bin")], capture_output=True, text=True)
+    assert r.returncode == 3 and "runtime_error" in r.stdout
+
+
+def test_facade_headers_name_every_reference_class():
+    """One header per reference header: the class names, the constructor arity and the virtuals a maintainer's
+    code would use are there."""
+    inc = os.path.join(ROOT, "include", "ROFT")
+    want = {
+        "SKFCorrection.h": ["class SKFCorrection : public bfl::GaussianCorrection", "std::unique_ptr<bfl::LinearMeasurementModel> measurement_model",
+                            "void correctStep(const bfl::GaussianMixture& pred_state, bfl::GaussianMixture& corr_state) override"],
+        "UKFCorrection.h": ["class UKFCorrection : public bfl::GaussianCorrection", "std::unique_ptr<bfl::MeasurementModel> meas_model",
+                            "void correctStep(const bfl::GaussianMixture& pred_state, bfl::GaussianMixture& corr_state) override"],
+        "ImageOpticalFlowMeasurement.hpp": ["class ImageOpticalFlowMeasurement : public bfl::LinearMeasurementModel", "bool freeze(const bfl::Data& data",
+                                            "predictedMeasure(", "innovation(", "getMeasurementMatrix() const override",
+                                            "getNoiseCovarianceMatrix() const override", "getMeasurementDescription() const override",
+                                            "bool setProperty(const std::string& property) override"],
+        "CartesianQuaternionMeasurement.h": ["class CartesianQuaternionMeasurement : public bfl::MeasurementModel",
+                                             "enum class MeasurementMode { Standard, RepeatOnlyVelocity, PopBufferedMeasurement }"],
+        "CartesianQuaternionModel.h": ["class CartesianQuaternionModel : public bfl::StateModel", "bool setSamplingTime(const double& sample_time) override"],
+        "SpatialVelocityModel.h": ["class SpatialVelocityModel : public bfl::LinearStateModel", "getStateTransitionMatrix() override"],
+        "ImageSegmentationOFAidedSource.hpp": ["class ImageSegmentationOFAidedSource : public RobotsIO::Utils::Segmentation", "bool step_frame() override"],
+        "ROFTFilter.h": ["class ROFTFilter : public bfl::FilteringAlgorithm", "const ModelParameters& model_parameters",
+                         "const bool pose_outlier_rejection_gain", "void filtering_step() override"],
+    }
+    for name, needles in want.items():
+        text = " ".join(open(os.path.join(inc, name)).read().split())
+        for needle in needles:
+            assert needle in text, (name, needle)
+
+
+@pytest.mark.gpu
+def test_facade_classes_match_operator_abi(tmp_path):
+    import util
+    from roft_amd import _lib as L
+    from roft_amd import ops
+    exe = build(tmp_path, "facade_check")
+    inp, (x, P, q, y, H, pm, pP, meas) = problem(tmp_path)
+    n_frames = 8
+    st = util.stream(35, n_frames, 2)
+    dump_stream(str(tmp_path / "s.bin"), st, n_frames)
+    out = str(tmp_path / "out.bin")
+    subprocess.check_call([exe, inp, out, str(tmp_path / "s.bin")])
+    raw = open(out, "rb").read()
+    pos = [0]
+
+    def take(count, dtype=np.float64):
+        a = np.frombuffer(raw, dtype, count, pos[0])
+        pos[0] += a.nbytes
+        return a
+
+    # velocity filter
+    xp, Pp = ops.kf_predict(x, P, q)
+    _, xc, Pc = ops.skf_correct(xp, Pp, y, H, (1.0, 1.0), True)
+    assert np.array_equal(take(6), xc) and np.array_equal(take(36).reshape(6, 6), Pc)
+    # pose filter
+    Q = ops.process_noise([1.0] * 3, [1.0] * 3, 1.0 / 30.0)
+    m1, P1 = ops.ukf_predict(pm, pP, Q, 1.0 / 30.0)
+    assert np.array_equal(take(13), m1) and np.array_equal(take(144).reshape(12, 12), P1)
+    r_vel, r_pose = [0.1] * 3 + [1e-4] * 3, [1e-3] * 3 + [1e-4] * 3
+    _, m2, P2 = ops.ukf_correct(m1, P1, L.MEAS_POSE_VELOCITY, meas, r_vel + r_pose)
+    assert np.array_equal(take(13), m2) and np.array_equal(take(144).reshape(12, 12), P2)
+    _, m3, P3 = ops.ukf_correct(m1, P1, L.MEAS_VELOCITY, meas[:6], r_vel)
+    assert np.array_equal(take(13), m3) and np.array_equal(take(144).reshape(12, 12), P3)
+    # host-side h(x) / innovation of the measurement model at the mean column: velocity v + w x (-x), pose difference
+    innov = take(12)
+    v, w, xx = m1[0:3], m1[3:6], m1[6:9]
+    want = np.concatenate([meas[0:3] - (v + np.cross(w, -xx)), meas[3:6] - w, meas[6:9] - xx])
+    assert np.abs(innov[:9] - want).max() < 1e-15
+    from roft_amd import synth
+    dq = synth.quat_mul(meas[9:13], m1[9:13] * np.array([1.0, -1.0, -1.0, -1.0]))
+    rot = 2.0 * np.arctan2(np.linalg.norm(dq[1:]), abs(dq[0])) * dq[1:] / np.linalg.norm(dq[1:]) * np.sign(dq[0])
+    assert np.abs(innov[9:] - rot).max() < 1e-14
+    # flow measurement model: frame 1 against mask and depth of frame 0
+    depth0, _, mask0, _ = util.frame_inputs(st, 0)
+    _, flow1, _, _ = util.frame_inputs(st, 1)
+    c = st.camera
+    n_ref, uv, yy, HH = ops.flow_measurement(L.Camera(c.width, c.height, c.fx, c.fy, c.cx, c.cy),
+                                             np.where(mask0 > 1, 255, 0).astype(np.uint8), depth0, flow1, st.dt)
+    n = int(take(1)[0])
+    assert n == n_ref and n >= 3
+    assert np.array_equal(take(2 * n), yy.ravel()) and np.array_equal(take(12 * n).reshape(2 * n, 6), HH)
+    # flow-aided segmentation source: frames 0 .. 7 with the new mask of frame 6
+    m = None
+    for k in range(n_frames):
+        _, flow, mask, _ = util.frame_inputs(st, k)
+        if k == 0:
+            m = mask.copy()
+        elif mask is not None:
+            m = ops.mask_propagate(mask, [util.frame_inputs(st, j)[1] for j in range(1, k + 1)], 6)
+        else:
+            m = m.copy()
+            m[0, 0] = 0
+            m = ops.mask_propagate(m, [flow], 6)
+    assert st.mask_delivery[6] >= 0
+    got = take(st.camera.width * st.camera.height, np.uint8).reshape(st.camera.height, st.camera.width)
+    assert np.array_equal(got, m)
+    assert pos[0] == len(raw)
+
+
+def test_whole_filter_facade_compiles_and_fails_loudly_without_device(tmp_path):
+    import util
+    from roft_amd import _lib
+    exe = build(tmp_path, "filter_check")
     if _lib.lib().roft_device_count() > 0:
         pytest.skip("a HIP device is present")
     st = util.stream(33, 3, 4)
@@ -128,17 +195,15 @@ def test_whole_filter_facade_compiles_and_fails_loudly_without_device(tmp_path):
 
 @pytest.mark.gpu
 def test_whole_filter_facade_equals_the_python_engine(tmp_path):
-    """ROFT::ROFTFilter (C++ facade) fed frame by frame == roft_amd.engine.ROFTFilterBatch on the same stream, and both
-    == the oracle."""
-    import sys
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    """ROFT::ROFTFilter (C++ facade, constructor of ROFTFilter.h:42-73 over in-memory sources, boot() / run()) ==
+    roft_amd.engine.ROFTFilterBatch on the same stream, and both == the oracle."""
     import util
     from oracle import binding as ob
     from test_engine_gpu import make_engine
     n = 20
     st = util.stream(34, n, 2)
     dump_stream(str(tmp_path / "s.bin"), st, n)
-    exe = build_filter_exe(tmp_path)
+    exe = build(tmp_path, "filter_check")
     subprocess.check_call([exe, str(tmp_path / "s.bin"), str(tmp_path / "o.bin")])
     got = np.fromfile(str(tmp_path / "o.bin"), np.float64).reshape(n, 19)
     eng = make_engine([st])
