@@ -57,6 +57,24 @@ def test_sequence_on_disk_with_stream_flow_equals_in_memory_engine(tmp_path, cap
     # (the poses file stores axis-angle and the logs 12 significant digits: equal up to that rounding)
     assert np.abs(est[:, 6:9] - pose_log[:, 0, 6:9]).max() < 1e-9
     assert np.abs(vel - twist_log[:, 0]).max() < 1e-9
+    # the same run configured the way test/test.sh configures ROFT-tracker: a configuration file in the reference's
+    # format plus `--group::key value` overrides for the initial condition and one filter switch
+    from roft_amd import config as K
+    c = st.camera
+    cfg_path = str(tmp_path / "config.cfg")
+    open(cfg_path, "w").write(K.default_text(c.width, c.height, 1.0, 1.0, 0.0, 0.0))   # (camera: cam_K.json of the sequence wins)
+    axis, angle = io.quat_to_axis_angle(m0[9:13])
+    common = ["--root", root, "--object", "box", "--mesh", mesh, "--flow-set", "analytic", "--mask-set", "gt", "--from", cfg_path,
+              "--initial_condition::pose::x", ", ".join("%.17g" % v for v in m0[6:9]),
+              "--initial_condition::pose::axis_angle", ", ".join("%.17g" % v for v in list(axis) + [angle])]
+    assert rs.main(common + ["--out", str(tmp_path / "b_")]) == 0
+    capsys.readouterr()
+    est_b = np.loadtxt(str(tmp_path / "b_pose_estimate"))
+    assert np.abs(est_b - est).max() < 1e-9          # (the axis-angle round trip of the initial orientation)
+    assert rs.main(common + ["--out", str(tmp_path / "c_"), "--measurement_model::use_pose_resync", "false"]) == 0
+    capsys.readouterr()
+    est_c = np.loadtxt(str(tmp_path / "c_pose_estimate"))
+    assert np.abs(est_c - est).max() > 1e-6          # the switch reached the filter
 
 
 def test_sequence_on_disk_with_produced_flow(tmp_path, capsys):

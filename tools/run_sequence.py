@@ -4,6 +4,11 @@ files (`pose_estimate`, `velocity_estimate`, ROFTFilter.cpp:386-394) -- what `te
 
   run_sequence.py --root DIR --object NAME --mesh model.obj [--flow-set nvof_1_slow] [--mask-set NAME]
                   [--pose-set dope] [--out PREFIX] [--compute-flow nvof1|nvof2] [--no-delay] [--init-pose x y z qw qx qy qz]
+                  [--from config_fast_ycb.cfg [--group::key value ...]]
+
+--from reads the filter parameters from one of the reference's configuration files (config/config_fast_ycb.cfg,
+config/config_ho3d.cfg) and applies `--a::b::c value` overrides exactly as ROFT-tracker's ConfigParser does
+(roft_amd/config.py); without it the defaults of those files are used (roft_default_config / roft_default_object).
 
 The camera comes from DIR/cam_K.json (width, height, fx, fy, cx, cy).  --compute-flow first runs tools/flow_dumper.py
 on DIR/rgb (the MI355X replacement of the NVOF dumper) into DIR/optical_flow/<flow-set>.  With DIR/gt/poses.txt present
@@ -34,7 +39,8 @@ def main(argv=None):
     ap.add_argument("--no-delay", action="store_true")
     ap.add_argument("--init-pose", type=float, nargs=7, default=None, metavar=("X", "Y", "Z", "QW", "QX", "QY", "QZ"),
                     help="initial_condition.pose (default: the first valid detection)")
-    args = ap.parse_args(argv)
+    ap.add_argument("--from", dest="cfg_file", default=None, help="ROFT configuration file (libconfig), overrides as --a::b::c value")
+    args, overrides = ap.parse_known_args(argv)
 
     from roft_amd import _lib as L
     from roft_amd import engine as E
@@ -60,17 +66,36 @@ def main(argv=None):
         sys.stderr.write("no optical flow frames in %s\n" % seq.flow_dir)
         return 1
     ftype, grid, scale = io.flow_format(first, W)
-    cfg = E.default_config(W, H, ftype, max_objects=1)
-    cfg.cam.fx, cfg.cam.fy, cfg.cam.cx, cfg.cam.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
-    cfg.flow_grid, cfg.flow_scale = grid, scale
+    init_from_cfg = False
+    if args.cfg_file:
+        from roft_amd import config as K
+        # the sequence's own camera (cam_K.json) unless the command line says otherwise, as test/test.sh passes it
+        cam_over = []
+        for k in ("width", "height", "fx", "fy", "cx", "cy"):
+            if "--camera_dataset::" + k not in overrides:
+                cam_over += ["--camera_dataset::" + k, str(cam[k])]
+        init_from_cfg = any(o.startswith("--initial_condition::pose::") for o in overrides)
+        cfg, d, _extras, rest = K.load(args.cfg_file, cam_over + overrides, flow_type=ftype, flow_grid=grid, flow_scale=scale)
+        if rest:
+            ap.error("unknown arguments: %s" % " ".join(rest))
+        if (cfg.cam.width, cfg.cam.height) != (W, H):
+            ap.error("camera_dataset::width / height do not match the sequence")
+    else:
+        if overrides:
+            ap.error("unknown arguments: %s (settings need --from FILE)" % " ".join(overrides))
+        cfg = E.default_config(W, H, ftype, max_objects=1)
+        cfg.cam.fx, cfg.cam.fy, cfg.cam.cx, cfg.cam.cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+        cfg.flow_grid, cfg.flow_scale = grid, scale
+        d = E.default_object()
     eng = E.ROFTFilterBatch(cfg)
     verts, tris = io.load_obj(args.mesh)
-    d = E.default_object()
-    # initial condition: the first valid detection (ROFT-tracker takes it from the config file)
-    k0 = int(np.argmax(seq.pose_ok)) if seq.pose_ok.any() else 0
-    init = args.init_pose if args.init_pose is not None else list(seq.poses[k0])
-    for i in range(7):
-        d.p_mean0[6 + i] = init[i]
+    # initial condition: the configuration's when it was given on the command line (test/test.sh:120-123 passes the first
+    # detection that way), else the first valid detection of the sequence
+    if not init_from_cfg:
+        k0 = int(np.argmax(seq.pose_ok)) if seq.pose_ok.any() else 0
+        init = args.init_pose if args.init_pose is not None else list(seq.poses[k0])
+        for i in range(7):
+            d.p_mean0[6 + i] = init[i]
     eng.add_object(d, verts, tris)
     n = len(seq)
     eng.enable_log(n)
