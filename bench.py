@@ -135,7 +135,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=60)
     p.add_argument("--warmup", type=int, default=12)
-    p.add_argument("--batch", type=int, default=6, help="frames per roft_frames_submit (1..8)")
+    p.add_argument("--batch", type=int, default=8, help="frames per roft_frames_submit (1..8)")
     p.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                    help="strong: --objects in total, block-sharded over the GPUs (BASELINE config #4); weak: --objects per GPU")
     p.add_argument("--objects", "--objects-per-gpu", dest="objects", type=int, default=64)
@@ -146,7 +146,7 @@ def parse():
     p.add_argument("--host-inputs", action="store_true",
                    help="hand the engine HOST buffers in the main run (PCIe-inclusive rate; never the headline value)")
     p.add_argument("--pcie-frames", type=int, default=12, help="timed frames of the two PCIe-inclusive legs (0: skip them)")
-    p.add_argument("--no-ramp", action="store_true", help="equal batches from the first timed frame on (no short first batches)")
+    p.add_argument("--no-ramp", action="store_true", help="full batches from the first timed frame on, the short one last")
     p.add_argument("--splits", default="", help="explicit batch sizes of the timed frames, e.g. 2,6,6,6 (must sum to --steps)")
     p.add_argument("--no-kernel-timing", action="store_true",
                    help="do not record HIP events in the timed region and skip the per-kernel breakdown")
@@ -154,17 +154,20 @@ def parse():
 
 
 def split_batches(first, last, T, ramp=False):
-    """[first, last) in consecutive batches of at most T frames.  ramp: the pipeline is empty at `first` -- short
-    batches first (1, 2, 4, ...), so that the pose chain of the first batch starts after one frame's image chains
-    instead of a whole batch's."""
+    """[first, last) in consecutive batches of at most T frames.  ramp: the pipeline is empty at `first` -- the batch
+    that is not full ((last - first) mod T frames) goes first, so that the velocity and pose chains start after a short
+    batch's image chains instead of a whole batch's; measured against 1, 2, 4, ... ramps, which cost more in launches
+    than they save in latency."""
     out = []
     k = first
-    t_next = 1 if ramp else T
+    r = (last - first) % T
+    if ramp and r:
+        out.append((k, r))
+        k += r
     while k < last:
-        t = min(t_next, T, last - k)
+        t = min(T, last - k)
         out.append((k, t))
         k += t
-        t_next = min(T, t_next * 2)
     return out
 
 

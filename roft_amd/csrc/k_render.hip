@@ -313,21 +313,24 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
 // pass, no global atomics, one launch instead of three.  A window that does not fit the LDS next to the vertices is
 // rendered in horizontal strips (every strip walks all triangles and all features); a mesh whose vertices do not fit is
 // projected per triangle.  Same per-pixel arithmetic as raster_triangle: the depths are bit-identical.
-// grid: (2 alternatives, n_obj).  dynamic LDS: [3 * vcache_cap floats] | [win_cap z values]
+// With few objects an alternative is shared by `parts` workgroups: each takes a horizontal band of the window (walks all
+// triangles, draws the rows of its band, sums the features that fall into it) and leaves its partial sums; the pose
+// chain segment that follows adds them up in band order and decides.
+// grid: (2 alternatives x parts, n_obj).  dynamic LDS: [3 * vcache_cap floats] | [win_cap z values]
 constexpr int kFusedThreads = 1024;
 // phase stamps (-DROFT_FUSED_PROFILE; PHASES=fused tools/k1_phase_profile.py): 100 MHz ticks -> ObjState::dbg[alt * 8 + phase]
 #ifdef ROFT_FUSED_PROFILE
-#define UTICK(i) do { __syncthreads(); if (threadIdx.x == 0) { long long _t = wall_clock64(); st.dbg[blockIdx.x * 8 + (i)] += _t - u_t0; u_t0 = _t; } } while (0)
+#define UTICK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4) { long long _t = wall_clock64(); st.dbg[blockIdx.x * 8 + (i)] += _t - u_t0; u_t0 = _t; } } while (0)
 #else
 #define UTICK(i) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArrays a, int lin, int vcache_cap, int win_cap)
+__global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArrays a, int lin, int vcache_cap, int win_cap, int parts)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double s_err[kFusedThreads / 64], s_cnt[kFusedThreads / 64];
     __shared__ int s_box[4];
-    const int obj = blockIdx.y, alt = blockIdx.x, tid = threadIdx.x;
+    const int obj = blockIdx.y, alt = blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
     ObjState& st = a.state[obj];
     PoseLane& pl = st.lane[lin];
     if (pl.pending_frame < 0) return;   // no outlier test pending between the pose chain segments
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     if (tid < 4) s_box[tid] = (tid < 2) ? INT32_MAX : -1;
 #ifdef ROFT_FUSED_PROFILE
     long long u_t0 = wall_clock64();
-    if (tid < 8) st.dbg[blockIdx.x * 8 + tid] = 0;
+    if (tid < 8 && blockIdx.x < 4) st.dbg[blockIdx.x * 8 + tid] = 0;
 #endif
     __syncthreads();
     // vertices -> screen; pixel bounding box of the triangles that can be drawn (pixel ranges as raster_projected clips
@@ -389,7 +392,14 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     // (a triangle's pixels lie between the smallest lower bound and the largest upper bound of its vertices; vertices
     //  left or above the target contribute lower bound 0, vertices right or below it the upper bound w - 1 / h - 1)
     UTICK(0);
-    const int i0 = min(s_box[0], tw - 1), j0 = min(s_box[1], th - 1), i1 = s_box[2], j1 = s_box[3];
+    const int i0 = min(s_box[0], tw - 1), i1 = s_box[2];
+    // this workgroup's band of the window's rows
+    int j0 = min(s_box[1], th - 1), j1 = s_box[3];
+    if (j1 >= j0 && parts > 1) {
+        const int rows_all = j1 - j0 + 1, b0 = j0 + (int)((long long)rows_all * part / parts), b1 = j0 + (int)((long long)rows_all * (part + 1) / parts) - 1;
+        j0 = b0;
+        j1 = b1;
+    }
     const int win_w = i1 - i0 + 1;
     const int fslot = (c.feat_read >= 0) ? c.feat_read : 0;
     const uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
@@ -458,9 +468,9 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
             __syncthreads();   // the next strip clears the window
             UTICK(3);
 #ifdef ROFT_FUSED_PROFILE
-            if (tid == 0) st.dbg[blockIdx.x * 8 + 4] += 1;
-            if (tid == 0) st.dbg[blockIdx.x * 8 + 5] = (long long)win_w * 100 ;
-            if (tid == 0) st.dbg[blockIdx.x * 8 + 6] = (long long)(j1 - j0 + 1) * 100;
+            if (tid == 0 && blockIdx.x < 4) st.dbg[blockIdx.x * 8 + 4] += 1;
+            if (tid == 0 && blockIdx.x < 4) st.dbg[blockIdx.x * 8 + 5] = (long long)win_w * 100 ;
+            if (tid == 0 && blockIdx.x < 4) st.dbg[blockIdx.x * 8 + 6] = (long long)(j1 - j0 + 1) * 100;
 #endif
         }
     }
@@ -470,8 +480,9 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     if (tid == 0) {
         double e = 0.0, n2 = 0.0;
         for (int w = 0; w < kFusedThreads / 64; ++w) { e += s_err[w]; n2 += s_cnt[w]; }
-        pl.outlier_L[alt] = (n2 == 0.0) ? 1.7976931348623157e308 : (e / n2) / 1.0;   // gain is a bool -> 1.0 (ROFTFilter.h:64)
-        pl.outlier_cnt[alt] = n2;
+        pl.part_err[alt][part] = e;
+        pl.part_cnt[alt][part] = n2;
+        if (alt == 0 && part == 0) pl.n_parts = parts;
     }
 }
 
@@ -496,8 +507,14 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(outlier_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
         attr_set = true;
     }
-    hipExtLaunchKernelGGL(outlier_fused_kernel, dim3(2, a.n_obj), dim3(kFusedThreads), (uint32_t)lds_total, s, nullptr, stop, 0, a, lin,
-                          vcache_cap, win_cap);
+    // bands per alternative: as many workgroups as the chip has CUs to spare
+    const int parts = std::max(1, std::min(kMaxOutlierParts, 256 / (2 * std::max(a.n_obj, 1))));
+    // (a band is a fraction of the window: request only the LDS it can need, so that other chains' workgroups fit next to it)
+    const size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + parts - 1) / parts + (size_t)a.tile_w);
+    const size_t lds = std::min(lds_total, (((cache ? vbytes : 0) + win_need + 15) & ~(size_t)15));
+    const int win_cap_lds = (int)((lds - (cache ? vbytes : 0)) / 4);
+    hipExtLaunchKernelGGL(outlier_fused_kernel, dim3(2 * parts, a.n_obj), dim3(kFusedThreads), (uint32_t)lds, s, nullptr, stop, 0, a, lin,
+                          vcache_cap, std::min(win_cap, win_cap_lds), parts);
 }
 
 void launch_outlier_only(const EngineArrays& a, hipStream_t s)

@@ -50,10 +50,12 @@ struct RecAccessor {
     double dt;
     // H rows with reciprocal multiplies instead of the ten IEEE divisions of the literal expression
     // (hpp:279-280): agrees with h_rows() to an ulp or two; the bit-exact assembly is expand_yh_kernel.
+    double ifx, ify;   // 1 / fx, 1 / fy: two of the three divisions per point are the same for every point
+    __device__ RecAccessor(const FlowRec* recs_, DevCamera cam_, double dt_) : recs(recs_), cam(cam_), dt(dt_), ifx(1.0 / cam_.fx), ify(1.0 / cam_.fy) {}
     __device__ __forceinline__ void get(int j, double h[12], double y[2]) const
     {
         const FlowRec r = recs[j];
-        const double iz = 1.0 / (double)r.z, ifx = 1.0 / cam.fx, ify = 1.0 / cam.fy;
+        const double iz = 1.0 / (double)r.z;
         const double uu = (r.u - cam.cx), vv = (r.v - cam.cy);
         h[0] = (cam.fx * iz) * dt;
         h[1] = 0.0;
@@ -95,7 +97,14 @@ __device__ __forceinline__ double innov_at(const Acc& acc, int k, const double* 
     return -(pred - y[k & 1]);
 }
 
-constexpr int kSkfThreads = 256;
+// One workgroup of eight waves per object.  A frame has 700 - 3 000 flow points (640x480 - 1280x720): more waves
+// shorten the passes over the points (a handful of dependent operations per point and thread) but lengthen every
+// reduction and barrier between them.  Measured per frame, chains overlapping: 256 threads 23 / 68 us
+// (640x480 / 1280x720), 512 threads 22 / 49 us, 1024 threads 32 / 52 us.
+#ifndef ROFT_SKF_THREADS
+#define ROFT_SKF_THREADS 512
+#endif
+constexpr int kSkfThreads = ROFT_SKF_THREADS;
 
 // phase stamps (build with -DROFT_SKF_PROFILE): SKFTICK(i) stores the 100 MHz wall clock ticks since the previous stamp
 #ifdef ROFT_SKF_PROFILE
@@ -230,10 +239,11 @@ __device__ bool spd_inverse6_wave(double* M)
     return ok;
 }
 
-constexpr int kSkfLdsN = 1024;  // measurement counts up to this keep innovations + norms in LDS
+constexpr int kSkfLdsN = 4096;  // measurement counts up to this keep innovations + norms in LDS (96 KB)
 constexpr int kBins = 1024;
 constexpr int kBucketCap = 256;
-static_assert(kBins == 4 * 256, "bucket_select2 scans 4 bins per thread of a 256-thread block");
+constexpr int kBinsPerThread = kBins / kSkfThreads;
+static_assert(kBins % kSkfThreads == 0 && kBinsPerThread >= 1, "bucket_select2 scans kBins / kSkfThreads bins per thread");
 
 struct SkfShared {
     double red[kSkfThreads / 64], red2[kSkfThreads / 64];
@@ -279,16 +289,20 @@ __device__ bool bucket_select2(const double* vals, int N, int ra, int rb, SkfSha
         atomicAdd(&S.hist[b], 1);
     }
     __syncthreads();
-    {   // exclusive prefix over the bins, 4 bins per thread
+    {   // exclusive prefix over the bins, kBinsPerThread bins per thread
         const int t = threadIdx.x;
-        const int h0 = S.hist[4 * t], h1 = S.hist[4 * t + 1], h2 = S.hist[4 * t + 2], h3 = S.hist[4 * t + 3];
+        int h[kBinsPerThread], sum = 0;
+#pragma unroll
+        for (int i = 0; i < kBinsPerThread; ++i) { h[i] = S.hist[kBinsPerThread * t + i]; sum += h[i]; }
         int total;
-        const int ex = block_exclusive_scan(h0 + h1 + h2 + h3, S.wave, &total);
-        const int pre[5] = {ex, ex + h0, ex + h0 + h1, ex + h0 + h1 + h2, ex + h0 + h1 + h2 + h3};
-        for (int q = 0; q < 2; ++q) {
-            const int r = q ? rb : ra;
-            for (int i = 0; i < 4; ++i)
-                if (r >= pre[i] && r < pre[i + 1]) { S.bin[q] = 4 * t + i; S.base[q] = pre[i]; }
+        int pre = block_exclusive_scan(sum, S.wave, &total);
+#pragma unroll
+        for (int i = 0; i < kBinsPerThread; ++i) {
+            for (int q = 0; q < 2; ++q) {
+                const int r = q ? rb : ra;
+                if (r >= pre && r < pre + h[i]) { S.bin[q] = kBinsPerThread * t + i; S.base[q] = pre; }
+            }
+            pre += h[i];
         }
     }
     __syncthreads();
@@ -374,11 +388,13 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
         if (b > 1e-4) {
             weighted = true;
             double m = 0.0;
+            __syncthreads();   // every thread has read the norms (the sum above): they make room for the likelihoods
             for (int j = threadIdx.x; j < N; j += blockDim.x) {
                 const double e0 = ein[2 * j], e1 = ein[2 * j + 1];
                 const double nj = sqrt(e0 * e0 + e1 * e1);
                 double l = 1.0 / (2 * b) * exp(-fabs(nj - mi) / b);
                 if (l < 1e-6) l = 1e-6;
+                qn[j] = l;     // (read back by the same thread in the accumulation below: same j -> same thread)
                 m = fmax(m, l);
             }
             lmax = block_max(m, S.red);
@@ -393,16 +409,18 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
         double h[12], y[2];
         acc_in.get(j, h, y);
-        double p0 = 0.0, p1 = 0.0;
-        for (int i = 0; i < 6; ++i) { p0 += h[i] * x[i]; p1 += h[6 + i] * x[i]; }
-        const double e0 = -(p0 - y[0]), e1 = -(p1 - y[1]);
-        double l = 1.0;
-        if (weighted) {
-            const double nj = sqrt(e0 * e0 + e1 * e1);
-            l = 1.0 / (2 * b) * exp(-fabs(nj - mi) / b);
-            if (l < 1e-6) l = 1e-6;
-            l /= lmax;
+        double e0, e1;
+        if (reweight) {   // innovations and likelihoods of the passes above
+            e0 = ein[2 * j];
+            e1 = ein[2 * j + 1];
+        } else {
+            double p0 = 0.0, p1 = 0.0;
+            for (int i = 0; i < 6; ++i) { p0 += h[i] * x[i]; p1 += h[6 + i] * x[i]; }
+            e0 = -(p0 - y[0]);
+            e1 = -(p1 - y[1]);
         }
+        double l = 1.0;
+        if (weighted) l = qn[j] / lmax;
         const double w0 = l * ir0, w1 = l * ir1;
         int t = 0;
         for (int i = 0; i < 6; ++i)
@@ -476,7 +494,7 @@ __global__ __launch_bounds__(kSkfThreads) void skf_chain_kernel(EngineArrays a, 
     for (int t = 0; t < a.T; ++t) {
         const int slot = t * a.n_obj + obj;
         stage_ctrl(&s_c, a.ctrl[slot]);   // (the barrier at the end of the previous frame precedes this overwrite)
-        if (threadIdx.x == 255) s_npts = a.npts[slot];
+        if (threadIdx.x == kSkfThreads - 1) s_npts = a.npts[slot];
         __syncthreads();
         const FrameCtrl& c = s_c;
         const int n_pts = c.vel_stage ? s_npts : -1;
@@ -511,7 +529,7 @@ __global__ __launch_bounds__(kSkfThreads) void skf_chain_kernel(EngineArrays a, 
         for (int i = 0; i < 6; ++i) x[i] = s_x[i];
         SKFTICK(0);
 
-        RecAccessor acc{a.recs + (size_t)slot * a.cand_cap, a.cam, c.dt};
+        RecAccessor acc(a.recs + (size_t)slot * a.cand_cap, a.cam, c.dt);
         const int rc = skf_core(acc, N, x, s_P, prm.r_flow, reweight, a.norms + (size_t)obj * 3 * a.cand_cap, S);
         // rc 3: numerically singular, belief left unchanged
         if (rc == 0 && threadIdx.x < 36) st.v_cov[threadIdx.x] = S.Lm[threadIdx.x];
@@ -574,7 +592,7 @@ __global__ __launch_bounds__(kSkfThreads) void skf_records_kernel(const double* 
     }
     double x[6], r[2] = {Rdiag[0], Rdiag[1]};
     for (int i = 0; i < 6; ++i) x[i] = x_pred[i];
-    RecAccessor acc{recs, cam, dt};
+    RecAccessor acc(recs, cam, dt);
     const int rc = skf_core(acc, N, x, P_pred, r, reweight, norms, S);
     if (threadIdx.x < 6) x_out[threadIdx.x] = (rc == 0) ? S.xo[threadIdx.x] : x_pred[threadIdx.x];
     if (threadIdx.x < 36) P_out[threadIdx.x] = (rc == 0) ? S.Lm[threadIdx.x] : P_pred[threadIdx.x];

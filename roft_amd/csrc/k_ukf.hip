@@ -1089,7 +1089,16 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
         // The outlier test between the segments (outlier_fused_kernel) left the likelihood of both alternatives:
         // pick_best_alternative's decision (ROFTFilter.cpp:581-583) and the chosen belief -> p_corr_belief_ (:670-675)
         const FrameCtrl& pc = frame_ctrl(a, pl.pending_frame, obj);
-        const double L0 = pl.outlier_L[0], L1 = pl.outlier_L[1];
+        // likelihood of an alternative = mean |depth - render| over its samples: the bands' partial sums in band order;
+        // no sample at all -> DBL_MAX (ROFTFilter.cpp:569-574); the gain is a bool in the reference, i.e. 1 (ROFTFilter.h:64)
+        double Lk[2];
+        for (int k = 0; k < 2; ++k) {
+            double e = 0.0, n2 = 0.0;
+            for (int p = 0; p < pl.n_parts; ++p) { e += pl.part_err[k][p]; n2 += pl.part_cnt[k][p]; }
+            Lk[k] = (n2 == 0.0) ? 1.7976931348623157e308 : (e / n2) / 1.0;
+            if (threadIdx.x == 0) { pl.outlier_L[k] = Lk[k]; pl.outlier_cnt[k] = n2; }
+        }
+        const double L0 = Lk[0], L1 = Lk[1];
         const int sel = (L0 > 2.0 * L1) ? 1 : 0;
         const PoseBelief& src = st.belief[b_alt(lin, sel)];
         PoseBelief& dst = st.belief[pc.cur_slot];

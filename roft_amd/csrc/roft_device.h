@@ -21,6 +21,7 @@ constexpr int kMaxBatch = ROFT_MAX_BATCH_FRAMES;   // frames per roft_frames_sub
 constexpr int kTwistRing = 64;         // twist history ring (velocity deque of the measurement model + frames in flight)
 constexpr int kMaxFlowHist = ROFT_MAX_FLOW_CHASE;  // flows a new mask can be chased through (30-entry queue of the
                                        // time-stamped source, OpticalFlowQueueHandler.cpp:18-26; "all buffered" otherwise)
+constexpr int kMaxOutlierParts = 8;    // workgroups one alternative of an outlier test is rendered by (horizontal bands)
 constexpr int kMaxSteps = 10;          // UKF steps per frame (re-sync replays <= pose_frames_between + 1 <= 9)
 constexpr int kPlaneSlots = 64;        // mask bit-plane ring per object (> frames in flight + one batch + 1)
 constexpr int kFeatRing = 12;          // buffered outlier-rejection feature sets per object (>= kMaxBatch + 2; the host
@@ -83,7 +84,9 @@ struct PoseLane {
     double outlier_L[2];
     double outlier_cnt[2];
     int ukf_status;
-    int pad_;
+    int n_parts;           // workgroups per alternative of the last outlier test (outlier_fused_kernel)
+    double part_err[2][kMaxOutlierParts];   // their partial sums of |depth - render| and sample counts, per alternative
+    double part_cnt[2][kMaxOutlierParts];
 };
 
 struct ObjState {

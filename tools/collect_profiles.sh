@@ -1,39 +1,63 @@
 #!/bin/bash
 # Collects the rocprofv3 / bench evidence of a round on the GPU box and condenses it into small files under
-# gpurun_out/<tag>/ (copy the ones to keep into profiles/).   usage: bash tools/collect_profiles.sh [tag]
+# gpurun_out/<tag>/ (copy the ones to keep into profiles/ with the tag as prefix).   usage: bash tools/collect_profiles.sh [tag]
 set -x
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r01}
+TAG=${1:-r02}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python bench.py > $O/bench_64obj.json 2> $O/bench.err
-python tools/run_baseline_configs.py --out $O/baseline_configs.json > /dev/null 2> $O/baseline.err
-python tools/live_latency.py --out $O/live_latency.json > /dev/null 2>&1
-python tools/bench_flow_producer.py > $O/flow_producer.jsonl
-python tools/bench_flow_producer.py --pairs 1 >> $O/flow_producer.jsonl
-python tools/bench_flow_producer.py --pairs 16 --shape B --flow s16 >> $O/flow_producer.jsonl
+# the driver-shaped run (what BENCH_rNN.json records) three times, the default run and a long steady-state run
+for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_driver_shaped_$i.json 2> $O/bench.err; done
+timeout 300 python bench.py > $O/bench_64obj.json 2>> $O/bench.err
+timeout 300 python bench.py --steps 240 --warmup 16 --no-cpu-baseline --pcie-frames 0 > $O/bench_steady_240.json 2>> $O/bench.err
+timeout 600 python tools/run_baseline_configs.py --out $O/baseline_configs.json > /dev/null 2> $O/baseline.err
+timeout 300 python tools/live_latency.py --out $O/live_latency.json > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> /dev/null
+# kernel stats + timeline of the driver-shaped run, chains overlapping
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-frames 0 > $O/bench_under_rocprof.json 2> /dev/null
 python3 $R/tools/prof_summary.py stats $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv
-# the roofline kernel over exactly the timed launches of that run (12 warm-up frames, then 60): compare with roofline.avg_launch_us
-# of bench_under_rocprof.json
-python3 $R/tools/prof_summary.py window $O/stats/*/*kernel_trace.csv flow_measure_kernel 12 60 > $O/k1_timed_launches_under_rocprof.txt
-python3 $R/tools/trace_timeline.py $O/stats/*/*kernel_trace.csv 600 > $O/pipeline_timeline.txt
-python3 $R/tools/trace_timeline.py $O/stats/*/*kernel_trace.csv 120 --list | head -130 >> $O/pipeline_timeline.txt
+# the roofline kernel over exactly the timed launches of that run (1 warm-up batch, then 3 timed ones): compare with roofline.avg_launch_us
+python3 $R/tools/prof_summary.py window $O/stats/*/*kernel_trace.csv flow_measure_kernel 1 3 > $O/k1_timed_launches_under_rocprof.txt
+python3 $R/tools/trace_list.py $O/stats/*/*kernel_trace.csv 1 > $O/pipeline_timeline.txt
 rm -rf $O/stats
-# the same kernels with the three chains serialised on one stream (the "alone" durations quoted in DESIGN.md section 5)
+# the same kernels with the chains serialised on one stream (each kernel's duration alone), on a longer run
 export ROFT_ONE_STREAM=1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --no-cpu-baseline > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --steps 48 --warmup 8 --no-cpu-baseline --pcie-frames 0 --no-kernel-timing > /dev/null 2>&1
 unset ROFT_ONE_STREAM
 python3 $R/tools/prof_summary.py stats $O/stats1/*/*kernel_stats.csv $O/bench_kernel_stats_one_stream.csv
 rm -rf $O/stats1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python3 $R/bench.py --steps 48 --warmup 8 --no-cpu-baseline --pcie-frames 0 --no-kernel-timing > /dev/null 2>&1
+python3 $R/tools/prof_summary.py stats $O/stats2/*/*kernel_stats.csv $O/bench_kernel_stats_48.csv
+rm -rf $O/stats2
+# HBM traffic, one counter per pass (FETCH_SIZE and WRITE_SIZE do not fit one pass); every launch of the roofline kernel
+# covers 8 frames x 64 objects in this run (24 timed frames after 8 warm-up frames, batches of 8)
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc -- python3 $R/bench.py --steps 12 --warmup 6 --no-cpu-baseline --no-kernel-timing > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc -- python3 $R/bench.py --steps 24 --warmup 8 --no-cpu-baseline --pcie-frames 0 --no-kernel-timing > /dev/null 2>&1
   python3 $R/tools/prof_summary.py pmc $O/pmc/*/*counter_collection.csv $O/pmc_$c.csv
   rm -rf $O/pmc
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/of -- python3 $R/tools/bench_flow_producer.py > /dev/null 2>&1
+python3 - <<PY
+import csv, json
+rows = {r["kernel"].split("<")[0].split("::")[-1]: r for r in csv.DictReader(open("$O/pmc_FETCH_SIZE.csv"))}
+k1 = rows["flow_measure_kernel"]
+per_launch_kb = float(k1["mean_value_per_dispatch"])
+obj_frames = 64 * 8
+plane = 640 * 480 // 8
+raw = per_launch_kb * 1024.0 / obj_frames
+json.dump({"objects": 64, "shape": "A", "flow": "f32", "batch": 8, "dispatches": int(k1["dispatches"]),
+           "fetch_size_kb_per_launch": per_launch_kb, "object_frames_per_launch": obj_frames,
+           "fetch_bytes_per_object_frame_raw": raw,
+           # MI355X_MICROARCH.md, HBM: FETCH_SIZE tallies the 128-byte requests of a wide coalesced 16 B / lane streaming read
+           # at 64 bytes -- the bit-plane read of this kernel is such a stream and is counted twice here; the 4- and 8-byte
+           # sample gathers are left as counted (uncalibrated)
+           "fetch_bytes_per_object_frame": raw + plane,
+           "source": "rocprofv3 --pmc FETCH_SIZE, bench.py --steps 24 --warmup 8 (tools/collect_profiles.sh), KB x 1024 / 512 object-frames per launch + 38400 B plane correction"},
+          open("$O/pmc_k1.json", "w"), indent=1)
+PY
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/of -- python3 $R/tools/bench_flow_producer.py > /dev/null 2>&1
 python3 $R/tools/prof_summary.py stats $O/of/*/*kernel_stats.csv $O/flow_producer_kernel_stats.csv
 rm -rf $O/of
+cd $R
+timeout 300 python tools/bench_flow_producer.py > $O/flow_producer.jsonl
 du -sh $O; ls -la $O

@@ -8,7 +8,7 @@
   #4 64 objects at 640x480 (the metric shape; `bench.py` is the full measurement of this one)
   #5 1280x720, 16 objects, outlier rejection + pose re-sync on a long sequence, tolerance vs the CPU path
 
-usage: python tools/run_baseline_configs.py [--frames5 600] [--out profiles/r01_baseline_configs.json]
+usage: python tools/run_baseline_configs.py [--frames5 600] [--out profiles/r02_baseline_configs.json]
 """
 import argparse
 import json
@@ -33,9 +33,12 @@ from oracle import binding as ob
 FAST_YCB_HALF_EXTENTS = synth.FAST_YCB_HALF_EXTENTS
 
 
-def make_engine(streams):
+BATCH = 8   # frames per roft_frames_submit: the configs are recorded sequences
+
+
+def make_engine(streams, batch=BATCH):
     st0 = streams[0]
-    cfg = E.default_config(st0.camera.width, st0.camera.height, st0.flow_type, max_objects=len(streams))
+    cfg = E.default_config(st0.camera.width, st0.camera.height, st0.flow_type, max_objects=len(streams), max_batch_frames=batch)
     c = st0.camera
     cfg.cam.fx, cfg.cam.fy, cfg.cam.cx, cfg.cam.cy = c.fx, c.fy, c.cx, c.cy
     cfg.flow_grid, cfg.flow_scale = st0.flow_grid, st0.flow_scale
@@ -49,24 +52,28 @@ def make_engine(streams):
     return eng
 
 
-def run_engine(streams, n_frames):
-    eng = make_engine(streams)
+def run_engine(streams, n_frames, batch=BATCH):
+    """The whole sequence through the engine, `batch` frames per submit (no warm-up: the first batch pays the start-up)."""
+    eng = make_engine(streams, batch)
     eng.enable_log(n_frames)
-    inputs = []
-    for k in range(n_frames):
-        frames = []
-        for st in streams:
-            mi = st.mask_delivery[k]
-            pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
-            frames.append(dict(depth=st.depth[k].data_ptr(), flow=st.flow[k].data_ptr() if st.flow_valid[k] else None,
-                               mask=st.mask_gt[mi].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt,
-                               mem_kind=L.MEM_DEVICE))
-        inputs.append(eng.build_inputs(frames))
+    batches = []
+    for k0 in range(0, n_frames, batch):
+        frames_list = []
+        for k in range(k0, min(n_frames, k0 + batch)):
+            frames = []
+            for st in streams:
+                mi = st.mask_delivery[k]
+                pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
+                frames.append(dict(depth=st.depth[k].data_ptr(), flow=st.flow[k].data_ptr() if st.flow_valid[k] else None,
+                                   mask=st.mask_gt[mi].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt,
+                                   mem_kind=L.MEM_DEVICE))
+            frames_list.append(frames)
+        batches.append(eng.build_batch(frames_list))
     eng.sync()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(n_frames):
-        eng.submit_raw(inputs[k][0])
+    for arr, _keep, t in batches:
+        eng.submit_batch_raw(arr, t)
         eng.step()
     eng.sync()
     dt = time.perf_counter() - t0
@@ -132,12 +139,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=240)
     ap.add_argument("--frames5", type=int, default=600)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r01_baseline_configs.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_baseline_configs.json"))
     args = ap.parse_args()
     L.require_device()
     dev = torch.device("cuda", 0)
     cam_b, cam_a = synth.Camera.shape_b(), synth.Camera.shape_a()
-    report = {"host_cores": os.cpu_count(), "device": torch.cuda.get_device_name(0)}
+    report = {"host_cores": os.cpu_count(), "device": torch.cuda.get_device_name(0), "frames_per_submit": BATCH}
 
     # ---- #1 / #2: single cracker-box object, shape B, CV_16SC2
     n = args.frames
