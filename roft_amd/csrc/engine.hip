@@ -258,6 +258,7 @@ struct roft_engine {
     hipStream_t vel_stream = nullptr;   // velocity chain: flow measurement, velocity filter
     hipStream_t pose_stream[kNumLin] = {nullptr, nullptr};  // pose chain, one stream per lane (BeliefSlot): UKF segments, outlier rejection
     hipStream_t up_stream = nullptr;    // uploads of HOST inputs and the copies of aged-out flows
+    struct StreamSet* streams = nullptr;   // the pooled set the four above come from
     // Batches in flight.  The image chains of batch b+1 do not depend on the pose chain of batch b, so they run ahead
     // of it.  The lead is bounded on the host: the submit call of batch b returns only when batch b - lead has ended
     // (its pose chain, which implies its other chains).  Rings are sized for it:
@@ -399,29 +400,66 @@ int roft_default_object(roft_object_desc* o)
 
 int roft_engine_destroy(roft_engine* e);
 
+// The HIP streams of the engines of this process.  The runtime maps streams onto a few hardware queues in the order in
+// which they are created; streams created after others were destroyed can end up sharing queues, and the chains of such
+// an engine then run one after the other (measured: the second engine of a process tracked at a third of the rate of
+// the first).  So a set of streams is created once per device and priority mode, handed to one engine at a time and
+// never destroyed.
+struct StreamSet {
+    hipStream_t mask = nullptr, vel = nullptr, pose[kNumLin] = {nullptr, nullptr}, up = nullptr;
+    int device = 0;
+    bool priorities = true, busy = false;
+};
+static std::mutex g_stream_mu;
+static std::vector<StreamSet*> g_stream_sets;
+
+static int acquire_streams(int device, bool priorities, StreamSet** out)
+{
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (StreamSet* s : g_stream_sets)
+        if (!s->busy && s->device == device && s->priorities == priorities) { s->busy = true; *out = s; return ROFT_OK; }
+    StreamSet* s = new StreamSet();
+    s->device = device;
+    s->priorities = priorities;
+    // the pose chain is the longest of the three: give its workgroups the dispatch priority
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (!priorities) greatest = least;
+    hipError_t err = hipSuccess;
+    for (int l = 0; l < kNumLin && err == hipSuccess; ++l) err = hipStreamCreateWithPriority(&s->pose[l], hipStreamNonBlocking, greatest);
+    if (err == hipSuccess) err = hipStreamCreateWithPriority(&s->vel, hipStreamNonBlocking, (least + greatest) / 2);
+    if (err == hipSuccess) err = hipStreamCreateWithPriority(&s->mask, hipStreamNonBlocking, least);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&s->up, hipStreamNonBlocking);
+    if (err != hipSuccess) { delete s; return fail(ROFT_ERR_DEVICE, std::string("stream creation: ") + hipGetErrorString(err)); }
+    s->busy = true;
+    g_stream_sets.push_back(s);
+    *out = s;
+    return ROFT_OK;
+}
+
+static void release_streams(StreamSet* s)
+{
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    if (s) s->busy = false;
+}
+
 static int engine_setup(roft_engine* e, const roft_config* cfg)
 {
     constexpr int R = roft_engine::kBatchRing;
-    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     // The image chains of batch b+1 do not depend on the pose chain of batch b (only the other way round, through
     // the twist ring and the mask planes), so the chains run on separate HIP streams, ordered by one event per batch
     // and edge.  ROFT_ONE_STREAM=1 serialises everything on one stream (debugging).
     const char* one = getenv("ROFT_ONE_STREAM");
     e->multi = !(one && one[0] == '1');
+    const char* np = getenv("ROFT_NO_STREAM_PRIORITY");
+    if (int rc = acquire_streams(cfg->device, !(np && np[0] == '1'), &e->streams)) return rc;
     if (e->multi) {
-        // the pose chain is the longest of the three: give its workgroups the dispatch priority
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const char* np = getenv("ROFT_NO_STREAM_PRIORITY");
-        if (np && np[0] == '1') greatest = least;
-        for (int l = 0; l < kNumLin; ++l) HIP_TRY(hipStreamCreateWithPriority(&e->pose_stream[l], hipStreamNonBlocking, greatest));
-        HIP_TRY(hipStreamCreateWithPriority(&e->vel_stream, hipStreamNonBlocking, (least + greatest) / 2));
-        HIP_TRY(hipStreamDestroy(e->stream));
-        e->stream = nullptr;
-        HIP_TRY(hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, least));
-        HIP_TRY(hipStreamCreateWithFlags(&e->up_stream, hipStreamNonBlocking));
+        e->stream = e->streams->mask;
+        e->vel_stream = e->streams->vel;
+        for (int l = 0; l < kNumLin; ++l) e->pose_stream[l] = e->streams->pose[l];
+        e->up_stream = e->streams->up;
     } else {
-        e->pose_stream[0] = e->pose_stream[1] = e->vel_stream = e->up_stream = e->stream;
+        e->stream = e->pose_stream[0] = e->pose_stream[1] = e->vel_stream = e->up_stream = e->streams->mask;
     }
     for (int i = 0; i < R; ++i) {
         HIP_TRY(e->dctrl[i].ensure((size_t)cfg->max_objects * e->T_max, true));
@@ -508,15 +546,10 @@ int roft_engine_destroy(roft_engine* e)
             if (ev) (void)hipEventDestroy(ev);
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
     }
-    if (e->multi) {
-        for (int l = 0; l < kNumLin; ++l) if (e->pose_stream[l]) (void)hipStreamDestroy(e->pose_stream[l]);
-        if (e->vel_stream) (void)hipStreamDestroy(e->vel_stream);
-        if (e->up_stream) (void)hipStreamDestroy(e->up_stream);
-    }
+    release_streams(e->streams);   // (idle: synchronised above)
     for (auto* o : e->objs) delete o;
     if (e->state_host) (void)hipHostFree(e->state_host);
     for (auto ev : e->tev) (void)hipEventDestroy(ev);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
     return ROFT_OK;
 }

@@ -495,11 +495,7 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     // cache the projected vertices when they leave room for a window of 8 k pixels (a window that large or larger is
     // rendered in strips) and for the widest row of the target
     const size_t min_win = (size_t)4 * std::max(8192, a.tile_w);
-#ifdef ROFT_EXP_NO_VCACHE
-    const bool cache = false;
-#else
     const bool cache = vbytes + min_win <= lds_total;
-#endif
     const int vcache_cap = cache ? a.max_verts : 0;
     const int win_cap = (int)((lds_total - (cache ? vbytes : 0)) / 4);
     static bool attr_set = false;
