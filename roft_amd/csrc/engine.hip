@@ -1056,9 +1056,14 @@ static int step_batch(roft_engine* e)
     CHECK_LAUNCH("mask chain");
     tmark(e, "mask_chain", 0);
     if (multi && T > 1 && full) { HIP_TRY(hipEventRecord(e->ev_mask[slot], s)); ++evops; }
-    // the pose chain waits for the features only when a test can read a set buffered in this very batch
-    const bool want_ev_feat = multi && e->any_feat && (T > 1 || e->any_feat_now);
-    if (e->any_feat) {
+    // Outlier-rejection features of the batch's pose frames (they read the planes the mask chain just wrote).  Batches:
+    // on the velocity stream behind the velocity filter -- that stream has waited for this mask chain, has time to spare,
+    // and the pose lanes wait for its end anyway, so the features cost the mask chain (the longest one) nothing and need
+    // no event of their own.  One-frame submits: on the mask chain's stream; the pose chain waits for them only when a
+    // test reads a set buffered in this very frame (older sets are covered by the velocity chain's wait on that stream).
+    const bool feat_on_vel = multi && T > 1;
+    const bool want_ev_feat = multi && e->any_feat && !feat_on_vel && (T > 1 || e->any_feat_now);
+    if (e->any_feat && !feat_on_vel) {
         launch_features(a, s, (want_ev_feat && !full) ? e->ev_feat[slot] : nullptr);
         ++launches;
         CHECK_LAUNCH("features");
@@ -1081,10 +1086,17 @@ static int step_batch(roft_engine* e)
         ++launches;
         CHECK_LAUNCH("flow measurement");
     }
-    launch_skf_chain(a, e->cfg.flow_weighting, sv, (multi && !full) ? e->ev_vel[slot] : nullptr);
+    const bool feat_last = feat_on_vel && e->any_feat;
+    launch_skf_chain(a, e->cfg.flow_weighting, sv, (multi && !full && !feat_last) ? e->ev_vel[slot] : nullptr);
     ++launches;
     CHECK_LAUNCH("velocity filter chain");
     tmark(e, "skf_chain", 2);
+    if (feat_last) {
+        launch_features(a, sv, !full ? e->ev_vel[slot] : nullptr);
+        ++launches;
+        CHECK_LAUNCH("features");
+        tmark(e, "features", 2);
+    }
     if (multi && full) { HIP_TRY(hipEventRecord(e->ev_vel[slot], sv)); ++evops; }
     HP_MARK(e, 5, hp_t);
 
