@@ -119,6 +119,7 @@ struct Arrays {
     DevBuf<double> norms;
     DevBuf<int> npts;
     DevBuf<MaskRec> mrec;
+    DevBuf<unsigned> mask_sync;
     DevBuf<uint32_t> feat_pix;
     DevBuf<float> feat_depth;
     DevBuf<uint32_t> zbuf;
@@ -141,6 +142,7 @@ struct Arrays {
         HIP_TRY(ctrl.ensure((size_t)n_obj * T, true));
         HIP_TRY(planes.ensure((size_t)n_obj * (kPlaneSlots + kMaxBatch) * 2 * a.plane_words, true));
         HIP_TRY(mrec.ensure((size_t)n_obj * (kMaxBatch + 1), true));
+        HIP_TRY(mask_sync.ensure(n_obj, true));
         HIP_TRY(map.ensure((size_t)n_obj * npix, true));
         HIP_TRY(cand.ensure((size_t)n_obj * T * a.cand_cap));
         HIP_TRY(recs.ensure((size_t)n_obj * T * a.cand_cap));
@@ -151,6 +153,7 @@ struct Arrays {
         HIP_TRY(zbuf.ensure((size_t)2 * a.tile_w * a.tile_h));   // operator level only (roft_depth_likelihood)
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
         a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.mrec = mrec.p;
+        a.mask_sync = mask_sync.p;
         a.T_prev = 0; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
         a.zbuf = zbuf.p;
         a.out_log = nullptr;

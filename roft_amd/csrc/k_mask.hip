@@ -205,7 +205,9 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
                 mine = words[my_e];
             } else {
                 const int my_grp = (int)(((my_yx >> 16) * (uint32_t)W + (my_yx & 0xFFFFu)) >> 6);
-                const unsigned long long w = *(const ROFT_GLOBAL unsigned long long*)(plane2 + my_grp);
+                // (agent-coherent: inside the chain kernel the word may come from a workgroup on another XCD)
+                const unsigned long long w = __hip_atomic_load((const ROFT_GLOBAL unsigned long long*)(plane2 + my_grp),
+                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 mine = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
             }
         }
@@ -345,11 +347,36 @@ __device__ __forceinline__ void plane_fill(uint32_t* d, uint32_t v, size_t n_wor
         for (size_t i = threadIdx.x; i < n_words / 2; i += blockDim.x) reinterpret_cast<uint2*>(d)[i] = make_uint2(v, v);
 }
 
+// The same through agent-coherent accesses (sc1: write-through stores, loads that miss the caches above the coherence
+// point), 8 bytes at a time: what the workgroups of an object, spread over XCDs with an L2 each, exchange INSIDE the
+// persistent chain kernel goes through these and through atomics only -- no cache write-back / invalidate per frame.
+__device__ __forceinline__ unsigned long long coh_load64(const void* p)
+{
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void coh_store64(void* p, unsigned long long v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void plane_copy_coherent(uint32_t* d, const uint32_t* s, size_t n_words)
+{
+    for (size_t i = threadIdx.x; i < n_words / 2; i += blockDim.x) coh_store64(d + 2 * i, coh_load64(s + 2 * i));
+}
+
+__device__ __forceinline__ void plane_fill_coherent(uint32_t* d, uint32_t v, size_t n_words)
+{
+    const unsigned long long vv = ((unsigned long long)v << 32) | v;
+    for (size_t i = threadIdx.x; i < n_words / 2; i += blockDim.x) coh_store64(d + 2 * i, vv);
+}
+
 // State carried into the batch + reset of the per-frame counters the ingest kernels accumulate into.
 __global__ void mask_carry_kernel(EngineArrays a)
 {
     const int obj = blockIdx.x * blockDim.x + threadIdx.x;
     if (obj >= a.n_obj) return;
+    a.mask_sync[obj] = 0u;   // arrivals at the object's barriers inside mask_chain_kernel
     if (a.T_prev > 0) {
         const MaskRec last = a.mrec[(size_t)a.T_prev * a.n_obj + obj];
         MaskRec& r0 = a.mrec[obj];
@@ -384,21 +411,46 @@ __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskR
     return r;
 }
 
+// Barrier among the nq workgroups of one object inside the persistent chain kernel: `counter` (zeroed by the carry
+// kernel) counts arrivals, `target` = nq * (barriers so far + 1).  Every thread releases its global writes of the frame
+// at agent scope before the workgroup arrives (the workgroups of an object run on different XCDs, each with an L2 of
+// its own), thread 0 arrives and polls, and everybody acquires afterwards.  All workgroups of the launch are resident
+// together (nq * n_obj <= the CU count, one workgroup fits every CU next to anything else the engine runs), and kernels
+// on the other streams never wait for this one, so the poll cannot starve; a poll that nevertheless lasts two seconds
+// aborts the kernel -- the engine then fails with a launch error instead of hanging the device.
+__device__ __forceinline__ void object_barrier(unsigned* counter, unsigned target)
+{
+    __builtin_amdgcn_s_waitcnt(0);   // every store / atomic of this thread acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 200000000ll) __builtin_trap();   // 100 MHz clock
+        }
+    }
+    __syncthreads();
+}
+
+// The binary-mask chain of a batch: ONE launch walks the T frames.  grid: (S, n_obj).  Workgroup q of an object owns
+// the 64-pixel groups q, q + S, ... of the source and the words [q, q+1) * plane_words / S of the planes it copies /
+// fills / zeroes; the S workgroups of an object meet at an object_barrier between two frames (the mask of frame t is
+// the source of frame t + 1), objects never wait for each other.
 // dynamic LDS: [plane_words] OR target | list of this workgroup's non-empty groups [| their plane words]
-// grid: (S, n_obj); frame t of the batch.  Workgroup q of an object owns the 64-pixel groups q, q + S, ... of the
-// source and the words [q, q+1) * plane_words / S of the planes it copies / fills / zeroes.
 #ifdef ROFT_MASK_PROFILE
-#define MTICK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4) { long long _t = wall_clock64(); a.state[blockIdx.y].dbg[blockIdx.x * 8 + (i)] = _t - m_t0; m_t0 = _t; } } while (0)
+#define MTICK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4) { long long _t = wall_clock64(); a.state[blockIdx.y].dbg[blockIdx.x * 8 + (i)] += _t - m_t0; m_t0 = _t; } } while (0)
 #else
 #define MTICK(i) do {} while (0)
 #endif
 
 template <int FT>
-__global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a, int t, int frames_between, int flow_aided,
-                                                                 int list_cap, int keep_words)
+__global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a, int frames_between, int flow_aided,
+                                                                  int list_cap, int keep_words)
 {
 #ifdef ROFT_MASK_PROFILE
     long long m_t0 = wall_clock64();
+    if (threadIdx.x < 8 && blockIdx.x < 4) a.state[blockIdx.y].dbg[blockIdx.x * 8 + threadIdx.x] = 0;
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ MaskShared S;
@@ -410,84 +462,98 @@ __global__ __launch_bounds__(kMaskThreads) void mask_step_kernel(EngineArrays a,
                                 : nullptr;
     const int W = a.cam.W, H = a.cam.H, n_grp = (W * H) >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
-    // control block and the two state records -> LDS with one load per thread
     __shared__ FrameCtrl s_c;
-    __shared__ MaskRec s_rec[2];
-    stage_ctrl(&s_c, frame_ctrl(a, t, obj));
+    __shared__ MaskRec s_rec[2];   // [0] state after the frame before (frame 0: the carry), [1] this frame's counters
     static_assert(sizeof(MaskRec) == 32, "two 16-byte loads per record");
-    if (tid >= 128 && tid < 132) {
-        const int k = tid - 128;   // 0, 1: record of frame t-1 (or the carry); 2, 3: this frame's
-        reinterpret_cast<uint4*>(s_rec)[k] = reinterpret_cast<const uint4*>(a.mrec + (size_t)(t + (k >> 1)) * a.n_obj + obj)[k & 1];
-    }
-    __syncthreads();
-    const FrameCtrl& c = s_c;
-    const MaskRec r = decide_frame(s_rec[0], s_rec[1], t, c, frames_between, flow_aided);
-    MTICK(0);
-    if (q == 0 && tid == 0) a.mrec[(size_t)(t + 1) * a.n_obj + obj] = r;   // (every workgroup computes the same record)
     // share of the plane words of this workgroup, in 16-byte units when the planes are 16-byte aligned
     const int unit = (a.plane_words & 3) ? 2 : 4;
     const int n_units = (int)(a.plane_words / unit);
     const int u0 = (int)((long long)n_units * q / nq) * unit, u1 = (int)((long long)n_units * (q + 1) / nq) * unit;
-    // the obj plane of the NEXT frame's slot is left zeroed for that frame's OR flush (nobody reads that slot any more:
-    // its last user is kPlaneSlots frames back)
-    plane_fill(a.planes + plane_offset(a, obj, (c.slot_cur + 1) % kPlaneSlots, 1) + u0, 0u, (size_t)(u1 - u0));
-    if (!r.src_binary) return;   // three-valued source: mask_general_kernel
-    const uint32_t* src = a.planes + plane_offset(a, obj, r.src_slot, 1);
-    uint32_t* dst = a.planes + plane_offset(a, obj, c.slot_cur, 1);
-    if (r.mode == 0) {
-        plane_copy(dst + u0, src + u0, (size_t)(u1 - u0));
-        return;
-    }
-    if (r.mode == 2 && (src[0] & 1u)) {
-        // mask(0,0) set in a new-mask frame: every target, mapped or not, samples a set pixel
-        plane_fill(dst + u0, ~0u, (size_t)(u1 - u0));
-        return;
-    }
-    if (tid < kMaxFlowHist) S.flows[tid] = (tid < r.n_flows) ? c.flow[tid] : nullptr;
-    if (tid == 0) S.n_list = 0;
-    plane_fill(s_tgt, 0u, a.plane_words);
-    __syncthreads();
-    MTICK(1);
-    // This workgroup's non-empty 64-pixel groups of the source (g = q + nq i) -> list (any order: the scatter is
-    // order-free), then their walks; in chunks of list_cap groups when the LDS next to the plane cannot list the whole
-    // share at once (a 1280x720 plane with one workgroup per object).
-    const uint2* plane2 = reinterpret_cast<const uint2*>(src);
-    const int share = (n_grp - q + nq - 1) / nq;
-    for (int c0 = 0; c0 < share; c0 += list_cap) {
-        if (c0 > 0) {
-            __syncthreads();   // the walks of the chunk before have read the list
-            if (tid == 0) S.n_list = 0;
-            __syncthreads();
-        }
-        const int c1 = min(share, c0 + list_cap);
-        for (int i0 = c0; i0 < c1; i0 += kMaskThreads) {
-            const int i = i0 + tid, g = q + nq * i;
-            bool ne = false;
-            uint2 w = make_uint2(0u, 0u);
-            if (i < c1) { w = plane2[g]; ne = (w.x | w.y) != 0u; }
-            const unsigned long long b = __ballot(ne);
-            int base = 0;
-            if (lane == 0 && b) base = atomicAdd(&S.n_list, __popcll(b));
-            base = __shfl(base, 0, 64);
-            if (ne) {
-                const int e = base + __popcll(b & ((1ull << lane) - 1ull));
-                const int p0 = g * 64, y0 = p0 / W;
-                s_list[e] = ((uint32_t)y0 << 16) | (uint32_t)(p0 - y0 * W);
-                if (s_words) s_words[e] = w;
-            }
+    const ChaseGeo geo = make_chase_geo(a.cam, a.ffmt);
+    unsigned n_barriers = 0;
+    for (int t = 0; t < a.T; ++t) {
+        // control block and the state records -> LDS with one load per thread
+        stage_ctrl(&s_c, frame_ctrl(a, t, obj));
+        if (tid >= 128 && tid < 132) {
+            const int k = tid - 128;   // 0, 1: the carry (first frame only; later the record decided below); 2, 3: this frame's
+            if (k >= 2 || t == 0)
+                reinterpret_cast<uint4*>(s_rec)[k] = reinterpret_cast<const uint4*>(a.mrec + (size_t)(t + (k >> 1)) * a.n_obj + obj)[k & 1];
         }
         __syncthreads();
-        MTICK(2);
-        propagate_binary<FT>(make_chase_geo(a.cam, a.ffmt), plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, s_tgt, s_words);
+        const FrameCtrl& c = s_c;
+        const MaskRec r = decide_frame(s_rec[0], s_rec[1], t, c, frames_between, flow_aided);
+        MTICK(0);
+        if (q == 0 && tid == 0) a.mrec[(size_t)(t + 1) * a.n_obj + obj] = r;   // (every workgroup computes the same record)
+        // the obj plane of the NEXT frame's slot is left zeroed for that frame's OR flush (nobody reads that slot any
+        // more: its last user is kPlaneSlots frames back)
+        plane_fill_coherent(a.planes + plane_offset(a, obj, (c.slot_cur + 1) % kPlaneSlots, 1) + u0, 0u, (size_t)(u1 - u0));
+        const uint32_t* src = a.planes + plane_offset(a, obj, r.src_slot, 1);
+        uint32_t* dst = a.planes + plane_offset(a, obj, c.slot_cur, 1);
+        if (!r.src_binary) {
+            // three-valued source: mask_general_kernel
+        } else if (r.mode == 0) {
+            plane_copy_coherent(dst + u0, src + u0, (size_t)(u1 - u0));
+        } else if (r.mode == 2 && (src[0] & 1u)) {
+            // mask(0,0) set in a new-mask frame: every target, mapped or not, samples a set pixel
+            plane_fill_coherent(dst + u0, ~0u, (size_t)(u1 - u0));
+        } else {
+            if (tid < kMaxFlowHist) S.flows[tid] = (tid < r.n_flows) ? c.flow[tid] : nullptr;
+            if (tid == 0) S.n_list = 0;
+            plane_fill(s_tgt, 0u, a.plane_words);
+            __syncthreads();
+            MTICK(1);
+            // This workgroup's non-empty 64-pixel groups of the source (g = q + nq i) -> list (any order: the scatter
+            // is order-free), then their walks; in chunks of list_cap groups when the LDS next to the plane cannot list
+            // the whole share at once (a 1280x720 plane with one workgroup per object).
+            const uint2* plane2 = reinterpret_cast<const uint2*>(src);
+            const int share = (n_grp - q + nq - 1) / nq;
+            for (int c0 = 0; c0 < share; c0 += list_cap) {
+                if (c0 > 0) {
+                    __syncthreads();   // the walks of the chunk before have read the list
+                    if (tid == 0) S.n_list = 0;
+                    __syncthreads();
+                }
+                const int c1 = min(share, c0 + list_cap);
+                for (int i0 = c0; i0 < c1; i0 += kMaskThreads) {
+                    const int i = i0 + tid, g = q + nq * i;
+                    bool ne = false;
+                    uint2 w = make_uint2(0u, 0u);
+                    if (i < c1) {
+                        const unsigned long long ww = coh_load64(plane2 + g);
+                        w = make_uint2((uint32_t)ww, (uint32_t)(ww >> 32));
+                        ne = ww != 0ull;
+                    }
+                    const unsigned long long b = __ballot(ne);
+                    int base = 0;
+                    if (lane == 0 && b) base = atomicAdd(&S.n_list, __popcll(b));
+                    base = __shfl(base, 0, 64);
+                    if (ne) {
+                        const int e = base + __popcll(b & ((1ull << lane) - 1ull));
+                        const int p0 = g * 64, y0 = p0 / W;
+                        s_list[e] = ((uint32_t)y0 << 16) | (uint32_t)(p0 - y0 * W);
+                        if (s_words) s_words[e] = w;
+                    }
+                }
+                __syncthreads();
+                MTICK(2);
+                propagate_binary<FT>(geo, plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, s_tgt, s_words);
+            }
+            __syncthreads();
+            MTICK(3);
+            // flush: the non-zero words of this workgroup's plane into the (zeroed) destination
+            for (int i = tid; i < (int)a.plane_words; i += kMaskThreads) {
+                const uint32_t v = s_tgt[i];
+                if (v) atomicOr(&dst[i], v);
+            }
+            MTICK(4);
+        }
+        if (t + 1 == a.T) break;
+        // the next frame reads this frame's planes and ORs into the slot zeroed above
+        if (nq > 1) object_barrier(a.mask_sync + obj, (unsigned)nq * ++n_barriers);
+        else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }   // (one workgroup, one CU: its L1 is written through)
+        if (tid == 0) s_rec[0] = r;   // (the staging barrier of the next frame publishes it)
+        MTICK(5);
     }
-    __syncthreads();
-    MTICK(3);
-    // flush: the non-zero words of this workgroup's plane into the (zeroed) destination
-    for (int i = tid; i < (int)a.plane_words; i += kMaskThreads) {
-        const uint32_t v = s_tgt[i];
-        if (v) atomicOr(&dst[i], v);
-    }
-    MTICK(4);
 }
 
 // One persistent workgroup per object at the end of the batch's mask chain: the frames whose source is three-valued.
@@ -581,24 +647,23 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
     static bool attr_set = false;
     if (!attr_set) {
         const int cap = 160 * 1024 - 4096;   // (the kernel's static LDS -- control block, records, flow pointers -- is ~1.2 KB)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_step_kernel<ROFT_FLOW_S16C2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_step_kernel<ROFT_FLOW_F32C2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_chain_kernel<ROFT_FLOW_S16C2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_chain_kernel<ROFT_FLOW_F32C2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
         attr_set = true;
     }
     int launches = 0;
     hipLaunchKernelGGL(mask_carry_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a);
     ++launches;
-    const bool s16 = a.ffmt.type == ROFT_FLOW_S16C2;
-    for (int t = 0; t < a.T; ++t) {
+    for (int t = 0; t < a.T; ++t)   // (the ingested masks land in slots of their own: all of them ahead of the chain)
         if (new_mask_frames & (1u << t)) { launch_mask_ingest(a, t, s); ++launches; }
-        if (s16)
-            hipLaunchKernelGGL(mask_step_kernel<ROFT_FLOW_S16C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a, t,
-                               frames_between, flow_aided, (int)list_cap, keep_words);
-        else
-            hipLaunchKernelGGL(mask_step_kernel<ROFT_FLOW_F32C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a, t,
-                               frames_between, flow_aided, (int)list_cap, keep_words);
-        ++launches;
-    }
+    const bool s16 = a.ffmt.type == ROFT_FLOW_S16C2;
+    if (s16)
+        hipLaunchKernelGGL(mask_chain_kernel<ROFT_FLOW_S16C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a,
+                           frames_between, flow_aided, (int)list_cap, keep_words);
+    else
+        hipLaunchKernelGGL(mask_chain_kernel<ROFT_FLOW_F32C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a,
+                           frames_between, flow_aided, (int)list_cap, keep_words);
+    ++launches;
     if (s16)
         hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_S16C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, stop, 0, a);
     else

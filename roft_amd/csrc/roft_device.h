@@ -176,6 +176,7 @@ struct EngineArrays {
     uint32_t* planes;        // [n_obj][kPlaneSlots + kMaxBatch][2][wpr*H]   (nz plane, obj plane)
     MaskRec* mrec;           // [kMaxBatch + 1][n_obj]
     int T_prev;              // frames of the batch before (row of mrec that carries the state in), 0: none
+    unsigned* mask_sync;     // [n_obj] arrivals at the barriers among an object's workgroups inside mask_chain_kernel
     int32_t* map;            // [n_obj][W*H] scatter map of the general (non-binary) mask path, all-zero between frames
     FlowRec* cand;           // [T][n_obj][cand_cap] candidate scratch
     FlowRec* recs;           // [T][n_obj][cand_cap] kept flow records
@@ -282,8 +283,8 @@ __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, i
 }
 
 void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s);   // frame t's new masks -> plane slot kSlotNew + t
-// Mask chain of the batch: carry of the state, then per frame [ingest of new masks +] one step kernel (binary masks),
-// and one persistent kernel for the frames of objects with three-valued masks.  new_mask_frames: bit t set when some
+// Mask chain of the batch: carry of the state, ingest of the new masks, one persistent kernel that walks the frames of
+// the batch (binary masks) and one persistent kernel for the frames of objects with three-valued masks.  new_mask_frames: bit t set when some
 // object receives a mask in frame t.  Returns the number of launches.
 int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s,
                       hipEvent_t stop = nullptr);

@@ -17,7 +17,7 @@ from roft_amd import _lib as L, synth
 import run_baseline_configs as rb
 
 n_obj = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-n = 14 if os.environ.get("PHASES") == "fused" else 12
+n = 14 if os.environ.get("PHASES") == "fused" else (32 if os.environ.get("PHASES") == "mask" else 12)
 dev = torch.device("cuda", 0)
 streams = [synth.make_stream(4000 + i, n, synth.Camera.shape_a(), device=dev) for i in range(n_obj)]
 eng = rb.make_engine(streams)
@@ -30,6 +30,37 @@ if os.environ.get("PHASES") == "fused":   # -DROFT_FUSED_PROFILE: alternative 0 
     names = ["vertices + box", "clear", "triangles", "features", "strips", "window w", "window h"]
 if os.environ.get("PHASES") == "skf":
     names = ["load", "innovations", "norms", "median", "mean abs dev", "max weight", "accumulate", "reduce", "solve"]
+if os.environ.get("PHASES") == "mask":
+    # the persistent chain kernel: batches of 8 frames, stamps summed over the frames of a batch (phase 5: the barrier
+    # among the object's workgroups between two frames)
+    names.append("object barrier")
+    T = 8
+    eng.close()
+    eng = rb.make_engine(streams, T)
+    for k0 in range(0, 32, T):
+        fl = []
+        for k in range(k0, k0 + T):
+            frames = []
+            for st in streams:
+                mi = st.mask_delivery[k]
+                pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
+                frames.append(dict(depth=st.depth[k].data_ptr(), flow=st.flow[k].data_ptr() if st.flow_valid[k] else None,
+                                   mask=st.mask_gt[mi].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE))
+            fl.append(frames)
+        arr, _keep, t = eng.build_batch(fl)
+        eng.submit_batch_raw(arr, t)
+        eng.step()
+        eng.sync()
+        rows = []
+        for o in range(n_obj):
+            buf = (C.c_longlong * 32)()
+            L.lib().roft_debug_get_dbg(eng._h, o, buf)
+            rows.append([max(buf[q * 8 + i] for q in range(4)) / 100.0 / T for i in range(len(names))])
+        r = np.array(rows)
+        print("batch at %d  mean us per frame and phase: " % k0 + ", ".join("%s %.2f" % (nm, v) for nm, v in zip(names, r.mean(0))) +
+              "  | sum %.2f (max over objects %.2f)" % (r.sum(1).mean(), r.sum(1).max()))
+    eng.close()
+    sys.exit(0)
 for k in range(n):
     frames = []
     for st in streams:
