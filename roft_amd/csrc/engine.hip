@@ -119,7 +119,7 @@ struct Arrays {
     DevBuf<double> norms;
     DevBuf<int> npts;
     DevBuf<MaskRec> mrec;
-    DevBuf<unsigned> mask_sync;
+    DevBuf<unsigned> mask_sync, mask_general;
     DevBuf<uint32_t> feat_pix;
     DevBuf<float> feat_depth;
     DevBuf<uint32_t> zbuf;
@@ -140,9 +140,10 @@ struct Arrays {
         HIP_TRY(params.ensure(n_obj, true));
         HIP_TRY(state.ensure(n_obj, true));
         HIP_TRY(ctrl.ensure((size_t)n_obj * T, true));
-        HIP_TRY(planes.ensure((size_t)n_obj * (kPlaneSlots + kMaxBatch) * 2 * a.plane_words, true));
-        HIP_TRY(mrec.ensure((size_t)n_obj * (kMaxBatch + 1), true));
-        HIP_TRY(mask_sync.ensure(n_obj, true));
+        HIP_TRY(planes.ensure((size_t)n_obj * kPlaneSlotsTotal * 2 * a.plane_words, true));
+        HIP_TRY(mrec.ensure((size_t)2 * n_obj * (kMaxBatch + 1), true));   // two tables (batch parity)
+        HIP_TRY(mask_sync.ensure((size_t)2 * n_obj, true));
+        HIP_TRY(mask_general.ensure(n_obj, true));
         HIP_TRY(map.ensure((size_t)n_obj * npix, true));
         HIP_TRY(cand.ensure((size_t)n_obj * T * a.cand_cap));
         HIP_TRY(recs.ensure((size_t)n_obj * T * a.cand_cap));
@@ -153,8 +154,8 @@ struct Arrays {
         HIP_TRY(zbuf.ensure((size_t)2 * a.tile_w * a.tile_h));   // operator level only (roft_depth_likelihood)
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
         a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.mrec = mrec.p;
-        a.mask_sync = mask_sync.p;
-        a.T_prev = 0; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
+        a.mask_sync = mask_sync.p; a.mask_general = mask_general.p;
+        a.mrec_carry = mrec.p; a.slot_new = kSlotNew; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
         a.zbuf = zbuf.p;
         a.out_log = nullptr;
         a.log_cap = 0;
@@ -189,9 +190,14 @@ void clear_ctrl(FrameCtrl& c)
 // FrameCtrl upload without the copy engine: a kernel reads the pinned (device-visible) staging block and
 // writes the device copy, so the control blocks of a batch travel in-order on the compute queue instead of
 // through an SDMA copy with its cross-engine signalling.
-__global__ void ctrl_upload_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+// Control blocks of a batch: pinned host staging -> device, and the reset of what the batch's mask chain accumulates
+// into (ingest counters, barrier arrivals) on the way.  (a.ctrl, a.mrec, a.mask_sync: this batch's.)
+__global__ void ctrl_upload_kernel(const uint4* __restrict__ src, EngineArrays a, size_t n16)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    uint4* dst = reinterpret_cast<uint4*>(a.ctrl);
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = i0; i < n16; i += stride) dst[i] = src[i];
+    for (size_t i = i0; i < (size_t)(a.T + 1) * a.n_obj; i += stride) roft::mask_reset_tables(a, i);
 }
 
 namespace {
@@ -279,6 +285,7 @@ struct roft_engine {
     hipEvent_t ev_up[kBatchRing] = {};     // uploads of the batch on the device
     hipEvent_t ev_ctrl[kBatchRing] = {};   // FrameCtrl blocks of the batch on the device (and the mask chain of the batch before)
     hipEvent_t ev_mask[kBatchRing] = {};   // mask chain kernel of the batch complete
+    hipEvent_t ev_prep[kBatchRing] = {};   // control blocks on the device, delivered masks ingested (batches: upload stream)
     hipEvent_t ev_feat[kBatchRing] = {};   // features of the batch complete
     hipEvent_t ev_vel[kBatchRing] = {};    // twists of the batch complete
     hipEvent_t ev_done[kBatchRing][kNumLin] = {};   // pose chain of the batch complete (per lane)
@@ -317,7 +324,7 @@ struct roft_engine {
     std::vector<float> tms;
     std::vector<int> tlaunches;
     std::vector<int> tmark;    // kernel id per event interval (-1 = chain start)
-    std::vector<int> tstream;  // stream of each mark (0 mask chain, 1 pose chain, 2 velocity chain)
+    std::vector<int> tstream;  // stream of each mark (0 mask chain, 1 / 3 pose lanes, 2 velocity chain, 4 upload / preparation)
 };
 
 static inline double host_now_us()
@@ -467,7 +474,7 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
     for (int i = 0; i < R; ++i) {
         HIP_TRY(e->dctrl[i].ensure((size_t)cfg->max_objects * e->T_max, true));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects * e->T_max));
-        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
+        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_prep[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
             HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
     DevFlowFmt ff;
@@ -545,7 +552,7 @@ int roft_engine_destroy(roft_engine* e)
     for (hipStream_t s : {e->stream, e->vel_stream, e->pose_stream[0], e->pose_stream[1], e->up_stream})
         if (s) (void)hipStreamSynchronize(s);
     for (int i = 0; i < R; ++i) {
-        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
+        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_prep[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
             if (ev) (void)hipEventDestroy(ev);
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
     }
@@ -990,7 +997,7 @@ static void tmark(roft_engine* e, const char* name, int which = 0)
     }
     e->tmark.push_back(id);
     e->tstream.push_back(which);
-    (void)hipEventRecord(e->tev[idx], which == 1 ? e->pose_stream[0] : (which == 3 ? e->pose_stream[1] : (which == 2 ? e->vel_stream : e->stream)));
+    (void)hipEventRecord(e->tev[idx], which == 1 ? e->pose_stream[0] : (which == 3 ? e->pose_stream[1] : (which == 2 ? e->vel_stream : (which == 4 ? e->up_stream : e->stream))));
 }
 
 // Timing of ONE kernel by a start / stop event pair bound to its dispatch (two consecutive marks: the first opens the
@@ -1036,29 +1043,62 @@ static int step_batch(roft_engine* e)
     double hp_t = e->host_prof ? host_now_us() : 0.0;
     (void)hipGetLastError();   // a stale error of another library on this thread is not this step's
     a.T = T;
-    a.T_prev = e->prev_T;
     a.ctrl = e->dctrl[slot].p;
+    {
+        // this batch's mask tables (parity) and the row of the other table that carries the state in
+        const size_t table = (size_t)(kMaxBatch + 1) * a.n_obj;
+        const int par = e->batch_counter & 1;
+        MaskRec* base = e->arr.mrec.p;
+        a.mrec = base + par * table;
+        a.mrec_carry = e->prev_T > 0 ? base + (1 - par) * table + (size_t)e->prev_T * a.n_obj : a.mrec;
+        a.slot_new = kSlotNew + par * kMaxBatch;
+        a.mask_sync = e->arr.mask_sync.p + (size_t)par * a.n_obj;
+    }
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
 
-    // ---- mask chain: control blocks of the batch, then every object's masks frame after frame
-    if (multi && e->had_uploads) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }
+    // ---- preparation of the mask chain: control blocks of the batch -> device (+ reset of the chain's counters), ingest
+    //      of the masks delivered with the batch.  Batches: on the upload stream -- nothing here depends on the chain of
+    //      the batch before, so it runs while that chain is still walking its frames; it writes this parity's tables and
+    //      ingest slots, last used by the chain two batches back.  One-frame submits: in order on the chain's stream.
+    const bool prep_ahead = multi && T > 1;
+    hipStream_t sp = prep_ahead ? e->up_stream : s;
+    const int wprep = prep_ahead ? 4 : 0;
+    if (prep_ahead && e->batch_counter >= 2) { HIP_TRY(hipStreamWaitEvent(sp, e->ev_mask[(e->batch_counter - 2) % R], 0)); ++evops; }
+    if (multi && !prep_ahead && e->had_uploads) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }
+    tmark(e, nullptr, wprep);
     {
         const size_t n16 = sizeof(FrameCtrl) * (size_t)a.n_obj * T / 16;
+        const bool last = prep_ahead && !full && e->new_mask_frames == 0;
         // Events that complete with a kernel (hipExtLaunchKernelGGL stop events) cost neither the barrier packet nor
         // the host call of a hipEventRecord behind it.
-        hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
-                              nullptr, (multi && T == 1) ? e->ev_ctrl[slot] : nullptr, 0,
-                              reinterpret_cast<const uint4*>(e->stage[slot]), reinterpret_cast<uint4*>(a.ctrl), n16);
+        hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, sp,
+                              nullptr, (multi && T == 1) ? e->ev_ctrl[slot] : (last ? e->ev_prep[slot] : nullptr), 0,
+                              reinterpret_cast<const uint4*>(e->stage[slot]), a, n16);
         ++launches;
     }
     CHECK_LAUNCH("FrameCtrl upload");
+    tmark(e, "ctrl_upload", wprep);
+    for (int t = 0; t < T; ++t)
+        if (e->new_mask_frames & (1u << t)) {
+            const bool last = prep_ahead && !full && (e->new_mask_frames >> (t + 1)) == 0;
+            launch_mask_ingest(a, t, sp, last ? e->ev_prep[slot] : nullptr);
+            ++launches;
+        }
+    CHECK_LAUNCH("mask ingest");
+    if (e->new_mask_frames) tmark(e, "mask_ingest", wprep);
+    if (prep_ahead) {
+        if (full) { HIP_TRY(hipEventRecord(e->ev_prep[slot], sp)); ++evops; }
+        HIP_TRY(hipStreamWaitEvent(s, e->ev_prep[slot], 0));
+        ++evops;
+    }
     HP_MARK(e, 3, hp_t);
+    // ---- mask chain: every object's masks frame after frame
     tmark(e, nullptr, 0);
-    launches += launch_mask_chain(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, e->new_mask_frames, s,
-                                  (multi && T > 1 && !full) ? e->ev_mask[slot] : nullptr);
+    launches += launch_mask_chain(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, s,
+                                  (multi && !full) ? e->ev_mask[slot] : nullptr);
     CHECK_LAUNCH("mask chain");
     tmark(e, "mask_chain", 0);
-    if (multi && T > 1 && full) { HIP_TRY(hipEventRecord(e->ev_mask[slot], s)); ++evops; }
+    if (multi && full) { HIP_TRY(hipEventRecord(e->ev_mask[slot], s)); ++evops; }
     // Outlier-rejection features of the batch's pose frames (they read the planes the mask chain just wrote).  Batches:
     // on the velocity stream behind the velocity filter -- that stream has waited for this mask chain, has time to spare,
     // and the pose lanes wait for its end anyway, so the features cost the mask chain (the longest one) nothing and need
@@ -1296,7 +1336,7 @@ int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, 
     const size_t nk = e->tnames_s.size();
     e->tms.assign(nk, 0.f);
     e->tlaunches.assign(nk, 0);
-    long prev[4] = {-1, -1, -1, -1};
+    long prev[5] = {-1, -1, -1, -1, -1};
     for (size_t i = 0; i < e->tmark.size(); ++i) {
         const int w = e->tstream[i];
         if (e->tmark[i] >= 0 && prev[w] >= 0) {
@@ -1576,8 +1616,10 @@ int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int
     // the step kernel ORs into a zeroed destination (inside the engine the frame before leaves it zeroed)
     HIP_TRY(hipMemsetAsync(c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 0), 0, sizeof(uint32_t) * 2 * c.arr.a.plane_words, c.stream));
     if (int rc = upload_ctrl(c, fc)) return rc;
-    c.arr.a.T_prev = 0;
-    launch_mask_chain(c.arr.a, frames_between, 1, 1u, c.stream);
+    c.arr.a.mrec_carry = c.arr.mrec.p;   // row 0: rec0[0]
+    launch_mask_reset(c.arr.a, c.stream);
+    launch_mask_ingest(c.arr.a, 0, c.stream);
+    launch_mask_chain(c.arr.a, frames_between, 1, c.stream);
     HIP_TRY(c.b2.ensure(npix));
     launch_planes_to_mask(c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 0), c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 1),
                           (int)npix, c.b2.p, c.stream);

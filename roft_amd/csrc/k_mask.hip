@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a, int t)
     int count = 0, ones = 0;
     if (g < n_grp)
         ingest_group(reinterpret_cast<const uint4*>(c.new_mask), g,
-                     reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, kSlotNew + t, 0)),
-                     reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, kSlotNew + t, 1)), count, ones);
+                     reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, a.slot_new + t, 0)),
+                     reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, a.slot_new + t, 1)), count, ones);
     for (int off = 32; off > 0; off >>= 1) { count += __shfl_xor(count, off, 64); ones += __shfl_xor(ones, off, 64); }
     if ((threadIdx.x & 63) == 0 && count) {
         MaskRec& r = a.mrec[(size_t)(t + 1) * a.n_obj + obj];
@@ -123,14 +123,27 @@ __global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a, int t)
     }
 }
 
-void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s)
+void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s, hipEvent_t stop)
 {
     const int n_grp = a.cam.W * a.cam.H / 64;
-    hipLaunchKernelGGL(mask_ingest_kernel, dim3((n_grp + 255) / 256, a.n_obj), dim3(256), 0, s, a, t);
+    hipExtLaunchKernelGGL(mask_ingest_kernel, dim3((n_grp + 255) / 256, a.n_obj), dim3(256), 0, s, nullptr, stop, 0, a, t);
+}
+
+__global__ void mask_reset_kernel(EngineArrays a)
+{
+    mask_reset_tables(a, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+void launch_mask_reset(const EngineArrays& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(mask_reset_kernel, dim3(((a.T + 1) * a.n_obj + 255) / 256), dim3(256), 0, s, a);
 }
 
 // ---- mask chain ------------------------------------------------------------------------------------
-constexpr int kMaskThreads = 1024;
+#ifndef ROFT_MASK_THREADS
+#define ROFT_MASK_THREADS 1024
+#endif
+constexpr int kMaskThreads = ROFT_MASK_THREADS;
 constexpr int kMaskWaves = kMaskThreads / 64;
 // (64-pixel groups whose walks through the flows are in flight together in one wave -- chase_groups' NCH: a pixel's
 //  walk is a chain of dependent loads, the chains of different groups are independent)
@@ -371,38 +384,19 @@ __device__ __forceinline__ void plane_fill_coherent(uint32_t* d, uint32_t v, siz
     for (size_t i = threadIdx.x; i < n_words / 2; i += blockDim.x) coh_store64(d + 2 * i, vv);
 }
 
-// State carried into the batch + reset of the per-frame counters the ingest kernels accumulate into.
-__global__ void mask_carry_kernel(EngineArrays a)
-{
-    const int obj = blockIdx.x * blockDim.x + threadIdx.x;
-    if (obj >= a.n_obj) return;
-    a.mask_sync[obj] = 0u;   // arrivals at the object's barriers inside mask_chain_kernel
-    if (a.T_prev > 0) {
-        const MaskRec last = a.mrec[(size_t)a.T_prev * a.n_obj + obj];
-        MaskRec& r0 = a.mrec[obj];
-        r0.fbuf_n = last.fbuf_n;
-        r0.binary = last.binary;
-    }
-    for (int t = 1; t <= a.T; ++t) {
-        MaskRec& r = a.mrec[(size_t)t * a.n_obj + obj];
-        r.new_count = 0;
-        r.new_ones = 0;
-    }
-}
-
 // The decisions of frame t (ImageSegmentationOFAidedSource::step_frame, hpp:169-226) from the state after frame t-1.
-__device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskRec& cur, int t, const FrameCtrl& c,
+__device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskRec& cur, int new_slot, const FrameCtrl& c,
                                                 int frames_between, int flow_aided)
 {
     MaskRec r = cur;   // new_count / new_ones of this frame
     const int new_count = c.has_new_mask ? r.new_count : 0;
     const int new_binary = r.new_ones == 0;
     if (flow_aided) {
-        r.mode = decide_mode(c, kSlotNew + t, prev.fbuf_n, new_count, frames_between, r.src_slot, r.n_flows);
+        r.mode = decide_mode(c, new_slot, prev.fbuf_n, new_count, frames_between, r.src_slot, r.n_flows);
         r.fbuf_n = next_fbuf(c, prev.fbuf_n, new_count, r.mode, frames_between);
     } else {  // no flow-aided segmentation: the delivered mask is used as is, otherwise the last one persists
         r.mode = 0;
-        r.src_slot = c.has_new_mask ? kSlotNew + t : c.slot_prev;
+        r.src_slot = c.has_new_mask ? new_slot : c.slot_prev;
         r.n_flows = 0;
         r.fbuf_n = 0;
     }
@@ -470,18 +464,20 @@ __global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a
     const int n_units = (int)(a.plane_words / unit);
     const int u0 = (int)((long long)n_units * q / nq) * unit, u1 = (int)((long long)n_units * (q + 1) / nq) * unit;
     const ChaseGeo geo = make_chase_geo(a.cam, a.ffmt);
-    unsigned n_barriers = 0;
+    unsigned n_barriers = 0, general = 0u;
     for (int t = 0; t < a.T; ++t) {
         // control block and the state records -> LDS with one load per thread
         stage_ctrl(&s_c, frame_ctrl(a, t, obj));
         if (tid >= 128 && tid < 132) {
             const int k = tid - 128;   // 0, 1: the carry (first frame only; later the record decided below); 2, 3: this frame's
-            if (k >= 2 || t == 0)
-                reinterpret_cast<uint4*>(s_rec)[k] = reinterpret_cast<const uint4*>(a.mrec + (size_t)(t + (k >> 1)) * a.n_obj + obj)[k & 1];
+            if (k >= 2)
+                reinterpret_cast<uint4*>(s_rec)[k] = reinterpret_cast<const uint4*>(a.mrec + (size_t)(t + 1) * a.n_obj + obj)[k & 1];
+            else if (t == 0)
+                reinterpret_cast<uint4*>(s_rec)[k] = reinterpret_cast<const uint4*>(a.mrec_carry + obj)[k & 1];
         }
         __syncthreads();
         const FrameCtrl& c = s_c;
-        const MaskRec r = decide_frame(s_rec[0], s_rec[1], t, c, frames_between, flow_aided);
+        const MaskRec r = decide_frame(s_rec[0], s_rec[1], a.slot_new + t, c, frames_between, flow_aided);
         MTICK(0);
         if (q == 0 && tid == 0) a.mrec[(size_t)(t + 1) * a.n_obj + obj] = r;   // (every workgroup computes the same record)
         // the obj plane of the NEXT frame's slot is left zeroed for that frame's OR flush (nobody reads that slot any
@@ -490,7 +486,7 @@ __global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a
         const uint32_t* src = a.planes + plane_offset(a, obj, r.src_slot, 1);
         uint32_t* dst = a.planes + plane_offset(a, obj, c.slot_cur, 1);
         if (!r.src_binary) {
-            // three-valued source: mask_general_kernel
+            general |= 1u << t;   // three-valued source: mask_general_kernel
         } else if (r.mode == 0) {
             plane_copy_coherent(dst + u0, src + u0, (size_t)(u1 - u0));
         } else if (r.mode == 2 && (src[0] & 1u)) {
@@ -547,7 +543,10 @@ __global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a
             }
             MTICK(4);
         }
-        if (t + 1 == a.T) break;
+        if (t + 1 == a.T) {
+            if (q == 0 && tid == 0) a.mask_general[obj] = general;
+            break;
+        }
         // the next frame reads this frame's planes and ORs into the slot zeroed above
         if (nq > 1) object_barrier(a.mask_sync + obj, (unsigned)nq * ++n_barriers);
         else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }   // (one workgroup, one CU: its L1 is written through)
@@ -567,9 +566,10 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
     const int obj = blockIdx.x;
     const int W = a.cam.W, H = a.cam.H, npix = W * H, n_grp = npix >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned todo = a.mask_general[obj];   // (almost always 0: every mask the reference's sources deliver is binary)
     for (int t = 0; t < a.T; ++t) {
+        if (!((todo >> t) & 1u)) continue;
         const MaskRec r = a.mrec[(size_t)(t + 1) * a.n_obj + obj];
-        if (r.src_binary) continue;
         const FrameCtrl& c = frame_ctrl(a, t, obj);
         const uint32_t* snz = a.planes + plane_offset(a, obj, r.src_slot, 0);
         const uint32_t* sob = a.planes + plane_offset(a, obj, r.src_slot, 1);
@@ -627,8 +627,7 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
     }
 }
 
-int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s,
-                      hipEvent_t stop)
+int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s, hipEvent_t stop)
 {
     const size_t n_grp = (size_t)a.cam.W * a.cam.H / 64;
     // workgroups per object: the step kernel's walks are instruction-bound on one CU, so an object is spread over as
@@ -652,10 +651,6 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
         attr_set = true;
     }
     int launches = 0;
-    hipLaunchKernelGGL(mask_carry_kernel, dim3((a.n_obj + 63) / 64), dim3(64), 0, s, a);
-    ++launches;
-    for (int t = 0; t < a.T; ++t)   // (the ingested masks land in slots of their own: all of them ahead of the chain)
-        if (new_mask_frames & (1u << t)) { launch_mask_ingest(a, t, s); ++launches; }
     const bool s16 = a.ffmt.type == ROFT_FLOW_S16C2;
     if (s16)
         hipLaunchKernelGGL(mask_chain_kernel<ROFT_FLOW_S16C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a,

@@ -173,10 +173,16 @@ struct EngineArrays {
     ObjState* state;         // [n_obj]
     int T;                   // frames of the current batch
     FrameCtrl* ctrl;         // [T][n_obj] (current batch)
-    uint32_t* planes;        // [n_obj][kPlaneSlots + kMaxBatch][2][wpr*H]   (nz plane, obj plane)
-    MaskRec* mrec;           // [kMaxBatch + 1][n_obj]
-    int T_prev;              // frames of the batch before (row of mrec that carries the state in), 0: none
+    uint32_t* planes;        // [n_obj][kPlaneSlotsTotal][2][wpr*H]   (nz plane, obj plane)
+    // The mask chain's per-batch tables exist twice (batch parity): the preparation of batch b + 1 -- control block
+    // upload, counter reset, ingest of the delivered masks -- runs on a stream of its own while the chain of batch b
+    // is still walking its frames.
+    MaskRec* mrec;           // [kMaxBatch + 1][n_obj] of this batch (row t + 1: frame t; row 0 is never written)
+    const MaskRec* mrec_carry;  // [n_obj] state after the last frame of the batch before (a row of the other table), or
+                             // row 0 of this one (zeros) for the first batch
+    int slot_new;            // plane slots receiving the masks ingested by this batch: slot_new + frame of the batch
     unsigned* mask_sync;     // [n_obj] arrivals at the barriers among an object's workgroups inside mask_chain_kernel
+    unsigned* mask_general;  // [n_obj] bit t: frame t of the batch is left to mask_general_kernel (three-valued source)
     int32_t* map;            // [n_obj][W*H] scatter map of the general (non-binary) mask path, all-zero between frames
     FlowRec* cand;           // [T][n_obj][cand_cap] candidate scratch
     FlowRec* recs;           // [T][n_obj][cand_cap] kept flow records
@@ -230,7 +236,8 @@ __device__ inline roft_object_output* log_row(const EngineArrays& a, const Frame
     return a.out_log + (size_t)(c.frame_idx % a.log_cap) * a.n_obj + obj;
 }
 
-constexpr int kSlotNew = kPlaneSlots;       // plane slots receiving the ingested masks: kSlotNew + frame of the batch
+constexpr int kSlotNew = kPlaneSlots;       // first plane slot receiving ingested masks (EngineArrays::slot_new)
+constexpr int kPlaneSlotsTotal = kPlaneSlots + 2 * kMaxBatch;   // ring + two sets of ingest slots (batch parity)
 
 // Mask mode of a frame (ImageSegmentationOFAidedSource::step_frame, hpp:169-226), decided on the device
 // because it depends on whether the newly delivered mask is empty:
@@ -279,15 +286,28 @@ __device__ inline int next_fbuf(const FrameCtrl& c, int fbuf_n, int new_count, i
 
 __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, int slot, int which)
 {
-    return (((size_t)obj * (kPlaneSlots + kMaxBatch) + slot) * 2 + which) * a.plane_words;
+    return (((size_t)obj * kPlaneSlotsTotal + slot) * 2 + which) * a.plane_words;
 }
 
-void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s);   // frame t's new masks -> plane slot kSlotNew + t
-// Mask chain of the batch: carry of the state, ingest of the new masks, one persistent kernel that walks the frames of
-// the batch (binary masks) and one persistent kernel for the frames of objects with three-valued masks.  new_mask_frames: bit t set when some
-// object receives a mask in frame t.  Returns the number of launches.
-int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s,
-                      hipEvent_t stop = nullptr);
+// frame t's new masks -> plane slot slot_new + t, their pixel counts -> mrec row t + 1 (zeroed before: mask_reset_tables)
+void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s, hipEvent_t stop = nullptr);
+// Zeroes what the ingest kernels and the chain accumulate into: the counters of mrec rows 1 .. T and mask_sync.
+// (Inside the engine the control block upload kernel does this; the operator-level entry points call it.)
+void launch_mask_reset(const EngineArrays& a, hipStream_t s);
+__device__ inline void mask_reset_tables(const EngineArrays& a, size_t i)   // thread i of a grid of >= (T + 1) * n_obj threads
+{
+    if (i < (size_t)a.T * a.n_obj) {
+        MaskRec& r = a.mrec[(size_t)a.n_obj + i];
+        r.new_count = 0;
+        r.new_ones = 0;
+    } else if (i < (size_t)(a.T + 1) * a.n_obj) {
+        a.mask_sync[i - (size_t)a.T * a.n_obj] = 0u;
+    }
+}
+// Mask chain of the batch (after the reset and the ingest of its new masks): one persistent kernel that walks the frames
+// of the batch (binary masks) and one persistent kernel for the frames of objects with three-valued masks.  Returns the
+// number of launches.
+int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s, hipEvent_t stop = nullptr);
 void launch_planes_to_mask(const uint32_t* nz, const uint32_t* ob, int npix, uint8_t* mask, hipStream_t s);
 // `stop` / `start` (optional): HIP events bound to the kernel's own dispatch (hipExtLaunchKernelGGL) -- they complete
 // with the kernel, without the extra barrier packet and host call of a hipEventRecord behind it.
