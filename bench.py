@@ -204,7 +204,7 @@ def main():
     n_obj = len(my_objects)
     if n_obj == 0:
         raise SystemExit("bench.py: rank %d owns no object (%d objects over %d ranks)" % (rank, total_obj, world))
-    n_extra = 0 if args.no_kernel_timing else 24   # frames after the timed region for the per-kernel breakdown
+    n_extra = 0 if args.no_kernel_timing else int(os.environ.get("ROFT_BENCH_EXTRA_FRAMES", "24"))   # frames after the timed region for the per-kernel breakdown
     n_timed_end = args.warmup + args.steps
     n_frames = n_timed_end + n_extra
     cam = synth.Camera.shape_a() if args.shape == "A" else synth.Camera.shape_b()

@@ -1337,8 +1337,18 @@ int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, 
     e->tms.assign(nk, 0.f);
     e->tlaunches.assign(nk, 0);
     long prev[5] = {-1, -1, -1, -1, -1};
+    // ROFT_DUMP_MARKS=<file>: every mark as "stream name end_us duration_us" relative to the first one -- the timeline
+    // of the chains without a profiler's launch overhead on the host (tools/marks_timeline.py)
+    FILE* dump = nullptr;
+    if (const char* path = getenv("ROFT_DUMP_MARKS")) dump = (e->timing_level > 1 && !e->tmark.empty()) ? fopen(path, "a") : nullptr;
     for (size_t i = 0; i < e->tmark.size(); ++i) {
         const int w = e->tstream[i];
+        if (dump) {
+            float t_ms = 0.f, d_ms = 0.f;
+            (void)hipEventElapsedTime(&t_ms, e->tev[0], e->tev[i]);
+            if (prev[w] >= 0) (void)hipEventElapsedTime(&d_ms, e->tev[prev[w]], e->tev[i]);
+            fprintf(dump, "%d %s %.1f %.1f\n", w, e->tmark[i] >= 0 ? e->tnames_s[e->tmark[i]].c_str() : "-", 1e3 * t_ms, 1e3 * d_ms);
+        }
         if (e->tmark[i] >= 0 && prev[w] >= 0) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, e->tev[prev[w]], e->tev[i]));
@@ -1347,6 +1357,7 @@ int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, 
         }
         prev[w] = (long)i;
     }
+    if (dump) fclose(dump);
     e->tmark.clear();
     e->tstream.clear();
     e->tnames.clear();

@@ -298,6 +298,79 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
     }
 }
 
+// One flow (every frame between two mask deliveries: mode 1): the walk of a pixel is a single step from an integer
+// position, so nothing but the loaded flow elements has to stay in registers while the loads are in flight -- two
+// VGPRs per group -- and ALL groups of a wave (about a dozen at 64 objects) go out in one round: the frame pays one
+// memory latency for its flow.  Position, bit and target are (re)computed when the data is back.  Same arithmetic as
+// chase_groups with n_flows == 1, operation by operation.  Needs the plane words of the listed groups in LDS (`words`).
+#ifndef ROFT_SINGLE_WALKS
+#define ROFT_SINGLE_WALKS 12
+#endif
+template <int FT, int MODE>
+__device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* list, const uint2* words, int n_list, bool clear00,
+                                            const void* flow, ROFT_LDS uint32_t* tgt)
+{
+    constexpr int NCH = ROFT_SINGLE_WALKS;
+    const int W = g.W, H = g.H;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long fl_bits = (unsigned long long)flow;
+    const ROFT_GLOBAL unsigned char* fl = (const ROFT_GLOBAL unsigned char*)(
+        ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fl_bits >> 32)) << 32) |
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fl_bits));
+    for (int e0 = wave; e0 < n_list; e0 += NCH * kMaskWaves) {
+        uint2 raw[NCH];
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int e = e0 + u * kMaskWaves;
+            raw[u] = make_uint2(0u, 0u);
+            if (e < n_list) {   // (wave-uniform)
+                const uint32_t yx = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[e]);
+                int px = (int)(yx & 0xFFFFu) + lane, py = (int)(yx >> 16);
+                if (W & 63) {
+                    if (px >= W) { px -= W; ++py; }
+                    if (px >= W) { px -= W; ++py; }
+                }
+                int fr, fc;
+                if (MODE == 2) { fr = py; fc = px; }
+                else { fr = trunc_clamped((float)py * g.inv_grid); fc = trunc_clamped((float)px * g.inv_grid); }
+                const uint32_t off = (uint32_t)(fr * g.cols + fc) * (FT == ROFT_FLOW_S16C2 ? 4u : 8u);
+                if (FT == ROFT_FLOW_S16C2) {
+                    raw[u] = make_uint2(*(const ROFT_GLOBAL uint32_t*)(fl + off), 0u);
+                } else {
+                    const unsigned long long w = *(const ROFT_GLOBAL unsigned long long*)(fl + off);
+                    raw[u] = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int e = e0 + u * kMaskWaves;
+            if (e < n_list) {
+                const uint32_t yx = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[e]);
+                const uint2 wd = words[e];
+                unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wd.y) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)wd.x);
+                if (clear00 && yx == 0u) bits &= ~1ull;                 // mask_.at<uchar>(0,0) = 0
+                int px = (int)(yx & 0xFFFFu) + lane, py = (int)(yx >> 16);
+                if (W & 63) {
+                    if (px >= W) { px -= W; ++py; }
+                    if (px >= W) { px -= W; ++py; }
+                }
+                float dx, dy;
+                if (FT == ROFT_FLOW_S16C2) { dx = (float)(short)(raw[u].x & 0xFFFFu); dy = (float)(short)(raw[u].x >> 16); }
+                else { dx = __uint_as_float(raw[u].x); dy = __uint_as_float(raw[u].y); }
+                if (MODE == 1) { dx *= g.inv_scale; dy *= g.inv_scale; }
+                const float t_x = (float)px + dx, t_y = (float)py + dy;
+                const int ix = trunc_clamped(t_x), iy = trunc_clamped(t_y);
+                if (((bits >> lane) & 1ull) && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) {
+                    const int tp = iy * W + ix;
+                    (void)__hip_atomic_fetch_or(tgt + (tp >> 5), 1u << (tp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+}
+
 // binary source: OR-scatter into the LDS plane.  kBinaryWalks walks in flight per wave: a workgroup's share of an object
 // is about a dozen groups per wave, so all their flow reads go out together and the frame pays ONE memory latency per
 // flow instead of one per eight groups.
@@ -310,6 +383,11 @@ __device__ __noinline__ void propagate_binary(ChaseGeo g, const uint2* plane2, c
                                               bool clear00, const void* const* flows, uint32_t* s_tgt, const uint2* words)
 {
     ROFT_LDS uint32_t* const tgt = pin_lds(s_tgt);
+    if (n_flows == 1 && words && g.mode != 0) {
+        if (g.mode == 2) walk_single<FT, 2>(g, list, words, n_list, clear00, flows[0], tgt);
+        else walk_single<FT, 1>(g, list, words, n_list, clear00, flows[0], tgt);
+        return;
+    }
     auto hit = [tgt](int tp, int, int, int) {
         (void)__hip_atomic_fetch_or(tgt + (tp >> 5), 1u << (tp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
