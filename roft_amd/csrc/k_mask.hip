@@ -307,10 +307,16 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
 #define ROFT_SINGLE_WALKS 12
 #endif
 template <int FT, int MODE>
-__device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* list, const uint2* words, int n_list, bool clear00,
+__device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* list_, const uint2* words_, int n_list, bool clear00,
                                             const void* flow, ROFT_LDS uint32_t* tgt)
 {
     constexpr int NCH = ROFT_SINGLE_WALKS;
+    // (LDS pointers as such: through generic pointers every read of the list is a flat load, and a flat load waits for
+    //  ALL outstanding memory operations -- the flow loads would go out one at a time)
+    const ROFT_LDS uint32_t* const list = (const ROFT_LDS uint32_t*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(uint32_t)(uintptr_t)(const ROFT_LDS uint32_t*)list_);
+    const ROFT_LDS uint32_t* const words = (const ROFT_LDS uint32_t*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(uint32_t)(uintptr_t)(const ROFT_LDS uint32_t*)reinterpret_cast<const uint32_t*>(words_));
     const int W = g.W, H = g.H;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long fl_bits = (unsigned long long)flow;
@@ -347,9 +353,8 @@ __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* li
             const int e = e0 + u * kMaskWaves;
             if (e < n_list) {
                 const uint32_t yx = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[e]);
-                const uint2 wd = words[e];
-                unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)wd.y) << 32) |
-                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)wd.x);
+                unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)words[2 * e + 1]) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)words[2 * e]);
                 if (clear00 && yx == 0u) bits &= ~1ull;                 // mask_.at<uchar>(0,0) = 0
                 int px = (int)(yx & 0xFFFFu) + lane, py = (int)(yx >> 16);
                 if (W & 63) {
@@ -364,6 +369,9 @@ __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* li
                 const int ix = trunc_clamped(t_x), iy = trunc_clamped(t_y);
                 if (((bits >> lane) & 1ull) && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) {
                     const int tp = iy * W + ix;
+#ifdef ROFT_EXP_DOUBLE_ATOMIC
+                    (void)__hip_atomic_fetch_or(tgt + (tp >> 5), 1u << (tp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                     (void)__hip_atomic_fetch_or(tgt + (tp >> 5), 1u << (tp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }

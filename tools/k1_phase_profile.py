@@ -44,7 +44,8 @@ if os.environ.get("PHASES") == "mask":
             for st in streams:
                 mi = st.mask_delivery[k]
                 pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
-                frames.append(dict(depth=st.depth[k].data_ptr(), flow=st.flow[k].data_ptr() if st.flow_valid[k] else None,
+                kf = 1 if os.environ.get("FLOWFIX") else k   # FLOWFIX=1: every frame reads the same flow image (warm caches / TLB)
+                frames.append(dict(depth=st.depth[k].data_ptr(), flow=st.flow[kf].data_ptr() if st.flow_valid[k] else None,
                                    mask=st.mask_gt[mi].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE))
             fl.append(frames)
         arr, _keep, t = eng.build_batch(fl)
