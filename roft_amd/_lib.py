@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO = os.path.join(CSRC, "libroft_hip.so")
+SO = os.environ.get("ROFT_LIB_SO") or os.path.join(CSRC, "libroft_hip.so")   # (override: A/B runs of two builds)
 
 OK = 0
 FLOW_S16C2 = 11

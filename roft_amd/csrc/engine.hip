@@ -1060,7 +1060,7 @@ static int step_batch(roft_engine* e)
     //      of the masks delivered with the batch.  Batches: on the upload stream -- nothing here depends on the chain of
     //      the batch before, so it runs while that chain is still walking its frames; it writes this parity's tables and
     //      ingest slots, last used by the chain two batches back.  One-frame submits: in order on the chain's stream.
-    const bool prep_ahead = multi && T > 1;
+    const bool prep_ahead = multi && T > 1 && getenv("ROFT_EXP_PREP_AHEAD");
     hipStream_t sp = prep_ahead ? e->up_stream : s;
     const int wprep = prep_ahead ? 4 : 0;
     if (prep_ahead && e->batch_counter >= 2) { HIP_TRY(hipStreamWaitEvent(sp, e->ev_mask[(e->batch_counter - 2) % R], 0)); ++evops; }

@@ -480,11 +480,15 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
 
 // One workgroup per object walks the frames of the batch: the velocity belief of frame k is the prior of frame k+1,
 // so the recursion is sequential per object; the flow records of all frames are already there (flow_measure_kernel).
+#ifndef PRIO_SKF
+#define PRIO_SKF 2
+#endif
 __global__ __launch_bounds__(kSkfThreads) void skf_chain_kernel(EngineArrays a, int reweight)
 {
     __shared__ SkfShared S;
     __shared__ double s_x[6];
     __shared__ double s_P[36];
+    __builtin_amdgcn_s_setprio(PRIO_SKF);   // (a per-object chain of barrier phases next to wide kernels: see ukf_chain_kernel)
 
     __shared__ FrameCtrl s_c;
     __shared__ int s_npts;

@@ -1064,12 +1064,33 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
 // that belong to lane `lin`, frame after frame.  A step followed by the depth-render outlier test ends
 // the segment -- the host enqueues launch_outlier and another segment behind it, which resumes at the lane's cursor
 // (PoseLane::pc_frame / pc_step) -- otherwise the segment runs to the end of the batch.
+#ifndef PRIO_UKF
+#define PRIO_UKF 3
+#endif
+#ifdef UKF_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(UKF_WAVES_PER_EU, UKF_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, UtTable ut, int first_segment, int lin)
 {
     // static LDS on purpose: with `extern __shared__` the compiler re-reads the dynamic-LDS base address from a
     // table in global memory inside every Jacobi round (two dependent global loads per round)
     __shared__ UkfLds L;
     __shared__ unsigned s_mine;
+    // A pose step is one long chain of dependent instructions on four waves; the CU it runs on is shared with the wide
+    // kernels of the other chains (mask walks, rasteriser, flow measurement), whose waves compete for the issue slots of
+    // the same SIMDs.  Highest wave priority: the chain's next instruction goes first whenever it is ready.
+    __builtin_amdgcn_s_setprio(PRIO_UKF);
+#ifdef ROFT_UKF_WALL
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) {
+        s_ticket = atomicAdd(reinterpret_cast<unsigned*>(&a.state[0].dbg[30 + 0]) + lin, 1u);
+        long long* rec = a.state[(s_ticket / a.n_obj) % a.n_obj].dbg + lin * 8;
+        const long long now = wall_clock64();
+        atomicMax(reinterpret_cast<unsigned long long*>(&rec[0]), (unsigned long long)((1ll << 62) - now));
+        atomicMax(reinterpret_cast<unsigned long long*>(&rec[1]), (unsigned long long)now);
+    }
+    __syncthreads();
+#endif
     const int obj = blockIdx.x;
     ObjState& st = a.state[obj];
     PoseLane& pl = st.lane[lin];
@@ -1119,6 +1140,13 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
     bool pending = false;
     __shared__ FrameCtrl s_c;
     int staged = -1;
+#ifdef ROFT_UKF_WALL   // wall time inside the step loop and steps walked, summed per object (tools/ukf_wall.py)
+    const long long w_t0 = wall_clock64();
+    int w_steps = 0;
+    // per launch of this lane (ticket / n_obj; launches of a lane are serialised): first / last workgroup start, last
+    // end, most and total steps -> dbg[lane * 8 ..] of object (launch % n_obj)
+    long long* w_rec = a.state[(s_ticket / a.n_obj) % a.n_obj].dbg + lin * 8;
+#endif
     while (t < a.T) {
         if (!((mine >> t) & 1u)) { ++t; step = 0; continue; }
         if (staged != t) {   // this frame's control block -> LDS
@@ -1131,11 +1159,25 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
         if (step == 0 && threadIdx.x == 0) pl.outlier_selected = -1;  // set again by outlier_kernel if it runs
         if (step >= c.n_steps) { ++t; step = 0; continue; }
         if (c.steps[step].op) ukf_one_step(a, c, obj, step, ut, L);
+#ifdef ROFT_UKF_WALL
+        ++w_steps;
+#endif
         __syncthreads();   // beliefs written by this step are read by the next one (same workgroup)
         pending = (step == c.outlier_step);
         ++step;
         if (pending) break;
     }
+#ifdef ROFT_UKF_WALL
+    if (threadIdx.x == 0) {
+        const long long w_t1 = wall_clock64();
+        atomicAdd(reinterpret_cast<unsigned long long*>(&st.dbg[28]), (unsigned long long)(w_t1 - w_t0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&st.dbg[29]), (unsigned long long)w_steps);
+        atomicMax(reinterpret_cast<unsigned long long*>(&w_rec[2]), (unsigned long long)w_t1);
+        atomicMax(reinterpret_cast<unsigned long long*>(&w_rec[3]), (unsigned long long)w_steps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&w_rec[4]), (unsigned long long)w_steps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&w_rec[5]), 1ull);
+    }
+#endif
     if (threadIdx.x == 0) {
         pl.pending_frame = pending ? t : -1;
         pl.pc_frame = t;     // == a.T when the chain of this batch is complete
