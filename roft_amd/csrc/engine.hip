@@ -285,7 +285,6 @@ struct roft_engine {
     hipEvent_t ev_up[kBatchRing] = {};     // uploads of the batch on the device
     hipEvent_t ev_ctrl[kBatchRing] = {};   // FrameCtrl blocks of the batch on the device (and the mask chain of the batch before)
     hipEvent_t ev_mask[kBatchRing] = {};   // mask chain kernel of the batch complete
-    hipEvent_t ev_prep[kBatchRing] = {};   // control blocks on the device, delivered masks ingested (batches: upload stream)
     hipEvent_t ev_feat[kBatchRing] = {};   // features of the batch complete
     hipEvent_t ev_vel[kBatchRing] = {};    // twists of the batch complete
     hipEvent_t ev_done[kBatchRing][kNumLin] = {};   // pose chain of the batch complete (per lane)
@@ -474,7 +473,7 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
     for (int i = 0; i < R; ++i) {
         HIP_TRY(e->dctrl[i].ensure((size_t)cfg->max_objects * e->T_max, true));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects * e->T_max));
-        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_prep[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
+        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
             HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
     DevFlowFmt ff;
@@ -552,7 +551,7 @@ int roft_engine_destroy(roft_engine* e)
     for (hipStream_t s : {e->stream, e->vel_stream, e->pose_stream[0], e->pose_stream[1], e->up_stream})
         if (s) (void)hipStreamSynchronize(s);
     for (int i = 0; i < R; ++i) {
-        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_prep[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
+        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
             if (ev) (void)hipEventDestroy(ev);
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
     }
@@ -1056,41 +1055,25 @@ static int step_batch(roft_engine* e)
     }
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
 
-    // ---- preparation of the mask chain: control blocks of the batch -> device (+ reset of the chain's counters), ingest
-    //      of the masks delivered with the batch.  Batches: on the upload stream -- nothing here depends on the chain of
-    //      the batch before, so it runs while that chain is still walking its frames; it writes this parity's tables and
-    //      ingest slots, last used by the chain two batches back.  One-frame submits: in order on the chain's stream.
-    const bool prep_ahead = multi && T > 1 && getenv("ROFT_EXP_PREP_AHEAD");
-    hipStream_t sp = prep_ahead ? e->up_stream : s;
-    const int wprep = prep_ahead ? 4 : 0;
-    if (prep_ahead && e->batch_counter >= 2) { HIP_TRY(hipStreamWaitEvent(sp, e->ev_mask[(e->batch_counter - 2) % R], 0)); ++evops; }
-    if (multi && !prep_ahead && e->had_uploads) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }
-    tmark(e, nullptr, wprep);
+    // ---- control blocks of the batch -> device (+ reset of the mask chain's counters), ingest of the masks delivered
+    //      with the batch (tables and ingest slots of this batch's parity: the carry of the chain before stays readable).
+    //      (Measured and not adopted: this preparation a batch ahead on the upload stream -- 3 % slower, the chains
+    //       compete for CUs, not for the mask stream's time.)
+    if (multi && e->had_uploads) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }
+    tmark(e, nullptr, 0);
     {
         const size_t n16 = sizeof(FrameCtrl) * (size_t)a.n_obj * T / 16;
-        const bool last = prep_ahead && !full && e->new_mask_frames == 0;
         // Events that complete with a kernel (hipExtLaunchKernelGGL stop events) cost neither the barrier packet nor
         // the host call of a hipEventRecord behind it.
-        hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, sp,
-                              nullptr, (multi && T == 1) ? e->ev_ctrl[slot] : (last ? e->ev_prep[slot] : nullptr), 0,
+        hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
+                              nullptr, (multi && T == 1) ? e->ev_ctrl[slot] : nullptr, 0,
                               reinterpret_cast<const uint4*>(e->stage[slot]), a, n16);
         ++launches;
     }
     CHECK_LAUNCH("FrameCtrl upload");
-    tmark(e, "ctrl_upload", wprep);
     for (int t = 0; t < T; ++t)
-        if (e->new_mask_frames & (1u << t)) {
-            const bool last = prep_ahead && !full && (e->new_mask_frames >> (t + 1)) == 0;
-            launch_mask_ingest(a, t, sp, last ? e->ev_prep[slot] : nullptr);
-            ++launches;
-        }
+        if (e->new_mask_frames & (1u << t)) { launch_mask_ingest(a, t, s); ++launches; }
     CHECK_LAUNCH("mask ingest");
-    if (e->new_mask_frames) tmark(e, "mask_ingest", wprep);
-    if (prep_ahead) {
-        if (full) { HIP_TRY(hipEventRecord(e->ev_prep[slot], sp)); ++evops; }
-        HIP_TRY(hipStreamWaitEvent(s, e->ev_prep[slot], 0));
-        ++evops;
-    }
     HP_MARK(e, 3, hp_t);
     // ---- mask chain: every object's masks frame after frame
     tmark(e, nullptr, 0);

@@ -716,9 +716,12 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
 int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s, hipEvent_t stop)
 {
     const size_t n_grp = (size_t)a.cam.W * a.cam.H / 64;
-    // workgroups per object: the step kernel's walks are instruction-bound on one CU, so an object is spread over as
-    // many CUs as the chip has to spare (256 CUs; at most 8 per object)
-    int S = 256 / (a.n_obj > 0 ? a.n_obj : 1);
+    // Workgroups per object: the walks are latency-bound on one CU, so an object is spread over several (at most 8).  A
+    // workgroup of 16 waves with 128 registers per thread fills the register file of its CU, and it stays for the whole
+    // batch: a quarter of the chip's 256 CUs is left to the per-object chains of the other streams (the pose and velocity
+    // filters need an empty CU each: 346 / 219 registers per thread) -- measured at 64 objects: 3 workgroups per object
+    // +4 % object-frames/s over 4, and the flow measurement's launch no longer waits for CUs (its duration was bimodal).
+    int S = (256 - 64) / (a.n_obj > 0 ? a.n_obj : 1);
     S = S < 1 ? 1 : (S > 8 ? 8 : S);
     const size_t lds_plane = (a.plane_words * 4 + 15) & ~(size_t)15;
     // list of a workgroup's groups next to its plane (4 B per group), their plane words behind it (8 B) if the CU's LDS

@@ -1,2 +1,4 @@
-for rep in 1 2 3 4; do for v in m1024 m512; do ROFT_LIB_SO=$PWD/build_ab/$v.so timeout 200 python bench.py --no-cpu-baseline --pcie-frames 0 --steps 20 --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', round(d['value']), round(d['roofline']['frac'],3), round(d['roofline']['avg_launch_us'],1))"; done; done
-bash tools/ab.sh "--steps 240 --warmup 16" m1024.so m512.so
+timeout 900 python -m pytest tests -m gpu -x -q --timeout 300 2>&1 | tail -3
+run() { timeout 200 python bench.py --no-cpu-baseline --pcie-frames 0 --no-kernel-timing "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],4))"; }
+for i in 1 2 3; do run --steps 20 --warmup 5; done
+run --steps 60 --warmup 12; run --steps 240 --warmup 16; run --steps 240 --warmup 16
