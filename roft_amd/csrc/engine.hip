@@ -155,7 +155,7 @@ struct Arrays {
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
         a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.mrec = mrec.p;
         a.mask_sync = mask_sync.p; a.mask_general = mask_general.p;
-        a.mrec_carry = mrec.p; a.slot_new = kSlotNew; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
+        a.mrec_carry = mrec.p; a.slot_new = kSlotNew; a.slot_prev0 = -1; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
         a.zbuf = zbuf.p;
         a.out_log = nullptr;
         a.log_cap = 0;
@@ -1051,6 +1051,7 @@ static int step_batch(roft_engine* e)
         a.mrec = base + par * table;
         a.mrec_carry = e->prev_T > 0 ? base + (1 - par) * table + (size_t)e->prev_T * a.n_obj : a.mrec;
         a.slot_new = kSlotNew + par * kMaxBatch;
+        a.slot_prev0 = (e->frame_counter + kPlaneSlots - 1) % kPlaneSlots;   // (submit_frames: slot_prev of every object)
         a.mask_sync = e->arr.mask_sync.p + (size_t)par * a.n_obj;
     }
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");

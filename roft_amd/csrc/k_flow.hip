@@ -120,13 +120,6 @@ struct FlowCtrl {
     const void* flow;
 };
 
-__device__ __forceinline__ FlowCtrl load_flow_ctrl(const FrameCtrl& c)
-{
-    FlowCtrl k{c.vel_stage, c.slot_prev, c.depth_prev, c.flow[0]};
-    asm volatile("" : "+v"(k.vel_stage), "+v"(k.slot_prev), "+v"(k.depth), "+v"(k.flow));
-    return k;
-}
-
 // Plane words held in registers: thread t owns the PER4 consecutive 16-byte groups starting at t * PER4 (no LDS copy
 // of the plane at all).  Needs plane_words % 4 == 0 and plane_words / 4 <= PER4 * kFlowThreads.
 template <int PER4>
@@ -142,17 +135,27 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays
 #ifdef ROFT_K1_PROFILE
     long long k1_t0 = wall_clock64();
 #endif
-    const FlowCtrl k = load_flow_ctrl(c);
+    // 1. this thread's words of the previous frame's obj plane (unconditional loads, all in flight together) -- and the
+    //    control block fields in the SAME round trip: inside the engine the plane's ring slot follows from the frame's
+    //    position in the batch (EngineArrays::slot_prev0), not from the control block
+    FlowCtrl k{c.vel_stage, c.slot_prev, c.depth_prev, c.flow[0]};
+    const int n4 = (int)(a.plane_words / 4), i0 = (int)threadIdx.x * PER4;
+    uint4 q[PER4];
+    if (a.slot_prev0 >= 0) {
+        const uint4* g4 = reinterpret_cast<const uint4*>(a.planes + plane_offset(a, obj, (a.slot_prev0 + (int)blockIdx.y) % kPlaneSlots, 1));
+#pragma unroll
+        for (int j = 0; j < PER4; ++j) q[j] = g4[min(i0 + j, n4 - 1)];
+        asm volatile("" : "+v"(k.vel_stage), "+v"(k.slot_prev), "+v"(k.depth), "+v"(k.flow), "+v"(q[0].x));
+    } else {
+        asm volatile("" : "+v"(k.vel_stage), "+v"(k.slot_prev), "+v"(k.depth), "+v"(k.flow));
+        const uint4* g4 = reinterpret_cast<const uint4*>(a.planes + plane_offset(a, obj, k.slot_prev, 1));
+#pragma unroll
+        for (int j = 0; j < PER4; ++j) q[j] = g4[min(i0 + j, n4 - 1)];
+    }
     if (!k.vel_stage) {
         if (threadIdx.x == 0) a.npts[slot] = -1;
         return;
     }
-    // 1. this thread's words of the previous frame's obj plane (unconditional loads, all in flight together)
-    const uint4* g4 = reinterpret_cast<const uint4*>(a.planes + plane_offset(a, obj, k.slot_prev, 1));
-    const int n4 = (int)(a.plane_words / 4), i0 = (int)threadIdx.x * PER4;
-    uint4 q[PER4];
-#pragma unroll
-    for (int j = 0; j < PER4; ++j) q[j] = g4[min(i0 + j, n4 - 1)];
     int cnt = 0;
 #pragma unroll
     for (int j = 0; j < PER4; ++j) {

@@ -181,6 +181,8 @@ struct EngineArrays {
     const MaskRec* mrec_carry;  // [n_obj] state after the last frame of the batch before (a row of the other table), or
                              // row 0 of this one (zeros) for the first batch
     int slot_new;            // plane slots receiving the masks ingested by this batch: slot_new + frame of the batch
+    int slot_prev0;          // ring slot of the mask BEFORE frame 0 of the batch (frame t reads slot_prev0 + t, mod the ring:
+                             // the flow measurement starts its plane loads without waiting for the control block), -1: unknown
     unsigned* mask_sync;     // [n_obj] arrivals at the barriers among an object's workgroups inside mask_chain_kernel
     unsigned* mask_general;  // [n_obj] bit t: frame t of the batch is left to mask_general_kernel (three-valued source)
     int32_t* map;            // [n_obj][W*H] scatter map of the general (non-binary) mask path, all-zero between frames
