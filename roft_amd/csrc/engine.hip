@@ -99,7 +99,7 @@ int check_geometry(int W, int H)
         return fail(ROFT_ERR_INVALID, "image width must be a multiple of 32 and width*height a multiple of 64");
     if ((size_t)W * H >= (1u << 24))
         return fail(ROFT_ERR_INVALID, "width*height must be < 2^24 (float-accumulated sampling index, hpp:237)");
-    // LDS of the mask step kernel: the OR target plane + a list of non-empty 64-pixel groups (any length); of the flow
+    // LDS of the mask chain kernel: the OR target plane + a list of non-empty 64-pixel groups (any length); of the flow
     // measurement / feature kernels: the plane + their work lists
     const size_t plane = (size_t)(W / 32) * H * 4;
     if (plane + 16384 + 128 > 160 * 1024 - 4096)
@@ -1608,7 +1608,7 @@ int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int
     std::memset(rec0, 0, sizeof(rec0));
     rec0[0].fbuf_n = used;
     HIP_TRY(hipMemcpyAsync(c.arr.mrec.p, rec0, sizeof(rec0), hipMemcpyHostToDevice, c.stream));
-    // the step kernel ORs into a zeroed destination (inside the engine the frame before leaves it zeroed)
+    // the chain kernel ORs into a zeroed destination (inside the engine the frame before leaves it zeroed)
     HIP_TRY(hipMemsetAsync(c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 0), 0, sizeof(uint32_t) * 2 * c.arr.a.plane_words, c.stream));
     if (int rc = upload_ctrl(c, fc)) return rc;
     c.arr.a.mrec_carry = c.arr.mrec.p;   // row 0: rec0[0]

@@ -9,19 +9,20 @@
 //   nz  = raw value != 0  (what cv::findNonZero sees inside the OF-aided source)
 //   obj = raw value  > 1  (what every consumer sees after the threshold)
 // The mask of frame k is the source of frame k+1: the recursion is sequential per object and frame.  Per frame of a
-// batch the chain is [mask_ingest_kernel on frames that deliver masks: u8 -> planes, counts] + mask_step_kernel:
+// batch the chain is mask_ingest_kernel on the frames that deliver masks (u8 -> planes, counts), then ONE launch of
+// mask_chain_kernel that walks the frames:
 //  * binary masks (no pixel of value 1, i.e. nz == obj -- decided on the device at ingest): every source pixel carries
 //    the same value, so the reference's "later writer wins" map + remap is an order-free OR of the target bits.  S
 //    workgroups per object (grid S x n_obj, S * n_obj ~ the CU count) each walk a share of the source's 64-pixel groups,
 //    OR into an LDS plane of their own (W*H/8 bytes, LDS atomics) and flush its non-zero words with global atomicOr into
-//    the destination, which the step kernel of the frame before left zeroed.  No map, no gather; only the obj plane of a
+//    the destination, which the frame before left zeroed.  No map, no gather; only the obj plane of a
 //    binary mask is written and read.
 //  * general masks ({0, 1, 255}): mask_general_kernel, one persistent workgroup per object at the end of the batch,
 //    handles the frames whose source is not binary: the winner among the sources of a target is the one with the LARGEST
 //    linear index = an atomicMax on a W*H int32 map whose zero value doubles as "unmapped -> sample mask(0,0)" exactly
 //    like the zero-initialised cv::Mat map (:237); the gather reads every entry inside the targets' bounding box with
 //    an atomic exchange (read + clear), so the map is never memset and never read through a stale L1 line.
-// The per-frame decisions (mode, source, flow count, binary or not) are made once, by the step kernel, and recorded in
+// The per-frame decisions (mode, source, flow count, binary or not) are made once, by the chain kernel, and recorded in
 // MaskRec rows that carry the state from frame to frame and from batch to batch.
 #include "roft_device.h"
 
