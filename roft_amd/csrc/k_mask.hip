@@ -391,7 +391,9 @@ template <int FT>
 __device__ __noinline__ void propagate_binary(ChaseGeo g, const uint2* plane2, const uint32_t* list, int n_list, int n_flows,
                                               bool clear00, const void* const* flows, uint32_t* s_tgt, const uint2* words)
 {
-    ROFT_LDS uint32_t* const tgt = pin_lds(s_tgt);
+    // (workgroup-uniform LDS address into a scalar register: arguments of a function arrive in vector registers)
+    ROFT_LDS uint32_t* const tgt = (ROFT_LDS uint32_t*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(uint32_t)(uintptr_t)(ROFT_LDS uint32_t*)s_tgt);
     if (n_flows == 1 && words && g.mode != 0) {
         if (g.mode == 2) walk_single<FT, 2>(g, list, words, n_list, clear00, flows[0], tgt);
         else walk_single<FT, 1>(g, list, words, n_list, clear00, flows[0], tgt);
@@ -499,12 +501,19 @@ __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskR
 // together (nq * n_obj <= the CU count, one workgroup fits every CU next to anything else the engine runs), and kernels
 // on the other streams never wait for this one, so the poll cannot starve; a poll that nevertheless lasts two seconds
 // aborts the kernel -- the engine then fails with a launch error instead of hanging the device.
-__device__ __forceinline__ void object_barrier(unsigned* counter, unsigned target)
+// In two halves, so that what a workgroup can do for the next frame without the others' results -- control block,
+// decisions, zeroing -- runs while the arrivals travel: arrive (every thread's stores and atomics acknowledged, one
+// atomic by thread 0) ... wait (thread 0 polls).
+__device__ __forceinline__ void object_arrive(unsigned* counter)
 {
     __builtin_amdgcn_s_waitcnt(0);   // every store / atomic of this thread acknowledged
     __syncthreads();
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void object_wait(unsigned* counter, unsigned target)
+{
     if (threadIdx.x == 0) {
-        (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
@@ -516,7 +525,7 @@ __device__ __forceinline__ void object_barrier(unsigned* counter, unsigned targe
 
 // The binary-mask chain of a batch: ONE launch walks the T frames.  grid: (S, n_obj).  Workgroup q of an object owns
 // the 64-pixel groups q, q + S, ... of the source and the words [q, q+1) * plane_words / S of the planes it copies /
-// fills / zeroes; the S workgroups of an object meet at an object_barrier between two frames (the mask of frame t is
+// fills / zeroes; the S workgroups of an object meet at a barrier in memory (object_arrive / object_wait) between two frames (the mask of frame t is
 // the source of frame t + 1), objects never wait for each other.
 // dynamic LDS: [plane_words] OR target | list of this workgroup's non-empty groups [| their plane words]
 #ifdef ROFT_MASK_PROFILE
@@ -552,24 +561,34 @@ __global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a
     const int u0 = (int)((long long)n_units * q / nq) * unit, u1 = (int)((long long)n_units * (q + 1) / nq) * unit;
     const ChaseGeo geo = make_chase_geo(a.cam, a.ffmt);
     unsigned n_barriers = 0, general = 0u;
-    for (int t = 0; t < a.T; ++t) {
-        // control block and the state records -> LDS with one load per thread
+    // What a frame needs before it can read its source: control block and state records -> LDS with one load per thread,
+    // the decisions, the obj plane of the NEXT frame's slot zeroed for that frame's OR flush (nobody reads that slot
+    // any more: its last user is kPlaneSlots frames back), the LDS plane zeroed.  Runs between the arrival at the
+    // barrier behind the frame before and the wait for the others.
+    auto prologue = [&](int t) -> MaskRec {
         stage_ctrl(&s_c, frame_ctrl(a, t, obj));
         if (tid >= 128 && tid < 132) {
-            const int k = tid - 128;   // 0, 1: the carry (first frame only; later the record decided below); 2, 3: this frame's
+            const int k = tid - 128;   // 0, 1: the carry (first frame only; later the record of the frame before); 2, 3: this frame's
             if (k >= 2)
                 reinterpret_cast<uint4*>(s_rec)[k] = reinterpret_cast<const uint4*>(a.mrec + (size_t)(t + 1) * a.n_obj + obj)[k & 1];
             else if (t == 0)
                 reinterpret_cast<uint4*>(s_rec)[k] = reinterpret_cast<const uint4*>(a.mrec_carry + obj)[k & 1];
         }
+        plane_fill(s_tgt, 0u, a.plane_words);
         __syncthreads();
-        const FrameCtrl& c = s_c;
-        const MaskRec r = decide_frame(s_rec[0], s_rec[1], a.slot_new + t, c, frames_between, flow_aided);
+        const MaskRec r = decide_frame(s_rec[0], s_rec[1], a.slot_new + t, s_c, frames_between, flow_aided);
         MTICK(0);
         if (q == 0 && tid == 0) a.mrec[(size_t)(t + 1) * a.n_obj + obj] = r;   // (every workgroup computes the same record)
-        // the obj plane of the NEXT frame's slot is left zeroed for that frame's OR flush (nobody reads that slot any
-        // more: its last user is kPlaneSlots frames back)
-        plane_fill_coherent(a.planes + plane_offset(a, obj, (c.slot_cur + 1) % kPlaneSlots, 1) + u0, 0u, (size_t)(u1 - u0));
+        plane_fill_coherent(a.planes + plane_offset(a, obj, (s_c.slot_cur + 1) % kPlaneSlots, 1) + u0, 0u, (size_t)(u1 - u0));
+        if (tid < kMaxFlowHist) S.flows[tid] = (tid < r.n_flows) ? s_c.flow[tid] : nullptr;
+        if (tid == 0) S.n_list = 0;
+        __syncthreads();
+        MTICK(1);
+        return r;
+    };
+    MaskRec r = prologue(0);
+    for (int t = 0; t < a.T; ++t) {
+        const FrameCtrl& c = s_c;
         const uint32_t* src = a.planes + plane_offset(a, obj, r.src_slot, 1);
         uint32_t* dst = a.planes + plane_offset(a, obj, c.slot_cur, 1);
         if (!r.src_binary) {
@@ -580,11 +599,6 @@ __global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a
             // mask(0,0) set in a new-mask frame: every target, mapped or not, samples a set pixel
             plane_fill_coherent(dst + u0, ~0u, (size_t)(u1 - u0));
         } else {
-            if (tid < kMaxFlowHist) S.flows[tid] = (tid < r.n_flows) ? c.flow[tid] : nullptr;
-            if (tid == 0) S.n_list = 0;
-            plane_fill(s_tgt, 0u, a.plane_words);
-            __syncthreads();
-            MTICK(1);
             // This workgroup's non-empty 64-pixel groups of the source (g = q + nq i) -> list (any order: the scatter
             // is order-free), then their walks; in chunks of list_cap groups when the LDS next to the plane cannot list
             // the whole share at once (a 1280x720 plane with one workgroup per object).
@@ -634,10 +648,12 @@ __global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a
             if (q == 0 && tid == 0) a.mask_general[obj] = general;
             break;
         }
-        // the next frame reads this frame's planes and ORs into the slot zeroed above
-        if (nq > 1) object_barrier(a.mask_sync + obj, (unsigned)nq * ++n_barriers);
+        // the next frame reads this frame's planes and ORs into the slot zeroed by this frame's prologue
+        if (nq > 1) object_arrive(a.mask_sync + obj);
         else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }   // (one workgroup, one CU: its L1 is written through)
-        if (tid == 0) s_rec[0] = r;   // (the staging barrier of the next frame publishes it)
+        if (tid == 0) s_rec[0] = r;   // (the staging barrier of the prologue publishes it)
+        r = prologue(t + 1);
+        if (nq > 1) object_wait(a.mask_sync + obj, (unsigned)nq * ++n_barriers);
         MTICK(5);
     }
 }
