@@ -188,3 +188,22 @@ def test_shared_scene_host_inputs_are_uploaded_once():
     assert s["h2d_bytes"] < 0.5 * n_obj * n * per_frame
     for p in poses[1:]:
         assert np.array_equal(p, poses[0])
+
+
+def test_mask_chain_result_independent_of_workgroups_per_object():
+    """The mask chain spreads an object over S = (256 - 64) / n_obj workgroups (at most 8, at least 1) that meet at a
+    barrier in memory between frames: 8 objects -> S = 8, 64 -> 3, 200 -> 1 (no barrier).  The same eight streams
+    tracked alone and as the first eight of 64 / 200 objects give the same rows and masks bit for bit."""
+    n = 22
+    base = [util.to_device(clone(util.stream(740 + i, n, scale=2, pose_drop_prob=0.2 if i == 3 else 0.03, device="cuda")))
+            for i in range(8)]
+    ref, ref_masks, _ = util.run_engine_logged(make_engine, base, n, T=8)
+    for n_obj in (64, 200):
+        streams = [base[i % 8] for i in range(n_obj)]
+        got, masks, _ = util.run_engine_logged(make_engine, streams, n, T=8)
+        for x, y in zip(ref, got):
+            assert np.array_equal(x[:, :8], y[:, :8]), n_obj
+            assert np.array_equal(x[:, :8], y[:, n_obj - 8:]), n_obj
+        for o in range(8):
+            assert np.array_equal(ref_masks[o], masks[o]), (n_obj, o)
+            assert np.array_equal(ref_masks[o], masks[n_obj - 8 + o]), (n_obj, o)
