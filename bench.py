@@ -146,6 +146,10 @@ def parse():
     p.add_argument("--host-inputs", action="store_true",
                    help="hand the engine HOST buffers in the main run (PCIe-inclusive rate; never the headline value)")
     p.add_argument("--pcie-frames", type=int, default=12, help="timed frames of the two PCIe-inclusive legs (0: skip them)")
+    p.add_argument("--clock-warm-ms", type=float, default=400.0,
+                   help="milliseconds of unrelated GPU work (a GEMM loop) right before the warm-up steps: the device idles at "
+                        "~520 MHz while the host prepares the batches and needs tens of milliseconds of load to clock up -- a "
+                        "2 ms timed window measured from idle reports the idle clock (0: off)")
     p.add_argument("--no-ramp", action="store_true", help="full batches from the first timed frame on, the short one last")
     p.add_argument("--splits", default="", help="explicit batch sizes of the timed frames, e.g. 2,6,6,6 (must sum to --steps)")
     p.add_argument("--no-kernel-timing", action="store_true",
@@ -285,6 +289,15 @@ def main():
             eng.step()
 
     barrier = parallel.barrier
+    if args.clock_warm_ms > 0:
+        # not tracker work and not timed: brings the device out of its idle power state (see --clock-warm-ms)
+        wa = torch.randn(4096, 4096, device=dev, dtype=torch.float32)
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) * 1e3 < args.clock_warm_ms:
+            for _ in range(8):
+                wa = (wa @ wa).mul_(1.0 / 4096.0)
+            torch.cuda.synchronize()
+        del wa
     run(warm_batches)
     eng.sync()
     torch.cuda.synchronize()

@@ -320,7 +320,7 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
 constexpr int kFusedThreads = 1024;
 // phase stamps (-DROFT_FUSED_PROFILE; PHASES=fused tools/k1_phase_profile.py): 100 MHz ticks -> ObjState::dbg[alt * 8 + phase]
 #ifdef ROFT_FUSED_PROFILE
-#define UTICK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4) { long long _t = wall_clock64(); st.dbg[blockIdx.x * 8 + (i)] += _t - u_t0; u_t0 = _t; } } while (0)
+#define UTICK(i) do { __syncthreads(); if (threadIdx.x == 0 && bx < 4) { long long _t = wall_clock64(); st.dbg[bx * 8 + (i)] += _t - u_t0; u_t0 = _t; } } while (0)
 #else
 #define UTICK(i) do {} while (0)
 #endif
@@ -330,7 +330,13 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double s_err[kFusedThreads / 64], s_cnt[kFusedThreads / 64];
     __shared__ int s_box[4];
-    const int obj = blockIdx.y, alt = blockIdx.x / parts, part = blockIdx.x % parts, tid = threadIdx.x;
+    // Workgroups are handed to the XCDs round robin by their linear index; the 2 x parts workgroups of an object read the
+    // same mesh (186 KB of indices + 98 KB of vertices at the bench's 15.5 k triangles): with the grid laid out as
+    // [group of 8 objects][workgroup of the object][object within the group] they share one XCD and one L2.
+    const int per = 2 * parts, lin_id = (int)blockIdx.x;
+    const int obj = (lin_id / (8 * per)) * 8 + (lin_id & 7), bx = (lin_id >> 3) % per;
+    if (obj >= a.n_obj) return;
+    const int alt = bx / parts, part = bx % parts, tid = threadIdx.x;
     ObjState& st = a.state[obj];
     PoseLane& pl = st.lane[lin];
     if (pl.pending_frame < 0) return;   // no outlier test pending between the pose chain segments
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     if (tid < 4) s_box[tid] = (tid < 2) ? INT32_MAX : -1;
 #ifdef ROFT_FUSED_PROFILE
     long long u_t0 = wall_clock64();
-    if (tid < 8 && blockIdx.x < 4) st.dbg[blockIdx.x * 8 + tid] = 0;
+    if (tid < 8 && bx < 4) st.dbg[bx * 8 + tid] = 0;
 #endif
     __syncthreads();
     // vertices -> screen; pixel bounding box of the triangles that can be drawn (pixel ranges as raster_projected clips
@@ -468,9 +474,9 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
             __syncthreads();   // the next strip clears the window
             UTICK(3);
 #ifdef ROFT_FUSED_PROFILE
-            if (tid == 0 && blockIdx.x < 4) st.dbg[blockIdx.x * 8 + 4] += 1;
-            if (tid == 0 && blockIdx.x < 4) st.dbg[blockIdx.x * 8 + 5] = (long long)win_w * 100 ;
-            if (tid == 0 && blockIdx.x < 4) st.dbg[blockIdx.x * 8 + 6] = (long long)(j1 - j0 + 1) * 100;
+            if (tid == 0 && bx < 4) st.dbg[bx * 8 + 4] += 1;
+            if (tid == 0 && bx < 4) st.dbg[bx * 8 + 5] = (long long)win_w * 100 ;
+            if (tid == 0 && bx < 4) st.dbg[bx * 8 + 6] = (long long)(j1 - j0 + 1) * 100;
 #endif
         }
     }
@@ -509,7 +515,7 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     const size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + parts - 1) / parts + (size_t)a.tile_w);
     const size_t lds = std::min(lds_total, (((cache ? vbytes : 0) + win_need + 15) & ~(size_t)15));
     const int win_cap_lds = (int)((lds - (cache ? vbytes : 0)) / 4);
-    hipExtLaunchKernelGGL(outlier_fused_kernel, dim3(2 * parts, a.n_obj), dim3(kFusedThreads), (uint32_t)lds, s, nullptr, stop, 0, a, lin,
+    hipExtLaunchKernelGGL(outlier_fused_kernel, dim3(2 * parts * ((a.n_obj + 7) / 8) * 8), dim3(kFusedThreads), (uint32_t)lds, s, nullptr, stop, 0, a, lin,
                           vcache_cap, std::min(win_cap, win_cap_lds), parts);
 }
 
