@@ -306,9 +306,6 @@ struct roft_engine {
     int cur_T = 0;
     int n_segments[kNumLin] = {1, 1};     // pose chain segments per lane (1 + outlier tests of the busiest object)
     bool lin_any[kNumLin] = {false, false};   // some object has a frame on the lane in the batch
-    hipEvent_t ev_seg[kBatchRing][kNumLin][kMaxBatch] = {};    // a pose chain segment that ends in an outlier step is complete
-    hipEvent_t ev_test[kBatchRing][kNumLin][kMaxBatch] = {};   // the outlier test behind it (upload stream) is complete
-    int speculate = 2;   // speculative continuation next to the outlier test: 0 never, 1 always, 2 while the pipeline is not full (ROFT_SPECULATE)
     int relabel_wait[kNumLin] = {-1, -1};     // batch of the OTHER lane this lane's launches must follow (slots that changed lanes)
     bool any_feat = false, any_feat_now = false, had_uploads = false;
     unsigned new_mask_frames = 0;   // bit t: some object receives a mask in frame t of the batch
@@ -478,13 +475,7 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects * e->T_max));
         for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
             HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-        for (int l = 0; l < kNumLin; ++l)
-            for (int g = 0; g < kMaxBatch; ++g) {
-                HIP_TRY(hipEventCreateWithFlags(&e->ev_seg[i][l][g], hipEventDisableTiming));
-                HIP_TRY(hipEventCreateWithFlags(&e->ev_test[i][l][g], hipEventDisableTiming));
-            }
     }
-    if (const char* sp = getenv("ROFT_SPECULATE")) e->speculate = (sp[0] == '0') ? 0 : (sp[0] == '1' ? 1 : 2);
     DevFlowFmt ff;
     ff.type = cfg->flow_type;
     ff.grid = cfg->flow_grid;
@@ -562,11 +553,6 @@ int roft_engine_destroy(roft_engine* e)
     for (int i = 0; i < R; ++i) {
         for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
             if (ev) (void)hipEventDestroy(ev);
-        for (int l = 0; l < kNumLin; ++l)
-            for (int g = 0; g < kMaxBatch; ++g) {
-                if (e->ev_seg[i][l][g]) (void)hipEventDestroy(e->ev_seg[i][l][g]);
-                if (e->ev_test[i][l][g]) (void)hipEventDestroy(e->ev_test[i][l][g]);
-            }
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
     }
     release_streams(e->streams);   // (idle: synchronised above)
@@ -1165,38 +1151,13 @@ static int step_batch(roft_engine* e)
             if (want_ev_feat && e->n_segments[lin] > 1) { HIP_TRY(hipStreamWaitEvent(sp, e->ev_feat[slot], 0)); ++evops; }
         }
         tmark(e, nullptr, which);
-        // Speculative continuation: the outlier test goes to the upload stream, and while it renders, the lane walks its
-        // following steps on BOTH alternatives (two workgroups per object); the next segment starts with the decision
-        // and finds the chosen alternative already advanced.  Takes the test (~90-140 us) off the lane's serial chain
-        // at the price of the steps of the alternative that loses.
-        const bool speculate = multi && e->speculate != 0 && (e->speculate == 1 || e->batch_counter - e->completed_batches <= 2);
         for (int seg = 0; seg < e->n_segments[lin]; ++seg) {
             const bool last = seg == e->n_segments[lin] - 1;
-            hipEvent_t ev_seg = (!last && speculate) ? e->ev_seg[slot][lin][seg] : nullptr;
-            launch_ukf_chain(a, e->cfg.ut, seg == 0, lin, sp, (last && !full) ? e->ev_done[slot][lin] : (full ? nullptr : ev_seg));
+            launch_ukf_chain(a, e->cfg.ut, seg == 0, lin, sp, (last && !full) ? e->ev_done[slot][lin] : nullptr);
             ++launches;
             CHECK_LAUNCH("pose chain segment");
             tmark(e, "ukf_chain", which);
-            if (!last && speculate) {
-                hipStream_t so = e->up_stream;
-                hipEvent_t ev_test = e->ev_test[slot][lin][seg];
-                if (full) { HIP_TRY(hipEventRecord(ev_seg, sp)); ++evops; }
-                HIP_TRY(hipStreamWaitEvent(so, ev_seg, 0));
-                ++evops;
-                tmark(e, nullptr, 4);
-                launch_outlier(a, lin, so, full ? nullptr : ev_test);
-                ++launches;
-                CHECK_LAUNCH("outlier rejection");
-                tmark(e, "outlier_render_likelihood", 4);
-                if (full) { HIP_TRY(hipEventRecord(ev_test, so)); ++evops; }
-                launch_ukf_chain(a, e->cfg.ut, false, lin, sp, nullptr, true);
-                ++launches;
-                CHECK_LAUNCH("speculative pose chain segment");
-                tmark(e, "ukf_chain_speculative", which);
-                HIP_TRY(hipStreamWaitEvent(sp, ev_test, 0));
-                ++evops;
-                tmark(e, nullptr, which);
-            } else if (!last) {
+            if (!last) {
                 launch_outlier(a, lin, sp, nullptr);
                 ++launches;
                 CHECK_LAUNCH("outlier rejection");

@@ -342,8 +342,8 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     if (pl.pending_frame < 0) return;   // no outlier test pending between the pose chain segments
     const FrameCtrl& c = frame_ctrl(a, pl.pending_frame, obj);
     const ObjParams& prm = a.params[obj];
-    // (the alternative's pose as the outlier step left it: its belief slot may be moving on already, see PoseLane)
-    const RenderPose P = make_pose(pl.render_mean[alt] + 6, pl.render_mean[alt] + 9);
+    const PoseBelief& bl = st.belief[b_alt(lin, alt)];
+    const RenderPose P = make_pose(bl.mean + 6, bl.mean + 9);
     const int d = a.cam.divider, W = a.cam.W, tw = a.tile_w, th = a.tile_h;
     const float fx = (float)(a.cam.fx / d), fy = (float)(a.cam.fy / d), cx = (float)(a.cam.cx / d), cy = (float)(a.cam.cy / d);
     const int nv = prm.n_verts, nt = prm.n_tris;

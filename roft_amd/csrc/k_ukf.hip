@@ -997,28 +997,14 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
 }
 
 // One launch = one StepDesc per object: optional prediction, then 0, 1 or 2 corrections of it.
-// spec >= 0: the step belongs to the speculative continuation of alternative `spec` -- the lineage's slot is the
-// alternative's (b_alt), its decomposition bases are the continuation's own copies, its output row goes to
-// PoseLane::spec_pose, and nothing else of the lane's state is touched.
-__device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj, int step, const UtTable& ut, UkfLds& L, int spec, int t_frame)
+__device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj, int step, const UtTable& ut, UkfLds& L)
 {
     ObjState& st = a.state[obj];
-    StepDesc sd = c.steps[step];
+    const StepDesc sd = c.steps[step];
     if (!sd.op) return;
     const ObjParams& prm = a.params[obj];
     const int lane = threadIdx.x;
-    const int lin = c.lane;
-    const int cur = spec >= 0 ? b_alt(lin, spec) : c.cur_slot;
-    if (spec >= 0) {
-        if (sd.src == c.cur_slot) sd.src = cur;
-        for (int k = 0; k < 2; ++k) if (sd.dst[k] == c.cur_slot) sd.dst[k] = cur;
-    }
-    double* const warm0 = spec >= 0 ? st.warm_spec[lin][spec][0] : st.warm_V[c.cur_slot][0];
-    double* const warm1 = spec >= 0 ? st.warm_spec[lin][spec][1] : st.warm_V[c.cur_slot][1];
-    int* const age0 = spec >= 0 ? &st.warm_spec_age[lin][spec][0] : &st.warm_age[c.cur_slot][0];
-    int* const age1 = spec >= 0 ? &st.warm_spec_age[lin][spec][1] : &st.warm_age[c.cur_slot][1];
-    roft_object_output* const row = spec >= 0 ? nullptr : log_row(a, c, obj);
-    double* const spec_row = spec >= 0 ? st.lane[lin].spec_pose[spec][t_frame] : nullptr;
+    const int lin = c.lane, cur = c.cur_slot;
 
 #ifdef ROFT_UKF_PROFILE
     if (lane < 32) L.dbg[lane] = 0;
@@ -1038,27 +1024,23 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
 
     TICK(L, 0);
     if (sd.do_predict) {
-        ukf_predict(L, prm, c.dt, ut, warm0, age0, a.ukf_chol_guard);
-        if (spec < 0) {
-            PoseBelief& pr = st.belief[B_PRED + lin];
-            for (int i = lane; i < 144; i += kUkfThreads) pr.cov[i] = L.cov[i];
-            if (lane < 13) pr.mean[lane] = L.mean[lane];
-        }
+        ukf_predict(L, prm, c.dt, ut, st.warm_V[cur][0], &st.warm_age[cur][0], a.ukf_chol_guard);
+        PoseBelief& pr = st.belief[B_PRED + lin];
+        for (int i = lane; i < 144; i += kUkfThreads) pr.cov[i] = L.cov[i];
+        if (lane < 13) pr.mean[lane] = L.mean[lane];
     }
     if (sd.n_corr == 0) {
         PoseBelief& d = st.belief[sd.dst[0]];
         for (int i = lane; i < 144; i += kUkfThreads) d.cov[i] = L.cov[i];
         if (lane < 13) d.mean[lane] = L.mean[lane];
-        if (lane < 13 && sd.dst[0] == cur) {
-            if (row) row->pose[lane] = L.mean[lane];
-            if (spec_row) spec_row[lane] = L.mean[lane];
-        }
+        if (roft_object_output* row = log_row(a, c, obj))
+            if (lane < 13 && sd.dst[0] == cur) row->pose[lane] = L.mean[lane];
         return;
     }
     TICK(L, 6);
     // square root of the predicted covariance, shared by both corrections of an outlier-rejection step
     if (!cholesky_state_sqrt(L, true, c.dt, a.ukf_chol_guard, a.ukf_chol_guard_bil))
-        decompose_state_cov(L, warm1, age1);
+        decompose_state_cov(L, st.warm_V[cur][1], &st.warm_age[cur][1]);
     TICK(L, 7);
     int status = 0;
     for (int k = 0; k < sd.n_corr; ++k) {
@@ -1066,23 +1048,11 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
         status |= rc << (4 * k);
         __syncthreads();
     }
-    if (lane == 0) {
-        if (spec >= 0) st.lane[lin].spec_status[spec] = status;
-        else st.lane[lin].ukf_status = status;
-    }
+    if (lane == 0) st.lane[lin].ukf_status = status;
     // output log: the corrected belief after this frame's last step is what ROFTFilter logs
-    if (row || spec_row) {
+    if (roft_object_output* row = log_row(a, c, obj)) {
         __syncthreads();
-        if (lane < 13) {
-            const double v = st.belief[cur].mean[lane];
-            if (row) row->pose[lane] = v;
-            else spec_row[lane] = v;
-        }
-    }
-    // an outlier-rejection step: the two alternatives' means for the test that follows (and for the frame's row)
-    if (spec < 0 && step == c.outlier_step && sd.n_corr == 2) {
-        __syncthreads();
-        if (lane < 26) st.lane[lin].render_mean[lane / 13][lane % 13] = st.belief[sd.dst[lane / 13]].mean[lane % 13];
+        if (lane < 13) row->pose[lane] = st.belief[cur].mean[lane];
     }
 #ifdef ROFT_UKF_PROFILE
     __syncthreads();
@@ -1100,9 +1070,7 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
 #ifdef UKF_WAVES_PER_EU
 __attribute__((amdgpu_waves_per_eu(UKF_WAVES_PER_EU, UKF_WAVES_PER_EU)))
 #endif
-// grid: (n_obj) -- or (n_obj, 2) for the speculative continuation (spec_mode = 1): workgroup (obj, k) continues alternative k
-// of the pending outlier test in its own slot while the test runs on another stream (PoseLane in roft_device.h).
-__global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, UtTable ut, int first_segment, int lin, int spec_mode)
+__global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, UtTable ut, int first_segment, int lin)
 {
     // static LDS on purpose: with `extern __shared__` the compiler re-reads the dynamic-LDS base address from a
     // table in global memory inside every Jacobi round (two dependent global loads per round)
@@ -1112,30 +1080,33 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
     // kernels of the other chains (mask walks, rasteriser, flow measurement), whose waves compete for the issue slots of
     // the same SIMDs.  Highest wave priority: the chain's next instruction goes first whenever it is ready.
     __builtin_amdgcn_s_setprio(PRIO_UKF);
+#ifdef ROFT_UKF_WALL
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) {
+        s_ticket = atomicAdd(reinterpret_cast<unsigned*>(&a.state[0].dbg[30 + 0]) + lin, 1u);
+        long long* rec = a.state[(s_ticket / a.n_obj) % a.n_obj].dbg + lin * 8;
+        const long long now = wall_clock64();
+        atomicMax(reinterpret_cast<unsigned long long*>(&rec[0]), (unsigned long long)((1ll << 62) - now));
+        atomicMax(reinterpret_cast<unsigned long long*>(&rec[1]), (unsigned long long)now);
+    }
+    __syncthreads();
+#endif
     const int obj = blockIdx.x;
-    const int spec = spec_mode ? (int)blockIdx.y : -1;
     ObjState& st = a.state[obj];
     PoseLane& pl = st.lane[lin];
     int t = first_segment ? 0 : pl.pc_frame, step = first_segment ? 0 : pl.pc_step;
     if (t >= a.T) return;   // (this lane's chain of the batch ended in an earlier segment)
-    if (spec >= 0 && pl.pending_frame < 0) return;   // (no test pending for this object: nothing to speculate on)
     // frames of the batch that belong to this lane (one load per frame, all in flight together)
     if (threadIdx.x == 0) s_mine = 0u;
     __syncthreads();
     if ((int)threadIdx.x < a.T && frame_ctrl(a, threadIdx.x, obj).lane == lin) atomicOr(&s_mine, 1u << threadIdx.x);
     __syncthreads();
     const unsigned mine = s_mine;
-    if (spec < 0 && (mine >> t) == 0u && !(pl.pending_frame >= 0 && !first_segment)) {   // nothing (left) to do for this lane in this batch
+    if ((mine >> t) == 0u) {   // nothing (left) to do for this lane in this batch
         if (threadIdx.x == 0) { pl.pending_frame = -1; pl.pc_frame = a.T; pl.pc_step = 0; }
         return;
     }
-    if (spec >= 0) {
-        // the lineage's decomposition bases as they are now -> this alternative's copies
-        const int cs = frame_ctrl(a, pl.pending_frame, obj).cur_slot;
-        for (int i = threadIdx.x; i < 2 * 144; i += kUkfThreads) (&st.warm_spec[lin][spec][0][0])[i] = (&st.warm_V[cs][0][0])[i];
-        if (threadIdx.x < 2) st.warm_spec_age[lin][spec][threadIdx.x] = st.warm_age[cs][threadIdx.x];
-        __syncthreads();
-    } else if (!first_segment && pl.pending_frame >= 0) {
+    if (!first_segment && pl.pending_frame >= 0) {
         // The outlier test between the segments (outlier_fused_kernel) left the likelihood of both alternatives:
         // pick_best_alternative's decision (ROFTFilter.cpp:581-583) and the chosen belief -> p_corr_belief_ (:670-675)
         const FrameCtrl& pc = frame_ctrl(a, pl.pending_frame, obj);
@@ -1150,32 +1121,14 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
         }
         const double L0 = Lk[0], L1 = Lk[1];
         const int sel = (L0 > 2.0 * L1) ? 1 : 0;
-        // (after a speculative continuation the chosen slot holds the lineage's belief behind the frames it walked)
-        const bool spec_done = pl.spec_done != 0;
-        const unsigned spec_frames = spec_done ? pl.spec_frames : 0u;
-        const int pend = pl.pending_frame;
         const PoseBelief& src = st.belief[b_alt(lin, sel)];
         PoseBelief& dst = st.belief[pc.cur_slot];
         for (int i = threadIdx.x; i < 144; i += kUkfThreads) dst.cov[i] = src.cov[i];
         if (threadIdx.x < 13) dst.mean[threadIdx.x] = src.mean[threadIdx.x];
         roft_object_output* row = log_row(a, pc, obj);
-        if (row && threadIdx.x < 13)
-            row->pose[threadIdx.x] = ((spec_frames >> pend) & 1u) ? pl.spec_pose[sel][pend][threadIdx.x] : pl.render_mean[sel][threadIdx.x];
-        if (spec_done) {
-            for (int f = pend + 1; f < a.T; ++f)
-                if ((spec_frames >> f) & 1u)
-                    if (roft_object_output* r2 = log_row(a, frame_ctrl(a, f, obj), obj))
-                        if (threadIdx.x < 13) r2->pose[threadIdx.x] = pl.spec_pose[sel][f][threadIdx.x];
-            for (int i = threadIdx.x; i < 2 * 144; i += kUkfThreads) (&st.warm_V[pc.cur_slot][0][0])[i] = (&st.warm_spec[lin][sel][0][0])[i];
-            if (threadIdx.x < 2) st.warm_age[pc.cur_slot][threadIdx.x] = st.warm_spec_age[lin][sel][threadIdx.x];
-            t = pl.spec_frame;
-            step = pl.spec_step;
-        }
-        __syncthreads();   // (everybody has read the lane's record)
+        if (row && threadIdx.x < 13) row->pose[threadIdx.x] = src.mean[threadIdx.x];
         if (threadIdx.x == 0) {
-            // (outlier_selected describes the lane's LAST frame: none if the continuation walked frames behind the test's)
-            pl.outlier_selected = (spec_frames >> (pend + 1)) ? -1 : sel;
-            if (spec_done) { pl.ukf_status = pl.spec_status[sel]; pl.spec_done = 0; }
+            pl.outlier_selected = sel;
             if (row) { row->outlier_selected = sel; row->outlier_L[0] = L0; row->outlier_L[1] = L1; }
         }
         __syncthreads();   // the next step of this workgroup reads the chosen belief
@@ -1185,9 +1138,15 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
     if (threadIdx.x < 10) L.wQ[threadIdx.x] = 0.0;
     __syncthreads();
     bool pending = false;
-    unsigned walked = 0u;
     __shared__ FrameCtrl s_c;
     int staged = -1;
+#ifdef ROFT_UKF_WALL   // wall time inside the step loop and steps walked, summed per object (tools/ukf_wall.py)
+    const long long w_t0 = wall_clock64();
+    int w_steps = 0;
+    // per launch of this lane (ticket / n_obj; launches of a lane are serialised): first / last workgroup start, last
+    // end, most and total steps -> dbg[lane * 8 ..] of object (launch % n_obj)
+    long long* w_rec = a.state[(s_ticket / a.n_obj) % a.n_obj].dbg + lin * 8;
+#endif
     while (t < a.T) {
         if (!((mine >> t) & 1u)) { ++t; step = 0; continue; }
         if (staged != t) {   // this frame's control block -> LDS
@@ -1197,33 +1156,41 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
             __syncthreads();
         }
         const FrameCtrl& c = s_c;
-        if (spec < 0 && step == 0 && threadIdx.x == 0) pl.outlier_selected = -1;  // set again by the decision if a test runs
+        if (step == 0 && threadIdx.x == 0) pl.outlier_selected = -1;  // set again by outlier_kernel if it runs
         if (step >= c.n_steps) { ++t; step = 0; continue; }
-        if (spec >= 0 && step == c.outlier_step) break;   // the next test's alternatives are not speculated on
-        if (c.steps[step].op) { ukf_one_step(a, c, obj, step, ut, L, spec, t); walked |= 1u << t; }
+        if (c.steps[step].op) ukf_one_step(a, c, obj, step, ut, L);
+#ifdef ROFT_UKF_WALL
+        ++w_steps;
+#endif
         __syncthreads();   // beliefs written by this step are read by the next one (same workgroup)
         pending = (step == c.outlier_step);
         ++step;
         if (pending) break;
     }
+#ifdef ROFT_UKF_WALL
     if (threadIdx.x == 0) {
-        if (spec >= 0) {
-            if (spec == 0) { pl.spec_frame = t; pl.spec_step = step; pl.spec_frames = walked; pl.spec_done = 1; }
-        } else {
-            pl.pending_frame = pending ? t : -1;
-            pl.pc_frame = t;     // == a.T when the chain of this batch is complete
-            pl.pc_step = step;
-        }
+        const long long w_t1 = wall_clock64();
+        atomicAdd(reinterpret_cast<unsigned long long*>(&st.dbg[28]), (unsigned long long)(w_t1 - w_t0));
+        atomicAdd(reinterpret_cast<unsigned long long*>(&st.dbg[29]), (unsigned long long)w_steps);
+        atomicMax(reinterpret_cast<unsigned long long*>(&w_rec[2]), (unsigned long long)w_t1);
+        atomicMax(reinterpret_cast<unsigned long long*>(&w_rec[3]), (unsigned long long)w_steps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&w_rec[4]), (unsigned long long)w_steps);
+        atomicAdd(reinterpret_cast<unsigned long long*>(&w_rec[5]), 1ull);
+    }
+#endif
+    if (threadIdx.x == 0) {
+        pl.pending_frame = pending ? t : -1;
+        pl.pc_frame = t;     // == a.T when the chain of this batch is complete
+        pl.pc_step = step;
     }
 }
 
-void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, int lin, hipStream_t s, hipEvent_t stop,
-                      bool speculative)
+void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, int lin, hipStream_t s, hipEvent_t stop)
 {
     UtTable tab;
     for (int k = 0; k < 3; ++k) tab.w[k] = ut_weights(18 + 3 * k, ut);
-    hipExtLaunchKernelGGL(ukf_chain_kernel, dim3(a.n_obj, speculative ? 2 : 1), dim3(kUkfThreads), 0, s, nullptr, stop, 0, a, tab,
-                          first_segment ? 1 : 0, lin, speculative ? 1 : 0);
+    hipExtLaunchKernelGGL(ukf_chain_kernel, dim3(a.n_obj), dim3(kUkfThreads), 0, s, nullptr, stop, 0, a, tab,
+                          first_segment ? 1 : 0, lin);
 }
 
 }  // namespace roft

@@ -87,16 +87,6 @@ struct PoseLane {
     int n_parts;           // workgroups per alternative of the last outlier test (outlier_fused_kernel)
     double part_err[2][kMaxOutlierParts];   // their partial sums of |depth - render| and sample counts, per alternative
     double part_cnt[2][kMaxOutlierParts];
-    // Speculative continuation (ukf_chain_kernel, spec = 1): while the outlier test renders the two alternatives, two
-    // workgroups walk the lane's following steps -- one on each alternative, IN its slot b_alt(lane, k) -- up to the next
-    // outlier step; the decision then takes the chosen slot as it is and jumps the cursor.  The test therefore reads the
-    // alternatives' poses from render_mean (as the outlier step left them), not from the slots.
-    double render_mean[2][13];
-    int spec_done;               // set by the continuation, cleared by the decision
-    int spec_frame, spec_step;   // cursor behind the continuation
-    unsigned spec_frames;        // bit t: a speculative step of frame t ran (the frame's output row comes from spec_pose)
-    int spec_status[2];
-    double spec_pose[2][kMaxBatch][13];   // per alternative and frame: p_corr after the frame's last speculative step
 };
 
 struct ObjState {
@@ -111,8 +101,6 @@ struct ObjState {
     // warm start of the covariance eigen-decomposition per lineage slot: [0] prediction input, [1] correction input
     double warm_V[kNumLin][2][144];
     int warm_age[kNumLin][2];  // 0 = no basis yet; a cold start is forced every kWarmRefresh uses
-    double warm_spec[kNumLin][2][2][144];   // [lane][alternative]: the lineage's bases as the speculative continuation leaves them
-    int warm_spec_age[kNumLin][2][2];
     long long dbg[32];     // phase cycle counters of the last ukf_step (ROFT_UKF_PROFILE builds only)
 };
 
@@ -342,8 +330,7 @@ void launch_kf_predict(const double* x, const double* P, const double* qdiag, do
 // Pose chain segment: every object runs its UKF steps from its cursor up to and including its next outlier-rejection
 // step (then launch_outlier and another segment follow) or to the end of the batch.
 // Of every object only the frames of lane `lin` are walked.
-void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, int lin, hipStream_t s, hipEvent_t stop = nullptr,
-                      bool speculative = false);
+void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, int lin, hipStream_t s, hipEvent_t stop = nullptr);
 void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // after the mask chain of the batch
 void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t stop = nullptr);   // render + likelihood + decision of the pending tests of a lineage
 void launch_outlier_only(const EngineArrays& a, hipStream_t s);  // likelihood + decision on filled z-buffers
