@@ -1,11 +1,6 @@
 run() { timeout 200 python bench.py --no-cpu-baseline --pcie-frames 0 --no-kernel-timing "$@" 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), end=' ')"; }
-timeout 600 python -m pytest tests/test_configs_gpu.py -x -q --timeout 300 2>&1 | tail -1
-sleep 15
-echo "after pytest+sleep, no clock warm:"; for i in 1 2 3; do run --steps 20 --warmup 5 --clock-warm-ms 0; done; echo
-sleep 15
-echo "clock warm 400:"; for i in 1 2 3; do run --steps 20 --warmup 5; done; echo
-sleep 15
-echo "clock warm 100:"; for i in 1 2 3; do run --steps 20 --warmup 5 --clock-warm-ms 100; done; echo
-sleep 15
-echo "clock warm 1500:"; for i in 1 2 3; do run --steps 20 --warmup 5 --clock-warm-ms 1500; done; echo
-echo "240 steps warm 0 / 400:"; run --steps 240 --warmup 16 --clock-warm-ms 0; run --steps 240 --warmup 16; echo
+echo "speculate 0 1 2(auto)"
+for a in "--steps 20 --warmup 5" "--steps 60 --warmup 12" "--steps 240 --warmup 16"; do for rep in 1 2 3; do for sp in 0 1 2; do ROFT_SPECULATE=$sp run $a; done; echo; done; done
+for sp in 0 1; do ROFT_SPECULATE=$sp timeout 300 python tools/live_latency.py --out /tmp/ll_$sp.json > /dev/null 2>&1; python -c "
+import json; l=json.load(open('/tmp/ll_$sp.json'))
+print('live speculate=$sp', {k:(round(v['median_us']), round(v['median_us_pose_frames'])) for k,v in l.items() if isinstance(v,dict)})"; done
