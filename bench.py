@@ -291,13 +291,18 @@ def main():
     barrier = parallel.barrier
     if args.clock_warm_ms > 0:
         # not tracker work and not timed: brings the device out of its idle power state (see --clock-warm-ms)
+        # (a GEMM for the shader clock, large copies for the memory / fabric clocks: the tracker's kernels are bound by
+        #  memory latency)
         wa = torch.randn(4096, 4096, device=dev, dtype=torch.float32)
+        wb = torch.empty(256 << 20, device=dev, dtype=torch.uint8)
+        wc = torch.empty_like(wb)
         t_w = time.perf_counter()
         while (time.perf_counter() - t_w) * 1e3 < args.clock_warm_ms:
-            for _ in range(8):
+            for _ in range(4):
                 wa = (wa @ wa).mul_(1.0 / 4096.0)
+                wc.copy_(wb)
             torch.cuda.synchronize()
-        del wa
+        del wa, wb, wc
     run(warm_batches)
     eng.sync()
     torch.cuda.synchronize()
