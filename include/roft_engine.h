@@ -184,7 +184,7 @@ typedef struct {
      * and falls back to the eigen-decomposition otherwise:
      *   prediction:  max var(theta) + T^2 max var(omega) <= ukf_cholesky_guard
      *   correction:  max var(theta) <= ukf_cholesky_guard  and  max var(omega) max var(x) <= ukf_cholesky_guard_bilinear
-     * Measured effect on the trajectories at the defaults (2e-4, 4e-3): <= 1e-10 (m, m/s, rad/s), DESIGN.md.
+     * Measured effect on the trajectories at the defaults (4e-4, 8e-3): <= 1e-10 (m, m/s, rad/s), DESIGN.md.
      * ukf_cholesky_guard = 0: always the eigen-decomposition; ukf_cholesky_guard_bilinear = 0: always for the
      * correction. */
     double ukf_cholesky_guard;

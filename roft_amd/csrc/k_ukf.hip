@@ -1158,8 +1158,18 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
         const FrameCtrl& c = s_c;
         if (step == 0 && threadIdx.x == 0) pl.outlier_selected = -1;  // set again by outlier_kernel if it runs
         if (step >= c.n_steps) { ++t; step = 0; continue; }
+#ifdef ROFT_UKF_WALL
+        const long long w_s0 = wall_clock64();
+#endif
         if (c.steps[step].op) ukf_one_step(a, c, obj, step, ut, L);
 #ifdef ROFT_UKF_WALL
+        if (threadIdx.x == 0 && w_steps > 0) {   // histogram of step durations (not the first step of a launch: cold)
+            const long long d = wall_clock64() - w_s0;
+            const int bin = d < 1800 ? 0 : (d < 2200 ? 1 : (d < 3000 ? 2 : 3));
+            atomicAdd(reinterpret_cast<unsigned long long*>(&st.dbg[20 + bin]), 1ull);
+            if (bin == 3) atomicAdd(reinterpret_cast<unsigned long long*>(&st.dbg[24]), (unsigned long long)d);
+            if (bin == 3) atomicAdd(reinterpret_cast<unsigned long long*>(&st.dbg[25]), (unsigned long long)(c.steps[step].n_corr * 100 + c.steps[step].type[0]));
+        }
         ++w_steps;
 #endif
         __syncthreads();   // beliefs written by this step are read by the next one (same workgroup)
@@ -1176,6 +1186,8 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
         atomicMax(reinterpret_cast<unsigned long long*>(&w_rec[3]), (unsigned long long)w_steps);
         atomicAdd(reinterpret_cast<unsigned long long*>(&w_rec[4]), (unsigned long long)w_steps);
         atomicAdd(reinterpret_cast<unsigned long long*>(&w_rec[5]), 1ull);
+        if (w_steps > 0) atomicMax(reinterpret_cast<unsigned long long*>(&w_rec[6]), (unsigned long long)((w_t1 - w_t0) / w_steps));
+        if (w_steps > 0) atomicMax(reinterpret_cast<unsigned long long*>(&w_rec[7]), (unsigned long long)(w_t1 - w_t0));
     }
 #endif
     if (threadIdx.x == 0) {

@@ -48,15 +48,19 @@ for mode in ("pipelined", "one batch at a time"):
         L.lib().roft_debug_get_dbg(eng._h, o, buf)
         tot += buf[28]
         steps += buf[29]
+        hb = globals().setdefault("hist_acc", [0, 0, 0, 0, 0, 0])
+        for i in range(6): hb[i] += buf[20 + i]
         for lane in range(2):
-            r = [buf[lane * 8 + i] for i in range(6)]
+            r = [buf[lane * 8 + i] for i in range(8)]
             if r[5]:
                 first = (1 << 62) - r[0]
-                recs.append((first, lane, (r[1] - first) / 100.0, (r[2] - first) / 100.0, r[3], r[4] / max(r[5], 1), r[5]))
+                recs.append((first, lane, (r[1] - first) / 100.0, (r[2] - first) / 100.0, r[3], r[4] / max(r[5], 1), r[5], r[6] / 100.0, r[7] / 100.0))
     recs.sort()
-    for first, lane, skew, dur, smax, smean, nwg in recs[:48]:
-        print("  lane %d  t %9.1f  last workgroup starts +%6.1f us, launch lasts %6.1f us, steps max %2d mean %5.2f, %d workgroups walked" % (
-            lane, (first - recs[0][0]) / 100.0, skew, dur, smax, smean, nwg))
+    for first, lane, skew, dur, smax, smean, nwg, ps_max, wg_max in recs[:48]:
+        print("  lane %d  t %9.1f  last workgroup starts +%6.1f us, launch lasts %6.1f us, steps max %2d mean %5.2f, %d workgroups walked; slowest workgroup %.1f us, slowest us/step %.1f" % (
+            lane, (first - recs[0][0]) / 100.0, skew, dur, smax, smean, nwg, wg_max, ps_max))
     print("%-20s %.1f us per frame; %d steps (%.2f per object-frame), %.2f us wall per step inside the kernel" % (
         mode, 1e6 * dt / n, steps, steps / (n * n_obj), tot / 100.0 / max(steps, 1)))
+    hb = globals().pop("hist_acc")
+    print("   steps (not the first of a launch) < 18 us: %d, 18-22: %d, 22-30: %d, > 30: %d (mean %.1f us; sum of n_corr*100+type: %d)" % (hb[0], hb[1], hb[2], hb[3], hb[4] / 100.0 / max(hb[3], 1), hb[5]))
     eng.close()
