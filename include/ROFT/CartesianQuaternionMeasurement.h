@@ -38,10 +38,9 @@ public:
                                    const bool enable_log)
         : pose_measurement_(std::move(pose_measurement)), velocity_measurement_(std::move(velocity_measurement)),
           camera_measurement_(std::move(camera_measurement)), segmentation_measurement_(std::move(segmentation_measurement)),
-          use_pose_measurement_(use_pose_measurement), use_velocity_measurement_(use_velocity_measurement)
+          use_pose_measurement_(use_pose_measurement), use_velocity_measurement_(use_velocity_measurement), enable_log_(enable_log)
     {
         (void)wait_source_initialization;
-        (void)enable_log;
         if (use_screw_velocity) throw std::runtime_error(log_name_ + "::ctor. Error: the screw form of the velocity is not supported (ROFTFilter.cpp:157 uses the origin form).");
         if (use_pose_measurement_ && !pose_measurement_) throw std::runtime_error(log_name_ + "::ctor. Error: null pose source.");
         if (use_velocity_measurement_ && !velocity_measurement_) throw std::runtime_error(log_name_ + "::ctor. Error: null velocity source.");
@@ -96,6 +95,7 @@ public:
             else if (pose_frames_between_iterations_ < 0 && pose_measurement_->transform_received())
                 while (buffer_velocities_.size() > 1) buffer_velocities_.pop_front();   // invalid pose, unknown rate (cpp:251-258)
         }
+        bool valid_freeze = true;
         if (is_first_velocity_in_ && is_pose_) {
             set_type(ROFT_MEAS_POSE_VELOCITY);
             buffer_velocities_.push_back(last_twist_);
@@ -106,9 +106,20 @@ public:
             set_type(ROFT_MEAS_POSE);
         } else {
             set_type(ROFT_MEAS_NONE);
-            return false;
+            valid_freeze = false;
         }
-        return true;
+        if (enable_log_) {
+            // `pose_measurements` = last received pose as x, axis, angle; `velocity_measurements` = v_O, w (cpp:332-345)
+            Eigen::VectorXd pose_vector(7), velocity_vector(6);
+            const double* q = last_pose_.quaternion();
+            const double n = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]), sgn = q[0] < 0.0 ? -1.0 : 1.0;
+            for (int i = 0; i < 3; ++i) pose_vector(i) = last_pose_.translation()[i];
+            for (int i = 0; i < 3; ++i) pose_vector(3 + i) = n > 0.0 ? sgn * q[1 + i] / n : (i == 0 ? 1.0 : 0.0);   // Eigen::AngleAxisd(Quaterniond)
+            pose_vector(6) = 2.0 * std::atan2(n, std::fabs(q[0]));
+            for (int i = 0; i < 6; ++i) velocity_vector(i) = last_twist_.v[i];
+            logger(pose_vector.transpose(), velocity_vector.transpose());
+        }
+        return valid_freeze;
     }
     std::pair<bool, bfl::Data> measure(const bfl::Data& = bfl::Data()) const override
     {
@@ -204,6 +215,13 @@ public:
     }
     std::size_t buffered_velocities() const { return buffer_velocities_.size(); }
 
+protected:
+    // bfl::Logger: enable_log(path, prefix) opens these two files (cpp:535-539)
+    std::vector<std::string> log_file_names(const std::string& prefix_path, const std::string& prefix_name) override
+    {
+        return {prefix_path + "/" + prefix_name + "pose_measurements", prefix_path + "/" + prefix_name + "velocity_measurements"};
+    }
+
 private:
     struct Twist { double v[6]; };
     Twist current_twist() const
@@ -256,7 +274,7 @@ private:
     std::shared_ptr<RobotsIO::Utils::SpatialVelocity> velocity_measurement_;
     std::shared_ptr<ROFT::CameraMeasurement> camera_measurement_;
     std::shared_ptr<ROFT::ImageSegmentationMeasurement> segmentation_measurement_;
-    const bool use_pose_measurement_, use_velocity_measurement_;
+    const bool use_pose_measurement_, use_velocity_measurement_, enable_log_;
     int pose_frames_between_iterations_ = -1;
     double r_velocity_[6], r_pose_[6];
     Eigen::MatrixXd measurement_;

@@ -1,7 +1,7 @@
 // Compat.h -- stand-ins for the third-party types the reference's filter classes are written against: Eigen (dense
 // matrices, Ref, Transform), BayesFilters (bfl::Data, VectorDescription, Gaussian, the model / prediction / correction
-// base classes, KFPrediction, UKFPrediction, FilteringAlgorithm), OpenCV (cv::Mat as an image buffer) and RobotsIO (camera
-// parameters, the Segmentation / Transform / SpatialVelocity source interfaces).  None of them is installed where this
+// base classes, KFPrediction, UKFPrediction, Logger, FilteringAlgorithm), OpenCV (cv::Mat as an image buffer) and RobotsIO
+// (camera parameters, the Segmentation / Transform / SpatialVelocity source interfaces, Probe / ProbeContainer / ImageFileProbe).  None of them is installed where this
 // repository is built; the facade classes of include/ROFT/ keep the reference's class names, constructor signatures and
 // virtuals over these types, and a maintainer integrating into the real ROFT tree drops this file (define
 // ROFT_HAVE_REAL_DEPENDENCIES and include the real headers first): the facades only use the members declared here.
@@ -14,12 +14,17 @@
 #include <cmath>
 #include <cstddef>
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <deque>
+#include <fstream>
 #include <memory>
+#include <ostream>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -51,6 +56,13 @@ public:
     const S& operator()(std::size_t i, std::size_t j = 0) const { return d_[i * c_ + j]; }
     S* data() { return d_.data(); }
     const S* data() const { return d_.data(); }
+    DenseMatrix transpose() const
+    {
+        DenseMatrix m(c_, r_);
+        for (std::size_t i = 0; i < r_; ++i)
+            for (std::size_t j = 0; j < c_; ++j) m(j, i) = (*this)(i, j);
+        return m;
+    }
     // diag(v) of a vector, as `v.asDiagonal()` is used in the reference's constructors
     DenseMatrix asDiagonal() const
     {
@@ -63,6 +75,32 @@ private:
     std::size_t r_ = 0, c_ = 0;
     std::vector<S> d_;
 };
+// `stream << matrix` with Eigen's default IOFormat: the stream's precision, coefficients separated by one space and padded
+// to the width of the widest one, rows by a newline -- what bfl::Logger writes into the reference's log files
+template <class S>
+std::ostream& operator<<(std::ostream& os, const DenseMatrix<S>& m)
+{
+    std::vector<std::string> cell(m.size());
+    std::size_t width = 0;
+    for (std::size_t i = 0; i < m.rows(); ++i)
+        for (std::size_t j = 0; j < m.cols(); ++j) {
+            std::ostringstream ss;
+            ss.copyfmt(os);
+            ss.width(0);
+            ss << m(i, j);
+            cell[i * m.cols() + j] = ss.str();
+            width = std::max(width, cell[i * m.cols() + j].size());
+        }
+    for (std::size_t i = 0; i < m.rows(); ++i) {
+        if (i) os << "\n";
+        for (std::size_t j = 0; j < m.cols(); ++j) {
+            if (j) os << " ";
+            const std::string& c = cell[i * m.cols() + j];
+            os << std::string(width - c.size(), ' ') << c;
+        }
+    }
+    return os;
+}
 using MatrixXd = DenseMatrix<double>;
 using VectorXd = DenseMatrix<double>;   // n x 1
 using MatrixXf = DenseMatrix<float>;    // depth images: (v, u)
@@ -91,6 +129,7 @@ private:
 // ---- OpenCV ---------------------------------------------------------------------------------------------------
 #ifndef CV_8UC1
 #define CV_8UC1 0
+#define CV_8UC3 16
 #define CV_16SC2 11
 #define CV_32FC2 13
 #endif
@@ -123,7 +162,7 @@ public:
     unsigned char* data = nullptr;
 
 private:
-    static std::size_t elem(int type) { return type == CV_32FC2 ? 8 : (type == CV_16SC2 ? 4 : 1); }
+    static std::size_t elem(int type) { return type == CV_32FC2 ? 8 : (type == CV_16SC2 ? 4 : (type == CV_8UC3 ? 3 : 1)); }
     int type_ = CV_8UC1;
     std::shared_ptr<std::vector<unsigned char>> buf_;
 };
@@ -231,6 +270,128 @@ private:
     double v_[3] = {0, 0, 0}, w_[3] = {0, 0, 0};
 };
 
+// RobotsIO::Utils::Probe / ProbeContainer (robots-io, src/RobotsIO/include/RobotsIO/Utils/{Probe,ProbeContainer}.h): named
+// sinks a filter hands its outputs to -- ROFTFilter offers output_pose, output_velocity, output_segmentation and
+// output_segmentation_refined (ROFTFilter.cpp:396-451), ROFT-tracker attaches image file probes to the last two
+// (src/roft/src/main.cpp:403-417)
+using Data = std::any;
+
+class Probe {
+public:
+    virtual ~Probe() = default;
+    void set_data(const Data& data)
+    {
+        data_ = data;
+        on_new_data();
+    }
+
+protected:
+    virtual void on_new_data() = 0;
+    Data get_data() { return data_; }
+
+private:
+    Data data_;
+};
+
+class ProbeContainer {
+public:
+    virtual ~ProbeContainer() = default;
+    bool set_probe(const std::string& name, std::unique_ptr<Probe> probe)
+    {
+        probes_[name] = std::move(probe);
+        return true;
+    }
+    Probe& get_probe(const std::string& name) const { return *(probes_.at(name)); }
+    bool is_probe(const std::string& name) const { return probes_.find(name) != probes_.end(); }
+
+protected:
+    std::unordered_map<std::string, std::unique_ptr<Probe>> probes_;
+};
+
+// 8-bit gray or BGR image -> PNG with stored (uncompressed) deflate blocks: enough for the debug images of the probes,
+// no zlib needed
+inline bool write_png(const std::string& path, const cv::Mat& img)
+{
+    const int ch = img.type() == CV_8UC3 ? 3 : (img.type() == CV_8UC1 ? 1 : 0);
+    if (!ch || img.empty()) return false;
+    static std::uint32_t crc_table[256];
+    static bool have_table = false;
+    if (!have_table) {
+        for (std::uint32_t n = 0; n < 256; ++n) {
+            std::uint32_t c = n;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crc_table[n] = c;
+        }
+        have_table = true;
+    }
+    auto be32 = [](std::vector<unsigned char>& v, std::uint32_t x) { for (int s = 24; s >= 0; s -= 8) v.push_back((unsigned char)(x >> s)); };
+    std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    auto chunk = [&](const char* tag, const std::vector<unsigned char>& body) {
+        be32(out, (std::uint32_t)body.size());
+        std::uint32_t c = 0xFFFFFFFFu;
+        auto upd = [&](unsigned char b) { c = crc_table[(c ^ b) & 0xFF] ^ (c >> 8); };
+        for (int i = 0; i < 4; ++i) { out.push_back((unsigned char)tag[i]); upd((unsigned char)tag[i]); }
+        for (unsigned char b : body) { out.push_back(b); upd(b); }
+        be32(out, c ^ 0xFFFFFFFFu);
+    };
+    std::vector<unsigned char> hdr;
+    be32(hdr, (std::uint32_t)img.cols);
+    be32(hdr, (std::uint32_t)img.rows);
+    hdr.insert(hdr.end(), {8, (unsigned char)(ch == 3 ? 2 : 0), 0, 0, 0});
+    chunk("IHDR", hdr);
+    // raw scanlines: filter byte 0 + the row (BGR -> RGB)
+    std::vector<unsigned char> raw;
+    raw.reserve((std::size_t)img.rows * (img.cols * ch + 1));
+    for (int r = 0; r < img.rows; ++r) {
+        raw.push_back(0);
+        const unsigned char* row = img.data + (std::size_t)r * img.cols * ch;
+        for (int c = 0; c < img.cols; ++c)
+            for (int k = 0; k < ch; ++k) raw.push_back(row[c * ch + (ch == 3 ? 2 - k : k)]);
+    }
+    std::vector<unsigned char> z = {0x78, 0x01};
+    std::uint32_t a = 1, b = 0;
+    for (std::size_t off = 0; off < raw.size();) {
+        const std::size_t n = std::min<std::size_t>(65535, raw.size() - off);
+        z.push_back(off + n >= raw.size() ? 1 : 0);
+        z.push_back((unsigned char)(n & 0xFF)); z.push_back((unsigned char)(n >> 8));
+        z.push_back((unsigned char)(~n & 0xFF)); z.push_back((unsigned char)((~n >> 8) & 0xFF));
+        for (std::size_t i = 0; i < n; ++i) { z.push_back(raw[off + i]); a = (a + raw[off + i]) % 65521u; b = (b + a) % 65521u; }
+        off += n;
+    }
+    be32(z, (b << 16) | a);
+    chunk("IDAT", z);
+    chunk("IEND", {});
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    f.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)out.size());
+    return (bool)f;
+}
+
+// RobotsIO::Utils::ImageFileProbe: one image file per set_data(cv::Mat), <path>/<prefix_><counter>.<format>
+// (only "png" is written here: 8-bit gray or BGR)
+class ImageFileProbe : public Probe {
+public:
+    ImageFileProbe(const std::string& output_path, const std::string& prefix, const std::string& output_format)
+        : output_prefix_(output_path), output_format_(output_format)
+    {
+        if (!output_prefix_.empty() && output_prefix_.back() != '/') output_prefix_ += '/';
+        if (!prefix.empty()) output_prefix_ += prefix + "_";
+    }
+
+protected:
+    void on_new_data() override
+    {
+        const cv::Mat img = std::any_cast<cv::Mat>(get_data());
+        if (!write_png(output_prefix_ + std::to_string(frame_counter_) + "." + output_format_, img))
+            throw std::runtime_error("ImageFileProbe::on_new_data. Error: cannot write " + output_prefix_ + std::to_string(frame_counter_));
+        frame_counter_++;
+    }
+
+private:
+    std::string output_prefix_, output_format_;
+    std::size_t frame_counter_ = 0;
+};
+
 }  // namespace Utils
 }  // namespace RobotsIO
 
@@ -286,7 +447,56 @@ private:
 };
 using GaussianMixture = Gaussian;  // the reference only ever uses one component (SKFCorrection.cpp:39)
 
-class MeasurementModel {
+// bfl::Logger (bayes-filters-lib, src/BayesFilters/include/BayesFilters/Logger.h): enable_log(folder, prefix) opens one
+// text file per name of log_file_names(), `<name>.txt`, appending; logger(a, b, ...) writes its i-th argument and a
+// newline to the i-th file.  Base class of the measurement models and of FilteringAlgorithm.
+class Logger {
+public:
+    virtual ~Logger() = default;
+    bool enable_log(const std::string& folder_path, const std::string& file_name_prefix)
+    {
+        if (log_enabled_) return false;
+        folder_path_ = folder_path;
+        if (!folder_path_.empty() && folder_path_.back() == '/') folder_path_.pop_back();
+        file_name_prefix_ = file_name_prefix;
+        file_names_ = log_file_names(folder_path_, file_name_prefix_);
+        log_files_.clear();
+        for (const std::string& name : file_names_) {
+            log_files_.emplace_back(name + ".txt", std::ofstream::out | std::ofstream::app);
+            if (!log_files_.back().is_open()) { log_files_.clear(); return false; }
+        }
+        log_enabled_ = true;
+        return true;
+    }
+    bool disable_log()
+    {
+        if (!log_enabled_) return false;
+        log_files_.clear();
+        log_enabled_ = false;
+        return true;
+    }
+    std::string get_folder_path() const { return folder_path_; }
+    std::string get_file_name_prefix() const { return file_name_prefix_; }
+    template <class... Data>
+    void logger(const Data&... data)
+    {
+        if (!log_enabled_) return;
+        std::size_t i = 0;
+        ((i < log_files_.size() ? void(log_files_[i] << data << std::endl) : void(0), ++i), ...);
+    }
+
+protected:
+    virtual std::vector<std::string> log_file_names(const std::string& /*folder_path*/, const std::string& /*file_name_prefix*/) { return {}; }
+    virtual void log() {}
+
+private:
+    std::string folder_path_, file_name_prefix_;
+    std::vector<std::string> file_names_;
+    std::vector<std::ofstream> log_files_;
+    bool log_enabled_ = false;
+};
+
+class MeasurementModel : public Logger {
 public:
     virtual ~MeasurementModel() = default;
     virtual bool freeze(const Data& data = Data()) = 0;
@@ -356,7 +566,7 @@ protected:
 
 // the filter loop of bfl::FilteringAlgorithm, run on the calling thread: boot() arms it, run() executes
 // initialization_step() and then filtering_step() while run_condition() holds, wait() returns when it is over
-class FilteringAlgorithm {
+class FilteringAlgorithm : public Logger {
 public:
     virtual ~FilteringAlgorithm() = default;
     bool boot() { booted_ = true; return true; }

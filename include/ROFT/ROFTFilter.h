@@ -4,6 +4,11 @@
 // filtering_step() polls the sources as the reference does and hands the frame to a one-object engine of the C ABI
 // (roft_frame_submit / roft_step, include/roft_engine.h), which runs the velocity stage, the flow-aided segmentation,
 // the pose stage with re-sync and the outlier test on the GPU.  Many objects at once: ROFT::ROFTFilterBatch (Filters.h).
+// Logging and probes as the reference has them: enable_log(path, prefix) (bfl::Logger) writes `pose_estimate`,
+// `velocity_estimate` and `execution_times` (cpp:247-252, 386-394, 448-451) and -- the measurement model's own log,
+// CartesianQuaternionMeasurement.cpp:332-345, 535-539 -- `pose_measurements` and `velocity_measurements`; the probes
+// output_pose, output_velocity, output_segmentation and output_segmentation_refined (RobotsIO::Utils::ProbeContainer,
+// cpp:396-446) are served when set, so the tail of src/roft/src/main.cpp:393-424 compiles against this class as it is.
 #pragma once
 
 #include <chrono>
@@ -47,7 +52,7 @@ inline void load_obj_mesh(const std::string& path, std::vector<float>& verts, st
     if (verts.empty() || tris.empty()) throw std::runtime_error("load_obj_mesh: no geometry in " + path);
 }
 
-class ROFTFilter : public bfl::FilteringAlgorithm {
+class ROFTFilter : public bfl::FilteringAlgorithm, public RobotsIO::Utils::ProbeContainer {
 public:
     ROFTFilter(std::shared_ptr<ROFT::CameraMeasurement> camera_measurement, std::shared_ptr<RobotsIO::Utils::Segmentation> segmentation_source,
                std::shared_ptr<ROFT::ImageOpticalFlowSource> flow_source, std::shared_ptr<RobotsIO::Utils::Transform> pose_measurement,
@@ -62,7 +67,7 @@ public:
                const std::string& log_path, const std::string& log_prefix)
         : p_corr_belief_(9, 1, true), v_corr_belief_(6, 0, false), camera_(std::move(camera_measurement)),
           segmentation_source_(std::move(segmentation_source)), flow_source_(std::move(flow_source)), pose_measurement_(std::move(pose_measurement)),
-          sample_time_(sample_time), enable_log_(enable_log), log_path_(log_path), log_prefix_(log_prefix)
+          sample_time_(sample_time)
     {
         (void)pose_outlier_rejection_gain;   // a bool in the reference as well: the gain is 1 (ROFTFilter.h:64)
         if (!camera_ || !segmentation_source_ || !flow_source_) throw std::runtime_error(log_name_ + "::ctor. Error: null source.");
@@ -113,6 +118,9 @@ public:
         else if (cfg_.outlier_rejection && cfg_.use_pose)
             throw std::runtime_error(log_name_ + "::ctor. Error: outlier rejection renders the object: ModelParameters::mesh_external_path is empty.");
         obj_.mesh = roft_mesh{verts_.data(), (int)(verts_.size() / 3), tris_.data(), (int)(tris_.size() / 3)};
+        // the measurement model of the pose filter logs what it was fed (cpp:157-160: constructed with enable_log and
+        // enabled right away; the filter's own log waits for enable_log(), src/roft/src/main.cpp:418-419)
+        if (enable_log) measurement_log_.enable_log(log_path, log_prefix);
     }
 
     virtual ~ROFTFilter() { if (engine_) roft_engine_destroy(engine_); }
@@ -140,6 +148,17 @@ public:
     }
     bool skip(const std::string&, const bool) override { return false; }
 
+    // pose (x, axis, angle) of a unit quaternion (w, x, y, z) as Eigen::AngleAxisd(Quaterniond) returns it (cpp:389-394):
+    // angle = 2 atan2(|vec|, |w|) in [0, pi], axis = vec / |vec| with the sign of w, (1, 0, 0) for the identity
+    static void axis_angle(const double q[4], double axis[3], double& angle)
+    {
+        const double n = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        axis[0] = 1.0; axis[1] = axis[2] = 0.0;
+        const double sgn = q[0] < 0.0 ? -1.0 : 1.0;
+        if (n > 0.0) for (int i = 0; i < 3; ++i) axis[i] = sgn * q[1 + i] / n;
+        angle = 2.0 * std::atan2(n, std::fabs(q[0]));
+    }
+
     const bfl::Gaussian& pose_belief() const { return p_corr_belief_; }         // mean: v w x q(w x y z)
     const bfl::Gaussian& velocity_belief() const { return v_corr_belief_; }     // mean: v_O w
     const roft_object_output& last_output() const { return out_; }
@@ -148,12 +167,23 @@ public:
     void step() { filtering_step(); }
 
 protected:
+    std::vector<std::string> log_file_names(const std::string& prefix_path, const std::string& prefix_name) override
+    {
+        return {prefix_path + "/" + prefix_name + "pose_estimate", prefix_path + "/" + prefix_name + "velocity_estimate",
+                prefix_path + "/" + prefix_name + "execution_times"};
+    }
+
     void filtering_step() override
     {
+        using clock = std::chrono::steady_clock;
+        auto ms_since = [](clock::time_point t0) { return (double)std::chrono::duration_cast<std::chrono::milliseconds>(clock::now() - t0).count(); };
+        const auto time0 = clock::now();
         if (!camera_->freeze(CameraMeasurementType::RGBD)) {   // cannot continue without a continuous depth stream (cpp:261-266)
             teardown();
             return;
         }
+        const double rgbd_load_time = ms_since(time0);
+        const auto std_time_0 = clock::now();   // start_time_count(): the RGB-D loading time is excluded (cpp:267-270)
         bool valid = false;
         bfl::Data cam_data;
         std::tie(valid, cam_data) = camera_->measure();
@@ -174,6 +204,7 @@ protected:
         cv::Mat mask;
         std::tie(new_mask, mask) = segmentation_source_->segmentation(false);
         mask_received_ = mask_received_ || new_mask;
+        if (new_mask) last_mask_ = mask.clone();
         if (!mask_received_) return;   // the segmentation is not available yet: nothing to filter (cpp:291)
 
         roft_frame_input in{};
@@ -183,10 +214,10 @@ protected:
         in.mask = new_mask ? mask.data : nullptr;
         in.mem_kind = ROFT_MEM_HOST;
         if (cfg_.use_pose && pose_measurement_->freeze(false)) {
-            const auto T = pose_measurement_->transform();
+            last_pose_ = pose_measurement_->transform();
             in.pose_valid = 1;
-            for (int i = 0; i < 3; ++i) in.pose_x[i] = T.translation()[i];
-            for (int i = 0; i < 4; ++i) in.pose_q[i] = T.quaternion()[i];
+            for (int i = 0; i < 3; ++i) in.pose_x[i] = last_pose_.translation()[i];
+            for (int i = 0; i < 4; ++i) in.pose_q[i] = last_pose_.quaternion()[i];
         }
         compat::throw_if(roft_frame_submit(engine_, &in, 1), "ROFTFilter::filtering_step");
         compat::throw_if(roft_step(engine_), "ROFTFilter::filtering_step");
@@ -194,23 +225,88 @@ protected:
                                         v_corr_belief_.covariance().data()), "ROFTFilter::filtering_step");
         compat::throw_if(roft_get_outputs(engine_, &out_, 1), "ROFTFilter::filtering_step");
         ++frames_;
-        if (enable_log_) log_row();
+        // stop_time_count(): what follows is "for debugging purposes only" (cpp:369-384); the time the sources spent
+        // loading data from disk is taken out of the execution time and reported next to the RGB-D loading time
+        double exec_time = ms_since(std_time_0);
+        const double load_time = flow_source_->get_data_loading_time() + segmentation_source_->get_data_loading_time();
+        segmentation_source_->reset_data_loading_time();
+        exec_time -= load_time;
+
+        // `pose_estimate` = v w x axis angle, `velocity_estimate` = v_O w, `execution_times` (cpp:386-394, 448-451)
+        Eigen::VectorXd p_mean(13), v_mean(6), execution_time(2);
+        for (int i = 0; i < 9; ++i) p_mean(i) = p_corr_belief_.mean(i);
+        double axis[3], angle;
+        axis_angle(p_corr_belief_.mean().data() + 9, axis, angle);
+        for (int i = 0; i < 3; ++i) p_mean(9 + i) = axis[i];
+        p_mean(12) = angle;
+        for (int i = 0; i < 6; ++i) v_mean(i) = v_corr_belief_.mean(i);
+        if (is_probe("output_pose")) {
+            Eigen::VectorXd pose(7);
+            for (int i = 0; i < 7; ++i) pose(i) = p_mean(6 + i);
+            get_probe("output_pose").set_data(pose);
+        }
+        if (is_probe("output_velocity")) get_probe("output_velocity").set_data(v_mean);
+        if (is_probe("output_segmentation") && is_probe("output_segmentation_refined")) probe_segmentation(cam_data);
+        execution_time(0) = exec_time;
+        execution_time(1) = load_time + rgbd_load_time;
+        logger(p_mean.transpose(), v_mean.transpose(), execution_time.transpose());
+        // CartesianQuaternionMeasurement::freeze(Standard), cpp:332-345: the last received pose as x, axis, angle and the
+        // twist handed over by the velocity filter this frame
+        {
+            Eigen::VectorXd pose_vector(7), velocity_vector(6);
+            for (int i = 0; i < 3; ++i) pose_vector(i) = last_pose_.translation()[i];
+            axis_angle(last_pose_.quaternion(), axis, angle);
+            for (int i = 0; i < 3; ++i) pose_vector(3 + i) = axis[i];
+            pose_vector(6) = angle;
+            for (int i = 0; i < 6; ++i) velocity_vector(i) = out_.twist[i];
+            measurement_log_.logger(pose_vector.transpose(), velocity_vector.transpose());
+        }
     }
 
 private:
-    // `pose_estimate` = v w x axis angle, `velocity_estimate` = v_O w, one row per frame (cpp:386-394, 448-451)
-    void log_row()
+    // bfl::Logger of the pose filter's measurement model (the engine walks that model's state machine itself)
+    class MeasurementLog : public bfl::Logger {
+    protected:
+        std::vector<std::string> log_file_names(const std::string& prefix_path, const std::string& prefix_name) override
+        {
+            return {prefix_path + "/" + prefix_name + "pose_measurements", prefix_path + "/" + prefix_name + "velocity_measurements"};
+        }
+    };
+
+    // Debug images of the masks (cpp:405-446).  output_segmentation_refined: the camera image with the mask the filter
+    // works on -- propagated through the optical flow to this frame (roft_get_mask) -- blended in green (alpha 0.8);
+    // output_segmentation: the camera image with the outline of the last mask the source delivered in red (the reference
+    // draws cv::findContours polygons 4 pixels thick; here every mask pixel within 2 pixels of the outside).  A camera
+    // without a colour image gets a black one.
+    void probe_segmentation(const bfl::Data& cam_data)
     {
-        const double* m = p_corr_belief_.mean().data();
-        const double w = m[9], n = std::sqrt(m[10] * m[10] + m[11] * m[11] + m[12] * m[12]);
-        double axis[3] = {1.0, 0.0, 0.0};
-        const double sgn = w < 0.0 ? -1.0 : 1.0;
-        if (n > 0.0) for (int i = 0; i < 3; ++i) axis[i] = sgn * m[10 + i] / n;
-        const double angle = 2.0 * std::atan2(n, std::fabs(w));
-        std::ofstream fp(log_path_ + "/" + log_prefix_ + "pose_estimate.txt", std::ios::app), fv(log_path_ + "/" + log_prefix_ + "velocity_estimate.txt", std::ios::app);
-        for (int i = 0; i < 9; ++i) fp << m[i] << " ";
-        fp << axis[0] << " " << axis[1] << " " << axis[2] << " " << angle << "\n";
-        for (int i = 0; i < 6; ++i) fv << v_corr_belief_.mean(i) << (i < 5 ? " " : "\n");
+        const int W = (int)camera_parameters_.width(), H = (int)camera_parameters_.height();
+        const cv::Mat& rgb_in = std::get<1>(*bfl::any::any_cast<CameraMeasurement::CameraMeasurementTuple>(&cam_data));
+        cv::Mat rgb = (rgb_in.type() == CV_8UC3 && rgb_in.rows == H && rgb_in.cols == W) ? rgb_in.clone() : cv::Mat(H, W, CV_8UC3);
+        cv::Mat refined = rgb.clone();
+        std::vector<std::uint8_t> m((std::size_t)W * H);
+        compat::throw_if(roft_get_mask(engine_, 0, m.data()), "ROFTFilter::filtering_step");
+        for (std::size_t p = 0; p < m.size(); ++p)
+            if (m[p]) {
+                const unsigned char g[3] = {0, 255, 0};
+                for (int k = 0; k < 3; ++k) refined.data[3 * p + k] = (unsigned char)std::lround(0.8 * g[k] + 0.2 * refined.data[3 * p + k]);
+            } else {
+                for (int k = 0; k < 3; ++k) refined.data[3 * p + k] = (unsigned char)std::lround(0.8 * refined.data[3 * p + k] + 0.2 * refined.data[3 * p + k]);
+            }
+        if (!last_mask_.empty())
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    if (!last_mask_.data[(std::size_t)y * W + x]) continue;
+                    bool edge = false;
+                    for (int dy = -2; dy <= 2 && !edge; ++dy)
+                        for (int dx = -2; dx <= 2 && !edge; ++dx) {
+                            const int yy = y + dy, xx = x + dx;
+                            edge = yy < 0 || yy >= H || xx < 0 || xx >= W || !last_mask_.data[(std::size_t)yy * W + xx];
+                        }
+                    if (edge) { unsigned char* px = rgb.data + 3 * ((std::size_t)y * W + x); px[0] = 0; px[1] = 0; px[2] = 255; }
+                }
+        get_probe("output_segmentation").set_data(rgb);
+        get_probe("output_segmentation_refined").set_data(refined);
     }
 
     bfl::Gaussian p_corr_belief_, v_corr_belief_;
@@ -229,8 +325,9 @@ private:
     double last_camera_stamp_ = -1;
     bool mask_received_ = false;
     long frames_ = 0;
-    const bool enable_log_;
-    const std::string log_path_, log_prefix_;
+    cv::Mat last_mask_;                                      // last mask delivered by the source (cpp:438-442)
+    Eigen::Transform<double, 3, Eigen::Affine> last_pose_;   // last pose delivered by the pose source
+    MeasurementLog measurement_log_;
     const std::string log_name_ = "ROFTFilter";
 };
 

@@ -25,6 +25,7 @@
  *        roft_render_depth       <- SICAD::superimpose(poses, ..., depth)  src/roft-lib/src/SICAD.cpp:924-1066
  *        roft_depth_likelihood   <- ROFTFilter::pick_best_alternative inner loop
  *                                   src/roft-lib/src/ROFTFilter.cpp:553-577
+ *        roft_outlier_test       <- ROFTFilter::pick_best_alternative  src/roft-lib/src/ROFTFilter.cpp:467-621
  *  (2) the batched engine -- ROFTFilter::filtering_step (src/roft-lib/src/ROFTFilter.cpp:255-452)
  *      for many objects at once with all filter state resident in HBM:
  *        roft_engine_create / roft_object_add / roft_frame_submit | roft_frames_submit / roft_step / roft_get_state.
@@ -137,12 +138,26 @@ int roft_ukf_correct(const double mean[13], const double P[144], int type, const
                      const double* Rdiag, const roft_ut_params* ut, double mean_out[13],
                      double P_out[144], int* status_out);
 
-/* tile: (H/divider) x (W/divider) float, 0 = background */
+/* tile: (H/divider) x (W/divider) float, 0 = background.  Drawn by the rasteriser of the engine's own outlier test
+ * (outlier_fused_kernel: projected vertices and the depth window in LDS). */
 int roft_render_depth(const roft_mesh* mesh, const double x[3], const double q[4],
                       const roft_camera* cam, int divider, float* tile);
-/* *L_out = mean |depth - render| over every second mask pixel, DBL_MAX if no sample */
+/* *L_out = mean |depth - render| over every second mask pixel, DBL_MAX if no sample -- for a tile rendered elsewhere
+ * (e.g. by the reference's SICAD); the engine itself never materialises a tile, see roft_outlier_test. */
 int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint8_t* mask,
                           const float* tile, int divider, double* L_out, long* samples_out);
+/* ROFTFilter::pick_best_alternative (src/roft-lib/src/ROFTFilter.cpp:467-621) for one object, on exactly the three launches
+ * the engine enqueues at a pose arrival: the outlier-rejection features of (depth, mask) are buffered (:624-646), the two
+ * alternatives x[0..2] q[0..3] (pose + velocity correction) and x[3..5] q[4..7] (velocity only) are rendered at
+ * (W/divider) x (H/divider) and scored against every second mask pixel with 0 < depth < 2 (:553-577), and the decision
+ * L_0 > 2 L_1 -> 1 (:581-583) is taken.  bands: workgroups one alternative is split over, 1..8 (0: by the CUs to spare, as
+ * the engine does); vertex_cache 0: project the vertices per triangle instead of once into LDS; window_pixels > 0 caps
+ * the LDS depth window (a larger window is rendered in strips).  None of the three changes a bit of the depths.
+ * tiles_out (optional): 2 x (H/divider) x (W/divider) floats, the renders as the kernel drew them, 0 = background.
+ * L_out: DBL_MAX when an alternative has no sample. */
+int roft_outlier_test(const roft_camera* cam, int divider, const float* depth, const uint8_t* mask, const roft_mesh* mesh,
+                      const double x[6], const double q[8], int bands, int vertex_cache, int window_pixels, double L_out[2],
+                      long samples_out[2], int* selected_out, float* tiles_out);
 
 /* ---- (2) batched engine --------------------------------------------------------------------- */
 

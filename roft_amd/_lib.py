@@ -87,7 +87,7 @@ class ObjectOutput(C.Structure):
 ABI_SYMBOLS = [
     "roft_last_error_string", "roft_device_count", "roft_flow_measurement", "roft_kf_predict",
     "roft_skf_correct", "roft_skf_correct_points", "roft_mask_propagate", "roft_pose_process_noise", "roft_ukf_predict",
-    "roft_ukf_correct", "roft_render_depth", "roft_depth_likelihood", "roft_default_config",
+    "roft_ukf_correct", "roft_render_depth", "roft_depth_likelihood", "roft_outlier_test", "roft_default_config",
     "roft_default_object", "roft_engine_create", "roft_engine_destroy", "roft_object_add",
     "roft_frame_submit", "roft_frames_submit", "roft_engine_retain_frames", "roft_engine_get_stats", "roft_step", "roft_sync", "roft_get_state", "roft_get_outputs", "roft_get_mask",
     "roft_engine_enable_log", "roft_engine_get_log", "roft_engine_get_log_rows", "roft_engine_stream", "roft_engine_enable_timing",
@@ -133,6 +133,7 @@ def lib():
     L.roft_ukf_correct.argtypes = [vp, vp, C.c_int, vp, vp, C.POINTER(UT), vp, vp, ip]
     L.roft_render_depth.argtypes = [C.POINTER(Mesh), vp, vp, C.POINTER(Camera), C.c_int, vp]
     L.roft_depth_likelihood.argtypes = [C.POINTER(Camera), vp, vp, vp, C.c_int, dp, C.POINTER(C.c_long)]
+    L.roft_outlier_test.argtypes = [C.POINTER(Camera), C.c_int, vp, vp, C.POINTER(Mesh), vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ip, vp]
     L.roft_default_config.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int]
     L.roft_default_object.argtypes = [C.POINTER(ObjectDesc)]
     L.roft_engine_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]

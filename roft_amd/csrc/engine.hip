@@ -43,6 +43,42 @@ int fail(int code, const std::string& msg)
 namespace roft {
 // shared with flow_producer.hip
 int set_last_error(int code, const std::string& msg) { return fail(code, msg); }
+
+int device_cu_count()
+{
+    static std::mutex mu;
+    static std::vector<int> cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 256;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)cus.size() <= dev) cus.resize(dev + 1, 0);
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+hipError_t set_max_dynamic_lds(const void* func, int bytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;   // (kernel, device) pairs already raised to >= bytes
+    static std::vector<int> done_bytes;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < done.size(); ++i)
+        if (done[i].first == func && done[i].second == dev) {
+            if (done_bytes[i] >= bytes) return hipSuccess;
+            const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e == hipSuccess) done_bytes[i] = bytes;
+            return e;
+        }
+    const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) { done.emplace_back(func, dev); done_bytes.push_back(bytes); }
+    return e;
+}
 }  // namespace roft
 
 namespace {
@@ -1727,31 +1763,127 @@ int roft_ukf_correct(const double mean[13], const double P[144], int type, const
     return op_ukf(mean, P, nullptr, 0.0, type, meas, Rdiag, ut, mean_out, P_out, status_out);
 }
 
+// The engine's outlier test on a one-object context: features of (depth, mask) buffered by features_kernel, both
+// alternatives rendered and scored by outlier_fused_kernel, the decision taken by the pose chain segment that follows -- the
+// three launches roft_step enqueues at a pose arrival.  depth / mask may be null (render only: no samples).
+static int op_outlier(const roft_camera* cam, int divider, const float* depth, const uint8_t* mask, const roft_mesh* mesh,
+                      const double* x2 /*2x3*/, const double* q2 /*2x4*/, const OutlierLaunchOpts& o_in, double L_out[2],
+                      long samples_out[2], int* selected_out, float* tiles_out)
+{
+    OpCtx& c = op();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (int rc = c.prepare(*cam, ROFT_FLOW_F32C2, 1, 1.0f, 35)) return rc;
+    EngineArrays& a = c.arr.a;
+    a.cam.divider = divider;
+    a.tile_w = cam->width / divider;
+    a.tile_h = cam->height / divider;
+    const size_t npix = (size_t)cam->width * cam->height, tpix = (size_t)a.tile_w * a.tile_h;
+    auto restore = [&]() {   // default tile geometry of this context
+        a.cam = make_cam(*cam);
+        a.tile_w = cam->width / a.cam.divider;
+        a.tile_h = cam->height / a.cam.divider;
+        a.max_verts = a.max_tris = 0;
+    };
+    if (int rc = to_dev(c.b0, mesh->verts, (size_t)3 * mesh->n_verts, c.stream)) return rc;
+    if (int rc = to_dev(c.b1, mesh->tris, (size_t)3 * mesh->n_tris, c.stream)) return rc;
+    ObjParams prm;
+    std::memset(&prm, 0, sizeof(prm));
+    prm.verts = reinterpret_cast<const float*>(c.b0.p);
+    prm.tris = reinterpret_cast<const int32_t*>(c.b1.p);
+    prm.n_verts = mesh->n_verts;
+    prm.n_tris = mesh->n_tris;
+    a.max_verts = mesh->n_verts;
+    a.max_tris = mesh->n_tris;
+    FrameCtrl fc;
+    clear_ctrl(fc);
+    fc.n_steps = 1;        // (walked already: the segment below only decides)
+    fc.outlier_step = 0;
+    fc.cur_slot = B_LIN0;
+    fc.lane = 0;
+    fc.feat_read = 0;
+    if (depth && mask) {
+        std::vector<uint8_t> zero;
+        if (int rc = to_dev(c.b2, mask, npix, c.stream)) return rc;
+        if (int rc = to_dev(c.b3, depth, npix, c.stream)) return rc;
+        fc.has_new_mask = 1;
+        fc.new_mask = c.b2.p;
+        fc.slot_cur = kSlotNew;
+        fc.depth_cur = reinterpret_cast<const float*>(c.b3.p);
+        fc.feat_write = 0;
+    }
+    ObjState* st = new ObjState();
+    init_state(*st);
+    st->lane[0].pending_frame = 0;
+    st->lane[0].pc_frame = 0;
+    st->lane[0].pc_step = 1;
+    for (int k = 0; k < 2; ++k) {
+        PoseBelief& b = st->belief[b_alt(0, k)];
+        for (int i = 0; i < 3; ++i) b.mean[6 + i] = x2[3 * k + i];
+        for (int i = 0; i < 4; ++i) b.mean[9 + i] = q2[4 * k + i];
+    }
+    hipError_t err = hipMemcpyAsync(c.arr.state.p, st, sizeof(ObjState), hipMemcpyHostToDevice, c.stream);
+    if (err == hipSuccess) err = hipMemcpyAsync(c.arr.params.p, &prm, sizeof(prm), hipMemcpyHostToDevice, c.stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
+    if (err != hipSuccess) { delete st; restore(); HIP_TRY(err); }
+    if (int rc = upload_ctrl(c, fc)) { delete st; restore(); return rc; }
+    OutlierLaunchOpts o = o_in;
+    if (tiles_out) {
+        err = c.b4.ensure(sizeof(float) * 2 * tpix);
+        if (err == hipSuccess) err = hipMemsetAsync(c.b4.p, 0, sizeof(float) * 2 * tpix, c.stream);
+        if (err != hipSuccess) { delete st; restore(); HIP_TRY(err); }
+        o.tile_dump = reinterpret_cast<float*>(c.b4.p);
+    }
+    if (depth && mask) {
+        launch_mask_ingest(a, 0, c.stream);
+        launch_features(a, c.stream);
+    }
+    launch_outlier(a, 0, c.stream, nullptr, &o);
+    roft_ut_params ut{1.0, 2.0, 0.0};
+    launch_ukf_chain(a, ut, false, 0, c.stream);   // decision (ROFTFilter.cpp:581-583) as the engine's next segment takes it
+    err = hipMemcpyAsync(st, c.arr.state.p, sizeof(ObjState), hipMemcpyDeviceToHost, c.stream);
+    if (err == hipSuccess && tiles_out) err = hipMemcpyAsync(tiles_out, c.b4.p, sizeof(float) * 2 * tpix, hipMemcpyDeviceToHost, c.stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(c.stream);
+    if (err == hipSuccess) err = hipGetLastError();
+    if (err == hipSuccess) {
+        for (int k = 0; k < 2; ++k) {
+            if (L_out) L_out[k] = st->lane[0].outlier_L[k];
+            if (samples_out) samples_out[k] = (long)st->lane[0].outlier_cnt[k];
+        }
+        if (selected_out) *selected_out = st->lane[0].outlier_selected;
+    }
+    delete st;
+    restore();
+    HIP_TRY(err);
+    return ROFT_OK;
+}
+
 int roft_render_depth(const roft_mesh* mesh, const double x[3], const double q[4], const roft_camera* cam, int divider,
                       float* tile)
 {
-    if (!mesh || !mesh->verts || !mesh->tris || !x || !q || !cam || !tile || divider <= 0)
+    if (!mesh || !mesh->verts || !mesh->tris || mesh->n_verts <= 0 || mesh->n_tris <= 0 || !x || !q || !cam || !tile || divider <= 0)
         return fail(ROFT_ERR_INVALID, "bad argument");
-    OpCtx& c = op();
-    std::lock_guard<std::mutex> lk(c.mu);
-    if (int rc = op_simple_prepare(c)) return rc;
-    DevCamera dc = make_cam(*cam);
-    dc.divider = divider;
-    const int n = (dc.W / divider) * (dc.H / divider);
-    if (int rc = to_dev(c.b0, mesh->verts, (size_t)3 * mesh->n_verts, c.stream)) return rc;
-    if (int rc = to_dev(c.b1, mesh->tris, (size_t)3 * mesh->n_tris, c.stream)) return rc;
-    double xq[7] = {x[0], x[1], x[2], q[0], q[1], q[2], q[3]};
-    if (int rc = to_dev(c.b2, xq, 7, c.stream)) return rc;
-    HIP_TRY(c.b3.ensure(sizeof(uint32_t) * n));
-    HIP_TRY(c.b4.ensure(sizeof(float) * n));
-    HIP_TRY(hipStreamSynchronize(c.stream));  // xq lives on this stack frame
-    launch_render(reinterpret_cast<const float*>(c.b0.p), reinterpret_cast<const int32_t*>(c.b1.p), mesh->n_tris,
-                  reinterpret_cast<const double*>(c.b2.p), dc, reinterpret_cast<uint32_t*>(c.b3.p),
-                  reinterpret_cast<float*>(c.b4.p), c.stream);
-    HIP_TRY(hipMemcpyAsync(tile, c.b4.p, sizeof(float) * n, hipMemcpyDeviceToHost, c.stream));
-    HIP_TRY(hipStreamSynchronize(c.stream));
-    HIP_TRY(hipGetLastError());
+    const size_t tpix = (size_t)(cam->width / divider) * (cam->height / divider);
+    std::vector<float> tiles(2 * tpix);
+    const double x2[6] = {x[0], x[1], x[2], x[0], x[1], x[2]};
+    const double q2[8] = {q[0], q[1], q[2], q[3], q[0], q[1], q[2], q[3]};
+    OutlierLaunchOpts o;
+    if (int rc = op_outlier(cam, divider, nullptr, nullptr, mesh, x2, q2, o, nullptr, nullptr, nullptr, tiles.data())) return rc;
+    std::memcpy(tile, tiles.data(), sizeof(float) * tpix);
     return ROFT_OK;
+}
+
+int roft_outlier_test(const roft_camera* cam, int divider, const float* depth, const uint8_t* mask, const roft_mesh* mesh,
+                      const double x[6], const double q[8], int bands, int vertex_cache, int window_pixels, double L_out[2],
+                      long samples_out[2], int* selected_out, float* tiles_out)
+{
+    if (!cam || !depth || !mask || !mesh || !mesh->verts || !mesh->tris || mesh->n_verts <= 0 || mesh->n_tris <= 0 || !x || !q ||
+        divider <= 0 || bands < 0 || bands > kMaxOutlierParts || window_pixels < 0)
+        return fail(ROFT_ERR_INVALID, "bad argument");
+    OutlierLaunchOpts o;
+    o.parts = bands;
+    o.no_vertex_cache = vertex_cache ? 0 : 1;
+    o.window_pixels = window_pixels;
+    return op_outlier(cam, divider, depth, mask, mesh, x, q, o, L_out, samples_out, selected_out, tiles_out);
 }
 
 int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint8_t* mask, const float* tile, int divider,

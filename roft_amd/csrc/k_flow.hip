@@ -251,13 +251,7 @@ void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, hi
         return;
     }
     const size_t lds = (a.plane_words * 4 + 15) & ~(size_t)15;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(flow_measure_lds_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - 256 - kCandLds * (int)sizeof(uint2) - 128);
-        attr_set = true;
-    }
+    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(flow_measure_lds_kernel), 160 * 1024 - 256 - kCandLds * (int)sizeof(uint2) - 128);
     hipExtLaunchKernelGGL(flow_measure_lds_kernel, dim3(a.n_obj, a.T), dim3(kFlowThreads), lds, s, start, stop, 0, a,
                           depth_max, radius);
 }

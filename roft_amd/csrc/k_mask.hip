@@ -749,12 +749,10 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
     if (lds_plane + ((list_cap * 4 + 15) & ~(size_t)15) > lds_cap) list_cap = ((lds_cap - lds_plane) / 4) & ~(size_t)3;
     const size_t lds_step = lds_plane + ((list_cap * 4 + 15) & ~(size_t)15) + (keep_words ? list_cap * 8 : 0);
     const size_t lds_gen = (n_grp * 4 + 15) & ~(size_t)15;
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         const int cap = 160 * 1024 - 4096;   // (the kernel's static LDS -- control block, records, flow pointers -- is ~1.2 KB)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_chain_kernel<ROFT_FLOW_S16C2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mask_chain_kernel<ROFT_FLOW_F32C2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        attr_set = true;
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_chain_kernel<ROFT_FLOW_S16C2>), cap);
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_chain_kernel<ROFT_FLOW_F32C2>), cap);
     }
     int launches = 0;
     const bool s16 = a.ffmt.type == ROFT_FLOW_S16C2;

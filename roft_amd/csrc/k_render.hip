@@ -120,12 +120,7 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
 
 void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(features_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - 256 - kFeatThreads * (int)sizeof(int) - 128);
-        attr_set = true;
-    }
+    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(features_kernel), 160 * 1024 - 256 - kFeatThreads * (int)sizeof(int) - 128);
     hipExtLaunchKernelGGL(features_kernel, dim3(a.n_obj, a.T), dim3(kFeatThreads), (uint32_t)((a.plane_words * 4 + 15) & ~(size_t)15), s,
                           nullptr, stop, 0, a);
 }
@@ -203,17 +198,6 @@ __device__ __forceinline__ void raster_projected(float x0, float y0, float z0, f
             store(i, j, z);
         }
     }
-}
-
-__device__ void raster_triangle(const float* verts, const int32_t* tri, const RenderPose& P, float fx, float fy,
-                                float cx, float cy, int w, int h, uint32_t* zbuf)
-{
-    float x0, y0, z0, x1, y1, z1, x2, y2, z2;
-    project_vertex(verts + (size_t)3 * tri[0], P, fx, fy, cx, cy, x0, y0, z0);
-    project_vertex(verts + (size_t)3 * tri[1], P, fx, fy, cx, cy, x1, y1, z1);
-    project_vertex(verts + (size_t)3 * tri[2], P, fx, fy, cx, cy, x2, y2, z2);
-    raster_projected(x0, y0, z0, x1, y1, z1, x2, y2, z2, w, h, 0, h - 1,
-                     [zbuf, w](int i, int j, float z) { atomicMin(&zbuf[(size_t)j * w + i], __float_as_uint(z)); });
 }
 
 // Operator level (roft_depth_likelihood): likelihood of both alternatives over the buffered features from z-buffers in
@@ -312,7 +296,9 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
 // resolved with LDS atomicMin, +inf = empty --, and the likelihood reads it in place.  No z-buffer in HBM, no clear
 // pass, no global atomics, one launch instead of three.  A window that does not fit the LDS next to the vertices is
 // rendered in horizontal strips (every strip walks all triangles and all features); a mesh whose vertices do not fit is
-// projected per triangle.  Same per-pixel arithmetic as raster_triangle: the depths are bit-identical.
+// projected per triangle.  The per-pixel arithmetic is raster_projected's, whatever the strips, bands and the vertex cache: the depths are bit-identical
+// to oracle/ro_render.c in every configuration (tests/test_parity_gpu.py drives this kernel through roft_render_depth and
+// roft_outlier_test).
 // With few objects an alternative is shared by `parts` workgroups: each takes a horizontal band of the window (walks all
 // triangles, draws the rows of its band, sums the features that fall into it) and leaves its partial sums; the pose
 // chain segment that follows adds them up in band order and decides.
@@ -325,7 +311,8 @@ constexpr int kFusedThreads = 1024;
 #define UTICK(i) do {} while (0)
 #endif
 
-__global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArrays a, int lin, int vcache_cap, int win_cap, int parts)
+__global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArrays a, int lin, int vcache_cap, int win_cap, int parts,
+                                                                     float* tile_dump)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double s_err[kFusedThreads / 64], s_cnt[kFusedThreads / 64];
@@ -450,6 +437,15 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
             }
             __syncthreads();
             UTICK(2);
+            // operator level (roft_render_depth / roft_outlier_test): the strip of the window as this workgroup drew it ->
+            // the caller's (zero-filled) render tile of the alternative, 0 = background as the reference reads it back
+            if (tile_dump) {
+                float* tile = tile_dump + (size_t)alt * tw * th;
+                for (int i = tid; i < npx; i += kFusedThreads) {
+                    const uint32_t b = s_z[i];
+                    tile[(size_t)(js + i / win_w) * tw + (i0 + i % win_w)] = (b == 0x7F800000u) ? 0.0f : __uint_as_float(b);
+                }
+            }
             // likelihood samples of this strip (feature slots in ascending order per thread, as outlier_kernel adds them)
             constexpr int kBatch = 16;
             for (int f0 = tid; f0 < n; f0 += kBatch * kFusedThreads) {
@@ -492,7 +488,7 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     }
 }
 
-void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t stop)
+void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t stop, const OutlierLaunchOpts* opts)
 {
     // objects that do not test this frame return immediately; the decision (ROFTFilter.cpp:581-583) is taken by the
     // pose chain segment that follows (ukf_chain_kernel)
@@ -501,56 +497,26 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     // cache the projected vertices when they leave room for a window of 8 k pixels (a window that large or larger is
     // rendered in strips) and for the widest row of the target
     const size_t min_win = (size_t)4 * std::max(8192, a.tile_w);
-    const bool cache = vbytes + min_win <= lds_total;
+    const bool cache = vbytes + min_win <= lds_total && !(opts && opts->no_vertex_cache);
     const int vcache_cap = cache ? a.max_verts : 0;
-    const int win_cap = (int)((lds_total - (cache ? vbytes : 0)) / 4);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(outlier_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total);
-        attr_set = true;
-    }
+    int win_cap = (int)((lds_total - (cache ? vbytes : 0)) / 4);
+    set_max_dynamic_lds(reinterpret_cast<const void*>(outlier_fused_kernel), (int)lds_total);
     // bands per alternative: as many workgroups as the chip has CUs to spare
-    const int parts = std::max(1, std::min(kMaxOutlierParts, 256 / (2 * std::max(a.n_obj, 1))));
+    int parts = std::max(1, std::min(kMaxOutlierParts, device_cu_count() / (2 * std::max(a.n_obj, 1))));
+    if (opts && opts->parts > 0) parts = std::min(opts->parts, kMaxOutlierParts);
     // (a band is a fraction of the window: request only the LDS it can need, so that other chains' workgroups fit next to it)
     const size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + parts - 1) / parts + (size_t)a.tile_w);
     const size_t lds = std::min(lds_total, (((cache ? vbytes : 0) + win_need + 15) & ~(size_t)15));
-    const int win_cap_lds = (int)((lds - (cache ? vbytes : 0)) / 4);
+    win_cap = std::min(win_cap, (int)((lds - (cache ? vbytes : 0)) / 4));
+    // (operator level: a smaller window forces the strip path)
+    if (opts && opts->window_pixels > 0) win_cap = std::max(a.tile_w, std::min(win_cap, opts->window_pixels));
     hipExtLaunchKernelGGL(outlier_fused_kernel, dim3(2 * parts * ((a.n_obj + 7) / 8) * 8), dim3(kFusedThreads), (uint32_t)lds, s, nullptr, stop, 0, a, lin,
-                          vcache_cap, std::min(win_cap, win_cap_lds), parts);
+                          vcache_cap, win_cap, parts, opts ? opts->tile_dump : nullptr);
 }
 
 void launch_outlier_only(const EngineArrays& a, hipStream_t s)
 {
     hipLaunchKernelGGL(outlier_kernel, dim3(a.n_obj), dim3(kOutlierThreads), 0, s, a, 0);
-}
-
-// ---- operator level: render one pose into a float tile ------------------------------------------
-__global__ __launch_bounds__(256) void raster_single_kernel(const float* verts, const int32_t* tris, int n_tris,
-                                                            const double* xq, DevCamera cam, uint32_t* zbuf)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tris) return;
-    const RenderPose P = make_pose(xq, xq + 3);
-    const int d = cam.divider;
-    const float fx = (float)(cam.fx / d), fy = (float)(cam.fy / d), cx = (float)(cam.cx / d), cy = (float)(cam.cy / d);
-    raster_triangle(verts, tris + (size_t)3 * t, P, fx, fy, cx, cy, cam.W / d, cam.H / d, zbuf);
-}
-
-__global__ __launch_bounds__(256) void zbuf_to_tile_kernel(const uint32_t* zbuf, float* tile, int n)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t b = zbuf[i];
-    tile[i] = (b == 0x7F800000u) ? 0.0f : __uint_as_float(b);
-}
-
-void launch_render(const float* verts, const int32_t* tris, int n_tris, const double* xq, DevCamera cam, uint32_t* zbuf,
-                   float* tile_out, hipStream_t s)
-{
-    const int n = (cam.W / cam.divider) * (cam.H / cam.divider);
-    (void)hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(zbuf), 0x7F800000, n, s);
-    hipLaunchKernelGGL(raster_single_kernel, dim3((n_tris + 255) / 256), dim3(256), 0, s, verts, tris, n_tris, xq, cam, zbuf);
-    hipLaunchKernelGGL(zbuf_to_tile_kernel, dim3((n + 255) / 256), dim3(256), 0, s, zbuf, tile_out, n);
 }
 
 }  // namespace roft

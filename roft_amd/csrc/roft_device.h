@@ -332,13 +332,26 @@ void launch_kf_predict(const double* x, const double* P, const double* qdiag, do
 // Of every object only the frames of lane `lin` are walked.
 void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, int lin, hipStream_t s, hipEvent_t stop = nullptr);
 void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // after the mask chain of the batch
-void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t stop = nullptr);   // render + likelihood + decision of the pending tests of a lineage
-void launch_outlier_only(const EngineArrays& a, hipStream_t s);  // likelihood + decision on filled z-buffers
+// Operator-level overrides of the outlier test's launch shape (roft_render_depth / roft_outlier_test: the parity tests drive
+// the engine's kernel through every configuration); the engine passes none.
+struct OutlierLaunchOpts {
+    int parts = 0;            // horizontal bands per alternative (0: by the CUs to spare)
+    int no_vertex_cache = 0;  // project the vertices per triangle instead of once into LDS
+    int window_pixels = 0;    // cap of the LDS depth window in pixels (> 0: forces the strip path for larger windows)
+    float* tile_dump = nullptr;   // [2][tile_h][tile_w], zero-filled: receives the rendered window of both alternatives
+};
+// render + likelihood of the pending tests of a lane (the decision is the first thing the next pose chain segment does)
+void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t stop = nullptr, const OutlierLaunchOpts* opts = nullptr);
+void launch_outlier_only(const EngineArrays& a, hipStream_t s);  // operator level: likelihood + decision on filled z-buffers
+
+// multiProcessorCount of the calling thread's current device (cached per device ordinal; 256 on MI355X)
+int device_cu_count();
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device): the attribute belongs to the kernel's code object
+// on ONE device, and a process may own engines on several
+hipError_t set_max_dynamic_lds(const void* func, int bytes);
 
 // operator-level helpers on raw device buffers (used by the C ABI operator entry points)
 void launch_expand_yh(const FlowRec* recs, const int* n, DevCamera cam, double dt, int32_t* uv, double* y,
                       double* H, int cap, hipStream_t s);
-void launch_render(const float* verts, const int32_t* tris, int n_tris, const double* xq /*7*/, DevCamera cam,
-                   uint32_t* zbuf, float* tile_out, hipStream_t s);
 
 }  // namespace roft

@@ -132,6 +132,13 @@ def read_data_txt(path):
     return a[:, 0], a[:, 1], a[:, 2:9]
 
 
+def pose_log_row(pose13):
+    """One row of ROFTFilter's `pose_estimate` log: v w x axis angle (ROFTFilter.cpp:386-394)."""
+    r = np.asarray(pose13, float)
+    axis, angle = quat_to_axis_angle(r[9:13])
+    return np.concatenate([r[:9], axis, [angle]])
+
+
 def write_estimate_logs(prefix, pose13, twist6):
     """ROFTFilter's `pose_estimate` (v w x axis angle, 13 columns) and `velocity_estimate` (6 columns)."""
     pose13 = np.atleast_2d(pose13)

@@ -146,6 +146,23 @@ def depth_likelihood(cam, depth, mask, tile, divider):
     return Lv.value, ns.value
 
 
+def outlier_test(cam, divider, depth, mask, mesh, x2, q2, bands=0, vertex_cache=True, window_pixels=0, tiles=True):
+    """ROFTFilter::pick_best_alternative (ROFTFilter.cpp:467-621) on the engine's own kernels (features_kernel,
+    outlier_fused_kernel, the deciding pose chain segment).  x2 (2, 3), q2 (2, 4): the two alternatives.
+    Returns (L[2], samples[2], selected, tiles (2, H/d, W/d) or None)."""
+    depth = np.ascontiguousarray(depth, np.float32)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    x2, q2 = _f64(np.asarray(x2).reshape(6)), _f64(np.asarray(q2).reshape(8))
+    Lv = np.zeros(2, np.float64)
+    ns = np.zeros(2, np.int64)
+    sel = C.c_int(-2)
+    t = np.zeros((2, cam.height // divider, cam.width // divider), np.float32) if tiles else None
+    L.check(L.lib().roft_outlier_test(C.byref(cam), divider, _p(depth), _p(mask), C.byref(mesh), _p(x2), _p(q2), bands,
+                                      1 if vertex_cache else 0, window_pixels, _p(Lv), _p(ns), C.byref(sel),
+                                      _p(t) if tiles else None))
+    return Lv, ns, sel.value, t
+
+
 def of_params(levels=3, radius=3, iterations=3, det_min=100.0):
     p = L.OFParams()
     L.check(L.lib().roft_default_of_params(C.byref(p)))

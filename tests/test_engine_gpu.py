@@ -15,6 +15,10 @@ pytestmark = pytest.mark.gpu
 POS_TOL = 1e-6    # m
 ROT_TOL = 1e-6    # rad
 TWIST_TOL = 1e-6  # m/s, rad/s
+# likelihoods of the outlier test inside the engine: the alternatives' poses differ from the oracle's by ~1e-11, which
+# moves a render depth by an ulp here and there (the kernel itself is bit exact on identical poses:
+# test_parity_gpu.py::test_outlier_test_hot_path_kernel)
+LIK_ENGINE_RTOL = 1e-9
 
 
 def make_engine(streams, **over):
@@ -59,7 +63,7 @@ def compare(streams, n_frames, check_masks=True, **over):
             assert got.outlier_selected == exp["sel"], (k, o, list(got.outlier_L), exp["L"])
             if exp["sel"] >= 0:
                 n_tests += 1
-                np.testing.assert_allclose(np.array(got.outlier_L), exp["L"], rtol=1e-6)
+                np.testing.assert_allclose(np.array(got.outlier_L), exp["L"], rtol=LIK_ENGINE_RTOL)
             pose = np.array(got.pose)
             np.testing.assert_allclose(pose[:9], exp["pose"][:9], rtol=0, atol=POS_TOL, err_msg="frame %d obj %d" % (k, o))
             assert rot_err(pose[9:], exp["pose"][9:]) < ROT_TOL, (k, o)

@@ -216,3 +216,114 @@ def test_whole_filter_facade_equals_the_python_engine(tmp_path):
         assert np.array_equal(got[k, :13], p) and np.array_equal(got[k, 13:], tw), k
         assert np.abs(got[k, :13] - ref[k]["pose"]).max() < 1e-8
     eng.close()
+
+
+def test_logger_probe_and_png_stand_ins(tmp_path):
+    """bfl::Logger / RobotsIO::Utils::Probe(Container) / ImageFileProbe of Compat.h without a device: the log files carry
+    what was logged in Eigen's default matrix format, a probe receives what set_data() hands it, and the PNG files of the
+    image probe decode to the images written."""
+    from roft_amd import io as rio
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include "ROFT/Compat.h"
+#include <cstdio>
+struct L : bfl::Logger {
+    std::vector<std::string> log_file_names(const std::string& p, const std::string& n) override { return {p + "/" + n + "a", p + "/" + n + "b"}; }
+};
+struct Keep : RobotsIO::Utils::Probe { int n = 0; double last = 0; void on_new_data() override { ++n; last = std::any_cast<Eigen::VectorXd>(get_data())(1); } };
+int main(int, char** argv) {
+    L l;
+    Eigen::VectorXd v(3); v(0) = 1.0; v(1) = -0.25; v(2) = 1234567.0;
+    l.logger(v.transpose(), v.transpose());                 // not enabled yet: nothing written
+    if (!l.enable_log(argv[1], "x_")) return 1;
+    if (l.enable_log(argv[1], "y_")) return 1;              // already enabled
+    l.logger(v.transpose(), 7);
+    l.logger(v.transpose(), 8);
+    l.disable_log();
+    RobotsIO::Utils::ProbeContainer c;
+    if (c.is_probe("p")) return 1;
+    auto* k = new Keep();
+    c.set_probe("p", std::unique_ptr<RobotsIO::Utils::Probe>(k));
+    if (!c.is_probe("p")) return 1;
+    c.get_probe("p").set_data(v);
+    if (k->n != 1 || k->last != -0.25) return 1;
+    RobotsIO::Utils::ImageFileProbe ip(std::string(argv[1]) + "/img", "", "png");
+    cv::Mat g(5, 300, CV_8UC1), bgr(70, 1000, CV_8UC3);    // the second one needs several stored deflate blocks
+    for (int i = 0; i < 1500; ++i) g.data[i] = (unsigned char)(i * 7);
+    for (int i = 0; i < 210000; ++i) bgr.data[i] = (unsigned char)(i * 13 + i / 3000);
+    RobotsIO::Utils::Probe& p = ip;
+    p.set_data(g);
+    p.set_data(bgr);
+    return 0;
+}''')
+    exe = str(tmp_path / "t")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", exe])
+    os.mkdir(tmp_path / "img")
+    subprocess.check_call([exe, str(tmp_path)])
+    rows = (tmp_path / "x_a.txt").read_text().splitlines()
+    # Eigen's default IOFormat: 6 significant digits, every coefficient padded to the width of the widest one
+    assert rows == [" ".join(c.rjust(11) for c in ("1", "-0.25", "1.23457e+06"))] * 2
+    assert (tmp_path / "x_b.txt").read_text().split() == ["7", "8"]
+    g = rio.read_png(str(tmp_path / "img" / "0.png"))
+    assert g.shape == (5, 300) and np.array_equal(g.ravel(), (np.arange(1500) * 7).astype(np.uint8))
+    c = rio.read_png(str(tmp_path / "img" / "1.png"))
+    i = np.arange(210000)
+    want = ((i * 13 + i // 3000) & 255).astype(np.uint8).reshape(70, 1000, 3)[:, :, ::-1]    # written BGR -> RGB
+    assert c.shape == (70, 1000, 3) and np.array_equal(c, want)
+
+
+def test_tracker_tail_compiles_against_the_facade(tmp_path):
+    """src/roft/src/main.cpp:393-424 -- constructor call, set_probe, enable_log, boot / run / wait -- compiles against
+    ROFT::ROFTFilter : bfl::FilteringAlgorithm, RobotsIO::Utils::ProbeContainer; without a device it fails loudly."""
+    import util
+    from roft_amd import _lib
+    exe = build(tmp_path, "tracker_tail_check")
+    if _lib.lib().roft_device_count() > 0:
+        pytest.skip("a HIP device is present")
+    st = util.stream(33, 3, 4)
+    dump_stream(str(tmp_path / "s.bin"), st, 3)
+    r = subprocess.run([exe, str(tmp_path / "s.bin"), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 3 and "runtime_error" in r.stdout
+
+
+@pytest.mark.gpu
+def test_tracker_tail_logs_match_the_engine(tmp_path):
+    """The five log files and the probe images the tail of ROFT-tracker's main() leaves, against the engine's own log
+    (row for row, at the 6 significant digits bfl::Logger writes) and its propagated masks."""
+    import util
+    from roft_amd import io as rio
+    from test_engine_gpu import make_engine
+    n = 14
+    st = util.stream(35, n, 2)
+    dump_stream(str(tmp_path / "s.bin"), st, n)
+    exe = build(tmp_path, "tracker_tail_check")
+    for d in ("segmentation", "segmentation_refined"):
+        os.mkdir(tmp_path / d)
+    subprocess.check_call([exe, str(tmp_path / "s.bin"), str(tmp_path)])
+    load = lambda name: np.loadtxt(str(tmp_path / (name + ".txt")), ndmin=2)
+    pose_est, vel_est, times = load("pose_estimate"), load("velocity_estimate"), load("execution_times")
+    pose_meas, vel_meas = load("pose_measurements"), load("velocity_measurements")
+    assert pose_est.shape == (n, 13) and vel_est.shape == (n, 6) and times.shape == (n, 2)
+    assert pose_meas.shape == (n, 7) and vel_meas.shape == (n, 6)
+    assert np.all(times == np.round(times)) and np.all(times[:, 1] >= 0)      # integer milliseconds (ROFTFilter.cpp:463)
+    eng = make_engine([st])
+    last_pose = np.array([0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0])     # identity until the first pose arrives
+    sig6 = lambda a: np.array([float("%.6g" % v) for v in np.ravel(a)])
+    for k in range(n):
+        depth, flow, mask, pose = util.frame_inputs(st, k)
+        eng.submit([dict(depth=depth, flow=flow, mask=mask, pose=pose, dt=st.dt)])
+        eng.step()
+        p, _, tw, _ = eng.state(0)
+        assert np.array_equal(pose_est[k], sig6(rio.pose_log_row(p))), k        # v w x axis angle
+        assert np.array_equal(vel_est[k], sig6(tw)), k
+        assert np.array_equal(vel_meas[k], sig6(tw)), k
+        if pose is not None:
+            last_pose = rio.pose_log_row(np.concatenate([np.zeros(6), pose[0], pose[1]]))[6:]
+        assert np.array_equal(pose_meas[k], sig6(last_pose)), k
+        refined = rio.read_png(str(tmp_path / "segmentation_refined" / ("%d.png" % k)))
+        assert refined.shape == (st.camera.height, st.camera.width, 3)
+        m = eng.mask(0) > 0
+        assert np.array_equal(refined[:, :, 1] == 204, m) and not refined[:, :, 0].any()    # 0.8 * green over a black image
+        outline = rio.read_png(str(tmp_path / "segmentation" / ("%d.png" % k)))
+        assert outline.shape == refined.shape and outline[:, :, 0].max() == 255 and not outline[:, :, 1].any()
+    eng.close()

@@ -318,6 +318,63 @@ def test_render_depth_bit_exact(oracle, scale, mesh_n):
     assert not t1.any()
 
 
+# The engine's own outlier test (features_kernel -> outlier_fused_kernel -> deciding pose chain segment), one object, in
+# every launch shape the engine can choose: 1 / 2 / 8 horizontal bands per alternative, the whole window in LDS or strips
+# of a few rows, projected vertices cached in LDS or re-projected per triangle.  Render: bit exact against
+# oracle/ro_render.c; likelihood: same samples, LIK_RTOL; decision identical.
+@pytest.mark.parametrize("shape,scale,mesh_n,div", [("A", 1, 36, 2), ("B", 1, 24, 4), ("A", 2, 12, 2)])
+def test_outlier_test_hot_path_kernel(oracle, shape, scale, mesh_n, div):
+    st = util.stream(18, 2, scale=scale, mesh_n=mesh_n, shape=shape)
+    verts, tris = st.mesh
+    ocam = util.oracle_camera(oracle, st.camera)
+    omesh = oracle.make_mesh(verts, tris)
+    mesh = ops.make_mesh(verts, tris)
+    depth = st.depth[0].numpy()
+    mask = st.mask_gt[0].numpy()
+    tw = st.camera.width // div
+    # alternative 0 off by a few centimetres and degrees (an outlier pose), alternative 1 near the truth
+    ang = 0.15
+    dq = np.array([np.cos(ang / 2), 0.0, np.sin(ang / 2), 0.0])
+    q0 = st.gt.q[0]
+    q_off = np.array([dq[0] * q0[0] - dq[1:] @ q0[1:], *(dq[0] * q0[1:] + q0[0] * dq[1:] + np.cross(dq[1:], q0[1:]))])
+    cases = [
+        (np.stack([st.gt.x[0] + [0.03, -0.02, 0.05], st.gt.x[0] + [0.001, 0.0, 0.002]]), np.stack([q_off, q0]), 1),
+        (np.stack([st.gt.x[0] + [0.002, 0.0, 0.001], st.gt.x[0] + [0.004, 0.001, 0.0]]), np.stack([q0, q0]), 0),
+        # alternative 1 off screen: no sample -> DBL_MAX, alternative 0 kept
+        (np.stack([st.gt.x[0], st.gt.x[0] + [50.0, 0.0, 0.0]]), np.stack([q0, q0]), 0),
+    ]
+    shapes = [dict(bands=1), dict(bands=2), dict(bands=8), dict(bands=0), dict(bands=1, window_pixels=3 * tw),
+              dict(bands=2, window_pixels=tw), dict(bands=1, vertex_cache=False), dict(bands=8, vertex_cache=False, window_pixels=2 * tw)]
+    for x2, q2, want_sel in cases:
+        t_ref = [oracle.render_depth(omesh, x2[k], q2[k], ocam, div) for k in range(2)]
+        ref = [oracle.depth_likelihood(ocam, depth, mask, t_ref[k], div) for k in range(2)]
+        assert (t_ref[0] > 0).sum() > 50
+        for kw in shapes:
+            Lv, ns, sel, tiles = ops.outlier_test(_cam(st), div, depth, mask, mesh, x2, q2, **kw)
+            for k in range(2):
+                assert np.array_equal(tiles[k], t_ref[k]), (kw, k, int((tiles[k] != t_ref[k]).sum()))
+                assert ns[k] == ref[k][1], (kw, k)
+                if ref[k][1] == 0:
+                    assert Lv[k] == ref[k][0] == np.finfo(np.float64).max
+                else:
+                    assert abs(Lv[k] - ref[k][0]) <= LIK_RTOL * abs(ref[k][0]), (kw, k)
+            assert sel == (1 if ref[0][0] > 2.0 * ref[1][0] else 0) == want_sel, kw
+
+
+def test_outlier_test_no_samples(oracle):
+    st = util.stream(18, 2, scale=2, mesh_n=12)
+    mesh = ops.make_mesh(*st.mesh)
+    x2 = np.stack([st.gt.x[0], st.gt.x[0]])
+    q2 = np.stack([st.gt.q[0], st.gt.q[0]])
+    depth = st.depth[0].numpy()
+    mask = st.mask_gt[0].numpy()
+    big = np.finfo(np.float64).max
+    # empty mask; depth out of the hard-coded (0, 2) gate (ROFTFilter.cpp:561)
+    for d, m in ((depth, np.zeros_like(mask)), (np.full_like(depth, 2.5), mask), (np.zeros_like(depth), mask)):
+        Lv, ns, sel, _ = ops.outlier_test(_cam(st), 2, d, m, mesh, x2, q2, tiles=False)
+        assert list(ns) == [0, 0] and Lv[0] == big and Lv[1] == big and sel == 0   # DBL_MAX > 2 DBL_MAX (= inf) is false
+
+
 def test_depth_likelihood_parity(oracle):
     st = util.stream(17, 2, scale=1, mesh_n=24)
     verts, tris = st.mesh
