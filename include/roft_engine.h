@@ -208,6 +208,14 @@ typedef struct {
     /* largest number of frames one roft_frames_submit may carry (1 .. ROFT_MAX_BATCH_FRAMES; 0 means 1).  Sizes the
      * engine's rings and, for zero-copy DEVICE inputs, the retention window (roft_engine_retain_frames). */
     int max_batch_frames;
+    /* Workgroups one object's mask propagation is spread over inside the persistent mask chain kernel (1..8; 0 = chosen
+     * from the device: (3/4 of its CUs) / max_objects).  With more than one, the workgroups of an object meet at a barrier
+     * in device memory between two frames, which needs all of them -- mask_workgroups_per_object x n_objects, each filling
+     * a CU -- resident at the same time.  That holds for one engine on a device of its own; several engines or processes
+     * running on ONE device at once should set 1 (no barrier).  A barrier that cannot complete is abandoned after ~2 s:
+     * the batch's results are invalid and the next roft_sync / roft_get_* / roft_frames_submit returns ROFT_ERR_DEVICE
+     * ("mask chain barrier timed out"); the process is not aborted. */
+    int mask_workgroups_per_object;
 } roft_config;
 
 typedef struct {
@@ -233,7 +241,10 @@ typedef struct {
  * because later flows were dropped (the reference clones every buffered flow) is copied into engine memory before
  * the window closes.  HOST buffers are copied into the engine's own ring before the submit call returns (the call
  * waits for the copies: the caller may re-use a HOST buffer as soon as it has returned); identical HOST pointers
- * within one frame -- a scene shared by several objects -- are uploaded once. */
+ * within one frame -- a scene shared by several objects -- are uploaded once.  The ring holds
+ * roft_engine_retain_frames() frames and grows, in 32 MiB pieces of device memory, to the bytes the largest frame
+ * staged so far needed: retain x (depth + flow + mask) x objects when every object has images of its own (64 objects at
+ * 640x480 CV_32FC2, batches of 8: 48 x 239 MB = 11.5 GB), retain x (one depth + flow + the masks) for a shared scene. */
 #define ROFT_RETAIN_FRAMES 16
 typedef struct {
     double dt;            /* RGB stamp delta; <= 0 means cfg.sample_time */
@@ -341,6 +352,17 @@ int roft_flow_producer_run(roft_flow_producer* fp, const uint8_t* const* prev, c
                            void* const* out, int n_pairs);
 int roft_flow_producer_sync(roft_flow_producer* fp);
 void* roft_flow_producer_stream(roft_flow_producer* fp);
+
+/* ---- (4) diagnostics (tests and profiling tools; not needed by an integration) --------------------------------- */
+/* The per-frame program builder without a device: the host-side mirror of CartesianQuaternionMeasurement::freeze's
+ * Standard / PopBufferedMeasurement / RepeatOnlyVelocity state machine (cpp:92-348) and of the re-sync loop of
+ * ROFTFilter::filtering_step (ROFTFilter.cpp:327-367) over n_frames pose-validity flags: per frame the number of UKF
+ * steps, of corrections, the index of the step followed by the outlier test (-1 none) and the twist-ring slots replayed
+ * (slots: n_frames x 10, -1 padded).  Any output may be NULL. */
+int roft_debug_plan(const roft_config* cfg, const int* pose_valid, int n_frames, int* n_steps, int* n_corrections,
+                    int* outlier, int* slots);
+/* phase counters of one object's last kernels (only filled by libraries built with a -DROFT_*_PROFILE switch) */
+int roft_debug_get_dbg(roft_engine* e, int obj_id, long long out[32]);
 
 #ifdef __cplusplus
 }

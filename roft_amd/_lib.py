@@ -55,7 +55,7 @@ class Config(C.Structure):
                 ("flow_aided_segmentation", C.c_int), ("mask_frames_between", C.c_int),
                 ("pose_frames_between", C.c_int), ("stamped_masks", C.c_int), ("max_objects", C.c_int), ("ukf_cholesky_guard", C.c_double),
                 ("ukf_cholesky_guard_bilinear", C.c_double),
-                ("device", C.c_int), ("max_batch_frames", C.c_int)]
+                ("device", C.c_int), ("max_batch_frames", C.c_int), ("mask_workgroups_per_object", C.c_int)]
 
 
 class ObjectDesc(C.Structure):
@@ -93,6 +93,7 @@ ABI_SYMBOLS = [
     "roft_engine_enable_log", "roft_engine_get_log", "roft_engine_get_log_rows", "roft_engine_stream", "roft_engine_enable_timing",
     "roft_engine_get_timing", "roft_default_of_params", "roft_optical_flow", "roft_flow_producer_create",
     "roft_flow_producer_destroy", "roft_flow_producer_run", "roft_flow_producer_sync", "roft_flow_producer_stream",
+    "roft_debug_plan", "roft_debug_get_dbg",
 ]
 
 

@@ -199,6 +199,8 @@ struct Arrays {
         a.max_verts = 0;
         a.ukf_chol_guard = 0.0;
         a.ukf_chol_guard_bil = 0.0;
+        a.mask_wgs = 0;
+        a.dev_error = nullptr;
         return ROFT_OK;
     }
 };
@@ -285,13 +287,20 @@ struct HostObject {
     ~HostObject() { for (auto* o : owned) delete o; }
 };
 
-// Device copies of HOST inputs: one slab for the whole retention window (allocated at the first HOST upload), a
-// bump allocator per frame slot; identical host pointers within a frame (a scene shared by several objects) share one
-// upload.
+// Device copies of HOST inputs: a ring of `retain` frame slots, each a bump allocator over chunks of device memory that
+// are allocated when a frame first needs them and kept (a slot grows to the largest frame it ever held: 64 objects with
+// their own 640x480 depth + CV_32FC2 flow + mask streams need 239 MB per slot, a shared scene 7 MB + the masks); identical
+// host pointers within a frame (a scene shared by several objects) share one upload.
 struct StageFrame {
-    size_t used = 0;
+    std::vector<DevBuf<unsigned char>*> chunks;
+    size_t cur = 0, used = 0;   // bump pointer: chunk index, bytes used of it
     std::vector<std::pair<const void*, void*>> seen;
+    StageFrame() = default;
+    StageFrame(StageFrame&&) = default;
+    StageFrame(const StageFrame&) = delete;
+    ~StageFrame() { for (auto* c : chunks) delete c; }
 };
+constexpr size_t kStageChunk = (size_t)32 << 20;
 
 }  // namespace
 
@@ -334,9 +343,8 @@ struct roft_engine {
     std::vector<Sched> backup;
     std::vector<ObjParams> h_params;
     std::vector<StageFrame> staging;       // [retain]
-    DevBuf<unsigned char> host_slab;       // retain x slot_bytes
-    size_t slot_bytes = 0;
     ObjState* state_host = nullptr;   // pinned landing block of roft_get_state (velocity belief + corrected pose belief)
+    int* dev_error = nullptr;         // pinned word a kernel raises when it gives up (EngineArrays::dev_error)
     // the submitted, not yet stepped batch
     bool submitted = false;
     int cur_T = 0;
@@ -368,6 +376,18 @@ static inline double host_now_us()
 }
 #define HP_MARK(e, slot, t) do { if ((e)->host_prof) { const double _n = host_now_us(); (e)->hp_acc[slot] += _n - (t); (t) = _n; } } while (0)
 
+// a kernel gave up (EngineArrays::dev_error): sticky -- the filter state of the objects is no longer what the reference
+// would hold
+static int check_dev_error(roft_engine* e)
+{
+    const int code = e->dev_error ? *reinterpret_cast<volatile int*>(e->dev_error) : 0;
+    if (code == 0) return ROFT_OK;
+    if (code == ROFT_DEV_ERROR_MASK_BARRIER)
+        return fail(ROFT_ERR_DEVICE, "mask chain barrier timed out: the workgroups of an object never became resident together "
+                                     "(several engines on one device? set roft_config::mask_workgroups_per_object = 1)");
+    return fail(ROFT_ERR_DEVICE, "a kernel reported error " + std::to_string(code));
+}
+
 // blocks until batch b (and therefore every earlier one) has ended on the GPU
 static int wait_batch(roft_engine* e, int b)
 {
@@ -376,7 +396,7 @@ static int wait_batch(roft_engine* e, int b)
         if (e->done_used[b % roft_engine::kBatchRing][l]) HIP_TRY(hipEventSynchronize(e->ev_done[b % roft_engine::kBatchRing][l]));
     e->completed_batches = b + 1;
     e->completed_frames = e->batch_end_frame[b % roft_engine::kBatchRing];
-    return ROFT_OK;
+    return check_dev_error(e);
 }
 
 extern "C" {
@@ -524,6 +544,14 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
     const int radius = (int)(size_t)cfg->subsampling_radius;
     if (int rc = e->arr.alloc(cfg->max_objects, e->T_max, make_cam(cfg->cam), ff, radius)) return rc;
     e->arr.a.n_obj = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->dev_error), sizeof(int), hipHostMallocMapped));
+    *e->dev_error = 0;
+    {
+        void* dp = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dp, e->dev_error, 0));
+        e->arr.a.dev_error = static_cast<int*>(dp);
+    }
+    e->arr.a.mask_wgs = cfg->mask_workgroups_per_object;
     e->arr.a.ukf_chol_guard = (cfg->ukf_cholesky_guard > 0.0) ? cfg->ukf_cholesky_guard : 0.0;
     e->arr.a.ukf_chol_guard_bil = (cfg->ukf_cholesky_guard_bilinear > 0.0) ? cfg->ukf_cholesky_guard_bilinear : 0.0;
     e->h_params.resize(cfg->max_objects);
@@ -546,6 +574,8 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
         return fail(ROFT_ERR_INVALID, "mask_frames_between > 30 (ROFT_MAX_FLOW_CHASE) is not supported");
     if (cfg->max_batch_frames < 0 || cfg->max_batch_frames > kMaxBatch)
         return fail(ROFT_ERR_INVALID, "max_batch_frames must be 0 .. ROFT_MAX_BATCH_FRAMES");
+    if (cfg->mask_workgroups_per_object < 0 || cfg->mask_workgroups_per_object > 8)
+        return fail(ROFT_ERR_INVALID, "mask_workgroups_per_object must be 0 (automatic) .. 8");
     if ((int)(size_t)cfg->subsampling_radius <= 0) return fail(ROFT_ERR_INVALID, "subsampling_radius must be >= 1");
     const int T = std::max(cfg->max_batch_frames, 1);
     // batches in flight: enough that the host never runs out of enqueued work while it waits for the oldest one -- a
@@ -597,6 +627,7 @@ int roft_engine_destroy(roft_engine* e)
     release_streams(e->streams);   // (idle: synchronised above)
     for (auto* o : e->objs) delete o;
     if (e->state_host) (void)hipHostFree(e->state_host);
+    if (e->dev_error) (void)hipHostFree(e->dev_error);
     for (auto ev : e->tev) (void)hipEventDestroy(ev);
     delete e;
     return ROFT_OK;
@@ -780,15 +811,16 @@ static int stage_host(roft_engine* e, int frame, const void* host, size_t bytes,
     StageFrame& sf = e->staging[frame % e->retain];
     for (auto& pr : sf.seen)
         if (pr.first == host) { *dev = pr.second; return ROFT_OK; }
-    if (!e->host_slab.p) {
-        const size_t npix = (size_t)e->cfg.cam.width * e->cfg.cam.height;
-        const size_t per_obj = ((npix * 4 + 255) & ~(size_t)255) + ((flow_bytes(e->arr.a.ffmt) + 255) & ~(size_t)255) + ((npix + 255) & ~(size_t)255);
-        e->slot_bytes = per_obj * (size_t)e->cfg.max_objects;
-        HIP_TRY(e->host_slab.ensure(e->slot_bytes * (size_t)e->retain));
-    }
     const size_t need = (bytes + 255) & ~(size_t)255;
-    if (sf.used + need > e->slot_bytes) return fail(ROFT_ERR_CAPACITY, "HOST staging slot exhausted");
-    unsigned char* d = e->host_slab.p + (size_t)(frame % e->retain) * e->slot_bytes + sf.used;
+    while (sf.cur < sf.chunks.size() && sf.used + need > sf.chunks[sf.cur]->n) { ++sf.cur; sf.used = 0; }
+    if (sf.cur == sf.chunks.size()) {
+        auto* c = new DevBuf<unsigned char>();
+        const hipError_t err = c->ensure(std::max(need, kStageChunk));
+        if (err != hipSuccess) { delete c; return fail(ROFT_ERR_DEVICE, std::string("HOST staging memory: ") + hipGetErrorString(err)); }
+        sf.chunks.push_back(c);
+        sf.used = 0;
+    }
+    unsigned char* d = sf.chunks[sf.cur]->p + sf.used;
     sf.used += need;
     HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, e->up_stream));
     e->stats.h2d_bytes += (long long)bytes;
@@ -832,6 +864,7 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
         const int frame = e->frame_counter + t;
         {   // the staging slot of this frame is free again: every frame that could read it has ended (in-flight bound)
             StageFrame& sf = e->staging[frame % e->retain];
+            sf.cur = 0;
             sf.used = 0;
             sf.seen.clear();
         }
@@ -1242,7 +1275,7 @@ int roft_sync(roft_engine* e)
     }
     e->completed_batches = e->batch_counter;
     e->completed_frames = e->frame_counter;
-    return ROFT_OK;
+    return check_dev_error(e);
 }
 
 int roft_get_state(roft_engine* e, int id, double pose13[13], double P12[144], double twist6[6], double Pv[36])
@@ -1953,8 +1986,8 @@ int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint
 
 }  // extern "C"
 
-// debugging aid (not part of the public ABI): phase cycle counters of the last ukf_step launch of one
-// object; only filled by builds with -DROFT_UKF_PROFILE
+// diagnostics (roft_engine.h section 4): phase counters of one object's last kernels; only filled by builds with a
+// -DROFT_*_PROFILE switch
 extern "C" int roft_debug_get_dbg(roft_engine* e, int id, long long out[32])
 {
     if (!e || id < 0 || id >= (int)e->objs.size()) return ROFT_ERR_INVALID;
@@ -1966,7 +1999,7 @@ extern "C" int roft_debug_get_dbg(roft_engine* e, int id, long long out[32])
     return err == hipSuccess ? ROFT_OK : ROFT_ERR_DEVICE;
 }
 
-// Host-logic check without a device (not part of the public ABI): runs the per-frame program builder -- the
+// Host-logic check without a device (roft_engine.h section 4): runs the per-frame program builder -- the
 // mirror of the Standard / PopBufferedMeasurement / RepeatOnlyVelocity state machine of
 // CartesianQuaternionMeasurement::freeze and of the re-sync loop of ROFTFilter::filtering_step -- over a
 // sequence of pose-validity flags and reports, per frame, the number of UKF launches, the number of

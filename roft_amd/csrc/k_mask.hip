@@ -24,6 +24,8 @@
 //    an atomic exchange (read + clear), so the map is never memset and never read through a stale L1 line.
 // The per-frame decisions (mode, source, flow count, binary or not) are made once, by the chain kernel, and recorded in
 // MaskRec rows that carry the state from frame to frame and from batch to batch.
+#include <algorithm>
+
 #include "roft_device.h"
 
 namespace roft {
@@ -141,10 +143,7 @@ void launch_mask_reset(const EngineArrays& a, hipStream_t s)
 }
 
 // ---- mask chain ------------------------------------------------------------------------------------
-#ifndef ROFT_MASK_THREADS
-#define ROFT_MASK_THREADS 1024
-#endif
-constexpr int kMaskThreads = ROFT_MASK_THREADS;
+constexpr int kMaskThreads = 1024;
 constexpr int kMaskWaves = kMaskThreads / 64;
 // (64-pixel groups whose walks through the flows are in flight together in one wave -- chase_groups' NCH: a pixel's
 //  walk is a chain of dependent loads, the chains of different groups are independent)
@@ -304,14 +303,12 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
 // VGPRs per group -- and ALL groups of a wave (about a dozen at 64 objects) go out in one round: the frame pays one
 // memory latency for its flow.  Position, bit and target are (re)computed when the data is back.  Same arithmetic as
 // chase_groups with n_flows == 1, operation by operation.  Needs the plane words of the listed groups in LDS (`words`).
-#ifndef ROFT_SINGLE_WALKS
-#define ROFT_SINGLE_WALKS 12
-#endif
+constexpr int kSingleWalks = 12;   // groups per wave whose flow loads are in flight together (16: slower, register pressure)
 template <int FT, int MODE>
 __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* list_, const uint2* words_, int n_list, bool clear00,
                                             const void* flow, ROFT_LDS uint32_t* tgt)
 {
-    constexpr int NCH = ROFT_SINGLE_WALKS;
+    constexpr int NCH = kSingleWalks;
     // (LDS pointers as such: through generic pointers every read of the list is a flat load, and a flat load waits for
     //  ALL outstanding memory operations -- the flow loads would go out one at a time)
     const ROFT_LDS uint32_t* const list = (const ROFT_LDS uint32_t*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane(
@@ -370,9 +367,6 @@ __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* li
                 const int ix = trunc_clamped(t_x), iy = trunc_clamped(t_y);
                 if (((bits >> lane) & 1ull) && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) {
                     const int tp = iy * W + ix;
-#ifdef ROFT_EXP_DOUBLE_ATOMIC
-                    (void)__hip_atomic_fetch_or(tgt + (tp >> 5), 1u << (tp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
                     (void)__hip_atomic_fetch_or(tgt + (tp >> 5), 1u << (tp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
@@ -383,10 +377,7 @@ __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* li
 // binary source: OR-scatter into the LDS plane.  kBinaryWalks walks in flight per wave: a workgroup's share of an object
 // is about a dozen groups per wave, so all their flow reads go out together and the frame pays ONE memory latency per
 // flow instead of one per eight groups.
-#ifndef ROFT_BINARY_WALKS
-#define ROFT_BINARY_WALKS 8
-#endif
-constexpr int kBinaryWalks = ROFT_BINARY_WALKS;
+constexpr int kBinaryWalks = 8;
 template <int FT>
 __device__ __noinline__ void propagate_binary(ChaseGeo g, const uint2* plane2, const uint32_t* list, int n_list, int n_flows,
                                               bool clear00, const void* const* flows, uint32_t* s_tgt, const uint2* words)
@@ -494,16 +485,20 @@ __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskR
     return r;
 }
 
-// Barrier among the nq workgroups of one object inside the persistent chain kernel: `counter` (zeroed by the carry
-// kernel) counts arrivals, `target` = nq * (barriers so far + 1).  Every thread releases its global writes of the frame
-// at agent scope before the workgroup arrives (the workgroups of an object run on different XCDs, each with an L2 of
-// its own), thread 0 arrives and polls, and everybody acquires afterwards.  All workgroups of the launch are resident
-// together (nq * n_obj <= the CU count, one workgroup fits every CU next to anything else the engine runs), and kernels
-// on the other streams never wait for this one, so the poll cannot starve; a poll that nevertheless lasts two seconds
-// aborts the kernel -- the engine then fails with a launch error instead of hanging the device.
-// In two halves, so that what a workgroup can do for the next frame without the others' results -- control block,
-// decisions, zeroing -- runs while the arrivals travel: arrive (every thread's stores and atomics acknowledged, one
+// Barrier among the nq workgroups of one object inside the persistent chain kernel: `counter` (zeroed by the control block
+// upload of the batch) counts arrivals, `target` = nq * (barriers so far + 1).  What the workgroups exchange goes through
+// agent-coherent accesses (sc1 stores / loads, device-scope atomics): a thread only has to wait for its own stores and
+// atomics to be acknowledged before the workgroup arrives.  In two halves, so that what a workgroup can do for the next
+// frame without the others' results -- control block, decisions, zeroing -- runs while the arrivals travel: arrive (one
 // atomic by thread 0) ... wait (thread 0 polls).
+// FORWARD PROGRESS: the poll ends only if the object's other workgroups run, i.e. the nq * n_obj workgroups of the launch
+// must become resident together.  HIP promises no dispatch order; what the launch relies on is (i) nq * n_obj <= the CUs
+// the launch may fill (launch_mask_chain: three quarters of the device's CUs, one workgroup fills a CU's register file;
+// nq = 1, no barrier at all, when that cannot hold), (ii) the hardware dispatching the workgroups of ONE launch in
+// order and (iii) no kernel of the other chains ever waiting for this one while it holds CUs.  Several engines -- or
+// processes -- running mask chains on one device at once can break (i); therefore the poll is bounded: after ~2 s the
+// workgroup raises EngineArrays::dev_error (pinned host memory: the host turns it into ROFT_ERR_DEVICE at its next
+// synchronisation, roft_engine.h) and leaves the kernel, and so does every workgroup that sees the flag raised.
 __device__ __forceinline__ void object_arrive(unsigned* counter)
 {
     __builtin_amdgcn_s_waitcnt(0);   // every store / atomic of this thread acknowledged
@@ -511,16 +506,28 @@ __device__ __forceinline__ void object_arrive(unsigned* counter)
     if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void object_wait(unsigned* counter, unsigned target)
+// returns false when the barrier was abandoned (dev_error raised)
+__device__ __forceinline__ bool object_wait(unsigned* counter, unsigned target, int* dev_error, int* s_ok)
 {
     if (threadIdx.x == 0) {
         const long long t0 = wall_clock64();
+        int ok = 1;
+        unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > 200000000ll) __builtin_trap();   // 100 MHz clock
+            if ((++spins & 1023u) == 0u) {   // ~ every 50 us: somebody else gave up, or two seconds have passed (100 MHz clock)
+                const bool raised = dev_error && __hip_atomic_load(dev_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
+                if (raised || wall_clock64() - t0 > 200000000ll) {
+                    if (dev_error && !raised) __hip_atomic_store(dev_error, ROFT_DEV_ERROR_MASK_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    ok = 0;
+                    break;
+                }
+            }
         }
+        *s_ok = ok;
     }
     __syncthreads();
+    return *s_ok != 0;
 }
 
 // The binary-mask chain of a batch: ONE launch walks the T frames.  grid: (S, n_obj).  Workgroup q of an object owns
@@ -553,6 +560,7 @@ __global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a
     const int W = a.cam.W, H = a.cam.H, n_grp = (W * H) >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
     __shared__ FrameCtrl s_c;
+    __shared__ int s_barrier_ok;
     __shared__ MaskRec s_rec[2];   // [0] state after the frame before (frame 0: the carry), [1] this frame's counters
     static_assert(sizeof(MaskRec) == 32, "two 16-byte loads per record");
     // share of the plane words of this workgroup, in 16-byte units when the planes are 16-byte aligned
@@ -653,7 +661,7 @@ __global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a
         else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }   // (one workgroup, one CU: its L1 is written through)
         if (tid == 0) s_rec[0] = r;   // (the staging barrier of the prologue publishes it)
         r = prologue(t + 1);
-        if (nq > 1) object_wait(a.mask_sync + obj, (unsigned)nq * ++n_barriers);
+        if (nq > 1 && !object_wait(a.mask_sync + obj, (unsigned)nq * ++n_barriers, a.dev_error, &s_barrier_ok)) return;
         MTICK(5);
     }
 }
@@ -735,10 +743,14 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
     const size_t n_grp = (size_t)a.cam.W * a.cam.H / 64;
     // Workgroups per object: the walks are latency-bound on one CU, so an object is spread over several (at most 8).  A
     // workgroup of 16 waves with 128 registers per thread fills the register file of its CU, and it stays for the whole
-    // batch: a quarter of the chip's 256 CUs is left to the per-object chains of the other streams (the pose and velocity
-    // filters need an empty CU each: 346 / 219 registers per thread) -- measured at 64 objects: 3 workgroups per object
-    // +4 % object-frames/s over 4, and the flow measurement's launch no longer waits for CUs (its duration was bimodal).
-    int S = (256 - 64) / (a.n_obj > 0 ? a.n_obj : 1);
+    // batch: a quarter of the device's CUs is left to the per-object chains of the other streams (the pose and velocity
+    // filters need a nearly empty CU each) -- measured at 64 objects on 256 CUs: 3 workgroups per object +4 %
+    // object-frames/s over 4, and the flow measurement's launch no longer waits for CUs.  All S * n_obj workgroups must be
+    // resident together (the barrier of object_wait): S = 1, no barrier, when three quarters of the CUs cannot hold two per
+    // object.  roft_config::mask_workgroups_per_object overrides the choice (clamped to what fits).
+    const int cus = device_cu_count(), n_obj = a.n_obj > 0 ? a.n_obj : 1;
+    const int fit = (cus - cus / 4) / n_obj;
+    int S = a.mask_wgs > 0 ? std::min(a.mask_wgs, std::max(cus / n_obj, 1)) : fit;
     S = S < 1 ? 1 : (S > 8 ? 8 : S);
     const size_t lds_plane = (a.plane_words * 4 + 15) & ~(size_t)15;
     // list of a workgroup's groups next to its plane (4 B per group), their plane words behind it (8 B) if the CU's LDS

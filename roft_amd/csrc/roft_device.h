@@ -201,7 +201,11 @@ struct EngineArrays {
     double ukf_chol_guard_bil;  // roft_config::ukf_cholesky_guard_bilinear
     roft_object_output* out_log;  // [log_cap][n_obj] per-frame outputs, or null
     int log_cap;
+    int mask_wgs;            // roft_config::mask_workgroups_per_object (0: by the device's CU count)
+    int* dev_error;          // one word of pinned host memory (or null): ROFT_DEV_ERROR_* raised by a kernel that gave up
 };
+
+constexpr int ROFT_DEV_ERROR_MASK_BARRIER = 1;   // mask_chain_kernel: an object's workgroups never became resident together
 
 #define ROFT_LDS __attribute__((address_space(3)))
 

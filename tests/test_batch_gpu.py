@@ -207,3 +207,20 @@ def test_mask_chain_result_independent_of_workgroups_per_object():
         for o in range(8):
             assert np.array_equal(ref_masks[o], masks[o]), (n_obj, o)
             assert np.array_equal(ref_masks[o], masks[n_obj - 8 + o]), (n_obj, o)
+
+
+def test_mask_workgroups_per_object_changes_nothing():
+    """roft_config::mask_workgroups_per_object: one workgroup per object (no barrier in memory), a few, or the automatic
+    choice -- the propagation is an order-free OR, so the whole trajectory is bit for bit the same."""
+    n = 20
+    streams = [util.to_device(st) for st in awkward_streams(n)]
+    ref = None
+    for wgs in (0, 1, 2, 5, 8):
+        log, masks, _ = util.run_engine_logged(make_engine, streams, n, T=8, mask_workgroups_per_object=wgs)
+        if ref is None:
+            ref = (log, masks)
+            continue
+        for a, b in zip(ref[0], log):
+            assert np.array_equal(a, b), wgs
+        for a, b in zip(ref[1], masks):
+            assert np.array_equal(a, b), wgs
