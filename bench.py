@@ -145,11 +145,17 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--host-inputs", action="store_true",
                    help="hand the engine HOST buffers in the main run (PCIe-inclusive rate; never the headline value)")
-    p.add_argument("--pcie-frames", type=int, default=12, help="timed frames of the two PCIe-inclusive legs (0: skip them)")
-    p.add_argument("--clock-warm-ms", type=float, default=400.0,
-                   help="milliseconds of unrelated GPU work (a GEMM loop) right before the warm-up steps: the device idles at "
-                        "~520 MHz while the host prepares the batches and needs tens of milliseconds of load to clock up -- a "
-                        "2 ms timed window measured from idle reports the idle clock (0: off)")
+    p.add_argument("--pcie-frames", type=int, default=48,
+                   help="timed frames of each run of the two PCIe-inclusive legs (three runs each, the median is reported; 0: skip them)")
+    p.add_argument("--no-extras", action="store_true", help="skip the cold run and the live per-frame latency measurement")
+    p.add_argument("--dump-rows", default="", help="rank 0 saves the gathered [objects, steps, 19] result rows of the timed region (.npy)")
+    p.add_argument("--rehearsal-ms", type=float, default=400.0,
+                   help="process warm-up before the W warm-up steps: scratch engines track the same W + K frames (untimed, results "
+                        "discarded) for at least this long -- kernels loaded, allocations sized, input pages touched by the "
+                        "tracker's own access pattern, device out of its idle power state under the tracker's own load.  The "
+                        "timed K steps then run on a fresh engine.  0: off (see also `value_cold` in the output)")
+    p.add_argument("--clock-warm-ms", type=float, default=0.0,
+                   help="milliseconds of unrelated GPU work (GEMMs + copies) before the warm-up steps (round 2's warm-up; off)")
     p.add_argument("--no-ramp", action="store_true", help="full batches from the first timed frame on, the short one last")
     p.add_argument("--splits", default="", help="explicit batch sizes of the timed frames, e.g. 2,6,6,6 (must sum to --steps)")
     p.add_argument("--no-kernel-timing", action="store_true",
@@ -289,6 +295,18 @@ def main():
             eng.step()
 
     barrier = parallel.barrier
+    if args.rehearsal_ms > 0:
+        t_w = time.perf_counter()
+        while True:
+            _c, scratch = new_engine(n_obj)
+            add_objects(scratch, streams)
+            for arr, _keep, t in warm_batches + timed_batches:
+                scratch.submit_batch_raw(arr, t)
+                scratch.step()
+            scratch.sync()
+            scratch.close()
+            if (time.perf_counter() - t_w) * 1e3 >= args.rehearsal_ms:
+                break
     if args.clock_warm_ms > 0:
         # not tracker work and not timed: brings the device out of its idle power state (see --clock-warm-ms)
         # (a GEMM for the shader clock, large copies for the memory / fabric clocks: the tracker's kernels are bound by
@@ -350,6 +368,14 @@ def main():
     value = total_obj * args.steps / elapsed
     if gathered is not None:
         assert tuple(gathered.shape) == (total_obj, args.steps, 19), gathered.shape
+    if args.dump_rows:
+        rows_out = gathered.cpu().numpy() if gathered is not None else np.ascontiguousarray(eng.get_log_rows(args.warmup, args.steps).transpose(1, 0, 2))
+        np.save(args.dump_rows, rows_out)
+    if world > 1:
+        # cpu_baseline, the PCIe-inclusive legs and the extras are N = 1 measurements (the other ranks wait at a barrier)
+        args.no_cpu_baseline = True
+        args.pcie_frames = 0
+        args.no_extras = True
 
     # ---- accuracy: ADD-S vs ground truth and vs the CPU reference path on the sampled objects
     pose_log, twist_log, npts_log, sel_log = eng.get_log(0, n_frames)
@@ -472,9 +498,71 @@ def main():
             return dict(value=n_obj * frames / dt_, unit="object-frames/s", frames=frames, ms_per_step=1e3 * dt_ / frames,
                         h2d_GB_per_s=(s1["h2d_bytes"] - s0["h2d_bytes"]) / dt_ / 1e9,
                         h2d_MB_per_step=(s1["h2d_bytes"] - s0["h2d_bytes"]) / frames / 1e6)
-        pcie = dict(per_object_streams=pcie_leg(False), shared_scene=pcie_leg(True),
+        def median_leg(shared):
+            runs = sorted((pcie_leg(shared) for _ in range(3)), key=lambda r: r["value"])
+            med = dict(runs[1])
+            med["runs"] = [r["value"] for r in runs]
+            return med
+        pcie = dict(per_object_streams=median_leg(False), shared_scene=median_leg(True),
                     note="pinned HOST inputs, copied by the submit call before it returns; per_object_streams: %d x (depth + "
-                         "flow [+ mask]) per frame; shared_scene: one depth + flow for all objects, masks per object" % n_obj)
+                         "flow [+ mask]) per frame; shared_scene: one depth + flow for all objects, masks per object; each leg: "
+                         "median of three runs of %d timed frames" % (n_obj, args.pcie_frames))
+
+    # ---- extras: the same timed sequence from a cold device, and the tracker used live (one frame at a time, state read
+    #      back before the next frame is submitted)
+    value_cold = None
+    live = None
+    if not args.no_extras:
+        def timed_sequence(e2, sts, k_warm, k_timed):
+            def bat(k0, t):
+                return e2.build_batch([[frame_dict(st, k, dict(depth=st.depth, flow=st.flow, mask=st.mask_gt), L.MEM_DEVICE) for st in sts]
+                                       for k in range(k0, k0 + t)])
+            wb = [bat(k0, t) for k0, t in split_batches(0, k_warm, T)]
+            tb = [bat(k0, t) for k0, t in (timed_splits if k_timed == args.steps and k_warm == args.warmup else split_batches(k_warm, k_warm + k_timed, T, ramp=True))]
+            for arr, _keep, t in wb:
+                e2.submit_batch_raw(arr, t)
+                e2.step()
+            e2.sync()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for arr, _keep, t in tb:
+                e2.submit_batch_raw(arr, t)
+                e2.step()
+            e2.sync()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+        # (the device has idled through the CPU baseline and the host work above: no clock warm-up precedes this run)
+        time.sleep(1.0)
+        _c, e2 = new_engine(n_obj)
+        add_objects(e2, streams)
+        dt_cold = timed_sequence(e2, streams, args.warmup, args.steps)
+        e2.close()
+        value_cold = dict(value=n_obj * args.steps / dt_cold, ms_per_step=1e3 * dt_cold / args.steps,
+                          note="the timed sequence again on a fresh engine after the device has idled (CPU baseline, host "
+                               "work, 1 s sleep) and WITHOUT the --clock-warm-ms load: what a short burst from an idle GPU gets")
+        # live: ROFTFilter::filtering_step followed by a reader of the estimate, one object, nothing in flight across frames
+        n_live = min(n_frames, 72)
+        cfg1 = E.default_config(cam.width, cam.height, ftype, max_objects=1, device=local_rank, max_batch_frames=1)
+        cfg1.cam.fx, cfg1.cam.fy, cfg1.cam.cx, cfg1.cam.cy = cam.fx, cam.fy, cam.cx, cam.cy
+        e1 = E.ROFTFilterBatch(cfg1)
+        add_objects(e1, streams[:1])
+        st = streams[0]
+        ins = [e1.build_inputs([frame_dict(st, k, dict(depth=st.depth, flow=st.flow, mask=st.mask_gt), L.MEM_DEVICE)]) for k in range(n_live)]
+        lat = np.zeros(n_live)
+        for k in range(n_live):
+            t1 = time.perf_counter()
+            e1.submit_raw(ins[k][0])
+            e1.step()
+            e1.state(0)
+            lat[k] = time.perf_counter() - t1
+        e1.close()
+        w = lat[12:] * 1e6
+        pf = np.array([bool(st.pose_valid[k]) for k in range(12, n_live)])
+        live = dict(median_us=float(np.median(w)), p99_us=float(np.percentile(w, 99)),
+                    median_us_pose_frames=float(np.median(w[pf])) if pf.any() else None,
+                    median_us_other_frames=float(np.median(w[~pf])) if (~pf).any() else None, frames=int(len(w)),
+                    note="one object, %dx%d: submit + step + get_state per frame, nothing in flight across frames (device inputs)" %
+                         (cam.width, cam.height))
 
     # ---- roofline of the masked flow + depth measurement kernel (north_star's target kernel)
     roofline = None
@@ -497,13 +585,20 @@ def main():
         dense_per_obj = cam.width * cam.height * 5 + flow_frame_bytes
         # HBM traffic of this kernel: a separate rocprofv3 --pmc pass of this same command, committed under profiles/
         # (see profiles/README.md for the gfx950 counting caveats); only quoted when the workload matches that pass
-        traffic, traffic_source = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_k1.json")
-        if os.path.exists(pmc_path):
+        traffic, traffic_raw, traffic_source = None, None, None
+        for tag in ("r03", "r02"):
+            pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_k1.json" % tag)
+            if not os.path.exists(pmc_path):
+                continue
             pm = json.load(open(pmc_path))
             if (pm.get("objects"), pm.get("shape"), pm.get("flow"), pm.get("batch")) == (n_obj, args.shape, args.flow, T):
+                # raw: the FETCH_SIZE counter as rocprofv3 reports it; corrected: + the bit-plane bytes once more, because
+                # on gfx950 FETCH_SIZE tallies the 128-byte requests of a wide coalesced stream at 64 bytes
+                # (MI355X_MICROARCH.md, HBM) -- the plane read is such a stream, the 4- and 8-byte gathers are left as counted
+                traffic_raw = pm["fetch_bytes_per_object_frame_raw"] * obj_frames_per_launch
                 traffic = pm["fetch_bytes_per_object_frame"] * obj_frames_per_launch
-                traffic_source = "profiles/r02_pmc_k1.json: %s" % pm.get("source", "")
+                traffic_source = "profiles/%s_pmc_k1.json: %s" % (tag, pm.get("source", ""))
+                break
         # the 100 % mark measured on this box next to the datasheet figure: a device-to-device copy of 1 GiB,
         # read + write bytes over the best of five
         copy_gbs = None
@@ -525,7 +620,8 @@ def main():
             copy_gbs = None
         roofline = dict(kernel="flow_measure_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         measured_copy_GBs=copy_gbs, frac_of_measured_copy=(achieved / copy_gbs) if copy_gbs else None,
-                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_source,
+                        frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_raw_counter=traffic_raw, traffic_source=traffic_source,
+                        frac_on_fetched_bytes=(traffic / dur_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                         algorithmic_bytes_per_launch=bytes_per_launch, algorithmic_bytes_per_object_frame=bytes_per_obj,
                         object_frames_per_launch=obj_frames_per_launch, avg_launch_us=k1_live["avg_us"],
                         launches=k1_live["launches"],
@@ -534,7 +630,9 @@ def main():
                              "launch measures every (frame, object) of a batch; the duration is measured live with a HIP "
                              "event pair on the kernel's own dispatch while the other chains run on their streams. The "
                              "north-star target of 0.70 is not met: the kernel reads ~60 KB per object-frame instead of the "
-                             "dense 4 MB and is bound by its dependent-load latency, not by HBM bandwidth")
+                             "dense 4 MB; every 4-byte depth and 8-byte flow sample costs a 64-byte sector, so the memory system "
+                             "moves `traffic` bytes (frac_on_fetched_bytes) for the declared ones -- the launch is bound by that "
+                             "scattered sector traffic and its dependent-load latency, not by streaming bandwidth")
     dominant = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])[0] if kernels else None
     d_frames = max(stats1["frames"] - stats0["frames"], 1)
 
@@ -573,6 +671,9 @@ def main():
         "value_pcie_inclusive": pcie["per_object_streams"]["value"] if pcie else None,
         "value_pcie_inclusive_shared_scene": pcie["shared_scene"]["value"] if pcie else None,
         "pcie_inclusive": pcie,
+        "value_cold": value_cold["value"] if value_cold else None,
+        "cold_run": value_cold,
+        "live_latency": live,
         "adds_vs_gt_mm": {"mean": 1e3 * float(adds_gt.mean()), "auc": metrics.auc(adds_gt)},
         "adds_vs_cpu_ref_mm": ({"mean": 1e3 * float(adds_cpu.mean()), "max": 1e3 * float(adds_cpu.max())}
                                if adds_cpu is not None else None),

@@ -84,9 +84,10 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
         for (int v = chunk * per; v < w; ++v) r0 += __popc(s_plane[v]);
         if (r0 & 1) bits &= bits - 1;                 // first set bit has an odd rank: skip it
         int slot = (r0 + 1) >> 1;
-        const int row = w / wpr, pix0 = row * W + (w - row * wpr) * 32;
+        const int row = w / wpr;
+        const uint32_t pix0 = ((uint32_t)row << 16) | (uint32_t)((w - row * wpr) * 32);   // (v << 16 | u): no division by W downstream
         while (bits) {
-            if (slot < a.feat_cap) fpix[slot] = (uint32_t)(pix0 + __builtin_ctz(bits));
+            if (slot < a.feat_cap) fpix[slot] = pix0 + (uint32_t)__builtin_ctz(bits);
             ++slot;
             bits &= bits - 1;                         // the kept bit ...
             bits &= bits - 1;                         // ... and its odd-ranked successor (no-op on 0)
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
             px[u] = (sl < n) ? fpix[sl] : 0u;
         }
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) d[u] = depth[px[u]];
+        for (int u = 0; u < kBatch; ++u) d[u] = depth[(size_t)(px[u] >> 16) * W + (px[u] & 0xFFFFu)];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
             const int sl = sb + u * (int)blockDim.x;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
     PoseLane& pl = st.lane[lin];
     if (pl.pending_frame < 0) return;
     const FrameCtrl& c = frame_ctrl(a, pl.pending_frame, obj);
-    const int W = a.cam.W, d = a.cam.divider, tw = a.tile_w;
+    const int d = a.cam.divider, tw = a.tile_w;
     const int fslot = (c.feat_read >= 0) ? c.feat_read : 0;
     const uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
     const float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
         uint32_t b0[kBatch], b1[kBatch];
 #pragma unroll
         for (int k = 0; k < kBatch; ++k) {
-            const int v = (int)(pix[k] / W), u = (int)(pix[k] - v * W);
+            const int v = (int)(pix[k] >> 16), u = (int)(pix[k] & 0xFFFFu);
             const size_t ti = (size_t)(v / d) * tw + (u / d);
             b0[k] = z0[ti];
             b1[k] = z1[ti];
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     const ObjParams& prm = a.params[obj];
     const PoseBelief& bl = st.belief[b_alt(lin, alt)];
     const RenderPose P = make_pose(bl.mean + 6, bl.mean + 9);
-    const int d = a.cam.divider, W = a.cam.W, tw = a.tile_w, th = a.tile_h;
+    const int d = a.cam.divider, tw = a.tile_w, th = a.tile_h;
     const float fx = (float)(a.cam.fx / d), fy = (float)(a.cam.fy / d), cx = (float)(a.cam.cx / d), cy = (float)(a.cam.cy / d);
     const int nv = prm.n_verts, nt = prm.n_tris;
     const bool cached = nv <= vcache_cap;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
 #pragma unroll
                 for (int k = 0; k < kBatch; ++k) {
                     if (!((dep[k] > 0) && ((double)dep[k] < 2.0))) continue;  // hard-coded 2.0 (ROFTFilter.cpp:561)
-                    const int v = (int)(pix[k] / W), u = (int)(pix[k] - v * W);
+                    const int v = (int)(pix[k] >> 16), u = (int)(pix[k] & 0xFFFFu);
                     const int tj = v / d, ti = u / d;
                     if (tj < js || tj > je || ti < i0 || ti > i1) continue;
                     const uint32_t b = s_z[(tj - js) * win_w + (ti - i0)];
@@ -500,7 +501,7 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     const bool cache = vbytes + min_win <= lds_total && !(opts && opts->no_vertex_cache);
     const int vcache_cap = cache ? a.max_verts : 0;
     int win_cap = (int)((lds_total - (cache ? vbytes : 0)) / 4);
-    set_max_dynamic_lds(reinterpret_cast<const void*>(outlier_fused_kernel), (int)lds_total);
+    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(outlier_fused_kernel), (int)lds_total);
     // bands per alternative: as many workgroups as the chip has CUs to spare
     int parts = std::max(1, std::min(kMaxOutlierParts, device_cu_count() / (2 * std::max(a.n_obj, 1))));
     if (opts && opts->parts > 0) parts = std::min(opts->parts, kMaxOutlierParts);

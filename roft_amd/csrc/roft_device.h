@@ -190,7 +190,7 @@ struct EngineArrays {
     FlowRec* recs;           // [T][n_obj][cand_cap] kept flow records
     int* npts;               // [T][n_obj] N of the velocity stage (-1: did not run)
     double* norms;           // [n_obj][3 * cand_cap] SKF scratch (innovations + norms when N > LDS capacity)
-    uint32_t* feat_pix;      // [n_obj][kFeatRing][feat_cap] buffered feature pixel (linear index)
+    uint32_t* feat_pix;      // [n_obj][kFeatRing][feat_cap] buffered feature pixel (v << 16 | u)
     float* feat_depth;       // [n_obj][kFeatRing][feat_cap]
     uint32_t* zbuf;          // [2][tile_h*tile_w] float bits, +inf = empty: z-buffers of the operator-level likelihood
     int cand_cap, feat_cap;

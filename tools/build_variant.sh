@@ -3,12 +3,13 @@
 # usage: bash tools/build_variant.sh <name> "<extra flags>"
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
+SRC=${ROFT_SRC:-$R}
 NAME=$1; EXTRA=$2
 B=$R/build_ab/obj_$NAME; mkdir -p $B
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-pass-failed $EXTRA"
 pids=()
 for f in k_mask k_flow k_skf k_ukf k_render k_opticalflow engine flow_producer; do
-  hipcc $FLAGS -c $R/roft_amd/csrc/$f.hip -o $B/$f.o &
+  hipcc $FLAGS -c $SRC/roft_amd/csrc/$f.hip -o $B/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

@@ -3,7 +3,7 @@
 # gpurun_out/<tag>/ (copy the ones to keep into profiles/ with the tag as prefix).   usage: bash tools/collect_profiles.sh [tag]
 set -x
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
