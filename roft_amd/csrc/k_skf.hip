@@ -147,6 +147,33 @@ __device__ __forceinline__ double wave_max_to_lane63(double v)
     return v;
 }
 
+// Wave reduction of up to 32 accumulators at once ("transpose-reduce"): in the step with lane distance `off` every lane
+// keeps one half of its values -- the lower half if its bit `off` is clear, the upper half otherwise -- and adds to each
+// the partner's copy of it, so the number of values per lane halves while the number of lanes summed doubles: 16 + 8 +
+// 4 + 2 + 1 + 1 = 32 exchanges instead of 6 per accumulator.  On return v[0] of lane l is the sum over all 64 lanes of the
+// accumulator with index  bit5(l) 16 + bit4(l) 8 + bit3(l) 4 + bit2(l) 2 + bit1(l)  (both lanes of a pair hold it).
+template <int H>
+__device__ __forceinline__ void transpose_reduce_step(double* v, int off)
+{
+    const bool up = (threadIdx.x & off) != 0;
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        const double keep = up ? v[k + H] : v[k];
+        const double send = up ? v[k] : v[k + H];
+        v[k] = keep + __shfl_xor(send, off, 64);
+    }
+}
+
+__device__ __forceinline__ void wave_transpose_reduce32(double v[32])
+{
+    transpose_reduce_step<16>(v, 32);
+    transpose_reduce_step<8>(v, 16);
+    transpose_reduce_step<4>(v, 8);
+    transpose_reduce_step<2>(v, 4);
+    transpose_reduce_step<1>(v, 2);
+    v[0] += __shfl_xor(v[0], 1, 64);
+}
+
 __device__ double block_sum(double v, double* s_red)
 {
     v = wave_sum_to_lane63(v);
@@ -403,8 +430,9 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
 
     SKFTICK(5);
     // information accumulation: 21 unique entries of sum l H'R^-1 H and 6 of sum l H'R^-1 e
-    double acc[27];
-    for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+    double acc[32];   // 27 used; padded for the transpose-reduce below
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc[i] = 0.0;
     const double ir0 = 1.0 / r_flow[0], ir1 = 1.0 / r_flow[1];
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
         double h[12], y[2];
@@ -423,16 +451,19 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
         if (weighted) l = qn[j] / lmax;
         const double w0 = l * ir0, w1 = l * ir1;
         int t = 0;
+#pragma unroll
         for (int i = 0; i < 6; ++i)
+#pragma unroll
             for (int k = i; k < 6; ++k) acc[t++] += w0 * h[i] * h[k] + w1 * h[6 + i] * h[6 + k];
+#pragma unroll
         for (int i = 0; i < 6; ++i) acc[21 + i] += w0 * h[i] * e0 + w1 * h[6 + i] * e1;
     }
     SKFTICK(6);
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 27; ++i) {
-        const double v = wave_sum_to_lane63(acc[i]);
-        if ((threadIdx.x & 63) == 63) S.acc[i][threadIdx.x >> 6] = v;
+    wave_transpose_reduce32(acc);
+    {
+        const int l = threadIdx.x & 63, idx = ((l >> 5) & 1) * 16 + ((l >> 4) & 1) * 8 + ((l >> 3) & 1) * 4 + ((l >> 2) & 1) * 2 + ((l >> 1) & 1);
+        if (!(l & 1) && idx < 27) S.acc[idx][threadIdx.x >> 6] = acc[0];
     }
     __syncthreads();
     SKFTICK(7);

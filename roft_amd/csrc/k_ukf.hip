@@ -118,6 +118,7 @@ struct UkfLds {
     double wP[12];       // its eigenvalues
     double S[144];       // matrix square root the sigma points are drawn from (see decompose_state_cov)
     uint2 jtab[11 * 36]; // Jacobi 12x12: per round and 2x2 block, the four entry offsets (16 bit each)
+    unsigned short tri12[78], tri6[21];   // upper triangles in row-major order: (i << 8 | j), i <= j
     double cs[2][6][2];  // rotations (c, s) of the current round, double-buffered by round parity
     double Q[100];       // process noise block padded to 10 x 10
     double VQ[100];
@@ -272,6 +273,12 @@ __device__ void jacobi12_table(UkfLds& L)
         L.jtab[i] = make_uint2((uint32_t)(pa * 12 + pb) | ((uint32_t)(pa * 12 + qb) << 16),
                                (uint32_t)(qa * 12 + pb) | ((uint32_t)(qa * 12 + qb) << 16));
     }
+    for (int e = threadIdx.x; e < 78 + 21; e += kUkfThreads) {
+        const int m = e < 78 ? 12 : 6;
+        int u = e < 78 ? e : e - 78, i = 0;
+        while (u >= m - i) { u -= m - i; ++i; }
+        (e < 78 ? L.tri12[e] : L.tri6[e - 78]) = (unsigned short)((i << 8) | (i + u));
+    }
 }
 
 // jacobi12(): the 12x12 state covariance, called by the WHOLE workgroup.  Wave 0 owns the 36 blocks of A and
@@ -363,6 +370,35 @@ __device__ __forceinline__ double weighted_dot(const double* ar, const double* b
     }
     for (; c < ncols; ++c) s0 = fma(ar[c], br[c], s0);
     return fma(ar[0] * br[0], wc0, ((s0 + s1) + (s2 + s3)) * wci);
+}
+
+// The same sum shared by TWO neighbouring lanes (an even / odd pair of one wave): `part` 0 takes the columns [1, mid),
+// part 1 the columns [mid, ncols), the halves meet through a quad_perm swap, and both lanes return the whole sum.  A
+// 12 x 12 covariance from 43 sigma columns is 78 distinct sums; one lane each they all take one 43-term chain of LDS
+// reads and dependent FMAs -- two lanes each they take half of it (156 lanes).  Every lane of the wave must call.
+__device__ __forceinline__ double weighted_dot_pair(const double* ar, const double* br, int ncols, double wc0, double wci, int part)
+{
+    const int mid = 1 + ((ncols - 1) >> 1);
+    int c = part ? mid : 1;
+    const int end = part ? ncols : mid;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (; c + 7 < end; c += 8) {
+        double av[8], bv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { av[u] = ar[c + u]; bv[u] = br[c + u]; }
+        s0 = fma(av[0], bv[0], s0); s1 = fma(av[1], bv[1], s1); s2 = fma(av[2], bv[2], s2); s3 = fma(av[3], bv[3], s3);
+        s0 = fma(av[4], bv[4], s0); s1 = fma(av[5], bv[5], s1); s2 = fma(av[6], bv[6], s2); s3 = fma(av[7], bv[7], s3);
+    }
+    for (; c + 3 < end; c += 4) {
+        s0 = fma(ar[c], br[c], s0);
+        s1 = fma(ar[c + 1], br[c + 1], s1);
+        s2 = fma(ar[c + 2], br[c + 2], s2);
+        s3 = fma(ar[c + 3], br[c + 3], s3);
+    }
+    for (; c < end; ++c) s0 = fma(ar[c], br[c], s0);
+    double sum = (s0 + s1) + (s2 + s3);
+    sum += __shfl_xor(sum, 1, 64);
+    return fma(ar[0] * br[0], wc0, sum * wci);
 }
 
 // Weighted means of `nrows` linear rows of Y (row stride kCols), eight lanes per row: lane l of the calling group
@@ -820,8 +856,12 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const UtT
         for (int i = 0; i < 3; ++i) L.D[(9 + i) * kCols + lane] = dq[i];
     }
     __syncthreads();
-    weighted_outer(L.D, 12, L.D, 12, w.ncols, w.wc0, w.wi, L.cov, 12);
-    if (lane < 13) L.mean[lane] = L.ymean[lane];
+    if (lane < 192) {   // (whole waves: the pair sum crosses lanes) 78 distinct entries x 2 lanes
+        const int e = min(lane >> 1, 77), ij = L.tri12[e], i = ij >> 8, j = ij & 0xFF;
+        const double v = weighted_dot_pair(L.D + i * kCols, L.D + j * kCols, w.ncols, w.wc0, w.wi, lane & 1);
+        if (lane < 156) L.cov[(lane & 1) ? j * 12 + i : i * 12 + j] = v;
+    }
+    if (lane >= 192 && lane < 205) L.mean[lane - 192] = L.ymean[lane - 192];
     __syncthreads();
     TICK(L, 5);
 }
@@ -872,15 +912,9 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
             x[i] = L.mean[6 + i] + d[6 + i];
         }
         quat_boxplus(L.mean + 9, d + 9, q);
-        // input deviations of the state dof rows (recomputed like bfl does)
-        for (int i = 0; i < 3; ++i) {
-            L.X[i * kCols + lane] = v[i] - L.mean[i];
-            L.X[(3 + i) * kCols + lane] = wv[i] - L.mean[3 + i];
-            L.X[(6 + i) * kCols + lane] = x[i] - L.mean[6 + i];
-        }
-        double dq[3];
-        quat_diff(q, L.mean + 9, dq);
-        for (int i = 0; i < 3; ++i) L.X[(9 + i) * kCols + lane] = dq[i];
+        // input deviations of the state dof rows: bfl recomputes them from the sigma points, (mean + d) - mean and
+        // log(exp(d) q q^-1) -- which is d again, to the last bit or two
+        for (int i = 0; i < 12; ++i) L.X[i * kCols + lane] = d[i];
 
         int row = 0;
         if (has_vel) {
@@ -937,7 +971,23 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
     TICK(L, 9);
     // Pxy (12 x m) on the first 12 m threads, the upper triangle of the symmetric Py (m x m) on the next
     // m (m + 1) / 2: at most 144 + 78 threads, one pass
-    {
+    if (m == 6) {   // 72 entries of Pxy + 21 distinct entries of Py, two lanes each (186 lanes, whole waves call)
+        if (lane < 192) {
+            const int e = min(lane >> 1, 92);
+            const double *ar, *br;
+            int o0, o1 = -1;
+            if (e < 72) { ar = L.X + (e / 6) * kCols; br = L.D + (e % 6) * kCols; o0 = e; }
+            else {
+                const int ij = L.tri6[e - 72], i = ij >> 8, j = ij & 0xFF;
+                ar = L.D + i * kCols; br = L.D + j * kCols; o0 = i * 6 + j; o1 = j * 6 + i;
+            }
+            const double v = weighted_dot_pair(ar, br, w.ncols, w.wc0, w.wi, lane & 1);
+            if (lane < 186) {
+                if (e < 72) { if (!(lane & 1)) L.Pxy[o0] = v; }
+                else L.Py[(lane & 1) ? o1 : o0] = v;
+            }
+        }
+    } else {
         const int nxy = 12 * m, ntri = m * (m + 1) / 2;
         if (lane < nxy) {
             const int i = lane / m, j = lane % m;
