@@ -148,6 +148,9 @@ def parse():
     p.add_argument("--pcie-frames", type=int, default=48,
                    help="timed frames of each run of the two PCIe-inclusive legs (three runs each, the median is reported; 0: skip them)")
     p.add_argument("--no-extras", action="store_true", help="skip the cold run and the live per-frame latency measurement")
+    p.add_argument("--shared-scene", action="store_true",
+                   help="all objects look at ONE camera stream (SURVEY 8e ii): rank 0 ingests depth + flow and broadcasts every batch "
+                        "of frames to the other ranks inside the timed region (RCCL); never the headline configuration")
     p.add_argument("--dump-rows", default="", help="rank 0 saves the gathered [objects, steps, 19] result rows of the timed region (.npy)")
     p.add_argument("--rehearsal-ms", type=float, default=400.0,
                    help="process warm-up before the W warm-up steps: scratch engines track the same W + K frames (untimed, results "
@@ -239,6 +242,15 @@ def main():
         scale = 0.8 + 0.4 * (((gid % 64) * 7) % 10) / 9.0
         half = tuple(h * scale for h in synth.CRACKER_BOX_HALF_EXTENTS)
         streams.append(synth.make_stream(seed, n_frames, cam, flow_type=ftype, half_extents=half, device=dev))
+    scene = None
+    if args.shared_scene:
+        # one scene for every object of every rank: all ranks build the same stream (masks, poses and the mesh stay local),
+        # but only the ingest rank keeps its images -- the others receive them batch by batch (parallel.broadcast_frames)
+        scene = synth.make_stream(4000, n_frames, cam, flow_type=ftype, device=dev)
+        streams = [scene] * n_obj
+        if world > 1 and rank != 0:
+            scene.depth.zero_()
+            scene.flow.zero_()
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
 
@@ -289,8 +301,22 @@ def main():
     timed_batches = [build(k0, t) for k0, t in timed_splits]
     extra_batches = [build(k0, t) for k0, t in split_batches(n_timed_end, n_frames, T)]
 
-    def run(batches):
-        for arr, _keep, t in batches:
+    bcast_bytes = [0]
+
+    def run(batches, splits=None):
+        for i, (arr, _keep, t) in enumerate(batches):
+            if scene is not None and world > 1 and splits is not None:
+                k0 = splits[i][0]
+                frames = [scene.depth[k0:k0 + t], scene.flow[k0:k0 + t]]
+                if backend == "nccl":
+                    parallel.broadcast_frames(frames, src=0)
+                else:   # (gloo, the one-GPU exercise of this path: staged through the host)
+                    host_frames = [f.cpu() for f in frames]
+                    parallel.broadcast_frames(host_frames, src=0)
+                    for f, h in zip(frames, host_frames):
+                        f.copy_(h)
+                torch.cuda.synchronize()   # the engine's streams are not torch's: the frames must have landed
+                bcast_bytes[0] += sum(f.numel() * f.element_size() for f in frames)
             eng.submit_batch_raw(arr, t)
             eng.step()
 
@@ -321,16 +347,18 @@ def main():
                 wc.copy_(wb)
             torch.cuda.synchronize()
         del wa, wb, wc
-    run(warm_batches)
+    warm_splits = split_batches(0, args.warmup, T)
+    run(warm_batches, warm_splits)
     eng.sync()
     torch.cuda.synchronize()
+    bcast_bytes[0] = 0
     if not args.no_kernel_timing:
         eng.enable_timing(1)   # a start/stop HIP event pair on the roofline kernel's own dispatch, nothing else
     stats0 = eng.stats()
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(timed_batches)
+    run(timed_batches, timed_splits)
     host_enqueue = time.perf_counter() - t0   # host side of the loop (frame programs + launches), GPU still running
     eng.sync()
     gathered = None
@@ -352,7 +380,7 @@ def main():
         # per-kernel breakdown over the next 24 frames of the same streams (outside the timed region: a marker event
         # after every launch costs throughput)
         eng.enable_timing(2)
-        run(extra_batches)
+        run(extra_batches, split_batches(n_timed_end, n_frames, T))
         eng.sync()
         for name, (ms, cnt) in eng.timing().items():
             kernels[name] = dict(total_ms=ms, marks=cnt, avg_us=1e3 * ms / max(cnt, 1))
@@ -660,6 +688,9 @@ def main():
                                 "%d per GPU" % n_obj if args.scaling == "strong" else "%d per GPU (weak scaling)" % n_obj, T),
                    "objects_per_gpu": n_obj, "objects_total": total_obj, "width": cam.width, "height": cam.height,
                    "batch_frames": T, "ranks": world, "backend": backend},
+        "shared_scene": ({"broadcast_MB_per_step": bcast_bytes[0] / args.steps / 1e6, "ingest_rank": 0,
+                          "note": "every object of every rank tracks in one camera stream; rank 0's depth + flow frames are "
+                                  "broadcast batch by batch inside the timed region"} if args.shared_scene else None),
         "frames_per_sec_per_object": args.steps / elapsed,
         "launches_per_frame": (stats1["launches"] - stats0["launches"]) / d_frames,
         "event_ops_per_frame": (stats1["event_ops"] - stats0["event_ops"]) / d_frames,

@@ -53,6 +53,18 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+def broadcast_frames(tensors, src=0):
+    """Shared-scene streams (SURVEY.md 8e ii): when all objects look at ONE camera stream, the rank that ingests it hands
+    the frames -- depth and optical flow; the masks stay per object -- to every other rank: one broadcast per tensor, in
+    place (RCCL over xGMI on the GPUs: the ring / tree forwards over the point-to-point links, so pass whole batches of
+    frames, not single images; gloo in the CPU tests).  No-op without a process group."""
+    if not dist.is_initialized():
+        return
+    for t in tensors:
+        assert t.is_contiguous()
+        dist.broadcast(t, src=src)
+
+
 def gather_records(records, device="cpu"):
     """All-gather [n_local, ...] float64 records (19 doubles per object-frame in the reference's logs) along the first
     axis; the shards may differ in n_local (block partition of an object count the ranks do not divide)."""

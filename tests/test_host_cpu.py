@@ -95,6 +95,11 @@ own[mine] = 1
 import torch.distributed as dist
 dist.all_reduce(own)
 assert bool((own == 1).all())
+# shared scene: the ingest rank's frames reach every rank in place
+depth = torch.arange(2 * 6 * 8, dtype=torch.float32).reshape(2, 6, 8) if rank == 0 else torch.zeros(2, 6, 8)
+flow = torch.full((2, 6, 8, 2), 0.25) if rank == 0 else torch.zeros(2, 6, 8, 2)
+parallel.broadcast_frames([depth, flow], src=0)
+assert bool((depth == torch.arange(2 * 6 * 8, dtype=torch.float32).reshape(2, 6, 8)).all()) and bool((flow == 0.25).all())
 print("rank", rank, "ok", mine)
 '''
 

@@ -15,10 +15,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def run_bench(tmp_path, n_ranks, tag, port):
+def run_bench(tmp_path, n_ranks, tag, port, extra=()):
     out = str(tmp_path / ("rows_%s.npy" % tag))
     args = ["bench.py", "--gpus", str(n_ranks), "--steps", "14", "--warmup", "4", "--objects", "5", "--no-cpu-baseline",
-            "--pcie-frames", "0", "--no-extras", "--no-kernel-timing", "--clock-warm-ms", "0", "--dump-rows", out]
+            "--pcie-frames", "0", "--no-extras", "--no-kernel-timing", "--rehearsal-ms", "0", "--dump-rows", out] + list(extra)
     env = dict(os.environ, ROFT_BENCH_DEVICE="0", ROFT_BENCH_BACKEND="gloo")
     if n_ranks > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
@@ -40,3 +40,15 @@ def test_two_ranks_gather_what_one_rank_logs(tmp_path):
     assert rows1.shape == rows2.shape == (5, 14, 19)
     assert np.array_equal(rows1, rows2)
     assert np.isfinite(rows2).all() and np.abs(rows2[:, :, 9:13]).max() <= 1.0 + 1e-12
+
+
+def test_shared_scene_broadcast_delivers_the_ingest_ranks_frames(tmp_path):
+    """--shared-scene: every object of both ranks tracks in ONE camera stream; rank 1 starts with zeroed images and only has
+    what rank 0 broadcasts batch by batch inside the timed region (SURVEY 8e ii) -- and logs what one rank holding the
+    stream itself logs."""
+    one, rows1 = run_bench(tmp_path, 1, "s1", 0, ["--shared-scene"])
+    two, rows2 = run_bench(tmp_path, 2, "s2", 29519, ["--shared-scene"])
+    assert two["shared_scene"]["broadcast_MB_per_step"] > 3.0      # 640x480: 1.2 MB depth + 2.5 MB flow per frame
+    assert one["shared_scene"]["broadcast_MB_per_step"] == 0.0
+    assert np.array_equal(rows1, rows2)
+    assert np.array_equal(rows2[0], rows2[4])                      # the same scene and object model for every tracker
