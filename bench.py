@@ -159,7 +159,9 @@ def parse():
                         "timed K steps then run on a fresh engine.  0: off (see also `value_cold` in the output)")
     p.add_argument("--clock-warm-ms", type=float, default=0.0,
                    help="milliseconds of unrelated GPU work (GEMMs + copies) before the warm-up steps (round 2's warm-up; off)")
-    p.add_argument("--no-ramp", action="store_true", help="full batches from the first timed frame on, the short one last")
+    p.add_argument("--no-align", action="store_true",
+                   help="cut the frames into full batches wherever they fall instead of ending every batch with a pose-arrival frame")
+    p.add_argument("--no-ramp", action="store_true", help="(with --no-align) full batches from the first timed frame on, the short one last")
     p.add_argument("--splits", default="", help="explicit batch sizes of the timed frames, e.g. 2,6,6,6 (must sum to --steps)")
     p.add_argument("--no-kernel-timing", action="store_true",
                    help="do not record HIP events in the timed region and skip the per-kernel breakdown")
@@ -289,7 +291,15 @@ def main():
                                            L.MEM_HOST if host else L.MEM_DEVICE) for o, st in enumerate(streams)])
         return eng.build_batch(frames_list)
 
-    warm_batches = [build(k0, t) for k0, t in split_batches(0, args.warmup, T)]
+    period = int(cfg.pose_frames_between)
+
+    def plan(first, last, ramp=False):
+        if args.no_align or period <= 0:
+            return split_batches(first, last, T, ramp=ramp)
+        return E.aligned_batches(first, last, T, period)
+
+    warm_splits = plan(0, args.warmup)
+    warm_batches = [build(k0, t) for k0, t in warm_splits]
     if args.splits:
         sizes = [int(x) for x in args.splits.split(",")]
         if sum(sizes) != args.steps or max(sizes) > T or min(sizes) < 1:
@@ -297,9 +307,10 @@ def main():
         starts = np.cumsum([args.warmup] + sizes[:-1])
         timed_splits = list(zip([int(x) for x in starts], sizes))
     else:
-        timed_splits = split_batches(args.warmup, n_timed_end, T, ramp=not args.no_ramp)
+        timed_splits = plan(args.warmup, n_timed_end, ramp=not args.no_ramp)
     timed_batches = [build(k0, t) for k0, t in timed_splits]
-    extra_batches = [build(k0, t) for k0, t in split_batches(n_timed_end, n_frames, T)]
+    extra_splits = plan(n_timed_end, n_frames)
+    extra_batches = [build(k0, t) for k0, t in extra_splits]
 
     bcast_bytes = [0]
 
@@ -347,7 +358,6 @@ def main():
                 wc.copy_(wb)
             torch.cuda.synchronize()
         del wa, wb, wc
-    warm_splits = split_batches(0, args.warmup, T)
     run(warm_batches, warm_splits)
     eng.sync()
     torch.cuda.synchronize()
@@ -380,7 +390,7 @@ def main():
         # per-kernel breakdown over the next 24 frames of the same streams (outside the timed region: a marker event
         # after every launch costs throughput)
         eng.enable_timing(2)
-        run(extra_batches, split_batches(n_timed_end, n_frames, T))
+        run(extra_batches, extra_splits)
         eng.sync()
         for name, (ms, cnt) in eng.timing().items():
             kernels[name] = dict(total_ms=ms, marks=cnt, avg_us=1e3 * ms / max(cnt, 1))
@@ -545,8 +555,8 @@ def main():
             def bat(k0, t):
                 return e2.build_batch([[frame_dict(st, k, dict(depth=st.depth, flow=st.flow, mask=st.mask_gt), L.MEM_DEVICE) for st in sts]
                                        for k in range(k0, k0 + t)])
-            wb = [bat(k0, t) for k0, t in split_batches(0, k_warm, T)]
-            tb = [bat(k0, t) for k0, t in (timed_splits if k_timed == args.steps and k_warm == args.warmup else split_batches(k_warm, k_warm + k_timed, T, ramp=True))]
+            wb = [bat(k0, t) for k0, t in warm_splits]
+            tb = [bat(k0, t) for k0, t in timed_splits]
             for arr, _keep, t in wb:
                 e2.submit_batch_raw(arr, t)
                 e2.step()
@@ -682,12 +692,12 @@ def main():
         "config": {"workload": "BASELINE config #4: %dx%d, %s flow grid %d, %d objects in total, %s "
                                "(sharded by object, no data-path collective; result rows all-gathered over RCCL at N > 1), "
                                "masks+poses at 5 fps with 6-frame delay, flow-aided masks, re-sync and outlier rejection on, "
-                               "frames submitted in batches of %d" %
+                               "frames submitted in batches of at most %d" %
                                (cam.width, cam.height, "CV_32FC2" if ftype == synth.FLOW_F32C2 else "CV_16SC2",
                                 cfg.flow_grid, total_obj,
                                 "%d per GPU" % n_obj if args.scaling == "strong" else "%d per GPU (weak scaling)" % n_obj, T),
                    "objects_per_gpu": n_obj, "objects_total": total_obj, "width": cam.width, "height": cam.height,
-                   "batch_frames": T, "ranks": world, "backend": backend},
+                   "batch_frames": T, "timed_batches": [t for _k0, t in timed_splits], "ranks": world, "backend": backend},
         "shared_scene": ({"broadcast_MB_per_step": bcast_bytes[0] / args.steps / 1e6, "ingest_rank": 0,
                           "note": "every object of every rank tracks in one camera stream; rank 0's depth + flow frames are "
                                   "broadcast batch by batch inside the timed region"} if args.shared_scene else None),

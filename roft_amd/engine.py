@@ -27,6 +27,26 @@ def default_object():
     return o
 
 
+def aligned_batches(first, last, T, period, phase=0):
+    """[first, last) in consecutive batches of at most T frames that END with a pose-arrival frame (frames f with
+    f % period == phase: the delayed pose source delivers every `period` frames).  Inside the engine a pose arrival hands
+    the pose chain from one belief lineage -- one lane -- to the other: with the arrival as the last frame of
+    a batch, every batch is one lineage's ordinary steps followed by the other's re-sync replay, the replay of batch b
+    overlaps the ordinary steps of batch b + 1 on the other lane, and no launch of a lane carries both.  Measured against
+    full batches of 8 cut anywhere (A/B in one box): +4 % at 20 steps, +5 % at 60, +3.5 % at 240."""
+    out = []
+    k = first
+    while k < last:
+        end = k + ((phase - k) % period) + 1 if period <= T else k + T
+        while period <= T and (end - k) % period == 0 and end + period - k <= T:   # (whole periods, as many as a batch holds)
+            end += period
+        end = min(end, last, k + T)
+        out.append((k, end - k))
+        k = end
+    return out
+
+
+
 class ROFTFilterBatch:
     def __init__(self, cfg):
         L.require_device()

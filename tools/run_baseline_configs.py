@@ -59,9 +59,10 @@ def run_engine(streams, n_frames, batch=BATCH):
     eng = make_engine(streams, batch)
     eng.enable_log(n_frames)
     batches = []
-    for k0 in range(0, n_frames, batch):
+    # batches end with a pose-arrival frame (every 6th frame of the synthetic streams): E.aligned_batches
+    for k0, tb in (E.aligned_batches(0, n_frames, batch, 6) if batch >= 6 else [(k, min(batch, n_frames - k)) for k in range(0, n_frames, batch)]):
         frames_list = []
-        for k in range(k0, min(n_frames, k0 + batch)):
+        for k in range(k0, k0 + tb):
             frames = []
             for st in streams:
                 mi = st.mask_delivery[k]
