@@ -551,6 +551,8 @@ def main():
     value_cold = None
     live = None
     if not args.no_extras:
+        cold_host = [0.0]
+
         def timed_sequence(e2, sts, k_warm, k_timed):
             def bat(k0, t):
                 return e2.build_batch([[frame_dict(st, k, dict(depth=st.depth, flow=st.flow, mask=st.mask_gt), L.MEM_DEVICE) for st in sts]
@@ -566,6 +568,7 @@ def main():
             for arr, _keep, t in tb:
                 e2.submit_batch_raw(arr, t)
                 e2.step()
+            cold_host[0] = time.perf_counter() - t1
             e2.sync()
             torch.cuda.synchronize()
             return time.perf_counter() - t1
@@ -575,7 +578,7 @@ def main():
         add_objects(e2, streams)
         dt_cold = timed_sequence(e2, streams, args.warmup, args.steps)
         e2.close()
-        value_cold = dict(value=n_obj * args.steps / dt_cold, ms_per_step=1e3 * dt_cold / args.steps,
+        value_cold = dict(value=n_obj * args.steps / dt_cold, ms_per_step=1e3 * dt_cold / args.steps, host_enqueue_ms_per_step=1e3 * cold_host[0] / args.steps,
                           note="the timed sequence again on a fresh engine after the device has idled (CPU baseline, host "
                                "work, 1 s sleep) and WITHOUT the --clock-warm-ms load: what a short burst from an idle GPU gets")
         # live: ROFTFilter::filtering_step followed by a reader of the estimate, one object, nothing in flight across frames

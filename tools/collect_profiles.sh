@@ -10,30 +10,46 @@ cd $R
 # the driver-shaped run (what BENCH_rNN.json records) three times, the default run and a long steady-state run
 for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_driver_shaped_$i.json 2> $O/bench.err; done
 timeout 300 python bench.py > $O/bench_64obj.json 2>> $O/bench.err
-timeout 300 python bench.py --steps 240 --warmup 16 --no-cpu-baseline --pcie-frames 0 > $O/bench_steady_240.json 2>> $O/bench.err
-timeout 600 python tools/run_baseline_configs.py --out $O/baseline_configs.json > /dev/null 2> $O/baseline.err
+timeout 300 python bench.py --steps 240 --warmup 16 --no-cpu-baseline --pcie-frames 0 --no-extras > $O/bench_steady_240.json 2>> $O/bench.err
+timeout 900 python tools/run_baseline_configs.py --out $O/baseline_configs.json > /dev/null 2> $O/baseline.err
+# objects per GPU: the per-GPU points of the 8 / 4 / 2 / 1-GPU strong-scaling curve of config #4 (64 / 32 / 16 / 8 objects) and beyond
+python - > $O/object_sweep.json <<PY
+import json, subprocess, sys
+out = []
+for n in (8, 16, 32, 64, 128, 256):
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "60", "--warmup", "12", "--objects", str(n), "--no-cpu-baseline", "--pcie-frames", "0", "--no-extras"],
+                       capture_output=True, text=True, timeout=600)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    out.append(dict(objects=n, value=d["value"], ms_per_step=d["ms_per_step"], frames_per_sec_per_object=d["frames_per_sec_per_object"],
+                    k1_avg_launch_us=d["roofline"]["avg_launch_us"], roofline_frac=d["roofline"]["frac"], launches_per_frame=d["launches_per_frame"],
+                    kernels=d["kernels_post_run_breakdown"]))
+json.dump(dict(what="python bench.py --steps 60 --warmup 12 --objects N (one MI355X): the per-GPU load of config #4 sharded over 8 / 4 / 2 / 1 GPUs is 8 / 16 / 32 / 64 objects", runs=out), sys.stdout, indent=1)
+PY
+# the N > 1 code path executed: two ranks on this one GPU over gloo (the driver's multi-GPU runs use one GPU per rank and RCCL)
+ROFT_BENCH_DEVICE=0 ROFT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2ranks_one_gpu_gloo.json 2>> $O/bench.err
+ROFT_BENCH_DEVICE=0 ROFT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 20 --warmup 5 --shared-scene > $O/bench_2ranks_one_gpu_gloo_shared_scene.json 2>> $O/bench.err
 timeout 300 python tools/live_latency.py --out $O/live_latency.json > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernel stats + timeline of the driver-shaped run, chains overlapping
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-frames 0 > $O/bench_under_rocprof.json 2> /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 > $O/bench_under_rocprof.json 2> /dev/null
 python3 $R/tools/prof_summary.py stats $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv
 # the roofline kernel over exactly the timed launches of that run (1 warm-up batch, then 3 timed ones): compare with roofline.avg_launch_us
-python3 $R/tools/prof_summary.py window $O/stats/*/*kernel_trace.csv flow_measure_kernel 1 3 > $O/k1_timed_launches_under_rocprof.txt
-python3 $R/tools/trace_list.py $O/stats/*/*kernel_trace.csv 1 > $O/pipeline_timeline.txt
+python3 $R/tools/prof_summary.py window $O/stats/*/*kernel_trace.csv flow_measure_kernel 2 4 > $O/k1_timed_launches_under_rocprof.txt
+python3 $R/tools/trace_list.py $O/stats/*/*kernel_trace.csv 2 --resources > $O/pipeline_timeline.txt
 rm -rf $O/stats
 # the same kernels with the chains serialised on one stream (each kernel's duration alone), on a longer run
 export ROFT_ONE_STREAM=1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --steps 48 --warmup 8 --no-cpu-baseline --pcie-frames 0 --no-kernel-timing > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --steps 48 --warmup 7 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
 unset ROFT_ONE_STREAM
 python3 $R/tools/prof_summary.py stats $O/stats1/*/*kernel_stats.csv $O/bench_kernel_stats_one_stream.csv
 rm -rf $O/stats1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python3 $R/bench.py --steps 48 --warmup 8 --no-cpu-baseline --pcie-frames 0 --no-kernel-timing > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python3 $R/bench.py --steps 48 --warmup 7 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
 python3 $R/tools/prof_summary.py stats $O/stats2/*/*kernel_stats.csv $O/bench_kernel_stats_48.csv
 rm -rf $O/stats2
 # HBM traffic, one counter per pass (FETCH_SIZE and WRITE_SIZE do not fit one pass); every launch of the roofline kernel
 # covers 8 frames x 64 objects in this run (24 timed frames after 8 warm-up frames, batches of 8)
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc -- python3 $R/bench.py --steps 24 --warmup 8 --no-cpu-baseline --pcie-frames 0 --no-kernel-timing > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc -- python3 $R/bench.py --steps 24 --warmup 8 --no-align --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
   python3 $R/tools/prof_summary.py pmc $O/pmc/*/*counter_collection.csv $O/pmc_$c.csv
   rm -rf $O/pmc
 done
