@@ -361,6 +361,11 @@ void* roft_flow_producer_stream(roft_flow_producer* fp);
  * (slots: n_frames x 10, -1 padded).  Any output may be NULL. */
 int roft_debug_plan(const roft_config* cfg, const int* pose_valid, int n_frames, int* n_steps, int* n_corrections,
                     int* outlier, int* slots);
+/* Which of the engine's HIP streams delay each other at the dispatch level (streams that the runtime mapped onto one hardware
+ * queue): out[a * 5 + b] = microseconds until a one-workgroup kernel on stream b completes while stream a is placing a grid
+ * larger than the device; ~15 = independent, >= 80 = queued behind it.  Order: pose lane 0, pose lane 1, velocity chain, mask
+ * chain, upload stream.  Takes ~20 ms; not for a hot loop. */
+int roft_debug_probe_streams(roft_engine* e, double out[25]);
 /* phase counters of one object's last kernels (only filled by libraries built with a -DROFT_*_PROFILE switch) */
 int roft_debug_get_dbg(roft_engine* e, int obj_id, long long out[32]);
 

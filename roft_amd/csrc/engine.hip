@@ -238,6 +238,17 @@ __global__ void ctrl_upload_kernel(const uint4* __restrict__ src, EngineArrays a
     for (size_t i = i0; i < (size_t)(a.T + 1) * a.n_obj; i += stride) roft::mask_reset_tables(a, i);
 }
 
+// Diagnostics (roft_debug_probe_streams): a dispatch that cannot be placed completely keeps its hardware queue busy until its
+// last workgroup is placed; a one-workgroup kernel on another stream completes at once unless the two streams share a queue.
+__global__ void probe_blocker_kernel(long long ticks)
+{
+    extern __shared__ unsigned char smem[];
+    smem[threadIdx.x] = 0;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void probe_tiny_kernel(int* p) { if (threadIdx.x == 0) *p = 1; }
+
 namespace {
 
 struct FlowEntry {
@@ -477,15 +488,43 @@ struct StreamSet {
     hipStream_t mask = nullptr, vel = nullptr, pose[kNumLin] = {nullptr, nullptr}, up = nullptr;
     int device = 0;
     bool priorities = true, busy = false;
+    bool parked = false;   // its busy streams share a hardware queue: kept alive (it shifts the runtime's round robin), never handed out
+    int conflicts = 0;     // pairs of busy streams on one hardware queue when the set was created
 };
 static std::mutex g_stream_mu;
 static std::vector<StreamSet*> g_stream_sets;
 
-static int acquire_streams(int device, bool priorities, StreamSet** out)
+// Microseconds until a one-workgroup kernel on `b` completes while `a` is placing a grid three times the size of the device
+// (one 150 KB-LDS workgroup per CU at a time, 100 us each): ~15 when the streams have hardware queues of their own, >= 80
+// when the runtime mapped them onto ONE queue -- b's packet then waits until a's dispatch has been placed completely.
+static double probe_pair_us(hipStream_t a, hipStream_t b, int* flag)
 {
-    std::lock_guard<std::mutex> lk(g_stream_mu);
-    for (StreamSet* s : g_stream_sets)
-        if (!s->busy && s->device == device && s->priorities == priorities) { s->busy = true; *out = s; return ROFT_OK; }
+    (void)hipDeviceSynchronize();
+    const double t0 = host_now_us();
+    hipLaunchKernelGGL(probe_blocker_kernel, dim3(3 * device_cu_count()), dim3(64), 150 * 1024, a, 10000ll);
+    hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, b, flag);
+    (void)hipStreamSynchronize(b);
+    const double dt = host_now_us() - t0;
+    (void)hipStreamSynchronize(a);
+    return dt;
+}
+
+// number of pairs among the four busy chains' streams (pose lanes, velocity, mask) that share a hardware queue
+static int stream_conflicts(const StreamSet* s, int* flag)
+{
+    hipStream_t st[4] = {s->pose[0], s->pose[1], s->vel, s->mask};
+    int n = 0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = a + 1; b < 4; ++b) {
+            double us = probe_pair_us(st[a], st[b], flag);
+            if (us >= 50.0) us = std::min(us, probe_pair_us(st[a], st[b], flag));   // (a slow host call is not a conflict)
+            if (us >= 50.0) ++n;
+        }
+    return n;
+}
+
+static int create_stream_set(int device, bool priorities, StreamSet** out)
+{
     StreamSet* s = new StreamSet();
     s->device = device;
     s->priorities = priorities;
@@ -499,9 +538,45 @@ static int acquire_streams(int device, bool priorities, StreamSet** out)
     if (err == hipSuccess) err = hipStreamCreateWithPriority(&s->mask, hipStreamNonBlocking, least);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&s->up, hipStreamNonBlocking);
     if (err != hipSuccess) { delete s; return fail(ROFT_ERR_DEVICE, std::string("stream creation: ") + hipGetErrorString(err)); }
-    s->busy = true;
-    g_stream_sets.push_back(s);
     *out = s;
+    return ROFT_OK;
+}
+
+// The runtime maps HIP streams round robin onto a few hardware queues (GPU_MAX_HW_QUEUES, four by default) in the order
+// in which the PROCESS creates them, whatever their priority: which of the engine's streams end up sharing a queue depends
+// on how many streams the application (or an earlier engine) created before.  Two busy chains on one queue serialise at the
+// dispatch level -- a launch that waits for CUs holds up the other chain's packets behind it: measured 6.9e5 instead of 8.5e5
+// object-frames/s with three streams created ahead of the engine's, 7.7e5 for the third engine of a process.  So a new set is
+// probed (stream_conflicts, ~3 ms), and while two of its busy streams share a queue the set is parked -- its streams stay
+// alive and shift the round robin -- and another one is created (at most four times; the least bad one is used then).
+static int acquire_streams(int device, bool priorities, StreamSet** out)
+{
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (StreamSet* s : g_stream_sets)
+        if (!s->busy && s->device == device && s->priorities == priorities) { s->busy = true; *out = s; return ROFT_OK; }
+    const char* np = getenv("ROFT_NO_STREAM_PROBE");
+    const bool probe = !(np && np[0] == '1');
+    DevBuf<int> flag;
+    if (probe) {
+        HIP_TRY(flag.ensure(1));
+        HIP_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(probe_blocker_kernel), 150 * 1024));
+    }
+    StreamSet* best = nullptr;
+    int best_conflicts = 1 << 30;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        StreamSet* s = nullptr;
+        if (int rc = create_stream_set(device, priorities, &s)) return rc;
+        const int c = probe ? stream_conflicts(s, flag.p) : 0;
+        s->conflicts = c;
+        if (c < best_conflicts) { best = s; best_conflicts = c; }
+        s->busy = true;                 // parked unless chosen below
+        s->parked = true;
+        g_stream_sets.push_back(s);
+        if (c == 0) break;
+    }
+    (void)hipGetLastError();
+    best->parked = false;
+    *out = best;
     return ROFT_OK;
 }
 
@@ -1997,6 +2072,38 @@ extern "C" int roft_debug_get_dbg(roft_engine* e, int id, long long out[32])
     if (err == hipSuccess) std::memcpy(out, st->dbg, sizeof(long long) * 32);
     delete st;
     return err == hipSuccess ? ROFT_OK : ROFT_ERR_DEVICE;
+}
+
+// Diagnostics (roft_engine.h section 4): which of the engine's HIP streams delay each other at the dispatch level.  out[a * 5
+// + b] = microseconds until a one-workgroup kernel on stream b completes while stream a is busy placing a grid of three
+// one-per-CU workgroups per CU (100 us each); ~15 us = independent, >= 80 us = b's launches queue behind a's.  Stream order:
+// pose lane 0, pose lane 1, velocity chain, mask chain, upload.
+extern "C" int roft_debug_probe_streams(roft_engine* e, double out[25])
+{
+    if (!e || !out) return ROFT_ERR_INVALID;
+    if (roft_sync(e) != ROFT_OK) return ROFT_ERR_DEVICE;
+    hipStream_t st[5] = {e->pose_stream[0], e->pose_stream[1], e->vel_stream, e->stream, e->up_stream};
+    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(probe_blocker_kernel), 150 * 1024);
+    DevBuf<int> flag;
+    if (flag.ensure(1) != hipSuccess) return ROFT_ERR_DEVICE;
+    const int cus = device_cu_count();
+    for (int a = 0; a < 5; ++a)
+        for (int b = 0; b < 5; ++b) {
+            out[a * 5 + b] = 0.0;
+            if (a == b || st[a] == st[b]) continue;
+            double best = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                (void)hipDeviceSynchronize();
+                const double t0 = host_now_us();
+                hipLaunchKernelGGL(probe_blocker_kernel, dim3(3 * cus), dim3(64), 150 * 1024, st[a], 10000ll);
+                hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, st[b], flag.p);
+                (void)hipStreamSynchronize(st[b]);
+                best = std::min(best, host_now_us() - t0);
+            }
+            out[a * 5 + b] = best;
+        }
+    (void)hipDeviceSynchronize();
+    return hipGetLastError() == hipSuccess ? ROFT_OK : ROFT_ERR_DEVICE;
 }
 
 // Host-logic check without a device (roft_engine.h section 4): runs the per-frame program builder -- the

@@ -7,10 +7,11 @@ import numpy as np
 import pytest
 import torch
 
+from roft_amd import _lib as L
 from roft_amd import synth
 
 import util
-from test_engine_gpu import compare
+from test_engine_gpu import compare, make_engine
 
 pytestmark = pytest.mark.gpu
 
@@ -260,3 +261,25 @@ def test_two_engines_interleaved_in_one_process():
         assert np.array_equal(x, y)
     ea.close()
     eb.close()
+
+
+def test_busy_streams_of_every_engine_have_hardware_queues_of_their_own():
+    """The runtime maps HIP streams round robin onto four hardware queues in creation order; two busy chains on one queue
+    serialise at the dispatch level.  A new stream set is probed and re-created until its four busy streams (pose lanes,
+    velocity, mask) are independent -- also for the third engine of a process and behind streams the application created."""
+    import ctypes as C
+    import torch
+    keep = [torch.cuda.Stream() for _ in range(3)]          # streams of the "application"
+    st = util.stream(41, 4, scale=2)
+    engines = []
+    for _ in range(3):
+        eng = make_engine([st])
+        out = (C.c_double * 25)()
+        L.check(L.lib().roft_debug_probe_streams(eng._h, out))
+        m = np.array(out).reshape(5, 5)
+        busy = m[:4, :4]
+        assert busy.max() < 50.0, np.round(m)
+        engines.append(eng)
+    for eng in engines:
+        eng.close()
+    del keep

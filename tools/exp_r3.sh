@@ -1,3 +1,2 @@
-run() { timeout 300 python bench.py --no-cpu-baseline --pcie-frames 0 $ARGS 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), d.get('value_cold') and round(d['value_cold']), round(d['roofline']['avg_launch_us'],1), end=' | ')"; }
-for pr in hhnl nnnh nnnl nnnh hhnl; do echo -n "prio $pr: "; for rep in 1 2 3; do env ROFT_EXP_PRIO=$pr bash -c "$(declare -f run); ARGS='--steps 20 --warmup 5' run"; done; echo; done
-for pr in hhnl nnnh; do echo -n "default run prio $pr: "; for rep in 1 2; do env ROFT_EXP_PRIO=$pr bash -c "$(declare -f run); ARGS='' run"; done; echo; done
+timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-frames 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['value_cold']), round(d['roofline']['avg_launch_us'],1), round(d['roofline']['frac'],3))"; done
