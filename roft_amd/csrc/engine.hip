@@ -499,7 +499,8 @@ static std::vector<StreamSet*> g_stream_sets;
 // when the runtime mapped them onto ONE queue -- b's packet then waits until a's dispatch has been placed completely.
 static double probe_pair_us(hipStream_t a, hipStream_t b, int* flag)
 {
-    (void)hipDeviceSynchronize();
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
     const double t0 = host_now_us();
     hipLaunchKernelGGL(probe_blocker_kernel, dim3(3 * device_cu_count()), dim3(64), 150 * 1024, a, 10000ll);
     hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, b, flag);
