@@ -132,11 +132,47 @@ def read_data_txt(path):
     return a[:, 0], a[:, 1], a[:, 2:9]
 
 
+def read_log(path, skip_cols=0):
+    """One of the tracker's log files (bfl::Logger rows: space-separated numbers, padded to a common width) as the
+    reference's evaluation reads it (evaluation/data_loader.py:99-108, `load_generic`; `skip_cols=6` drops the velocity
+    columns of `pose_estimate[_ycb]` like `load_ours` does, :238-241)."""
+    rows = []
+    with open(path, newline="") as f:
+        for row in f:
+            rows.append([float(tok.rstrip()) for tok in row.rstrip().split(sep=" ") if tok != ""])
+    a = np.array(rows)
+    return a[:, skip_cols:] if skip_cols else a
+
+
 def pose_log_row(pose13):
     """One row of ROFTFilter's `pose_estimate` log: v w x axis angle (ROFTFilter.cpp:386-394)."""
     r = np.asarray(pose13, float)
     axis, angle = quat_to_axis_angle(r[9:13])
     return np.concatenate([r[:9], axis, [angle]])
+
+
+def write_data_txt(path, n_frames, fps=30.0):
+    """data.txt as tools/dataset/data_txt_generation/generate_data_txt.py:16-27 writes it: one row per frame,
+    `stamp_rgb stamp_depth` = i / fps twice and the identity camera pose `0.0 0.0 0.0 1.0 0.0 0.0 0.0`."""
+    with open(path, "w") as f:
+        for i in range(n_frames):
+            stamp = (1.0 / fps) * i
+            f.write(str(stamp) + " " + str(stamp) + " 0.0 0.0 0.0 1.0 0.0 0.0 0.0\n")
+
+
+def find_initial_pose(path, fps):
+    """What test/test_ho3d.sh:68 asks tools/dataset/dope_pose_finder/pose_finder.py (:13-33) for: the first row of a 30 fps
+    poses.txt that is not the invalid detection `0.0 0.0 0.0 0.0 0.0 0.0 0.0` AND lies on the grid of a source running at
+    `fps`; returns (frame the tracker starts at -- the row index + 6, the delay of the source, unless it is row 0 --,
+    the row's text) or None."""
+    steps = (1.0 / fps) / (1 / 30.0)
+    invalid = ("0.0 " * 7)[:-1]
+    with open(path) as f:
+        for i, line in enumerate(f.readlines()):
+            line = line.rstrip()
+            if line != invalid and i % steps == 0:
+                return (i + 6 if i != 0 else 0), line
+    return None
 
 
 def write_estimate_logs(prefix, pose13, twist6):
@@ -332,7 +368,8 @@ def write_poses(path, pose7, valid=None):
     with open(path, "w") as f:
         for i, r in enumerate(pose7):
             if valid is not None and not valid[i]:
-                f.write(" ".join(["0"] * 7) + "\n")
+                # (spelled as the reference's tools recognise an invalid detection: tools/dataset/dope_pose_finder/pose_finder.py:23)
+                f.write(" ".join(["0.0"] * 7) + "\n")
                 continue
             axis, angle = quat_to_axis_angle(r[3:7])
             f.write(" ".join("%.17g" % v for v in list(r[:3]) + list(axis) + [angle]) + "\n")
@@ -347,9 +384,7 @@ def write_sequence(root, st, object_name, mask_set="gt", pose_set="dope", flow_s
     n = int(st.n_frames)
     for d in ("rgb", "depth", os.path.join("masks", mask_set), pose_set, "gt"):
         os.makedirs(os.path.join(root, d), exist_ok=True)
-    with open(os.path.join(root, "data.txt"), "w") as f:
-        for k in range(n):
-            f.write("%.15g %.15g 0 0 0 1 0 0 0\n" % (k * st.dt, k * st.dt))
+    write_data_txt(os.path.join(root, "data.txt"), n, 1.0 / st.dt)
     c = st.camera
     with open(os.path.join(root, "cam_K.json"), "w") as f:
         json.dump(dict(width=c.width, height=c.height, fx=c.fx, fy=c.fy, cx=c.cx, cy=c.cy), f)

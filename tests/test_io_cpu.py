@@ -199,3 +199,49 @@ def test_flow_dumper_argument_errors(capsys):
     bad[4] = "six"
     assert fd.main(bad + ["nvof1", "/tmp/out"]) == 1
     assert "Invalid value six for parameter <heading_zeros>." in capsys.readouterr().err
+
+
+def test_log_files_as_the_references_evaluation_reads_them(tmp_path):
+    """tests/golden/log_fixtures.json: the five log files written by the facade's bfl::Logger stand-in, and the arrays the
+    reference's evaluation/data_loader.py (imported in the dev container by make_log_fixtures.py) parses out of them.  The
+    writer must still produce those texts byte for byte, and roft_amd.io.read_log must read what the reference reads."""
+    import json
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "log_fixtures.json")))
+    exe = str(tmp_path / "log_writer")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "golden", "log_writer.cpp"), "-o", exe])
+    subprocess.check_call([exe, str(tmp_path)])
+    for name, want in fx.items():
+        path = str(tmp_path / (name + ".txt"))
+        assert open(path).read() == want["text"], name
+        got = io.read_log(path, skip_cols=6 if name == "pose_estimate" else 0)
+        assert np.array_equal(got, np.array(want["parsed"])), name
+    assert np.array(fx["pose_estimate"]["parsed"]).shape == (4, 7) and np.array(fx["execution_times"]["parsed"]).shape == (4, 2)
+
+
+def test_dataset_scripts_of_the_reference(tmp_path):
+    """tests/golden/script_fixtures.json holds what the reference's own scripts printed / wrote when run (in the dev container)
+    on files written by roft_amd.io: the initial-pose finder of test/test_ho3d.sh:68 and the data.txt generator."""
+    import json
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "script_fixtures.json")))
+    for i, c in enumerate(fx["pose_finder"]):
+        p = str(tmp_path / ("p%d.txt" % i))
+        open(p, "w").write(c["poses_txt"])
+        got = io.find_initial_pose(p, c["fps"])
+        want = c["stdout"].strip()
+        assert (want == "" and got is None) or (got is not None and "%d %s" % got == want), (i, got, want)
+        # the rows the finder skipped are the ones read_poses reports as invalid detections
+        pose, ok = io.read_poses(p)
+        if got is not None:
+            row = got[0] - 6 if got[0] else 0
+            assert ok[row] and not ok[:row][::6].any()
+    assert any(c["stdout"].strip() == "" for c in fx["pose_finder"]) and any(c["stdout"].startswith("0 ") for c in fx["pose_finder"])
+    for c in fx["data_txt"]:
+        p = str(tmp_path / ("d%d.txt" % c["frames"]))
+        io.write_data_txt(p, c["frames"], 30.0)
+        assert open(p).read() == c["text"]
+        rgb, depth, cam = io.read_data_txt(p)
+        assert len(rgb) == c["frames"] and np.array_equal(rgb, depth) and np.all(cam[:, 3] == 1.0)

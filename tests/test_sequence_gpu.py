@@ -89,3 +89,15 @@ def test_sequence_on_disk_with_produced_flow(tmp_path, capsys):
     assert sorted(os.listdir(os.path.join(root, "optical_flow", "lk_2")))[0] == "1.float"
     assert len(os.listdir(os.path.join(root, "optical_flow", "lk_2"))) == n - 1
     assert rep["adds_auc"] > 75.0 and rep["rmse_position_cm"] < 3.0
+    # started where test/test_ho3d.sh starts the tracker: the first detection on the 5 fps grid, six frames (the delay of
+    # the source) after the frame it was computed on
+    pp = os.path.join(root, "dope", "poses.txt")
+    rows = open(pp).read().splitlines()
+    rows[0] = "0.0 0.0 0.0 0.0 0.0 0.0 0.0"
+    open(pp, "w").write("\n".join(rows) + "\n")
+    assert rs.main(["--root", root, "--object", "box", "--mesh", mesh, "--flow-set", "lk_2", "--mask-set", "gt",
+                    "--start-at-first-detection", "--out", str(tmp_path / "d_")]) == 0
+    rep = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rep["first_frame"] == 12 and rep["frames"] == n - 12
+    assert np.loadtxt(str(tmp_path / "d_pose_estimate")).shape == (n - 12, 13)
+    assert rep["rmse_position_cm"] < 5.0

@@ -4,6 +4,7 @@ files (`pose_estimate`, `velocity_estimate`, ROFTFilter.cpp:386-394) -- what `te
 
   run_sequence.py --root DIR --object NAME --mesh model.obj [--flow-set nvof_1_slow] [--mask-set NAME]
                   [--pose-set dope] [--out PREFIX] [--compute-flow nvof1|nvof2] [--no-delay] [--init-pose x y z qw qx qy qz]
+                  [--start-at-first-detection]
                   [--from config_fast_ycb.cfg [--group::key value ...]]
 
 --from reads the filter parameters from one of the reference's configuration files (config/config_fast_ycb.cfg,
@@ -37,6 +38,9 @@ def main(argv=None):
     ap.add_argument("--out", default=None)
     ap.add_argument("--compute-flow", choices=["nvof1", "nvof2"], default=None)
     ap.add_argument("--no-delay", action="store_true")
+    ap.add_argument("--start-at-first-detection", action="store_true",
+                    help="start where test/test_ho3d.sh:68-80 starts the tracker: at the frame and with the pose "
+                         "tools/dataset/dope_pose_finder/pose_finder.py reports for the 5 fps pose source")
     ap.add_argument("--init-pose", type=float, nargs=7, default=None, metavar=("X", "Y", "Z", "QW", "QX", "QY", "QZ"),
                     help="initial_condition.pose (default: the first valid detection)")
     ap.add_argument("--from", dest="cfg_file", default=None, help="ROFT configuration file (libconfig), overrides as --a::b::c value")
@@ -91,31 +95,46 @@ def main(argv=None):
     verts, tris = io.load_obj(args.mesh)
     # initial condition: the configuration's when it was given on the command line (test/test.sh:120-123 passes the first
     # detection that way), else the first valid detection of the sequence
+    start = 0
+    if args.start_at_first_detection:
+        found = io.find_initial_pose(os.path.join(args.root, args.pose_set, "poses.txt"), 5.0)
+        if found is None:
+            sys.stderr.write("no valid detection on the 5 fps grid\n")
+            return 1
+        start = found[0]
+        aa = [float(v) for v in found[1].split()]
+        if args.init_pose is None:
+            args.init_pose = aa[:3] + list(io.axis_angle_to_quat(np.array(aa[3:6]), aa[6]))
+        init_from_cfg = False
     if not init_from_cfg:
         k0 = int(np.argmax(seq.pose_ok)) if seq.pose_ok.any() else 0
         init = args.init_pose if args.init_pose is not None else list(seq.poses[k0])
         for i in range(7):
             d.p_mean0[6 + i] = init[i]
     eng.add_object(d, verts, tris)
-    n = len(seq)
+    n = len(seq) - start
+    if n <= 0:
+        sys.stderr.write("the first detection arrives after the last frame\n")
+        return 1
     eng.enable_log(n)
-    for k in range(n):
+    for k in range(start, len(seq)):
         eng.submit([seq.frame(k)])
         eng.step()
     pose, twist, npts, sel = eng.get_log(0, n)
     eng.close()
     prefix = args.out if args.out is not None else os.path.join(args.root, "roft_mi355x_")
     io.write_estimate_logs(prefix, pose[:, 0], twist[:, 0])
-    report = dict(frames=n, logs=[prefix + "pose_estimate", prefix + "velocity_estimate"], flow_type=int(ftype), flow_grid=int(grid))
+    report = dict(frames=n, first_frame=start, logs=[prefix + "pose_estimate", prefix + "velocity_estimate"], flow_type=int(ftype), flow_grid=int(grid))
     gt_path = os.path.join(args.root, "gt", "poses.txt")
     if os.path.exists(gt_path):
         gt, _ = io.read_poses(gt_path)
         est = np.concatenate([pose[:, 0, 6:9], pose[:, 0, 9:13]], 1)
         pts = verts.astype(np.float64)[:: max(1, len(verts) // 500)]
-        dist = metrics.trajectory_adds(est[12:], gt[12:n], pts)
+        g = gt[start + 12:start + n]
+        dist = metrics.trajectory_adds(est[12:], g, pts)
         report.update(adds_mm_mean=1e3 * float(dist.mean()), adds_auc=metrics.auc(dist),
-                      rmse_position_cm=metrics.rmse_cartesian_3d(gt[12:n, :3], est[12:, :3]),
-                      rmse_orientation_deg=metrics.rmse_angular(gt[12:n, 3:], est[12:, 3:]))
+                      rmse_position_cm=metrics.rmse_cartesian_3d(g[:, :3], est[12:, :3]),
+                      rmse_orientation_deg=metrics.rmse_angular(g[:, 3:], est[12:, 3:]))
     print(json.dumps(report))
     return 0
 
