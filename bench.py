@@ -659,8 +659,35 @@ def main():
             del src_t, dst_t
         except Exception:   # (not enough free memory next to the streams: the datasheet figure stands alone)
             copy_gbs = None
+        # what this box gives SCATTERED 64-byte sectors (the depth and flow samples of K1 are 35 mask pixels apart: one sector
+        # each, whatever the order): 2^24 words gathered at random sector-aligned offsets of a 4 GiB buffer, best of five
+        # (tools/micro/sector_probe.hip measures the same with a kernel of its own: 51 G sectors/s = 3.3 TB/s, and a launch of
+        # K1's shape without any arithmetic at K1's duration)
+        sector_rate = None
+        try:
+            words = torch.empty(1 << 30, device=dev, dtype=torch.int32)
+            words.zero_()
+            idx = torch.randint(0, (1 << 30) // 16, (1 << 24,), device=dev) * 16
+            got = torch.empty(1 << 24, device=dev, dtype=torch.int32)
+            best = None
+            for _ in range(6):
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                torch.index_select(words, 0, idx, out=got)
+                ev1.record()
+                torch.cuda.synchronize()
+                ms = ev0.elapsed_time(ev1)
+                best = ms if best is None else min(best, ms)
+            sector_rate = float(1 << 24) / (best * 1e-3)
+            del words, idx, got
+        except Exception:
+            sector_rate = None
+        gather_sectors = 2.0 * cand * obj_frames_per_launch       # one depth + one flow sector per candidate
         roofline = dict(kernel="flow_measure_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                         measured_copy_GBs=copy_gbs, frac_of_measured_copy=(achieved / copy_gbs) if copy_gbs else None,
+                        gather_sectors_per_launch=gather_sectors, gather_Gsectors_per_s=gather_sectors / dur_s / 1e9,
+                        measured_random_Gsectors_per_s=(sector_rate / 1e9) if sector_rate else None,
+                        frac_of_measured_random_sector_rate=(gather_sectors / dur_s / sector_rate) if sector_rate else None,
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_raw_counter=traffic_raw, traffic_source=traffic_source,
                         frac_on_fetched_bytes=(traffic / dur_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                         algorithmic_bytes_per_launch=bytes_per_launch, algorithmic_bytes_per_object_frame=bytes_per_obj,
@@ -672,8 +699,10 @@ def main():
                              "event pair on the kernel's own dispatch while the other chains run on their streams. The "
                              "north-star target of 0.70 is not met: the kernel reads ~60 KB per object-frame instead of the "
                              "dense 4 MB; every 4-byte depth and 8-byte flow sample costs a 64-byte sector, so the memory system "
-                             "moves `traffic` bytes (frac_on_fetched_bytes) for the declared ones -- the launch is bound by that "
-                             "scattered sector traffic and its dependent-load latency, not by streaming bandwidth")
+                             "moves `traffic` bytes (frac_on_fetched_bytes) for the declared ones -- the launch is bound by the RATE at which "
+                             "the memory system serves scattered sectors (measured_random_Gsectors_per_s on this box = 0.4 of the "
+                             "streaming peak; frac_of_measured_random_sector_rate = the kernel's gathers alone against it, the "
+                             "plane stream and the record writes not counted), not by streaming bandwidth")
     dominant = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])[0] if kernels else None
     d_frames = max(stats1["frames"] - stats0["frames"], 1)
 
