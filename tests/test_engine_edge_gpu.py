@@ -274,9 +274,13 @@ def test_busy_streams_of_every_engine_have_hardware_queues_of_their_own():
     engines = []
     for _ in range(3):
         eng = make_engine([st])
-        out = (C.c_double * 25)()
-        L.check(L.lib().roft_debug_probe_streams(eng._h, out))
-        m = np.array(out).reshape(5, 5)
+        # (a shared queue shows in every repetition: hundreds of microseconds; a hiccup of the box in one of them does not count)
+        m = None
+        for _rep in range(3):
+            out = (C.c_double * 25)()
+            L.check(L.lib().roft_debug_probe_streams(eng._h, out))
+            m1 = np.array(out).reshape(5, 5)
+            m = m1 if m is None else np.minimum(m, m1)
         busy = m[:4, :4]
         assert busy.max() < 50.0, np.round(m)
         engines.append(eng)
