@@ -17,6 +17,7 @@ be fed from -- and its output compared with -- a Fast-YCB / HO-3D style director
 
 Pure numpy / stdlib (zlib for PNG); no OpenCV.
 """
+import json
 import os
 import struct
 import zlib
@@ -149,6 +150,12 @@ def pose_log_row(pose13):
     r = np.asarray(pose13, float)
     axis, angle = quat_to_axis_angle(r[9:13])
     return np.concatenate([r[:9], axis, [angle]])
+
+
+def write_cam_k(path, c):
+    """cam_K.json of a sequence (read by test/test.sh:46-49 and by evaluation/data_loader.py:110-121)."""
+    with open(path, "w") as f:
+        json.dump(dict(width=c.width, height=c.height, fx=c.fx, fy=c.fy, cx=c.cx, cy=c.cy), f)
 
 
 def write_data_txt(path, n_frames, fps=30.0):
@@ -380,14 +387,11 @@ def write_sequence(root, st, object_name, mask_set="gt", pose_set="dope", flow_s
     carries gray images), depth/<i>.float, masks/<mask_set>/<object>_<i>.png, <pose_set>/poses.txt (the per-frame
     detections the delayed source replays), gt/poses.txt, model.obj and -- if flow_set is given -- the stream's own
     optical_flow/<flow_set>/<i>.float.  Returns the path of the mesh."""
-    import json
     n = int(st.n_frames)
     for d in ("rgb", "depth", os.path.join("masks", mask_set), pose_set, "gt"):
         os.makedirs(os.path.join(root, d), exist_ok=True)
     write_data_txt(os.path.join(root, "data.txt"), n, 1.0 / st.dt)
-    c = st.camera
-    with open(os.path.join(root, "cam_K.json"), "w") as f:
-        json.dump(dict(width=c.width, height=c.height, fx=c.fx, fy=c.fy, cx=c.cx, cy=c.cy), f)
+    write_cam_k(os.path.join(root, "cam_K.json"), st.camera)
     depth, masks = st.depth.cpu().numpy(), st.mask_gt.cpu().numpy()
     gray = st.gray.cpu().numpy() if getattr(st, "gray", None) is not None else None
     flow = st.flow.cpu().numpy() if flow_set else None

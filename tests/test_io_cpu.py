@@ -213,12 +213,22 @@ def test_log_files_as_the_references_evaluation_reads_them(tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "golden", "log_writer.cpp"), "-o", exe])
     subprocess.check_call([exe, str(tmp_path)])
+    ours = fx.pop("load_ours")
     for name, want in fx.items():
         path = str(tmp_path / (name + ".txt"))
         assert open(path).read() == want["text"], name
         got = io.read_log(path, skip_cols=6 if name == "pose_estimate" else 0)
         assert np.array_equal(got, np.array(want["parsed"])), name
     assert np.array(fx["pose_estimate"]["parsed"]).shape == (4, 7) and np.array(fx["execution_times"]["parsed"]).shape == (4, 2)
+    # the whole results tree through the reference's DataLoader("ours").load(): the five contents under the names and the
+    # layout it expects, cam_K.json as roft_amd.io writes it
+    from roft_amd import synth
+    io.write_cam_k(str(tmp_path / "cam_K.json"), synth.Camera.shape_b())
+    assert open(str(tmp_path / "cam_K.json")).read() == ours["cam_k_json"]
+    cam = synth.Camera.shape_b()
+    assert ours["cam_intrinsics"] == dict(fx=cam.fx, fy=cam.fy, cx=cam.cx, cy=cam.cy)
+    assert ours["shapes"] == dict(time=[4, 2], pose=[4, 7], velocity=[4, 6], pose_meas=[4, 7], vel_meas=[4, 6])
+    assert np.array_equal(np.array(ours["pose"]), np.array(fx["pose_estimate"]["parsed"]))
 
 
 def test_dataset_scripts_of_the_reference(tmp_path):
