@@ -36,9 +36,44 @@
 namespace Eigen {
 
 template <class S>
+class DenseMatrix;
+
+// `v.head<3>()`, `v.segment<3>(i)`, `v.tail<4>()` of a vector: a window that can be assigned to and indexed, as
+// src/roft/src/main.cpp:286-325 composes the filter's parameter vectors
+template <class S>
+class VectorBlock {
+public:
+    VectorBlock(S* p, std::size_t n) : p_(p), n_(n) {}
+    std::size_t size() const { return n_; }
+    S& operator()(std::size_t i) { return p_[i]; }
+    const S& operator()(std::size_t i) const { return p_[i]; }
+    VectorBlock& operator=(const DenseMatrix<S>& v);
+    VectorBlock& operator=(const VectorBlock& v)
+    {
+        if (v.n_ != n_) throw std::runtime_error("Eigen stand-in: block assignment of mismatching size");
+        for (std::size_t i = 0; i < n_; ++i) p_[i] = v.p_[i];
+        return *this;
+    }
+
+private:
+    S* p_;
+    std::size_t n_;
+};
+
+template <class S>
 class DenseMatrix {
 public:
     DenseMatrix() = default;
+    DenseMatrix(const VectorBlock<S>& b) : r_(b.size()), c_(1), d_(b.size())
+    {
+        for (std::size_t i = 0; i < d_.size(); ++i) d_[i] = b(i);
+    }
+    VectorBlock<S> head(std::size_t n) { return block(0, n); }
+    VectorBlock<S> tail(std::size_t n) { return block(d_.size() - n, n); }
+    VectorBlock<S> segment(std::size_t i, std::size_t n) { return block(i, n); }
+    template <int N> VectorBlock<S> head() { return block(0, N); }
+    template <int N> VectorBlock<S> tail() { return block(d_.size() - N, N); }
+    template <int N> VectorBlock<S> segment(std::size_t i) { return block(i, N); }
     DenseMatrix(std::size_t r, std::size_t c) : r_(r), c_(c), d_(r * c, S(0)) {}
     explicit DenseMatrix(std::size_t n) : r_(n), c_(1), d_(n, S(0)) {}
     static DenseMatrix Zero(std::size_t r, std::size_t c = 1) { return DenseMatrix(r, c); }
@@ -72,9 +107,21 @@ public:
     }
 
 private:
+    VectorBlock<S> block(std::size_t i, std::size_t n)
+    {
+        if (i + n > d_.size() || (r_ != 1 && c_ != 1)) throw std::runtime_error("Eigen stand-in: block outside of the vector");
+        return VectorBlock<S>(d_.data() + i, n);
+    }
     std::size_t r_ = 0, c_ = 0;
     std::vector<S> d_;
 };
+template <class S>
+VectorBlock<S>& VectorBlock<S>::operator=(const DenseMatrix<S>& v)
+{
+    if (v.size() != n_) throw std::runtime_error("Eigen stand-in: block assignment of mismatching size");
+    for (std::size_t i = 0; i < n_; ++i) p_[i] = v.data()[i];
+    return *this;
+}
 // `stream << matrix` with Eigen's default IOFormat: the stream's precision, coefficients separated by one space and padded
 // to the width of the widest one, rows by a newline -- what bfl::Logger writes into the reference's log files
 template <class S>
@@ -108,6 +155,39 @@ using MatrixXf = DenseMatrix<float>;    // depth images: (v, u)
 // `Eigen::Ref<const Eigen::MatrixXd>` in a signature accepts a matrix by reference
 template <class T>
 using Ref = T&;
+
+// rotation of `angle` about a UNIT `axis` and the quaternion of it (main.cpp:290: Quaterniond(AngleAxisd(angle, axis)))
+template <class S>
+class AngleAxis {
+public:
+    template <class Vec>
+    AngleAxis(const S& angle, const Vec& axis) : angle_(angle) { for (int i = 0; i < 3; ++i) axis_[i] = axis(i); }
+    const S& angle() const { return angle_; }
+    const S* axis() const { return axis_; }
+
+private:
+    S angle_, axis_[3];
+};
+template <class S>
+class Quaternion {
+public:
+    Quaternion(const S& w, const S& x, const S& y, const S& z) : q_{w, x, y, z} {}
+    Quaternion(const AngleAxis<S>& aa)
+    {
+        const S h = aa.angle() / S(2), s = std::sin(h);
+        q_[0] = std::cos(h);
+        for (int i = 0; i < 3; ++i) q_[1 + i] = s * aa.axis()[i];
+    }
+    const S& w() const { return q_[0]; }
+    const S& x() const { return q_[1]; }
+    const S& y() const { return q_[2]; }
+    const S& z() const { return q_[3]; }
+
+private:
+    S q_[4];
+};
+using AngleAxisd = AngleAxis<double>;
+using Quaterniond = Quaternion<double>;
 
 enum TransformTraits { Affine = 1 };
 // rigid transform as the pose sources deliver it: translation + unit quaternion (w, x, y, z)

@@ -13,6 +13,7 @@
 
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <sstream>
 
@@ -114,7 +115,16 @@ public:
         }
         obj_.v_meas_cov_flow[0] = measurement_covariance_v(0);
         obj_.v_meas_cov_flow[1] = measurement_covariance_v(1);
-        if (!model_parameters.mesh_external_path().empty()) load_obj_mesh(model_parameters.mesh_external_path(), verts_, tris_);
+        // MeshResource.cpp:34-62: the internal data base -- meshes/<internal_db_name>/<name>.obj, compiled into the reference's
+        // library as resources -- or a file.  This library embeds no meshes: the data base is the directory ROFT_MESH_DB names
+        // (the reference's src/roft-lib/meshes has that layout).
+        if (model_parameters.use_internal_db()) {
+            const char* db = std::getenv("ROFT_MESH_DB");
+            if (!db) throw std::runtime_error("MeshResource::ctor. Cannot find requested mesh among available resources (no meshes are compiled into "
+                                              "this library: set ROFT_MESH_DB to a directory holding <internal_db_name>/<name>.obj, or model.use_internal_db = false "
+                                              "and model.external_path).");
+            load_obj_mesh(std::string(db) + "/" + model_parameters.internal_db_name() + "/" + model_parameters.name() + ".obj", verts_, tris_);
+        } else if (!model_parameters.mesh_external_path().empty()) load_obj_mesh(model_parameters.mesh_external_path(), verts_, tris_);
         else if (cfg_.outlier_rejection && cfg_.use_pose)
             throw std::runtime_error(log_name_ + "::ctor. Error: outlier rejection renders the object: ModelParameters::mesh_external_path is empty.");
         obj_.mesh = roft_mesh{verts_.data(), (int)(verts_.size() / 3), tris_.data(), (int)(tris_.size() / 3)};

@@ -304,6 +304,33 @@ def default_text(width, height, fx, fy, cx, cy):
         "unscented_transform: { alpha = %r; beta = %r; kappa = %r; }" % (c.ut.alpha, c.ut.beta, c.ut.kappa), ""])
 
 
+def dump_cfg(cfg, indent=0):
+    """Nested dict -> text in the reference's format (the inverse of parse_cfg)."""
+    pad, out = "    " * indent, []
+    for k, v in cfg.items():
+        if isinstance(v, dict):
+            out += ["%s%s:" % (pad, k), pad + "{", dump_cfg(v, indent + 1).rstrip("\n"), pad + "}"]
+        else:
+            one = lambda x: ("true" if x else "false") if isinstance(x, bool) else ('"%s"' % x.replace("\\", "\\\\").replace('"', '\\"') if isinstance(x, str) else repr(x))
+            out.append("%s%s = %s;" % (pad, k, "[" + ", ".join(one(x) for x in v) + "]" if isinstance(v, list) else one(v)))
+    return "\n".join(out) + "\n"
+
+
+def tracker_text(width, height, fx, fy, cx, cy):
+    """A COMPLETE configuration file of ROFT-tracker (every key src/roft/src/main.cpp:43-147 reads, laid out like
+    config/config_fast_ycb.cfg): the filter defaults of default_text() plus the data-set, log and model sections with the
+    placeholders test/test.sh overrides on the command line."""
+    cfg = parse_cfg(default_text(width, height, fx, fy, cx, cy))
+    cfg["camera_dataset"].update(path="?", data_prefix="/", rgb_prefix="rgb/", depth_prefix="depth/", data_format="txt", rgb_format="png",
+                                 depth_format="float", heading_zeros=0, index_offset=0)
+    cfg["log"] = dict(enable=True, enable_segmentation=False, path="?")
+    cfg["model"] = dict(name="?", use_internal_db=True, internal_db_name="DOPE", external_path="?")
+    cfg["optical_flow_dataset"] = dict(path="?", set="nvof", heading_zeros=0, index_offset=0)
+    cfg["pose_dataset"] = dict(dict(path="?", skip_rows=0, skip_cols=0), **cfg["pose_dataset"])
+    cfg["segmentation_dataset"] = dict(dict(path="?", format="png", set="mrcnn", heading_zeros=0, index_offset=0), **cfg["segmentation_dataset"])
+    return dump_cfg(dict(sorted(cfg.items(), key=lambda kv: (isinstance(kv[1], dict), kv[0]))))
+
+
 def all_keys(cfg, prefix=""):
     for k, v in cfg.items():
         if isinstance(v, dict):
@@ -312,5 +339,5 @@ def all_keys(cfg, prefix=""):
             yield prefix + k
 
 
-__all__ = ["parse_cfg", "apply_overrides", "lookup", "to_engine", "load", "frames_between", "default_text", "FILTER_KEYS", "DATASET_KEYS",
+__all__ = ["parse_cfg", "apply_overrides", "lookup", "to_engine", "load", "frames_between", "default_text", "tracker_text", "dump_cfg", "FILTER_KEYS", "DATASET_KEYS",
            "all_keys"]

@@ -327,3 +327,261 @@ def test_tracker_tail_logs_match_the_engine(tmp_path):
         outline = rio.read_png(str(tmp_path / "segmentation" / ("%d.png" % k)))
         assert outline.shape == refined.shape and outline[:, :, 0].max() == 255 and not outline[:, :, 1].any()
     eng.close()
+
+
+# ---- the reference's executable sources against the facade ------------------------------------------------------------------
+REF_MAIN = "/root/reference/src/roft/src/main.cpp"
+REF_BIN = os.path.join(ROOT, "tests", "cpp", "_ref_build", "ROFT-tracker")
+
+
+def build_sources_check(tmp_path):
+    from roft_amd import _lib
+    _lib.build()
+    exe = str(tmp_path / "sources_check")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include", "compat"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "sources_check.cpp"), "-o", exe,
+                           "-L", CSRC, "-lroft_hip", "-Wl,-rpath," + CSRC, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_reference_main_compiles_against_the_facade():
+    """src/roft/src/main.cpp of the reference, UNMODIFIED and where it lies, compiles against include/ (+ include/compat for the
+    header names of the third-party libraries): the drop-in claim of the class API.  Dev container only."""
+    if not os.path.exists(REF_MAIN):
+        pytest.skip("the reference checkout is not here")
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include", "compat"), "-I", os.path.join(ROOT, "include"), REF_MAIN])
+
+
+def test_config_parser_cpp_reads_what_the_python_reader_reads(tmp_path):
+    """include/compat/ConfigParser.h against roft_amd/config.py on a complete configuration with command-line overrides of
+    every type (as test/test.sh passes them), and -- in the dev container -- on the reference's own configuration files."""
+    from roft_amd import config as K
+    exe = build_sources_check(tmp_path)
+    cfg_path = str(tmp_path / "tracker.cfg")
+    open(cfg_path, "w").write("# a comment\n" + K.tracker_text(640, 480, 614.7, 615.5, 320.0, 240.0) + "/* trailing\n comment */\n")
+    over = ["--camera_dataset::fx", "600.25", "--camera_dataset::width", "320", "--initial_condition::pose::x", "0.1, -0.2,0.7",
+            "--initial_condition::pose::axis_angle", "0,0,1,0.5", "--measurement_model::use_pose_resync", "false", "--model::name", "003_cracker_box",
+            "--log::path", str(tmp_path), "--optical_flow_dataset::set", "nvof_1_slow/", "--measurement_model::pose::cov_q", "0.01,0.02,0.03",
+            "--kinematic_model::pose::sigma_angular", "1e-2,0.01,0.01"]
+    cases = [(cfg_path, over), (cfg_path, [])]
+    for name in ("config_fast_ycb.cfg", "config_ho3d.cfg"):
+        p = os.path.join("/root/reference/config", name)
+        if os.path.exists(p):
+            cases.append((p, over))
+    for path, ov in cases:
+        out = str(tmp_path / "cfg_out.txt")
+        subprocess.check_call([exe, "cfg", out, "ROFT-tracker", "--from", path] + ov)
+        got = dict(line.rstrip("\n").split("=", 1) for line in open(out))
+        cfg = K.parse_cfg(open(path).read())
+        assert K.apply_overrides(cfg, ["--from", path] + ov) == []
+        assert len(got) == 76 == len(list(K.all_keys(cfg)))
+        for key in K.all_keys(cfg):
+            want = K.lookup(cfg, key)
+            if isinstance(want, bool):
+                assert got[key] == ("true" if want else "false"), key
+            elif isinstance(want, list):
+                assert [float(v) for v in got[key].split(",")] == [float(v) for v in want], key
+            elif isinstance(want, str):
+                assert got[key] == want, key
+            else:
+                assert float(got[key]) == float(want), key
+    # errors are loud: an argument that is not a setting, a malformed value, a missing file
+    for bad in (["--no_such::key", "1"], ["--camera_dataset::width", "1.5"], ["--measurement_model::use_pose", "yes"],
+                ["--initial_condition::pose::x", "1,2"]):
+        r = subprocess.run([exe, "cfg", str(tmp_path / "x.txt"), "ROFT-tracker", "--from", cfg_path] + bad, capture_output=True, text=True)
+        assert r.returncode == 3 and "ConfigParser" in r.stdout, (bad, r.stdout)
+    r = subprocess.run([exe, "cfg", str(tmp_path / "x.txt"), "ROFT-tracker"], capture_output=True, text=True)
+    assert r.returncode == 3 and "--from" in r.stdout
+
+
+def _png_with_filters(path, img, level=6):
+    """PNG with a different filter type per row (0 .. 4 round robin) and real deflate blocks (dynamic Huffman codes)."""
+    import zlib
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    rows = img.reshape(h, w * ch).astype(np.int32)
+    raw = bytearray()
+    prev = np.zeros(w * ch, np.int32)
+    for y in range(h):
+        ft = y % 5
+        cur = rows[y]
+        a = np.concatenate([np.zeros(ch, np.int32), cur[:-ch]])
+        c = np.concatenate([np.zeros(ch, np.int32), prev[:-ch]])
+        if ft == 0:
+            pr = 0
+        elif ft == 1:
+            pr = a
+        elif ft == 2:
+            pr = prev
+        elif ft == 3:
+            pr = (a + prev) >> 1
+        else:
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            pr = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+        raw += bytes([ft]) + ((cur - pr) & 255).astype(np.uint8).tobytes()
+        prev = cur
+    chunk = lambda t, b: struct.pack(">I", len(b)) + t + b + struct.pack(">I", zlib.crc32(t + b) & 0xFFFFFFFF)
+    z = zlib.compress(bytes(raw), level)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, {1: 0, 2: 4, 3: 2, 4: 6}[ch], 0, 0, 0)) +
+                chunk(b"IDAT", z[:len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b""))
+
+
+def test_png_decoder_of_the_file_sources(tmp_path):
+    """compat::read_png (its own inflate) against roft_amd.io.read_png (zlib): gray, gray + alpha, RGB, RGBA; all five filter
+    types; stored, fixed and dynamic deflate blocks; BGR order and the OpenCV gray conversion."""
+    from roft_amd import io
+    exe = build_sources_check(tmp_path)
+    rng = np.random.default_rng(3)
+    smooth = (np.add.outer(np.arange(37), np.arange(53)) * 3 % 256).astype(np.uint8)
+    cases = {"gray": smooth, "noise": rng.integers(0, 256, (29, 31), dtype=np.uint8), "mask": (smooth > 128).astype(np.uint8) * 255,
+             "rgb": np.stack([smooth, smooth.T[:37, :53] if False else 255 - smooth, rng.integers(0, 256, smooth.shape, dtype=np.uint8)], -1),
+             "rgba": rng.integers(0, 256, (17, 19, 4), dtype=np.uint8), "ga": rng.integers(0, 256, (8, 9, 2), dtype=np.uint8)}
+    for name, img in cases.items():
+        for level in (0, 1, 9):
+            p = str(tmp_path / ("%s_%d.png" % (name, level)))
+            _png_with_filters(p, img, level)
+            ref = io.read_png(p)
+            assert np.array_equal(ref, img)
+            for mode in ("png", "gray"):
+                out = str(tmp_path / "png.bin")
+                subprocess.check_call([exe, mode, p, out])
+                raw = open(out, "rb").read()
+                rows, cols, esz = struct.unpack("3i", raw[:12])
+                got = np.frombuffer(raw[12:], np.uint8).reshape(rows, cols, esz) if esz > 1 else np.frombuffer(raw[12:], np.uint8).reshape(rows, cols)
+                if img.ndim == 2 or img.shape[2] == 2:
+                    want = img if img.ndim == 2 else img[..., 0]
+                elif mode == "png":
+                    want = img[..., 2::-1]                      # B, G, R as cv::imread orders them
+                else:
+                    want = io.rgb_to_gray(img)
+                assert np.array_equal(got, want), (name, level, mode)
+    # written by the stand-in of cv::imwrite (stored blocks) and read back
+    io.write_png(str(tmp_path / "w.png"), smooth)
+    subprocess.check_call([exe, "png", str(tmp_path / "w.png"), str(tmp_path / "png.bin")])
+    assert np.array_equal(np.frombuffer(open(str(tmp_path / "png.bin"), "rb").read()[12:], np.uint8).reshape(smooth.shape), smooth)
+    # a missing file and a truncated one come back empty
+    open(str(tmp_path / "bad.png"), "wb").write(open(str(tmp_path / "w.png"), "rb").read()[:60])
+    for p in ("none.png", "bad.png"):
+        subprocess.check_call([exe, "png", str(tmp_path / p), str(tmp_path / "png.bin")])
+        assert struct.unpack("3i", open(str(tmp_path / "png.bin"), "rb").read()[:12]) == (0, 0, 0)
+
+
+def test_file_sources_deliver_on_the_references_schedule(tmp_path):
+    """DatasetImageSegmentation(Delayed), DatasetTransform(Delayed) and DatasetCamera over a directory roft_amd.io wrote: masks
+    and poses arrive on the frames roft_amd.io.delivery_schedule (the restatement of DatasetImageSegmentationDelayed.cpp:42-63
+    the Python sequence reader uses) says, missing detections are skipped, stamps / depth / camera pose are those of the files."""
+    from roft_amd import io, synth
+    exe = build_sources_check(tmp_path)
+    root, n, w, h = str(tmp_path / "seq"), 20, 8, 6
+    for d in ("rgb", "depth", "masks/gt", "dope"):
+        os.makedirs(os.path.join(root, d))
+    io.write_data_txt(os.path.join(root, "data.txt"), n, 30.0)
+    pose = np.zeros((n, 7))
+    pose[:, 3] = 1.0
+    pose[:, 0] = 0.25 + 0.125 * np.arange(n)
+    ok = np.ones(n, bool)
+    ok[12] = False                                              # a missing detection: its slot stays empty
+    io.write_poses(os.path.join(root, "dope", "poses.txt"), pose, ok)
+    for k in range(n):
+        io.write_png(os.path.join(root, "masks", "gt", "box_%d.png" % k), np.full((h, w), 10 + k, np.uint8))
+        io.write_png(os.path.join(root, "rgb", "%d.png" % k), np.full((h, w), 100 + k, np.uint8))
+        io.write_depth(os.path.join(root, "depth", "%d.float" % k), np.full((h, w), 0.5 + k, np.float32))
+    for fps, sim, delayed in ((30.0, 5.0, 1), (30.0, 5.0, 0), (30.0, 10.0, 1), (30.0, 30.0, 1)):
+        r = subprocess.run([exe, "sched", root, "box", "gt", os.path.join(root, "dope", "poses.txt"), str(n), str(w), str(h), str(fps), str(sim), str(delayed)],
+                           capture_output=True, text=True, check=True)
+        lines = r.stdout.strip().splitlines()
+        assert lines[0].split() == ["between", str(int(fps / sim)), str(int(fps / sim)), "-1", "-1"]
+        sched = io.delivery_schedule(n, fps, sim, simulate_inference_time=bool(delayed))
+        for k, line in enumerate(lines[1:]):
+            f = line.split()
+            assert int(f[0]) == k
+            assert int(f[1]) == (10 + sched[k] if sched[k] >= 0 else -1), (fps, sim, delayed, k)
+            want = pose[sched[k], 0] if sched[k] >= 0 and ok[sched[k]] else float("nan")
+            assert (np.isnan(want) and f[2] == "nan") or float(f[2]) == want, (fps, sim, delayed, k, f[2], want)
+            assert int(f[3]) == 10 + k                          # the plain sources: every frame its own mask and pose
+            assert (not ok[k] and f[4] == "nan") or float(f[4]) == pose[k, 0]
+    r = subprocess.run([exe, "camera", root, str(w), str(h)], capture_output=True, text=True, check=True)
+    rows = [line.split() for line in r.stdout.strip().splitlines() if not line.startswith("Dataset")]
+    assert len(rows) == n
+    stamps, _, _ = io.read_data_txt(os.path.join(root, "data.txt"))
+    for k, f in enumerate(rows):
+        assert int(f[0]) == k and float(f[1]) == stamps[k] == float(f[2]) and int(f[3]) == 1
+        assert float(f[4]) == 0.5 + k == float(f[5]) and float(f[6]) == 0.0 and float(f[7]) == 1.0 and int(f[8]) == 100 + k
+
+
+@pytest.mark.gpu
+def test_reference_tracker_runs_on_this_engine(tmp_path, capsys):
+    """The reference's own src/roft/src/main.cpp -- unmodified, built by __graft_entry__.build() in the dev container against
+    include/ROFT + include/compat and linked with libroft_hip.so -- started the way test/test.sh starts ROFT-tracker on a
+    sequence directory: it must write the five log files, and they must say what tools/run_sequence.py (the Python host over
+    the same engine, same files, same configuration and overrides) says, to the six digits bfl::Logger prints."""
+    import importlib.util
+    import json
+    import util
+    from roft_amd import config as K
+    from roft_amd import io, synth
+    if not os.path.exists(REF_BIN):
+        pytest.skip("tests/cpp/_ref_build/ROFT-tracker is built where the reference checkout is (python __graft_entry__.py)")
+    n = 40
+    import copy
+    st = copy.copy(util.stream(703, n, 2, with_gray=True))
+    st.pose_meas = st.pose_meas.copy()
+    st.pose_meas[0] = st.pose_meas[6]            # one detection per source frame in a pose file (see test_sequence_gpu.py)
+    root = str(tmp_path / "seq")
+    mesh = io.write_sequence(root, st, "box", flow_set="analytic")
+    c = st.camera
+    cfg_path = str(tmp_path / "config.cfg")
+    open(cfg_path, "w").write(K.tracker_text(c.width, c.height, 1.0, 1.0, 0.0, 0.0))
+    m0 = synth.initial_pose_from_stream(st)
+    axis, angle = io.quat_to_axis_angle(m0[9:13])
+    out_dir = str(tmp_path / "out")
+    os.makedirs(out_dir)
+    # test/test.sh:135-157, with the mesh as a file instead of the compiled-in data base
+    args = ["--from", cfg_path,
+            "--camera_dataset::fx", repr(c.fx), "--camera_dataset::fy", repr(c.fy), "--camera_dataset::cx", repr(c.cx), "--camera_dataset::cy", repr(c.cy),
+            "--camera_dataset::path", root,
+            "--initial_condition::pose::x", ",".join("%.17g" % v for v in m0[6:9]),
+            "--initial_condition::pose::axis_angle", ",".join("%.17g" % v for v in list(axis) + [angle]),
+            "--kinematic_model::pose::sigma_angular", "1.0,1.0,1.0",
+            "--log::path", out_dir, "--log::enable_segmentation", "true",
+            "--measurement_model::pose::cov_q", "0.0001,0.0001,0.0001",
+            "--measurement_model::use_pose", "true", "--measurement_model::use_pose_resync", "true", "--measurement_model::use_velocity", "true",
+            "--model::name", "box", "--model::use_internal_db", "false", "--model::external_path", mesh,
+            "--optical_flow_dataset::path", root, "--optical_flow_dataset::set", "analytic/",
+            "--outlier_rejection::enable", "true",
+            "--pose_dataset::path", os.path.join(root, "dope", "poses.txt"),
+            "--segmentation_dataset::flow_aided", "true", "--segmentation_dataset::path", root, "--segmentation_dataset::set", "gt"]
+    for d in ("segmentation", "segmentation_refined"):
+        os.makedirs(os.path.join(out_dir, d))
+    r = subprocess.run([REF_BIN] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "DatasetImageOpticalFlow::ctor." in r.stdout and "Unscented transform:" in r.stdout
+    logs = {name: io.read_log(os.path.join(out_dir, name + ".txt")) for name in
+            ("pose_estimate", "velocity_estimate", "execution_times", "pose_measurements", "velocity_measurements")}
+    assert logs["pose_estimate"].shape == (n, 13) and logs["velocity_estimate"].shape == (n, 6) and logs["execution_times"].shape == (n, 2)
+    assert logs["pose_measurements"].shape == (n, 7) and logs["velocity_measurements"].shape == (n, 6)
+    assert len(os.listdir(os.path.join(out_dir, "segmentation"))) == n == len(os.listdir(os.path.join(out_dir, "segmentation_refined")))
+    # the Python host over the same engine
+    spec = importlib.util.spec_from_file_location("run_sequence", os.path.join(ROOT, "tools", "run_sequence.py"))
+    rs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rs)
+    keep = [a for a in args[2:]]
+    drop = {"--camera_dataset::path", "--log::path", "--log::enable_segmentation", "--model::name", "--model::use_internal_db", "--model::external_path",
+            "--optical_flow_dataset::path", "--optical_flow_dataset::set", "--pose_dataset::path", "--segmentation_dataset::path", "--segmentation_dataset::set"}
+    over = []
+    for i in range(0, len(keep), 2):
+        if keep[i] not in drop:
+            over += keep[i:i + 2]
+    open(str(tmp_path / "filter.cfg"), "w").write(K.default_text(c.width, c.height, 1.0, 1.0, 0.0, 0.0))
+    assert rs.main(["--root", root, "--object", "box", "--mesh", mesh, "--flow-set", "analytic", "--mask-set", "gt", "--out", str(tmp_path / "py_"),
+                    "--from", str(tmp_path / "filter.cfg")] + over) == 0
+    rep = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+    assert rep["frames"] == n and rep["adds_auc"] > 80.0
+    est = np.loadtxt(str(tmp_path / "py_pose_estimate"))
+    vel = np.loadtxt(str(tmp_path / "py_velocity_estimate"))
+    # six significant digits per value in the C++ logs
+    assert np.allclose(logs["pose_estimate"], est, rtol=2e-5, atol=1e-6), np.abs(logs["pose_estimate"] - est).max()
+    assert np.allclose(logs["velocity_estimate"], vel, rtol=2e-5, atol=1e-6), np.abs(logs["velocity_estimate"] - vel).max()
