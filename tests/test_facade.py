@@ -106,10 +106,24 @@ def test_facade_headers_name_every_reference_class():
         "ROFTFilter.h": ["class ROFTFilter : public bfl::FilteringAlgorithm", "const ModelParameters& model_parameters",
                          "const bool pose_outlier_rejection_gain", "void filtering_step() override"],
     }
+    want.update({
+        "DatasetImageOpticalFlow.h": ["class DatasetImageOpticalFlow : public ImageOpticalFlowSource", "const std::size_t& heading_zeros = 0, const std::size_t& index_offset = 0"],
+        "DatasetImageSegmentation.h": ["class DatasetImageSegmentation : public RobotsIO::Utils::Segmentation", "const bool simulate_missing_detections = false"],
+        "DatasetImageSegmentationDelayed.h": ["class DatasetImageSegmentationDelayed : public DatasetImageSegmentation", "const float& fps, const float& simulated_fps, const bool simulate_inference_time",
+                                              "int get_frames_between_iterations() const override"],
+        "OpticalFlowUtilities.h": ["inline bool is_flow_valid(const float& f_x, const float& f_y)", "read_flow(const std::string& file_name)"],
+    })
     for name, needles in want.items():
         text = " ".join(open(os.path.join(inc, name)).read().split())
         for needle in needles:
             assert needle in text, (name, needle)
+    # every header name ROFT-tracker's main.cpp includes resolves (src/roft/src/main.cpp:8-30)
+    for name in ("CameraMeasurement.h", "ImageOpticalFlowSource.h", "ImageOpticalFlowNVOF.h", "ModelParameters.h", "ImageSegmentationMeasurement.h"):
+        assert os.path.exists(os.path.join(inc, name)), name
+    for name in ("ConfigParser.h", "BayesFilters/FilteringAlgorithm.h", "RobotsIO/Camera/Camera.h", "RobotsIO/Camera/DatasetCamera.h",
+                 "RobotsIO/Camera/CameraParameters.h", "RobotsIO/Utils/DatasetTransform.h", "RobotsIO/Utils/DatasetTransformDelayed.h",
+                 "RobotsIO/Utils/ImageFileProbe.h", "RobotsIO/Utils/Parameters.h", "RobotsIO/Utils/Segmentation.h"):
+        assert os.path.exists(os.path.join(ROOT, "include", "compat", name)), name
 
 
 @pytest.mark.gpu
