@@ -312,7 +312,7 @@ public:
     // (valid, mask): valid == a NEW mask arrived with this frame
     virtual std::pair<bool, cv::Mat> segmentation(const bool& blocking) = 0;
     virtual std::pair<bool, cv::Mat> latest_segmentation() { return {false, cv::Mat()}; }
-    virtual std::pair<bool, double> get_time_stamp() { return {false, 0.0}; }
+    virtual double get_time_stamp() { return -1.0; }   // stamp of the image the delivered mask was computed on (s)
     virtual void set_rgb_image(const cv::Mat& /*image*/, const double& /*timestamp*/) {}
 };
 

@@ -20,6 +20,7 @@
 #include "CartesianQuaternionModel.h"
 #include "ImageOpticalFlowMeasurement.hpp"
 #include "ImageSegmentationOFAidedSource.hpp"
+#include "MeshResource.h"
 #include "SKFCorrection.h"
 #include "SpatialVelocityModel.h"
 #include "UKFCorrection.h"
@@ -28,10 +29,8 @@ namespace ROFT {
 
 // Wavefront OBJ as the reference's meshes are written (`v x y z [r g b]`, `f a//n b//n c//n`, also a/t/n and plain
 // indices; polygons are fanned): src/roft-lib/meshes/DOPE/*.obj
-inline void load_obj_mesh(const std::string& path, std::vector<float>& verts, std::vector<std::int32_t>& tris)
+inline void parse_obj_mesh(std::istream& in, const std::string& what, std::vector<float>& verts, std::vector<std::int32_t>& tris)
 {
-    std::ifstream in(path);
-    if (!in) throw std::runtime_error("load_obj_mesh: cannot open " + path);
     std::string line;
     while (std::getline(in, line)) {
         std::istringstream ls(line);
@@ -50,7 +49,13 @@ inline void load_obj_mesh(const std::string& path, std::vector<float>& verts, st
             for (std::size_t k = 1; k + 1 < idx.size(); ++k) { tris.push_back(idx[0]); tris.push_back(idx[k]); tris.push_back(idx[k + 1]); }
         }
     }
-    if (verts.empty() || tris.empty()) throw std::runtime_error("load_obj_mesh: no geometry in " + path);
+    if (verts.empty() || tris.empty()) throw std::runtime_error("load_obj_mesh: no geometry in " + what);
+}
+inline void load_obj_mesh(const std::string& path, std::vector<float>& verts, std::vector<std::int32_t>& tris)
+{
+    std::ifstream in(path);
+    if (!in) throw std::runtime_error("load_obj_mesh: cannot open " + path);
+    parse_obj_mesh(in, path, verts, tris);
 }
 
 class ROFTFilter : public bfl::FilteringAlgorithm, public RobotsIO::Utils::ProbeContainer {
@@ -115,16 +120,11 @@ public:
         }
         obj_.v_meas_cov_flow[0] = measurement_covariance_v(0);
         obj_.v_meas_cov_flow[1] = measurement_covariance_v(1);
-        // MeshResource.cpp:34-62: the internal data base -- meshes/<internal_db_name>/<name>.obj, compiled into the reference's
-        // library as resources -- or a file.  This library embeds no meshes: the data base is the directory ROFT_MESH_DB names
-        // (the reference's src/roft-lib/meshes has that layout).
-        if (model_parameters.use_internal_db()) {
-            const char* db = std::getenv("ROFT_MESH_DB");
-            if (!db) throw std::runtime_error("MeshResource::ctor. Cannot find requested mesh among available resources (no meshes are compiled into "
-                                              "this library: set ROFT_MESH_DB to a directory holding <internal_db_name>/<name>.obj, or model.use_internal_db = false "
-                                              "and model.external_path).");
-            load_obj_mesh(std::string(db) + "/" + model_parameters.internal_db_name() + "/" + model_parameters.name() + ".obj", verts_, tris_);
-        } else if (!model_parameters.mesh_external_path().empty()) load_obj_mesh(model_parameters.mesh_external_path(), verts_, tris_);
+        // the mesh the outlier test renders (ROFTFilter.cpp:186: MeshResource mesh_resource(model_parameters))
+        if (model_parameters.use_internal_db() || !model_parameters.mesh_external_path().empty()) {
+            std::istringstream mesh_text(MeshResource(model_parameters).as_string());
+            parse_obj_mesh(mesh_text, model_parameters.use_internal_db() ? model_parameters.name() : model_parameters.mesh_external_path(), verts_, tris_);
+        }
         else if (cfg_.outlier_rejection && cfg_.use_pose)
             throw std::runtime_error(log_name_ + "::ctor. Error: outlier rejection renders the object: ModelParameters::mesh_external_path is empty.");
         obj_.mesh = roft_mesh{verts_.data(), (int)(verts_.size() / 3), tris_.data(), (int)(tris_.size() / 3)};

@@ -5,6 +5,8 @@
 //   sources_check gray <file.png> <out.bin>                   the same through bgr_to_gray
 //   sources_check sched <root> <object> <set> <poses.txt> <frames> <w> <h> <fps> <simulated_fps> <delay 0|1>
 //                                                             per frame: mask delivered (value of pixel 0, -1 = none), pose x (nan = none)
+//   sources_check queue                                       OpticalFlowQueueHandler: window, region after a stamp, unknown stamp
+//   sources_check mesh <name> <set> <external path>           MeshResource: sizes of the internal-data-base and external texts
 //   sources_check camera <root> <w> <h>                       per frame: index stamp_rgb stamp_depth depth(0,0) depth(h-1,w-1) pose x qw
 #include <cmath>
 #include <cstdio>
@@ -13,6 +15,8 @@
 #include <ConfigParser.h>
 #include <ROFT/DatasetImageOpticalFlow.h>
 #include <ROFT/DatasetImageSegmentationDelayed.h>
+#include <ROFT/MeshResource.h>
+#include <ROFT/OpticalFlowQueueHandler.h>
 
 static std::string str(const Eigen::VectorXd& v)
 {
@@ -24,7 +28,7 @@ static std::string str(const Eigen::VectorXd& v)
 
 int main(int argc, char** argv)
 {
-    if (argc < 3) return 2;
+    if (argc < 2) return 2;
     const std::string mode = argv[1];
     try {
         if (mode == "cfg") {
@@ -92,6 +96,35 @@ int main(int argc, char** argv)
                 std::printf("%d %d %.17g %d %.17g\n", k, m.first ? (int)m.second.data[0] : -1, got ? tr.transform().translation()[0] : NAN,
                             pm.first ? (int)pm.second.data[0] : -1, pgot ? plain_tr.transform().translation()[0] : NAN);
             }
+            return 0;
+        }
+        if (mode == "queue") {
+            ROFT::OpticalFlowQueueHandler q(4);
+            for (int k = 0; k < 7; ++k) {
+                cv::Mat m(1, 1, CV_32FC2);
+                m.at<float>(0, 0) = (float)k;
+                q.add_flow(m, k / 30.0);      // entries 3, 4, 5, 6 survive
+            }
+            auto show = [&](double stamp) {
+                std::printf("%.6f:", stamp);
+                for (const cv::Mat& m : q.get_buffer_region(stamp)) std::printf(" %d", (int)m.at<float>(0, 0));
+                std::printf("\n");
+            };
+            show(4 / 30.0); show(4 / 30.0 + 5e-4); show(4 / 30.0 + 2e-3); show(2 / 30.0); show(6 / 30.0); show(3 / 30.0);
+            q.clear();
+            show(4 / 30.0);
+            return 0;
+        }
+        if (mode == "mesh") {
+            ROFT::ModelParameters mp;
+            mp.name(argv[2]);
+            mp.internal_db_name(argv[3]);
+            mp.mesh_external_path(argv[4]);
+            mp.use_internal_db(false);
+            std::printf("external %zu\n", ROFT::MeshResource(mp).as_string().size());
+            mp.use_internal_db(true);
+            std::printf("internal %zu\n", ROFT::MeshResource(mp).as_string().size());
+            std::printf("named %zu\n", ROFT::MeshResource(argv[2], argv[3]).as_string().size());
             return 0;
         }
         if (mode == "camera") {

@@ -605,3 +605,61 @@ def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
     # six significant digits per value in the C++ logs
     assert np.allclose(logs["pose_estimate"], est, rtol=2e-5, atol=1e-6), np.abs(logs["pose_estimate"] - est).max()
     assert np.allclose(logs["velocity_estimate"], vel, rtol=2e-5, atol=1e-6), np.abs(logs["velocity_estimate"] - vel).max()
+
+
+def test_queue_handler_and_mesh_resource(tmp_path):
+    """OpticalFlowQueueHandler (window of the last n flows, the region AFTER the entry with a stamp, 1 ms tolerance, unknown
+    stamp -> empty) and MeshResource (external file; the internal data base = $ROFT_MESH_DB/<set>/<name>.obj; loud when absent)."""
+    exe = build_sources_check(tmp_path)
+    r = subprocess.run([exe, "queue"], capture_output=True, text=True, check=True)
+    assert r.stdout.split("\n")[:7] == ["0.133333: 5 6", "0.133833: 5 6", "0.135333:", "0.066667:", "0.200000:", "0.100000: 4 5 6", "0.133333:"]
+    db = tmp_path / "db" / "DOPE"
+    db.mkdir(parents=True)
+    (db / "box.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    (tmp_path / "ext.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1 2 3\nf 1 2 4\n")
+    env = dict(os.environ, ROFT_MESH_DB=str(tmp_path / "db"))
+    r = subprocess.run([exe, "mesh", "box", "DOPE", str(tmp_path / "ext.obj")], capture_output=True, text=True, env=env, check=True)
+    n_int, n_ext = len((db / "box.obj").read_text()), len((tmp_path / "ext.obj").read_text())
+    assert r.stdout.split() == ["external", str(n_ext), "internal", str(n_int), "named", str(n_int)]
+    env.pop("ROFT_MESH_DB")
+    r = subprocess.run([exe, "mesh", "box", "DOPE", str(tmp_path / "ext.obj")], capture_output=True, text=True, env=env)
+    assert r.returncode == 3 and ("external %d" % n_ext) in r.stdout and "Cannot find requested mesh among available resources" in r.stdout
+    r = subprocess.run([exe, "mesh", "box", "DOPE", str(tmp_path / "none.obj")], capture_output=True, text=True, env=env)
+    assert r.returncode == 3 and "Cannot open model from external path" in r.stdout
+
+
+@pytest.mark.gpu
+def test_stamped_source_facade_equals_the_oracle(tmp_path):
+    """ROFT::ImageSegmentationOFAidedSourceStamped<cv::Vec2f> (host bookkeeping + roft_mask_propagate) against the oracle's
+    restatement of the same source on an irregular live delivery (tests/test_stamped.py::schedule: late masks, a stamp that is not
+    in the queue, a mask older than the frames_between window): the mask held after every frame, bit for bit."""
+    import util
+    import test_stamped as ts
+    from oracle import binding as ob
+    n = 48
+    st = util.stream(95, n, 4)
+    deliver = ts.schedule(n, 5)
+    want = ts.run_oracle(ob, st, n, deliver)
+    # the recorded stream with the masks on their delivery frames
+    import copy
+    rec = copy.copy(st)
+    rec.mask_delivery = np.full(n, -1, np.int64)
+    for k, (src, _stamp) in deliver.items():
+        rec.mask_delivery[k] = src
+    dump_stream(str(tmp_path / "s.bin"), rec, n)
+    with open(str(tmp_path / "stamps.txt"), "w") as f:
+        for k in range(n):
+            f.write("%.17g %.17g\n" % (k / 30.0, deliver[k][1] if k in deliver else -1.0))
+    exe = build(tmp_path, "stamped_check")
+    subprocess.check_call([exe, str(tmp_path / "s.bin"), str(tmp_path / "stamps.txt"), "6", str(tmp_path / "out.bin")])
+    raw = open(str(tmp_path / "out.bin"), "rb").read()
+    H, W = st.mask_gt.shape[1:]
+    pos = 0
+    for k in range(n):
+        have = raw[pos]
+        pos += 1
+        assert have == 1
+        got = np.frombuffer(raw[pos:pos + W * H], np.uint8).reshape(H, W)
+        pos += W * H
+        assert np.array_equal(np.where(got > 1, 255, 0).astype(np.uint8), want[k]["mask"]), k
+    assert pos == len(raw)
