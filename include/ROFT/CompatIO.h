@@ -299,7 +299,9 @@ public:
         if (data_.empty()) throw std::runtime_error("DatasetCamera::ctor. Error: no frames in " + root_ + data_prefix + "data." + data_format);
         reset();
     }
-    bool status() const override { return frame_ - (long)index_offset_ < (long)data_.size(); }
+    // (frame indices are absolute: with index_offset = k the first frame is rgb/<k>, depth/<k> and row k of the data file,
+    //  as test/test_ho3d.sh:142 starts the tracker in the middle of a sequence)
+    bool status() const override { return frame_ < (long)data_.size(); }
     bool step_frame() override { ++frame_; return status(); }
     bool reset() override { frame_ = -1 + (long)index_offset_; return true; }
     std::pair<bool, CameraParameters> parameters() const override { return {true, parameters_}; }
@@ -334,8 +336,8 @@ public:
     std::int32_t frame_index() const override { return (std::int32_t)frame_; }
 
 private:
-    bool in_range() const { return frame_ >= (long)index_offset_ && status(); }
-    const std::vector<double>& row() const { return data_[(std::size_t)(frame_ - (long)index_offset_)]; }
+    bool in_range() const { return frame_ >= 0 && status(); }
+    const std::vector<double>& row() const { return data_[(std::size_t)frame_]; }
     std::string root_, rgb_prefix_, depth_prefix_, rgb_format_, depth_format_;
     std::size_t heading_zeros_, index_offset_;
     CameraParameters parameters_;

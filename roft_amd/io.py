@@ -329,7 +329,10 @@ class Sequence:
     delivery schedule to masks and poses."""
 
     def __init__(self, root, object_name, flow_set="nvof_1_slow", mask_set="mrcnn_ycbv_bop_pbr", pose_set="dope",
-                 width=1280, height=720, original_fps=30.0, desired_fps=5.0, delayed=True):
+                 width=1280, height=720, original_fps=30.0, desired_fps=5.0, delayed=True, first_frame=0):
+        """first_frame: where the tracker starts (test/test_ho3d.sh:142-160 passes it as `index_offset` of the camera, flow and
+        mask sources and as `skip_rows` of the pose file): the mask schedule counts from that frame on file indices, the
+        pose schedule on the rows that are left -- the first frame delivers ITS OWN row, later ones the row six frames back."""
         self.root, self.obj = root, object_name
         self.flow_dir = os.path.join(root, "optical_flow", flow_set)
         self.mask_dir = os.path.join(root, "masks", mask_set)
@@ -338,9 +341,15 @@ class Sequence:
         self.poses, self.pose_ok = read_poses(os.path.join(root, pose_set, "poses.txt"))
         self.n = len(self.stamp)
         self.size = (width, height)
-        sched = delivery_schedule(self.n, original_fps, desired_fps) if delayed else np.arange(self.n)
-        self.mask_src = sched
-        self.pose_src = sched
+        first, run = int(first_frame), self.n - int(first_frame)
+        self.mask_src = np.full(self.n, -1, np.int64)
+        self.pose_src = np.full(self.n, -1, np.int64)
+        if delayed:
+            self.mask_src[first:] = delivery_schedule(run, original_fps, desired_fps, head_0=first)
+            rows = delivery_schedule(run, original_fps, desired_fps)
+            self.pose_src[first:] = np.where(rows >= 0, rows + first, -1)
+        else:
+            self.mask_src[first:] = self.pose_src[first:] = np.arange(first, self.n)
 
     def __len__(self):
         return self.n

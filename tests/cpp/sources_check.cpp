@@ -79,15 +79,16 @@ int main(int argc, char** argv)
             const int frames = std::atoi(argv[6]), w = std::atoi(argv[7]), h = std::atoi(argv[8]);
             const double fps = std::atof(argv[9]), sim = std::atof(argv[10]);
             const bool delay = std::atoi(argv[11]) != 0;
+            const std::size_t offset = argc > 12 ? (std::size_t)std::atoi(argv[12]) : 0;   // where the tracker starts (test_ho3d.sh:142-160)
             ROFT::ModelParameters mp;
             mp.name(object);
-            ROFT::DatasetImageSegmentationDelayed seg((float)fps, (float)sim, delay, root, "png", w, h, set, mp);
-            RobotsIO::Utils::DatasetTransformDelayed tr(fps, sim, delay, poses, 0, 0, 7);
-            ROFT::DatasetImageSegmentation plain(root, "png", w, h, set, mp);
-            RobotsIO::Utils::DatasetTransform plain_tr(poses, 0, 0, 7);
+            ROFT::DatasetImageSegmentationDelayed seg((float)fps, (float)sim, delay, root, "png", w, h, set, mp, 0, offset);
+            RobotsIO::Utils::DatasetTransformDelayed tr(fps, sim, delay, poses, offset, 0, 7);
+            ROFT::DatasetImageSegmentation plain(root, "png", w, h, set, mp, 0, offset);
+            RobotsIO::Utils::DatasetTransform plain_tr(poses, offset, 0, 7);
             std::printf("between %d %d %d %d\n", seg.get_frames_between_iterations(), tr.get_frames_between_iterations(),
                         plain.get_frames_between_iterations(), plain_tr.get_frames_between_iterations());
-            for (int k = 0; k < frames; ++k) {
+            for (int k = (int)offset; k < frames; ++k) {
                 seg.step_frame();
                 plain.step_frame();
                 const auto m = seg.segmentation(false);
@@ -129,7 +130,7 @@ int main(int argc, char** argv)
         }
         if (mode == "camera") {
             const int w = std::atoi(argv[3]), h = std::atoi(argv[4]);
-            RobotsIO::Camera::DatasetCamera cam(argv[2], "/", "rgb/", "depth/", "txt", "png", "float", 0, 0, w, h, 1.0, 2.0, 3.0, 4.0);
+            RobotsIO::Camera::DatasetCamera cam(argv[2], "/", "rgb/", "depth/", "txt", "png", "float", 0, argc > 5 ? (std::size_t)std::atoi(argv[5]) : 0, w, h, 1.0, 2.0, 3.0, 4.0);
             while (cam.step_frame()) {
                 const auto d = cam.depth(true);
                 const auto p = cam.pose(true);

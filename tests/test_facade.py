@@ -517,6 +517,26 @@ def test_file_sources_deliver_on_the_references_schedule(tmp_path):
             assert (np.isnan(want) and f[2] == "nan") or float(f[2]) == want, (fps, sim, delayed, k, f[2], want)
             assert int(f[3]) == 10 + k                          # the plain sources: every frame its own mask and pose
             assert (not ok[k] and f[4] == "nan") or float(f[4]) == pose[k, 0]
+    # started in the middle of the sequence as test/test_ho3d.sh:142-160 does (index_offset of camera / flow / mask sources,
+    # skip_rows of the pose file): the schedule of roft_amd.io.Sequence(first_frame=...)
+    for first in (6, 12):
+        r = subprocess.run([exe, "sched", root, "box", "gt", os.path.join(root, "dope", "poses.txt"), str(n), str(w), str(h), "30.0", "5.0", "1", str(first)],
+                           capture_output=True, text=True, check=True)
+        lines = r.stdout.strip().splitlines()[1:]
+        seq = io.Sequence(root, "box", flow_set="none", mask_set="gt", pose_set="dope", width=w, height=h, first_frame=first)
+        assert len(lines) == n - first
+        for line in lines:
+            f = line.split()
+            k = int(f[0])
+            assert int(f[1]) == (10 + seq.mask_src[k] if seq.mask_src[k] >= 0 else -1), (first, k)
+            pi = seq.pose_src[k]
+            want = pose[pi, 0] if pi >= 0 and ok[pi] else float("nan")
+            assert (np.isnan(want) and f[2] == "nan") or float(f[2]) == want, (first, k, f[2], want)
+        assert seq.pose_src[first] == first and seq.pose_src[first + 6] == first and seq.mask_src[first] == first - 6
+        r = subprocess.run([exe, "camera", root, str(w), str(h), str(first)], capture_output=True, text=True, check=True)
+        rows = [line.split() for line in r.stdout.strip().splitlines() if not line.startswith("Dataset")]
+        assert [int(f[0]) for f in rows] == list(range(first, n)) and float(rows[0][4]) == 0.5 + first and int(rows[0][8]) == 100 + first
+        assert float(rows[0][1]) == io.read_data_txt(os.path.join(root, "data.txt"))[0][first]
     r = subprocess.run([exe, "camera", root, str(w), str(h)], capture_output=True, text=True, check=True)
     rows = [line.split() for line in r.stdout.strip().splitlines() if not line.startswith("Dataset")]
     assert len(rows) == n
@@ -527,7 +547,7 @@ def test_file_sources_deliver_on_the_references_schedule(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["A_f32_grid1", "B_s16_grid4"])
+@pytest.mark.parametrize("shape", ["A_f32_grid1", "B_s16_grid4", "A_from_first_detection"])
 def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
     """The reference's own src/roft/src/main.cpp -- unmodified, built by __graft_entry__.build() in the dev container against
     include/ROFT + include/compat and linked with libroft_hip.so -- started the way test/test.sh starts ROFT-tracker on a
@@ -541,7 +561,7 @@ def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
     if not os.path.exists(REF_BIN):
         pytest.skip("tests/cpp/_ref_build/ROFT-tracker is built where the reference checkout is (python __graft_entry__.py)")
     import copy
-    if shape == "A_f32_grid1":     # config_ho3d.cfg's shape: 640x480 (here halved), CV_32FC2 flow per pixel
+    if shape != "B_s16_grid4":     # config_ho3d.cfg's shape: 640x480 (here halved), CV_32FC2 flow per pixel
         n = 40
         st = copy.copy(util.stream(703, n, 2, with_gray=True))
     else:                          # config_fast_ycb.cfg's: 1280x720, CV_16SC2 flow on a grid of 4, render divider 4
@@ -556,6 +576,23 @@ def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
     open(cfg_path, "w").write(K.tracker_text(c.width, c.height, 1.0, 1.0, 0.0, 0.0))
     m0 = synth.initial_pose_from_stream(st)
     axis, angle = io.quat_to_axis_angle(m0[9:13])
+    first, start_args, py_start = 0, [], []
+    if shape == "A_from_first_detection":
+        # test/test_ho3d.sh:68-72, 142-160: no detection on frame 0 -> the tracker starts at the frame tools/dataset/
+        # dope_pose_finder/pose_finder.py reports, with that detection as its initial pose
+        pp = os.path.join(root, "dope", "poses.txt")
+        rows = open(pp).read().splitlines()
+        rows[0] = "0.0 0.0 0.0 0.0 0.0 0.0 0.0"
+        open(pp, "w").write("\n".join(rows) + "\n")
+        first, line = io.find_initial_pose(pp, 5.0)
+        assert first % 6 == 0 and 12 <= first <= 24
+        aa = [float(v) for v in line.split()]
+        m0 = np.array(m0)
+        m0[6:9], axis, angle = aa[:3], aa[3:6], aa[6]
+        start_args = ["--camera_dataset::index_offset", str(first), "--optical_flow_dataset::index_offset", str(first),
+                      "--pose_dataset::skip_rows", str(first), "--segmentation_dataset::index_offset", str(first)]
+        py_start = ["--start-at-first-detection"]
+        n -= first
     out_dir = str(tmp_path / "out")
     os.makedirs(out_dir)
     # test/test.sh:135-157, with the mesh as a file instead of the compiled-in data base
@@ -572,13 +609,13 @@ def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
             "--optical_flow_dataset::path", root, "--optical_flow_dataset::set", "analytic/",
             "--outlier_rejection::enable", "true",
             "--pose_dataset::path", os.path.join(root, "dope", "poses.txt"),
-            "--segmentation_dataset::flow_aided", "true", "--segmentation_dataset::path", root, "--segmentation_dataset::set", "gt"]
+            "--segmentation_dataset::flow_aided", "true", "--segmentation_dataset::path", root, "--segmentation_dataset::set", "gt"] + start_args
     for d in ("segmentation", "segmentation_refined"):
         os.makedirs(os.path.join(out_dir, d))
     r = subprocess.run([REF_BIN] + args, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DatasetImageOpticalFlow::ctor." in r.stdout and "Unscented transform:" in r.stdout
-    assert ("grid size: 1" in r.stdout and "CV_32FC2" in r.stdout) if shape == "A_f32_grid1" else ("grid size: 4" in r.stdout and "scaling factor: 32" in r.stdout)
+    assert ("grid size: 1" in r.stdout and "CV_32FC2" in r.stdout) if shape != "B_s16_grid4" else ("grid size: 4" in r.stdout and "scaling factor: 32" in r.stdout)
     logs = {name: io.read_log(os.path.join(out_dir, name + ".txt")) for name in
             ("pose_estimate", "velocity_estimate", "execution_times", "pose_measurements", "velocity_measurements")}
     assert logs["pose_estimate"].shape == (n, 13) and logs["velocity_estimate"].shape == (n, 6) and logs["execution_times"].shape == (n, 2)
@@ -589,7 +626,8 @@ def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
     rs = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(rs)
     keep = [a for a in args[2:]]
-    drop = {"--camera_dataset::path", "--log::path", "--log::enable_segmentation", "--model::name", "--model::use_internal_db", "--model::external_path",
+    drop = {"--camera_dataset::index_offset", "--optical_flow_dataset::index_offset", "--pose_dataset::skip_rows", "--segmentation_dataset::index_offset",
+            "--camera_dataset::path", "--log::path", "--log::enable_segmentation", "--model::name", "--model::use_internal_db", "--model::external_path",
             "--optical_flow_dataset::path", "--optical_flow_dataset::set", "--pose_dataset::path", "--segmentation_dataset::path", "--segmentation_dataset::set"}
     over = []
     for i in range(0, len(keep), 2):
@@ -597,9 +635,9 @@ def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
             over += keep[i:i + 2]
     open(str(tmp_path / "filter.cfg"), "w").write(K.default_text(c.width, c.height, 1.0, 1.0, 0.0, 0.0))
     assert rs.main(["--root", root, "--object", "box", "--mesh", mesh, "--flow-set", "analytic", "--mask-set", "gt", "--out", str(tmp_path / "py_"),
-                    "--from", str(tmp_path / "filter.cfg")] + over) == 0
+                    "--from", str(tmp_path / "filter.cfg")] + over + py_start) == 0
     rep = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
-    assert rep["frames"] == n and rep["adds_auc"] > (80.0 if shape == "A_f32_grid1" else 60.0)
+    assert rep["frames"] == n and rep["first_frame"] == first and rep["adds_auc"] > (80.0 if shape == "A_f32_grid1" else 60.0)
     est = np.loadtxt(str(tmp_path / "py_pose_estimate"))
     vel = np.loadtxt(str(tmp_path / "py_velocity_estimate"))
     # six significant digits per value in the C++ logs

@@ -59,8 +59,18 @@ def main(argv=None):
                               str(W), str(H), args.compute_flow, out])
         if rc != 0:
             return rc
+    start = 0
+    if args.start_at_first_detection:
+        found = io.find_initial_pose(os.path.join(args.root, args.pose_set, "poses.txt"), 5.0)
+        if found is None:
+            sys.stderr.write("no valid detection on the 5 fps grid\n")
+            return 1
+        start = found[0]
+        aa = [float(v) for v in found[1].split()]
+        if args.init_pose is None:
+            args.init_pose = aa[:3] + list(io.axis_angle_to_quat(np.array(aa[3:6]), aa[6]))
     seq = io.Sequence(args.root, args.object, flow_set=args.flow_set, mask_set=args.mask_set, pose_set=args.pose_set,
-                      width=W, height=H, delayed=not args.no_delay)
+                      width=W, height=H, delayed=not args.no_delay, first_frame=start)
     first = None
     for k in range(len(seq)):
         ok, first = io.read_flow(os.path.join(seq.flow_dir, "%d.float" % k))
@@ -95,16 +105,7 @@ def main(argv=None):
     verts, tris = io.load_obj(args.mesh)
     # initial condition: the configuration's when it was given on the command line (test/test.sh:120-123 passes the first
     # detection that way), else the first valid detection of the sequence
-    start = 0
     if args.start_at_first_detection:
-        found = io.find_initial_pose(os.path.join(args.root, args.pose_set, "poses.txt"), 5.0)
-        if found is None:
-            sys.stderr.write("no valid detection on the 5 fps grid\n")
-            return 1
-        start = found[0]
-        aa = [float(v) for v in found[1].split()]
-        if args.init_pose is None:
-            args.init_pose = aa[:3] + list(io.axis_angle_to_quat(np.array(aa[3:6]), aa[6]))
         init_from_cfg = False
     if not init_from_cfg:
         k0 = int(np.argmax(seq.pose_ok)) if seq.pose_ok.any() else 0
