@@ -697,6 +697,16 @@ inline void diagonal_of(const Eigen::MatrixXd& m, double* out, std::size_t n)
     else throw std::runtime_error("covariance of unexpected size");
 }
 
+// cv::cvtColor(COLOR_BGR2GRAY) on 8-bit data (fixed point, 14 fractional bits)
+inline cv::Mat bgr_to_gray(const cv::Mat& m)
+{
+    if (m.type() != CV_8UC3) return m;
+    cv::Mat g(m.rows, m.cols, CV_8UC1);
+    for (std::size_t p = 0; p < m.total(); ++p)
+        g.data[p] = (unsigned char)((m.data[3 * p + 2] * 4899 + m.data[3 * p + 1] * 9617 + m.data[3 * p] * 1868 + 8192) >> 14);
+    return g;
+}
+
 // names kept from the first version of the facade
 using Gaussian = bfl::Gaussian;
 using MatrixXd = Eigen::MatrixXd;

@@ -224,16 +224,6 @@ inline cv::Mat read_png(const std::string& path)
     return out;
 }
 
-// cv::cvtColor(COLOR_BGR2GRAY) on 8-bit data (fixed point, 14 fractional bits)
-inline cv::Mat bgr_to_gray(const cv::Mat& m)
-{
-    if (m.type() != CV_8UC3) return m;
-    cv::Mat g(m.rows, m.cols, CV_8UC1);
-    for (std::size_t p = 0; p < m.total(); ++p)
-        g.data[p] = (unsigned char)((m.data[3 * p + 2] * 4899 + m.data[3 * p + 1] * 9617 + m.data[3 * p] * 1868 + 8192) >> 14);
-    return g;
-}
-
 // `<index>` left-padded with zeros to `digits` characters (compose_file_name of the reference's data-set sources)
 inline std::string padded_index(long index, std::size_t digits)
 {

@@ -151,17 +151,28 @@ public:
 class ImageOpticalFlowHIP : public ImageOpticalFlowSource {
 public:
     enum class NVOFPerformance_1_0 { Slow, Medium, Fast };
+    enum class NVOFPerformance_2_0 { Slow, Medium, Fast };
     enum class Product { NVOF_1_0 = 1, NVOF_2_0 = 2 };   // CV_16SC2 S10.5 at grid 4 | CV_32FC2 at grid 1 (cpp:19-80)
-    ImageOpticalFlowHIP(int width, int height, Product product) : w_(width), h_(height), product_(product)
-    {
-        compat::throw_if(roft_default_of_params(&prm_), "ImageOpticalFlowHIP");
-        if (width <= 0 || height <= 0) throw std::runtime_error("ImageOpticalFlowHIP: bad image size");
-        flow_ = cv::Mat(height / (int)get_grid_size(), width / (int)get_grid_size(), get_matrix_type());
-    }
+    ImageOpticalFlowHIP(int width, int height, Product product) : w_(width), h_(height), product_(product) { init(); }
+    // the reference's constructors (ImageOpticalFlowNVOF.h:43-46): frames come from the camera measurement, which the FILTER
+    // steps; the performance setting and the temporal hints of the NVIDIA engine have no counterpart here
+    ImageOpticalFlowHIP(std::shared_ptr<ROFT::CameraMeasurement> camera_measurement, const NVOFPerformance_1_0&, const bool = false)
+        : camera_(std::move(camera_measurement)), product_(Product::NVOF_1_0) { init_from_camera(); }
+    ImageOpticalFlowHIP(std::shared_ptr<ROFT::CameraMeasurement> camera_measurement, const NVOFPerformance_2_0&, const bool = false)
+        : camera_(std::move(camera_measurement)), product_(Product::NVOF_2_0) { init_from_camera(); }
     // the next camera frame (gray, width x height); step_frame() then computes the flow from the previous one to it
     void set_gray_image(const std::uint8_t* gray) { pending_.assign(gray, gray + (std::size_t)w_ * h_); }
     bool step_frame() override
     {
+        if (camera_) {   // cv::cvtColor(frame, COLOR_BGR2GRAY) of the latched camera image (ImageOpticalFlowNVOF.cpp:112-123)
+            bool valid = false;
+            bfl::Data data;
+            std::tie(valid, data) = camera_->measure();
+            if (!valid) return false;
+            const cv::Mat gray = compat::bgr_to_gray(std::get<1>(bfl::any::any_cast<CameraMeasurement::CameraMeasurementTuple>(data)));
+            if (gray.empty() || gray.cols != w_ || gray.rows != h_) return false;
+            return step_frame(gray.data);
+        }
         if (pending_.empty()) return false;
         return step_frame(pending_.data());
     }
@@ -189,7 +200,24 @@ public:
     roft_of_params& parameters() { return prm_; }
 
 private:
-    int w_, h_;
+    void init()
+    {
+        compat::throw_if(roft_default_of_params(&prm_), "ImageOpticalFlowHIP");
+        if (w_ <= 0 || h_ <= 0) throw std::runtime_error("ImageOpticalFlowHIP: bad image size");
+        flow_ = cv::Mat(h_ / (int)get_grid_size(), w_ / (int)get_grid_size(), get_matrix_type());
+    }
+    void init_from_camera()
+    {
+        if (!camera_) throw std::runtime_error("ImageOpticalFlowHIP::ctor. Error: null camera measurement.");
+        bool valid = false;
+        RobotsIO::Camera::CameraParameters p;
+        std::tie(valid, p) = camera_->camera_parameters();
+        if (!valid) throw std::runtime_error("ImageOpticalFlowHIP::ctor. Error: cannot get camera parameters.");
+        w_ = (int)p.width(); h_ = (int)p.height();
+        init();
+    }
+    std::shared_ptr<ROFT::CameraMeasurement> camera_;
+    int w_ = 0, h_ = 0;
     Product product_;
     roft_of_params prm_{};
     std::vector<std::uint8_t> last_, pending_;

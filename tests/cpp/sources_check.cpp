@@ -7,6 +7,7 @@
 //                                                             per frame: mask delivered (value of pixel 0, -1 = none), pose x (nan = none)
 //   sources_check queue                                       OpticalFlowQueueHandler: window, region after a stamp, unknown stamp
 //   sources_check mesh <name> <set> <external path>           MeshResource: sizes of the internal-data-base and external texts
+//   sources_check nvof <root> <w> <h> <1|2> <out.bin>          (GPU) ImageOpticalFlowNVOF(camera, ...) over the camera images: per frame a flag + the flow
 //   sources_check camera <root> <w> <h>                       per frame: index stamp_rgb stamp_depth depth(0,0) depth(h-1,w-1) pose x qw
 #include <cmath>
 #include <cstdio>
@@ -126,6 +127,26 @@ int main(int argc, char** argv)
             mp.use_internal_db(true);
             std::printf("internal %zu\n", ROFT::MeshResource(mp).as_string().size());
             std::printf("named %zu\n", ROFT::MeshResource(argv[2], argv[3]).as_string().size());
+            return 0;
+        }
+        if (mode == "nvof") {
+            const int w = std::atoi(argv[3]), h = std::atoi(argv[4]), product = std::atoi(argv[5]);
+            auto cam = std::make_shared<ROFT::CameraMeasurement>(std::make_unique<RobotsIO::Camera::DatasetCamera>(
+                argv[2], "/", "rgb/", "depth/", "txt", "png", "float", 0, 0, w, h, 1.0, 2.0, 3.0, 4.0));
+            std::shared_ptr<ROFT::ImageOpticalFlowSource> flow;
+            if (product == 1) flow = std::make_shared<ROFT::ImageOpticalFlowNVOF>(cam, ROFT::ImageOpticalFlowNVOF::NVOFPerformance_1_0::Slow, false);
+            else flow = std::make_shared<ROFT::ImageOpticalFlowNVOF>(cam, ROFT::ImageOpticalFlowNVOF::NVOFPerformance_2_0::Slow);
+            std::FILE* out = std::fopen(argv[6], "wb");
+            while (cam->freeze(ROFT::CameraMeasurementType::RGBD)) {
+                flow->step_frame();
+                bool valid = false;
+                cv::Mat f;
+                std::tie(valid, f) = flow->flow(false);
+                const int hdr[4] = {(int)valid, f.rows, f.cols, f.type()};
+                std::fwrite(hdr, sizeof(hdr), 1, out);
+                if (valid) std::fwrite(f.data, 1, f.total() * f.elemSize(), out);
+            }
+            std::fclose(out);
             return 0;
         }
         if (mode == "camera") {

@@ -701,3 +701,38 @@ def test_stamped_source_facade_equals_the_oracle(tmp_path):
         pos += W * H
         assert np.array_equal(np.where(got > 1, 255, 0).astype(np.uint8), want[k]["mask"]), k
     assert pos == len(raw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("product", [1, 2])
+def test_live_flow_source_with_the_references_constructor(tmp_path, product):
+    """ROFT::ImageOpticalFlowNVOF(camera_measurement, performance, hints) -- the reference's constructor (ImageOpticalFlowNVOF.h:43-46)
+    over the HIP flow producer -- fed by CameraMeasurement(DatasetCamera) from a sequence directory: no flow on the first frame,
+    then frame after frame what roft_optical_flow gives for the two images, in the format of the product (1: CV_16SC2 on a grid of
+    4, scale 32; 2: CV_32FC2 per pixel)."""
+    import util
+    from roft_amd import io, ops, synth
+    n = 5
+    st = util.stream(710, n, 2, with_gray=True)
+    root = str(tmp_path / "seq")
+    io.write_sequence(root, st, "box")
+    H, W = st.mask_gt.shape[1:]
+    exe = build_sources_check(tmp_path)
+    out = str(tmp_path / "flow.bin")
+    subprocess.check_call([exe, "nvof", root, str(W), str(H), str(product), out])
+    raw = open(out, "rb").read()
+    gray = [io.rgb_to_gray(io.read_png(os.path.join(root, "rgb", "%d.png" % k))) for k in range(n)]
+    pos = 0
+    for k in range(n):
+        valid, rows, cols, typ = struct.unpack("4i", raw[pos:pos + 16])
+        pos += 16
+        assert valid == (k > 0)
+        if not valid:
+            continue
+        want = ops.optical_flow(gray[k - 1], gray[k], flow_type=synth.FLOW_S16C2 if product == 1 else synth.FLOW_F32C2)
+        assert (rows, cols) == want.shape[:2] and typ == (11 if product == 1 else 13)
+        nbytes = want.size * want.itemsize
+        got = np.frombuffer(raw[pos:pos + nbytes], want.dtype).reshape(want.shape)
+        pos += nbytes
+        assert np.array_equal(got, want), k
+    assert pos == len(raw)
