@@ -13,13 +13,21 @@
 //   ROFTFilter (ROFTFilter.h:38-194)                         ROFTFilter.h                         roft_engine_* (one object)
 //   CameraMeasurement, ImageSegmentationMeasurement,
 //   ImageOpticalFlowSource, ImageOpticalFlowNVOF,
-//   ModelParameters                                          Sources.h                            roft_optical_flow (producer)
+//   ModelParameters                                          Sources.h (+ a header per name)       roft_optical_flow (producer)
+//   ImageSegmentationOFAidedSourceStamped<T>,
+//   OpticalFlowQueueHandler                                  the same names                       roft_mask_propagate
+//   DatasetImageOpticalFlow, DatasetImageSegmentation,
+//   DatasetImageSegmentationDelayed, OpticalFlowUtilities,
+//   MeshResource                                             the same names                       (files)
 //
 // Conventions kept from the reference: predict(prev, pred) / correct(pred, corr) on Gaussians; an invalid / empty
 // measurement leaves corr = pred (SKFCorrection.cpp:46-69, UKFCorrection.cpp:64-68); constructors and unrecoverable errors
 // throw std::runtime_error; freeze() returns a validity bool.  Header-only; link with libroft_hip.so.
 #pragma once
 
+#include "DatasetImageOpticalFlow.h"
+#include "DatasetImageSegmentationDelayed.h"
+#include "ImageSegmentationOFAidedSourceStamped.hpp"
 #include "ROFTFilter.h"
 
 namespace ROFT {
