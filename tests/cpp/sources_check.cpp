@@ -8,6 +8,7 @@
 //   sources_check queue                                       OpticalFlowQueueHandler: window, region after a stamp, unknown stamp
 //   sources_check mesh <name> <set> <external path>           MeshResource: sizes of the internal-data-base and external texts
 //   sources_check nvof <root> <w> <h> <1|2> <out.bin>          (GPU) ImageOpticalFlowNVOF(camera, ...) over the camera images: per frame a flag + the flow
+//   sources_check obj <file.obj>                              load_obj_mesh: vertices, triangles, index checksum, bounding box
 //   sources_check camera <root> <w> <h>                       per frame: index stamp_rgb stamp_depth depth(0,0) depth(h-1,w-1) pose x qw
 #include <cmath>
 #include <cstdio>
@@ -18,6 +19,7 @@
 #include <ROFT/DatasetImageSegmentationDelayed.h>
 #include <ROFT/MeshResource.h>
 #include <ROFT/OpticalFlowQueueHandler.h>
+#include <ROFT/ROFTFilter.h>
 
 static std::string str(const Eigen::VectorXd& v)
 {
@@ -147,6 +149,17 @@ int main(int argc, char** argv)
                 if (valid) std::fwrite(f.data, 1, f.total() * f.elemSize(), out);
             }
             std::fclose(out);
+            return 0;
+        }
+        if (mode == "obj") {
+            std::vector<float> v;
+            std::vector<std::int32_t> t;
+            ROFT::load_obj_mesh(argv[2], v, t);
+            long long sum = 0;
+            for (std::size_t i = 0; i < t.size(); ++i) sum += (long long)t[i] * (long long)(i % 7 + 1);
+            float lo[3] = {1e30f, 1e30f, 1e30f}, hi[3] = {-1e30f, -1e30f, -1e30f};
+            for (std::size_t i = 0; i < v.size(); ++i) { lo[i % 3] = std::min(lo[i % 3], v[i]); hi[i % 3] = std::max(hi[i % 3], v[i]); }
+            std::printf("%zu %zu %lld %.9g %.9g %.9g %.9g %.9g %.9g\n", v.size() / 3, t.size() / 3, sum, lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]);
             return 0;
         }
         if (mode == "camera") {

@@ -547,7 +547,7 @@ def test_file_sources_deliver_on_the_references_schedule(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", ["A_f32_grid1", "B_s16_grid4", "A_from_first_detection"])
+@pytest.mark.parametrize("shape", ["A_f32_grid1", "B_s16_grid4", "A_from_first_detection", "A_internal_mesh_db"])
 def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
     """The reference's own src/roft/src/main.cpp -- unmodified, built by __graft_entry__.build() in the dev container against
     include/ROFT + include/compat and linked with libroft_hip.so -- started the way test/test.sh starts ROFT-tracker on a
@@ -570,7 +570,19 @@ def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
     st.pose_meas = st.pose_meas.copy()
     st.pose_meas[0] = st.pose_meas[6]            # one detection per source frame in a pose file (see test_sequence_gpu.py)
     root = str(tmp_path / "seq")
+    obj_name, env = "box", dict(os.environ)
     mesh = io.write_sequence(root, st, "box", flow_set="analytic")
+    if shape == "A_internal_mesh_db":
+        # test/test.sh leaves model.use_internal_db = true / internal_db_name = "DOPE" of the configuration file alone and
+        # only names the object: the mesh comes from the library's data base -- here the directory ROFT_MESH_DB names, holding
+        # the reference's own 003_cracker_box.obj (copied next to the binary by __graft_entry__.build())
+        db = os.path.join(os.path.dirname(REF_BIN), "meshes")
+        if not os.path.exists(os.path.join(db, "DOPE", "003_cracker_box.obj")):
+            pytest.skip("no mesh data base next to the binary")
+        obj_name, env["ROFT_MESH_DB"] = "003_cracker_box", db
+        mesh = os.path.join(db, "DOPE", "003_cracker_box.obj")
+        for k in range(n):
+            os.rename(os.path.join(root, "masks", "gt", "box_%d.png" % k), os.path.join(root, "masks", "gt", "%s_%d.png" % (obj_name, k)))
     c = st.camera
     cfg_path = str(tmp_path / "config.cfg")
     open(cfg_path, "w").write(K.tracker_text(c.width, c.height, 1.0, 1.0, 0.0, 0.0))
@@ -605,14 +617,14 @@ def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
             "--log::path", out_dir, "--log::enable_segmentation", "true",
             "--measurement_model::pose::cov_q", "0.0001,0.0001,0.0001",
             "--measurement_model::use_pose", "true", "--measurement_model::use_pose_resync", "true", "--measurement_model::use_velocity", "true",
-            "--model::name", "box", "--model::use_internal_db", "false", "--model::external_path", mesh,
+            "--model::name", obj_name] + ([] if shape == "A_internal_mesh_db" else ["--model::use_internal_db", "false", "--model::external_path", mesh]) + [
             "--optical_flow_dataset::path", root, "--optical_flow_dataset::set", "analytic/",
             "--outlier_rejection::enable", "true",
             "--pose_dataset::path", os.path.join(root, "dope", "poses.txt"),
             "--segmentation_dataset::flow_aided", "true", "--segmentation_dataset::path", root, "--segmentation_dataset::set", "gt"] + start_args
     for d in ("segmentation", "segmentation_refined"):
         os.makedirs(os.path.join(out_dir, d))
-    r = subprocess.run([REF_BIN] + args, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([REF_BIN] + args, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "DatasetImageOpticalFlow::ctor." in r.stdout and "Unscented transform:" in r.stdout
     assert ("grid size: 1" in r.stdout and "CV_32FC2" in r.stdout) if shape != "B_s16_grid4" else ("grid size: 4" in r.stdout and "scaling factor: 32" in r.stdout)
@@ -634,7 +646,7 @@ def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
         if keep[i] not in drop:
             over += keep[i:i + 2]
     open(str(tmp_path / "filter.cfg"), "w").write(K.default_text(c.width, c.height, 1.0, 1.0, 0.0, 0.0))
-    assert rs.main(["--root", root, "--object", "box", "--mesh", mesh, "--flow-set", "analytic", "--mask-set", "gt", "--out", str(tmp_path / "py_"),
+    assert rs.main(["--root", root, "--object", obj_name, "--mesh", mesh, "--flow-set", "analytic", "--mask-set", "gt", "--out", str(tmp_path / "py_"),
                     "--from", str(tmp_path / "filter.cfg")] + over + py_start) == 0
     rep = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
     assert rep["frames"] == n and rep["first_frame"] == first and rep["adds_auc"] > (80.0 if shape == "A_f32_grid1" else 60.0)
@@ -736,3 +748,35 @@ def test_live_flow_source_with_the_references_constructor(tmp_path, product):
         pos += nbytes
         assert np.array_equal(got, want), k
     assert pos == len(raw)
+
+
+def test_the_references_meshes_load(tmp_path):
+    """Dev container only: the seven meshes the reference compiles into its library (src/roft-lib/meshes/DOPE/*.obj, Meshlab
+    output with `vn` lines and `f a//n b//n c//n` faces) through the facade's OBJ reader and through roft_amd.io.load_obj: same
+    vertices and triangles; and the directory IS a valid ROFT_MESH_DB for MeshResource's internal data base."""
+    from roft_amd import io
+    db = "/root/reference/src/roft-lib/meshes"
+    if not os.path.isdir(db):
+        pytest.skip("the reference checkout is not here")
+    exe = build_sources_check(tmp_path)
+    names = sorted(f for f in os.listdir(os.path.join(db, "DOPE")) if f.endswith(".obj"))
+    assert len(names) >= 6
+    for name in names:
+        path = os.path.join(db, "DOPE", name)
+        verts, tris = io.load_obj(path)
+        r = subprocess.run([exe, "obj", path], capture_output=True, text=True, check=True)
+        f = r.stdout.split()
+        assert int(f[0]) == len(verts) and int(f[1]) == len(tris) and len(verts) > 5000 and len(tris) > 10000
+        assert tris.min() == 0 and tris.max() == len(verts) - 1
+        flat = tris.reshape(-1).astype(np.int64)
+        assert int(f[2]) == int((flat * (np.arange(flat.size) % 7 + 1)).sum())
+        lo, hi = verts.min(0), verts.max(0)
+        assert np.allclose([float(v) for v in f[3:]], [lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]], rtol=0, atol=1e-7)
+    # SURVEY 8d quotes the extents of the cracker box
+    verts, _ = io.load_obj(os.path.join(db, "DOPE", "003_cracker_box.obj"))
+    assert np.allclose(verts.min(0), [-0.080, -0.102, -0.036], atol=2e-3) and np.allclose(verts.max(0), [0.084, 0.112, 0.035], atol=2e-3)
+    env = dict(os.environ, ROFT_MESH_DB=db)
+    (tmp_path / "e.obj").write_text("v 0 0 0\n")
+    r = subprocess.run([exe, "mesh", "003_cracker_box", "DOPE", str(tmp_path / "e.obj")], capture_output=True, text=True, env=env, check=True)
+    size = os.path.getsize(os.path.join(db, "DOPE", "003_cracker_box.obj"))
+    assert r.stdout.split() == ["external", "8", "internal", str(size), "named", str(size)]

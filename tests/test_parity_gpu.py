@@ -361,6 +361,49 @@ def test_outlier_test_hot_path_kernel(oracle, shape, scale, mesh_n, div):
             assert sel == (1 if ref[0][0] > 2.0 * ref[1][0] else 0) == want_sel, kw
 
 
+def test_render_and_outlier_test_on_a_mesh_of_the_reference(oracle):
+    """The reference's own 003_cracker_box.obj (7 866 vertices, 15 728 triangles of very different sizes, as Meshlab wrote it; copied
+    next to the built tracker by __graft_entry__.build() in the dev container -- data, git-ignored) instead of the synthetic
+    subdivided boxes: depth render bit exact against oracle/ro_render.c at both shapes, and the engine's outlier test in all its
+    launch shapes on a scene rendered from that mesh."""
+    import os
+    from roft_amd import io, synth
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "_ref_build", "meshes", "DOPE", "003_cracker_box.obj")
+    if not os.path.exists(path):
+        pytest.skip("tests/cpp/_ref_build/meshes is filled where the reference checkout is (python __graft_entry__.py)")
+    verts, tris = io.load_obj(path)
+    omesh, mesh = oracle.make_mesh(verts, tris), ops.make_mesh(verts, tris)
+    rng = np.random.default_rng(21)
+    for cam, div in ((synth.Camera.shape_a(), 2), (synth.Camera.shape_b(), 4)):
+        ocam = util.oracle_camera(oracle, cam)
+        dcam = L.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy)
+        for _ in range(3):
+            q = rng.normal(size=4)
+            q /= np.linalg.norm(q)
+            x = np.array([rng.uniform(-0.15, 0.15), rng.uniform(-0.1, 0.1), rng.uniform(0.5, 0.9)])
+            t0 = oracle.render_depth(omesh, x, q, ocam, div)
+            t1 = ops.render_depth(mesh, x, q, dcam, div)
+            assert (t0 > 0).sum() > 500 and np.array_equal(t0, t1)
+        # a scene of that object: full-resolution depth = the oracle's render over a background plane, mask = its silhouette
+        full = oracle.render_depth(omesh, x, q, ocam, 1)
+        depth = np.where(full > 0, full, 1.5).astype(np.float32)
+        mask = (full > 0).astype(np.uint8) * 255
+        ang = 0.2
+        dq = np.array([np.cos(ang / 2), np.sin(ang / 2), 0.0, 0.0])
+        q_off = np.array([dq[0] * q[0] - dq[1:] @ q[1:], *(dq[0] * q[1:] + q[0] * dq[1:] + np.cross(dq[1:], q[1:]))])
+        x2 = np.stack([x + [0.03, 0.02, 0.04], x + [0.001, 0.0, 0.001]])
+        q2 = np.stack([q_off, q])
+        t_ref = [oracle.render_depth(omesh, x2[k], q2[k], ocam, div) for k in range(2)]
+        ref = [oracle.depth_likelihood(ocam, depth, mask, t_ref[k], div) for k in range(2)]
+        tw = cam.width // div
+        for kw in (dict(bands=1), dict(bands=2), dict(bands=8), dict(bands=0), dict(bands=2, window_pixels=tw), dict(bands=1, vertex_cache=False)):
+            Lv, ns, sel, tiles = ops.outlier_test(dcam, div, depth, mask, mesh, x2, q2, **kw)
+            for k in range(2):
+                assert np.array_equal(tiles[k], t_ref[k]), (kw, k, int((tiles[k] != t_ref[k]).sum()))
+                assert ns[k] == ref[k][1] > 0 and abs(Lv[k] - ref[k][0]) <= LIK_RTOL * abs(ref[k][0]), (kw, k)
+            assert sel == 1 == (1 if ref[0][0] > 2.0 * ref[1][0] else 0), kw
+
+
 def test_outlier_test_no_samples(oracle):
     st = util.stream(18, 2, scale=2, mesh_n=12)
     mesh = ops.make_mesh(*st.mesh)
