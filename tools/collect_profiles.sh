@@ -48,7 +48,8 @@ python3 $R/tools/prof_summary.py stats $O/stats2/*/*kernel_stats.csv $O/bench_ke
 rm -rf $O/stats2
 # HBM traffic, one counter per pass (FETCH_SIZE and WRITE_SIZE do not fit one pass); every launch of the roofline kernel
 # covers 8 frames x 64 objects in this run (24 timed frames after 8 warm-up frames, batches of 8)
-for c in FETCH_SIZE WRITE_SIZE; do
+# + the L2's view of the same launches: hits, misses and read requests to the fabric (K1's gathers miss: one request each)
+for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum; do
   timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc -- python3 $R/bench.py --steps 24 --warmup 8 --no-align --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
   python3 $R/tools/prof_summary.py pmc $O/pmc/*/*counter_collection.csv $O/pmc_$c.csv
   rm -rf $O/pmc
