@@ -660,27 +660,15 @@ def main():
         except Exception:   # (not enough free memory next to the streams: the datasheet figure stands alone)
             copy_gbs = None
         # what this box gives SCATTERED 64-byte sectors (the depth and flow samples of K1 are 35 mask pixels apart: one sector
-        # each, whatever the order): 2^24 words gathered at random sector-aligned offsets of a 4 GiB buffer, best of five
-        # (tools/micro/sector_probe.hip measures the same with a kernel of its own: 51 G sectors/s = 3.3 TB/s, and a launch of
-        # K1's shape without any arithmetic at K1's duration)
+        # each, whatever the order): roft_debug_sector_rate -- 16 M reads at random sector-aligned offsets of a 2 GiB buffer,
+        # best of four launches (tools/micro/sector_probe.hip is the stand-alone version with the skeleton of K1's launch)
         sector_rate = None
         try:
-            words = torch.empty(1 << 30, device=dev, dtype=torch.int32)
-            words.zero_()
-            idx = torch.randint(0, (1 << 30) // 16, (1 << 24,), device=dev) * 16
-            got = torch.empty(1 << 24, device=dev, dtype=torch.int32)
-            best = None
-            for _ in range(6):
-                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ev0.record()
-                torch.index_select(words, 0, idx, out=got)
-                ev1.record()
-                torch.cuda.synchronize()
-                ms = ev0.elapsed_time(ev1)
-                best = ms if best is None else min(best, ms)
-            sector_rate = float(1 << 24) / (best * 1e-3)
-            del words, idx, got
-        except Exception:
+            import ctypes as C
+            rate = C.c_double(0.0)
+            L.check(L.lib().roft_debug_sector_rate(int(torch.cuda.current_device()), C.byref(rate)))
+            sector_rate = float(rate.value)
+        except Exception:   # (not enough free memory next to the streams)
             sector_rate = None
         gather_sectors = 2.0 * cand * obj_frames_per_launch       # one depth + one flow sector per candidate
         roofline = dict(kernel="flow_measure_kernel", bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
@@ -700,9 +688,9 @@ def main():
                              "north-star target of 0.70 is not met: the kernel reads ~60 KB per object-frame instead of the "
                              "dense 4 MB; every 4-byte depth and 8-byte flow sample costs a 64-byte sector, so the memory system "
                              "moves `traffic` bytes (frac_on_fetched_bytes) for the declared ones -- the launch is bound by the RATE at which "
-                             "the memory system serves scattered sectors (measured_random_Gsectors_per_s on this box = 0.4 of the "
-                             "streaming peak; frac_of_measured_random_sector_rate = the kernel's gathers alone against it, the "
-                             "plane stream and the record writes not counted), not by streaming bandwidth")
+                             "the memory system serves scattered sectors (measured_random_Gsectors_per_s: roft_debug_sector_rate on this box, "
+                             "x 64 B = 0.4 of the streaming peak; frac_of_measured_random_sector_rate = the kernel's gathers alone against "
+                             "it, the plane stream and the record writes not counted), not by streaming bandwidth")
     dominant = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])[0] if kernels else None
     d_frames = max(stats1["frames"] - stats0["frames"], 1)
 

@@ -366,6 +366,10 @@ int roft_debug_plan(const roft_config* cfg, const int* pose_valid, int n_frames,
  * larger than the device; ~15 = independent, >= 80 = queued behind it.  Order: pose lane 0, pose lane 1, velocity chain, mask
  * chain, upload stream.  Takes ~20 ms; not for a hot loop. */
 int roft_debug_probe_streams(roft_engine* e, double out[25]);
+/* The rate (sectors per second) at which the device serves scattered 64-byte sectors: 16 M reads at random sector-aligned offsets
+ * of a 2 GiB scratch buffer, best of four launches -- the roofline of a gather-bound kernel such as the flow measurement (its
+ * depth and flow samples are one sector each).  Allocates and frees 2 GiB of device memory; ~30 ms. */
+int roft_debug_sector_rate(int device, double* sectors_per_second);
 /* phase counters of one object's last kernels (only filled by libraries built with a -DROFT_*_PROFILE switch) */
 int roft_debug_get_dbg(roft_engine* e, int obj_id, long long out[32]);
 

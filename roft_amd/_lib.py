@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "roft_engine_enable_log", "roft_engine_get_log", "roft_engine_get_log_rows", "roft_engine_stream", "roft_engine_enable_timing",
     "roft_engine_get_timing", "roft_default_of_params", "roft_optical_flow", "roft_flow_producer_create",
     "roft_flow_producer_destroy", "roft_flow_producer_run", "roft_flow_producer_sync", "roft_flow_producer_stream",
-    "roft_debug_plan", "roft_debug_get_dbg", "roft_debug_probe_streams",
+    "roft_debug_plan", "roft_debug_get_dbg", "roft_debug_probe_streams", "roft_debug_sector_rate",
 ]
 
 

@@ -249,6 +249,21 @@ __global__ void probe_blocker_kernel(long long ticks)
 }
 __global__ void probe_tiny_kernel(int* p) { if (threadIdx.x == 0) *p = 1; }
 
+// Diagnostics (roft_debug_sector_rate): every thread reads eight words at hashed, 64-byte-aligned offsets of a large buffer --
+// the access pattern of the flow measurement's depth and flow gathers, without anything else.
+__global__ __launch_bounds__(1024) void probe_sectors_kernel(const unsigned* buf, unsigned sector_mask, unsigned salt, unsigned* sink)
+{
+    const unsigned t = blockIdx.x * 1024u + threadIdx.x;
+    unsigned acc = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned x = t * 8u + (unsigned)j + salt;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        acc += buf[(size_t)(x & sector_mask) * 16];
+    }
+    if (acc == 0x12345678u) sink[t] = acc;   // (never: keeps the loads)
+}
+
 namespace {
 
 struct FlowEntry {
@@ -2083,6 +2098,42 @@ extern "C" int roft_debug_get_dbg(roft_engine* e, int id, long long out[32])
 // + b] = microseconds until a one-workgroup kernel on stream b completes while stream a is busy placing a grid of three
 // one-per-CU workgroups per CU (100 us each); ~15 us = independent, >= 80 us = b's launches queue behind a's.  Stream order:
 // pose lane 0, pose lane 1, velocity chain, mask chain, upload.
+// The rate at which this device serves SCATTERED 64-byte sectors (sectors per second): 16 M reads at random sector-aligned
+// offsets of a 2 GiB scratch buffer, best of four launches.  The roofline of a gather-bound kernel such as the flow
+// measurement (bench.py reports its gathers against this figure).  Allocates and frees 2 GiB; ~30 ms.
+extern "C" int roft_debug_sector_rate(int device, double* sectors_per_second)
+{
+    if (!sectors_per_second) return fail(ROFT_ERR_INVALID, "null output");
+    HIP_TRY(hipSetDevice(device));
+    const size_t bytes = (size_t)2 << 30;
+    unsigned* buf = nullptr;
+    unsigned* sink = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&buf), bytes));
+    const int grid = 2048;   // x 1024 threads x 8 loads = 16 M sectors
+    hipError_t err = hipMalloc(reinterpret_cast<void**>(&sink), (size_t)grid * 1024 * sizeof(unsigned));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (err == hipSuccess) err = hipMemset(buf, 0, bytes);
+    if (err == hipSuccess) err = hipEventCreate(&e0);
+    if (err == hipSuccess) err = hipEventCreate(&e1);
+    float best_ms = 0.f;
+    for (int rep = 0; rep < 5 && err == hipSuccess; ++rep) {
+        (void)hipEventRecord(e0, nullptr);
+        hipLaunchKernelGGL(probe_sectors_kernel, dim3(grid), dim3(1024), 0, nullptr, buf, (unsigned)(bytes / 64 - 1), 0x9e3779b9u * (unsigned)(rep + 1), sink);
+        (void)hipEventRecord(e1, nullptr);
+        err = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+        if (rep > 0 && (best_ms == 0.f || ms < best_ms)) best_ms = ms;   // (the first launch loads the code object)
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    (void)hipFree(buf);
+    if (err != hipSuccess || !(best_ms > 0.f)) return fail(ROFT_ERR_DEVICE, std::string("sector-rate probe: ") + hipGetErrorString(err));
+    *sectors_per_second = (double)grid * 1024.0 * 8.0 / ((double)best_ms * 1e-3);
+    return ROFT_OK;
+}
+
 extern "C" int roft_debug_probe_streams(roft_engine* e, double out[25])
 {
     if (!e || !out) return ROFT_ERR_INVALID;
