@@ -232,6 +232,39 @@ inline std::string padded_index(long index, std::size_t digits)
     return ss.str();
 }
 
+// the files of one channel of a sequence directory: <directory><stem><index, zero padded><suffix>, walked by a cursor that
+// starts one before `first` (the sources step before they read)
+class IndexedFiles {
+public:
+    IndexedFiles() = default;
+    IndexedFiles(std::string directory, std::string stem, std::size_t digits, std::string suffix, std::size_t first)
+        : directory_(std::move(directory)), stem_(std::move(stem)), suffix_(std::move(suffix)), digits_(digits), first_((long)first), cursor_((long)first - 1)
+    {
+        if (!directory_.empty() && directory_.back() != '/') directory_ += '/';
+    }
+    std::string path(long index) const { return directory_ + stem_ + padded_index(index, digits_) + suffix_; }
+    std::string current() const { return path(cursor_); }
+    long advance() { return ++cursor_; }
+    void rewind() { cursor_ = first_ - 1; }
+    long cursor() const { return cursor_; }
+    long first() const { return first_; }
+    const std::string& directory() const { return directory_; }
+
+private:
+    std::string directory_, stem_, suffix_;
+    std::size_t digits_ = 0;
+    long first_ = 0, cursor_ = -1;
+};
+
+// wall-clock milliseconds a callable took (the data-loading times the filter subtracts from its execution time)
+template <class F>
+double milliseconds_of(F&& f)
+{
+    const auto started = std::chrono::steady_clock::now();
+    f();
+    return (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - started).count();
+}
+
 // rows of doubles of a text file: `skip_rows` leading rows and `skip_cols` leading columns dropped, rows with fewer than
 // `cols` values left ignored
 inline std::vector<std::vector<double>> read_rows(const std::string& path, std::size_t skip_rows, std::size_t skip_cols, std::size_t cols)
@@ -249,6 +282,17 @@ inline std::vector<std::vector<double>> read_rows(const std::string& path, std::
         if (v.size() >= skip_cols + cols) rows.emplace_back(v.begin() + (long)skip_cols, v.begin() + (long)(skip_cols + cols));
     }
     return rows;
+}
+
+// Which stored item a rate-reduced, late source hands out at frame `head` (counted like the file indices, `first` = index of
+// the first frame): only every `period`-th frame carries one; with `late` it is the item of the frame one period back, except
+// before the first period has passed, when it is the first item.  -1: nothing at this frame.
+// (src/roft-lib/src/DatasetImageSegmentationDelayed.cpp:42-63; the pose source of main.cpp:340-346 follows the same rule.)
+inline long delayed_item(long head, long first, long period, bool late)
+{
+    const long item = late ? head - period : head;
+    if ((item - first) % period != 0) return -1;
+    return item < 0 ? first : item;
 }
 
 // x y z axis angle -> rigid transform (translation + unit quaternion w x y z)
@@ -385,12 +429,9 @@ public:
     // the pose computed on frame k is delivered at frame k + delay, and only every delay-th frame carries one
     bool freeze(const bool = false) override
     {
-        ++head_;
-        long index = head_;
-        if (simulate_inference_time_) index -= delay_;
-        if (index % delay_ != 0) { received_ = false; return false; }
-        if (index < 0) index = 0;
-        return latch(index);
+        const long item = ROFT::compat::delayed_item(++head_, 0, delay_, simulate_inference_time_);
+        if (item < 0) { received_ = false; return false; }
+        return latch(item);
     }
     int get_frames_between_iterations() const override { return delay_; }
 

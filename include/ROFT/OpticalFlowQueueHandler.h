@@ -16,29 +16,27 @@ public:
         cv::Mat frame;
         double timestamp;
     };
-    explicit OpticalFlowQueueHandler(const std::size_t& window_size) : window_size_(window_size) {}
+    explicit OpticalFlowQueueHandler(const std::size_t& window_size) : capacity_(window_size) {}
     void add_flow(const cv::Mat& frame, const double& time_stamp)
     {
-        buffer_.push_back(Entry{frame.clone(), time_stamp});
-        if (buffer_.size() > window_size_) buffer_.pop_front();
+        if (capacity_ == 0) return;
+        if (queue_.size() == capacity_) queue_.pop_front();
+        queue_.push_back(Entry{frame.clone(), time_stamp});
     }
     std::vector<cv::Mat> get_buffer_region(const double& initial_time_stamp)
     {
+        // the entry stamped `initial_time_stamp` (to a millisecond) is the flow INTO that image: what follows it is the region
+        auto at = std::find_if(queue_.begin(), queue_.end(), [&](const Entry& e) { return std::fabs(e.timestamp - initial_time_stamp) < 1e-3; });
         std::vector<cv::Mat> region;
-        std::size_t index = 0;
-        bool found = false;
-        for (; index < buffer_.size(); ++index)
-            if (std::fabs(buffer_[index].timestamp - initial_time_stamp) < 1e-3) { found = true; break; }
-        if (!found) return region;
-        // (a flow refers to the image before it: the region starts with the next entry)
-        for (++index; index < buffer_.size(); ++index) region.push_back(buffer_[index].frame.clone());
+        if (at != queue_.end())
+            for (++at; at != queue_.end(); ++at) region.push_back(at->frame.clone());
         return region;
     }
-    void clear() { buffer_.clear(); }
+    void clear() { queue_.clear(); }
 
 private:
-    std::size_t window_size_;
-    std::deque<Entry> buffer_;
+    std::size_t capacity_;
+    std::deque<Entry> queue_;
 };
 
 }  // namespace ROFT
