@@ -780,3 +780,76 @@ def test_the_references_meshes_load(tmp_path):
     r = subprocess.run([exe, "mesh", "003_cracker_box", "DOPE", str(tmp_path / "e.obj")], capture_output=True, text=True, env=env, check=True)
     size = os.path.getsize(os.path.join(db, "DOPE", "003_cracker_box.obj"))
     assert r.stdout.split() == ["external", "8", "internal", str(size), "named", str(size)]
+
+
+@pytest.mark.gpu
+def test_batched_tracker_front_end_equals_one_tracker_per_object(tmp_path, capsys):
+    """tools/track_many.cpp (ROFT-tracker-batch): ROFT-tracker's configuration file, overrides and file-backed sources, but three
+    objects -- three sequence directories -- advanced by ONE engine in batches of six frames.  Objects do not interact in
+    ROFTFilter::filtering_step, so every object's logs must say what a tracker of its own says (tools/run_sequence.py over
+    the same engine code, frame by frame), to the digits bfl::Logger prints."""
+    import copy
+    import importlib.util
+    import json
+    import util
+    from roft_amd import _lib
+    from roft_amd import config as K
+    from roft_amd import io
+    _lib.build()
+    exe = str(tmp_path / "ROFT-tracker-batch")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include", "compat"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "track_many.cpp"), "-o", exe, "-L", CSRC, "-lroft_hip", "-Wl,-rpath," + CSRC,
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    n = 32
+    seqs = []
+    for i in range(3):
+        st = copy.copy(util.stream(720 + i, n, 2, with_gray=True))
+        st.pose_meas = st.pose_meas.copy()
+        st.pose_meas[0] = st.pose_meas[6]
+        root = str(tmp_path / ("seq%d" % i))
+        name = "box%d" % i
+        mesh = io.write_sequence(root, st, name, flow_set="analytic")
+        seqs.append((root, name, mesh, st))
+    c = seqs[0][3].camera
+    cfg_path = str(tmp_path / "config.cfg")
+    open(cfg_path, "w").write(K.tracker_text(c.width, c.height, c.fx, c.fy, c.cx, c.cy))
+    args = ["--from", cfg_path, "--pose_dataset::path", "dope/poses.txt", "--optical_flow_dataset::set", "analytic", "--segmentation_dataset::set", "gt",
+            "--model::use_internal_db", "false", "--measurement_model::pose::cov_q", "0.0002,0.0002,0.0002",
+            "--log_root", str(tmp_path / "out"), "--batch_frames", "6"]
+    for root, name, mesh, _ in seqs:
+        args += ["--object", root, name, mesh]
+    r = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "tracked 3 objects over %d frames" % n in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    spec = importlib.util.spec_from_file_location("run_sequence", os.path.join(ROOT, "tools", "run_sequence.py"))
+    rs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rs)
+    open(str(tmp_path / "filter.cfg"), "w").write(K.default_text(c.width, c.height, c.fx, c.fy, c.cx, c.cy))
+    for i, (root, name, mesh, _) in enumerate(seqs):
+        assert rs.main(["--root", root, "--object", name, "--mesh", mesh, "--flow-set", "analytic", "--mask-set", "gt", "--out", str(tmp_path / ("py%d_" % i)),
+                        "--from", str(tmp_path / "filter.cfg"), "--measurement_model::pose::cov_q", "0.0002,0.0002,0.0002"]) == 0
+        rep = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        assert rep["frames"] == n
+        est = np.loadtxt(str(tmp_path / ("py%d_pose_estimate" % i)))
+        vel = np.loadtxt(str(tmp_path / ("py%d_velocity_estimate" % i)))
+        got_p = io.read_log(str(tmp_path / "out" / name / "pose_estimate.txt"))
+        got_v = io.read_log(str(tmp_path / "out" / name / "velocity_estimate.txt"))
+        assert got_p.shape == (n, 13) and got_v.shape == (n, 6)
+        assert np.allclose(got_p, est, rtol=2e-5, atol=1e-6), (i, np.abs(got_p - est).max())
+        assert np.allclose(got_v, vel, rtol=2e-5, atol=1e-6), (i, np.abs(got_v - vel).max())
+    # the three trajectories differ from each other (the objects were not mixed up)
+    a = io.read_log(str(tmp_path / "out" / "box0" / "pose_estimate.txt"))
+    b = io.read_log(str(tmp_path / "out" / "box1" / "pose_estimate.txt"))
+    assert np.abs(a - b).max() > 1e-2
+
+
+def test_batched_tracker_front_end_compiles_and_explains_itself(tmp_path):
+    from roft_amd import _lib
+    _lib.build()
+    exe = str(tmp_path / "ROFT-tracker-batch")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include", "compat"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "track_many.cpp"), "-o", exe, "-L", CSRC, "-lroft_hip", "-Wl,-rpath," + CSRC,
+                           "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage: ROFT-tracker-batch --from config.cfg" in r.stderr
+    r = subprocess.run([exe, "--log_root", str(tmp_path), "--object", str(tmp_path), "box"], capture_output=True, text=True)
+    assert r.returncode == 1 and "--from" in r.stderr
