@@ -836,6 +836,14 @@ def test_batched_tracker_front_end_equals_one_tracker_per_object(tmp_path, capsy
         assert got_p.shape == (n, 13) and got_v.shape == (n, 6)
         assert np.allclose(got_p, est, rtol=2e-5, atol=1e-6), (i, np.abs(got_p - est).max())
         assert np.allclose(got_v, vel, rtol=2e-5, atol=1e-6), (i, np.abs(got_v - vel).max())
+    # two processes with a shard each (one per GPU on a node: --device r --shard r G) write the same files
+    for rank in range(2):
+        sh = [a if a != str(tmp_path / "out") else str(tmp_path / "out_sharded") for a in args] + ["--device", "0", "--shard", str(rank), "2"]
+        r = subprocess.run([exe] + sh, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and ("tracked %d objects" % (2 if rank == 0 else 1)) in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+    for _, name, _, _ in seqs:
+        for f in ("pose_estimate.txt", "velocity_estimate.txt"):
+            assert open(str(tmp_path / "out" / name / f)).read() == open(str(tmp_path / "out_sharded" / name / f)).read(), (name, f)
     # the three trajectories differ from each other (the objects were not mixed up)
     a = io.read_log(str(tmp_path / "out" / "box0" / "pose_estimate.txt"))
     b = io.read_log(str(tmp_path / "out" / "box1" / "pose_estimate.txt"))

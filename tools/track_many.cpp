@@ -4,8 +4,11 @@
 // ROFTFilter::filtering_step, so this is the same computation per object (tests/test_facade.py compares the two).
 //
 //   ROFT-tracker-batch --from config.cfg [--group::key value ...]        the reference's configuration file and overrides
-//                      --log_root DIR [--batch_frames T]
+//                      --log_root DIR [--batch_frames T] [--device D] [--shard RANK WORLD]
 //                      --object SEQUENCE_DIR NAME [MESH.obj] [--object ...]
+//
+// Several GPUs: one process per GPU, each given the same object list, `--device r --shard r G`: process r tracks the r-th block
+// of ceil(n / G) objects (the partition of roft_amd/parallel.py) -- no process talks to another.
 //
 // Per object: camera / flow / mask / pose sources exactly as main.cpp:327-381 builds them from the configuration, rooted at
 // SEQUENCE_DIR (`pose_dataset.path` is taken relative to it), the initial pose = the first row of its pose file
@@ -66,7 +69,7 @@ int main(int argc, char** argv)
         // ---- split the command line: what is ours, what is the configuration's
         std::vector<ObjectArgs> objects;
         std::string log_root;
-        int batch_frames = 6;
+        int batch_frames = 6, device = 0, shard_rank = 0, shard_world = 1;
         std::vector<char*> cfg_argv = {argv[0]};
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
@@ -78,9 +81,18 @@ int main(int argc, char** argv)
                 objects.push_back(o);
             } else if (a == "--log_root" && i + 1 < argc) log_root = argv[++i];
             else if (a == "--batch_frames" && i + 1 < argc) batch_frames = std::atoi(argv[++i]);
+            else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+            else if (a == "--shard" && i + 2 < argc) { shard_rank = std::atoi(argv[i + 1]); shard_world = std::atoi(argv[i + 2]); i += 2; }
             else cfg_argv.push_back(argv[i]);
         }
-        if (objects.empty() || log_root.empty()) throw std::runtime_error("usage: ROFT-tracker-batch --from config.cfg [--group::key value ...] --log_root DIR [--batch_frames T] --object SEQUENCE_DIR NAME [MESH.obj] ...");
+        if (objects.empty() || log_root.empty()) throw std::runtime_error("usage: ROFT-tracker-batch --from config.cfg [--group::key value ...] --log_root DIR [--batch_frames T] [--device D] [--shard RANK WORLD] --object SEQUENCE_DIR NAME [MESH.obj] ...");
+        if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) throw std::runtime_error("--shard RANK WORLD: 0 <= RANK < WORLD");
+        {
+            const std::size_t per = (objects.size() + (std::size_t)shard_world - 1) / (std::size_t)shard_world;
+            const std::size_t lo = std::min(objects.size(), per * (std::size_t)shard_rank), hi = std::min(objects.size(), lo + per);
+            objects = std::vector<ObjectArgs>(objects.begin() + (long)lo, objects.begin() + (long)hi);
+            if (objects.empty()) { std::printf("tracked 0 objects over 0 frames\n"); return EXIT_SUCCESS; }
+        }
         ConfigParser conf((int)cfg_argv.size(), cfg_argv.data());
 
         // ---- the settings main.cpp:43-147 reads
@@ -176,6 +188,7 @@ int main(int argc, char** argv)
         cfg.mask_frames_between = tracked[0].segmentation->get_frames_between_iterations();
         cfg.pose_frames_between = std::max(0, tracked[0].pose->get_frames_between_iterations());
         cfg.max_objects = (int)tracked.size();
+        cfg.device = device;
         if (batch_frames < 1 || batch_frames > ROFT_MAX_BATCH_FRAMES) throw std::runtime_error("--batch_frames out of range");
         cfg.max_batch_frames = batch_frames;
         ROFTFilterBatch engine(cfg);
