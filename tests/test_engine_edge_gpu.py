@@ -287,3 +287,13 @@ def test_busy_streams_of_every_engine_have_hardware_queues_of_their_own():
     for eng in engines:
         eng.close()
     del keep
+
+
+def test_more_objects_than_the_device_has_room_for_mask_workgroups():
+    """200 objects (not a multiple of eight, more than the 192 CUs the mask chain may take): one mask workgroup per object, no
+    barrier in memory, several rounds of every kernel's grid -- every object against the oracle, masks included, through a
+    pose arrival with its re-sync replay and outlier test."""
+    n_obj, n = 200, 8
+    streams = [util.stream(3000 + i, n, scale=4, mesh_n=6, device="cuda") for i in range(n_obj)]
+    n_tests = compare(streams, n)
+    assert n_tests >= n_obj          # an outlier test per object at the arrival on frame 6
