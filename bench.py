@@ -163,6 +163,8 @@ def parse():
                    help="cut the frames into full batches wherever they fall instead of ending every batch with a pose-arrival frame")
     p.add_argument("--no-ramp", action="store_true", help="(with --no-align) full batches from the first timed frame on, the short one last")
     p.add_argument("--splits", default="", help="explicit batch sizes of the timed frames, e.g. 2,6,6,6 (must sum to --steps)")
+    p.add_argument("--mask-workgroups", type=int, default=0,
+                   help="roft_config::mask_workgroups_per_object (0: the engine's choice, (CUs - CUs / 4) / objects)")
     p.add_argument("--no-kernel-timing", action="store_true",
                    help="do not record HIP events in the timed region and skip the per-kernel breakdown")
     return p.parse_args()
@@ -259,6 +261,7 @@ def main():
     def new_engine(max_objects):
         cfg = E.default_config(cam.width, cam.height, ftype, max_objects=max_objects, device=local_rank, max_batch_frames=T)
         cfg.cam.fx, cfg.cam.fy, cfg.cam.cx, cfg.cam.cy = cam.fx, cam.fy, cam.cx, cam.cy
+        cfg.mask_workgroups_per_object = args.mask_workgroups
         return cfg, E.ROFTFilterBatch(cfg)
 
     def add_objects(eng, sts):
