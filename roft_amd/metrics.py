@@ -99,3 +99,79 @@ def time_metrics(exec_ms):
     """Mean execution time and the number of frames above the 33 ms real-time budget (metrics.py:347-369)."""
     t = np.asarray(exec_ms, float)
     return float(t.mean()), int((t > 33.0).sum())
+
+
+# ---- the reference's Metric interface (evaluation/metrics.py:20-369) ---------------------------------------------------
+class Metric:
+    """`Metric(name).evaluate(object_name, reference, signal, time)` as evaluation/evaluate.py calls it.  `reference` / `signal`:
+    arrays whose rows are what evaluation/data_loader.py hands over -- poses `x y z axis angle` (7 columns) for the pose
+    metrics, `v w` (6 columns) for the velocity metrics --, `time`: rows `[execution_ms, loading_ms]`; for the object name
+    'ALL' all three are dicts name -> array and the rows of all objects are pooled (metrics.py:72-81).  `auc_points`: name ->
+    [P, 3] model points for 'add' / 'adi' (the reference reads YCB_Video_Models/<name>/points.xyz, metrics.py:47-49)."""
+
+    NAMES = ("rmse_cartesian_3d", "rmse_cartesian_x", "rmse_cartesian_y", "rmse_cartesian_z", "rmse_angular", "rmse_linear_velocity",
+             "rmse_angular_velocity", "max_linear_velocity", "max_angular_velocity", "add", "adi", "time", "excess_33_ms")
+
+    def __init__(self, name, auc_points=None):
+        if name not in self.NAMES:
+            raise ValueError("Metric " + name + " does not exist.")
+        self.name = name
+        self.auc_points = auc_points or {}
+
+    @staticmethod
+    def _pool(object_name, x):
+        if object_name == "ALL":
+            return np.concatenate([np.asarray(x[k], float) for k in x], axis=0)
+        return np.asarray(x, float)
+
+    @staticmethod
+    def _rot(aa):
+        """axis (3) + angle -> rotation matrix, the axis used as given (pyquaternion normalises it; pose files hold unit axes)."""
+        from .io import axis_angle_to_quat
+        return quat_to_rot(axis_angle_to_quat(aa[:3], aa[3]))
+
+    @staticmethod
+    def _rms(err):
+        return float(np.linalg.norm(err) / np.sqrt(err.shape[0]))
+
+    def evaluate(self, object_name, reference, signal, time):
+        n = self.name
+        if n in ("time", "excess_33_ms"):
+            t = self._pool(object_name, time)[:, 0]
+            return float(t.mean()) if n == "time" else float((t > 33.0).sum())
+        if n in ("add", "adi"):
+            return self.auc(object_name, reference, signal, n)[1]
+        ref, sig = self._pool(object_name, reference), self._pool(object_name, signal)
+        if n == "rmse_cartesian_3d":
+            return self._rms(np.linalg.norm((ref[:, :3] - sig[:, :3]) * 100.0, axis=1))                  # cm
+        if n.startswith("rmse_cartesian_"):
+            i = "xyz".index(n[-1])
+            return self._rms((ref[:, i] - sig[:, i]) * 100.0)
+        if n == "rmse_angular":
+            err = np.empty(len(ref))
+            for k in range(len(ref)):
+                R = self._rot(ref[k, 3:7]) @ self._rot(sig[k, 3:7]).T
+                err[k] = np.degrees(np.arccos(np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0)))          # |log R|
+            return self._rms(err)
+        if n == "rmse_linear_velocity":
+            return self._rms(np.linalg.norm((ref[:, :3] - sig[:, :3]) * 100.0, axis=1))                  # cm/s
+        if n == "rmse_angular_velocity":
+            return self._rms(np.linalg.norm(np.degrees(ref[:, 3:6] - sig[:, 3:6]), axis=1))              # deg/s
+        if n == "max_linear_velocity":
+            return float(np.linalg.norm(ref[:, :3], axis=1).max())                                       # of the REFERENCE (metrics.py:189-198)
+        return float(np.degrees(np.linalg.norm(ref[:, 3:6], axis=1).max()))
+
+    def auc(self, object_name, reference, signal, ad_name):
+        """(distances, AUC x 100) of ADD ('add') or ADD-S ('adi'), pooled over the objects for 'ALL' (metrics.py:303-344)."""
+        if object_name == "ALL":
+            names = list(signal)
+        else:
+            names, signal, reference = [object_name], {object_name: signal}, {object_name: reference}
+        dists = []
+        for name in names:
+            pts = np.asarray(self.auc_points[name], float)
+            for r, s in zip(np.asarray(reference[name], float), np.asarray(signal[name], float)):
+                f = add if ad_name == "add" else adds
+                dists.append(f(self._rot(s[3:7]), s[:3], self._rot(r[3:7]), r[:3], pts))
+        dists = np.array(dists)
+        return dists, auc(dists)

@@ -5,6 +5,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from roft_amd import parallel, synth
 
@@ -140,3 +141,61 @@ def test_rmse_metrics():
     body = metrics.object_velocity_from_twist(st.gt.twist, st.gt.x)
     fd = np.gradient(st.gt.x, st.dt, axis=0)
     assert np.abs(body[2:-2, :3] - fd[2:-2]).max() < 0.02
+
+
+def test_metric_class_of_the_references_evaluation():
+    """roft_amd.metrics.Metric = the interface of evaluation/metrics.py (which cannot be imported here: pyquaternion): every
+    metric name, per object and pooled over 'ALL', against values worked out by hand and against the functions pinned by the
+    bop_pose_error fixtures."""
+    from roft_amd import io, metrics as M
+    rng = np.random.default_rng(4)
+    assert set(M.Metric.NAMES) == {"rmse_cartesian_3d", "rmse_cartesian_x", "rmse_cartesian_y", "rmse_cartesian_z", "rmse_angular",
+                                   "rmse_linear_velocity", "rmse_angular_velocity", "max_linear_velocity", "max_angular_velocity",
+                                   "add", "adi", "time", "excess_33_ms"}
+    with pytest.raises(ValueError):
+        M.Metric("nope")
+    # poses: reference at rest, signal 1 cm off in x and rotated by 10 deg about z on every second row
+    n = 6
+    ref = np.zeros((n, 7)); ref[:, 3:] = [0.0, 0.0, 1.0, 0.0]
+    sig = ref.copy(); sig[:, 0] = 0.01; sig[::2, 6] = np.radians(10.0)
+    assert np.isclose(M.Metric("rmse_cartesian_3d").evaluate("a", ref, sig, None), 1.0)
+    assert np.isclose(M.Metric("rmse_cartesian_x").evaluate("a", ref, sig, None), 1.0)
+    assert M.Metric("rmse_cartesian_y").evaluate("a", ref, sig, None) == 0.0 == M.Metric("rmse_cartesian_z").evaluate("a", ref, sig, None)
+    assert np.isclose(M.Metric("rmse_angular").evaluate("a", ref, sig, None), 10.0 * np.sqrt(0.5))
+    # the same through the quaternion form used by bench.py
+    q = lambda rows: np.array([io.axis_angle_to_quat(r[3:6], r[6]) for r in rows])
+    assert np.isclose(M.Metric("rmse_angular").evaluate("a", ref, sig, None), M.rmse_angular(q(ref), q(sig)))
+    # velocities
+    vr = rng.normal(size=(n, 6)); vs = vr.copy(); vs[:, 0] += 0.02; vs[:, 5] -= np.radians(3.0)
+    assert np.isclose(M.Metric("rmse_linear_velocity").evaluate("a", vr, vs, None), 2.0)
+    assert np.isclose(M.Metric("rmse_angular_velocity").evaluate("a", vr, vs, None), 3.0)
+    assert np.isclose(M.Metric("max_linear_velocity").evaluate("a", vr, vs, None), np.linalg.norm(vr[:, :3], axis=1).max())
+    assert np.isclose(M.Metric("max_angular_velocity").evaluate("a", vr, vs, None), np.degrees(np.linalg.norm(vr[:, 3:], axis=1).max()))
+    # times
+    t = np.array([[10.0, 1.0], [40.0, 2.0], [33.0, 0.0], [34.0, 0.0]])
+    assert M.Metric("time").evaluate("a", None, None, t) == 29.25 and M.Metric("excess_33_ms").evaluate("a", None, None, t) == 2.0
+    # 'ALL': rows of all objects pooled
+    two = {"a": ref, "b": ref[:2]}
+    two_s = {"a": sig, "b": ref[:2]}
+    pooled = np.sqrt((n * 1.0) / (n + 2))
+    assert np.isclose(M.Metric("rmse_cartesian_3d").evaluate("ALL", two, two_s, None), pooled)
+    assert M.Metric("time").evaluate("ALL", None, None, {"a": t, "b": t[:1]}) == np.mean([10.0, 40.0, 33.0, 34.0, 10.0])
+    # ADD / ADD-S AUC: per object and pooled, against the functions the bop_pose_error fixtures pin
+    pts = {"a": rng.normal(size=(200, 3)) * 0.05, "b": rng.normal(size=(150, 3)) * 0.03}
+    poses = {}
+    for name in pts:
+        r = np.zeros((5, 7)); r[:, :3] = rng.normal(size=(5, 3)) * 0.1 + [0, 0, 0.7]
+        ax = rng.normal(size=(5, 3)); r[:, 3:6] = ax / np.linalg.norm(ax, axis=1, keepdims=True); r[:, 6] = rng.uniform(0, 2, 5)
+        s = r.copy(); s[:, :3] += rng.normal(size=(5, 3)) * 0.01; s[:, 6] += rng.normal(size=5) * 0.05
+        poses[name] = (r, s)
+    for ad, f in (("add", M.add), ("adi", M.adds)):
+        m = M.Metric(ad, auc_points=pts)
+        want_all = []
+        for name, (r, s) in poses.items():
+            d = [f(M.Metric._rot(s[k, 3:]), s[k, :3], M.Metric._rot(r[k, 3:]), r[k, :3], pts[name]) for k in range(5)]
+            want_all += d
+            assert np.isclose(m.evaluate(name, r, s, None), M.auc(np.array(d)))
+        ref_d = {k: v[0] for k, v in poses.items()}
+        sig_d = {k: v[1] for k, v in poses.items()}
+        assert np.isclose(m.evaluate("ALL", ref_d, sig_d, None), M.auc(np.array(want_all)))
+        assert 0.0 < m.evaluate("ALL", ref_d, sig_d, None) <= 100.0
