@@ -553,6 +553,7 @@ def main():
     #      back before the next frame is submitted)
     value_cold = None
     live = None
+    k1_alone = None
     if not args.no_extras:
         cold_host = [0.0]
 
@@ -584,6 +585,21 @@ def main():
         value_cold = dict(value=n_obj * args.steps / dt_cold, ms_per_step=1e3 * dt_cold / args.steps, host_enqueue_ms_per_step=1e3 * cold_host[0] / args.steps,
                           note="the timed sequence again on a fresh engine after the device has idled (CPU baseline, host "
                                "work, 1 s sleep) and WITHOUT the --clock-warm-ms load: what a short burst from an idle GPU gets")
+        # the roofline kernel with the device to itself: the same frames, every batch waited for before the next one is
+        # submitted (its launch then overlaps nothing but the tail of its own batch's mask chain)
+        _c, e3 = new_engine(n_obj)
+        add_objects(e3, streams)
+        e3.enable_timing(1)
+        for k0, t in warm_splits + timed_splits:
+            arr, _keep, tt = e3.build_batch([[frame_dict(st, k, dict(depth=st.depth, flow=st.flow, mask=st.mask_gt), L.MEM_DEVICE) for st in streams]
+                                             for k in range(k0, k0 + t)])
+            e3.submit_batch_raw(arr, tt)
+            e3.step()
+            e3.sync()
+        ms_alone, n_alone = e3.timing()["flow_measure"]
+        e3.close()
+        k1_alone = dict(avg_launch_us=1e3 * ms_alone / max(n_alone, 1), launches=n_alone,
+                        object_frames_per_launch=n_obj * (args.warmup + args.steps) / max(n_alone, 1))
         # live: ROFTFilter::filtering_step followed by a reader of the estimate, one object, nothing in flight across frames
         n_live = min(n_frames, 72)
         cfg1 = E.default_config(cam.width, cam.height, ftype, max_objects=1, device=local_rank, max_batch_frames=1)
@@ -694,6 +710,10 @@ def main():
                              "the memory system serves scattered sectors (measured_random_Gsectors_per_s: roft_debug_sector_rate on this box, "
                              "x 64 B = 0.4 of the streaming peak; frac_of_measured_random_sector_rate = the kernel's gathers alone against "
                              "it, the plane stream and the record writes not counted), not by streaming bandwidth")
+    if roofline is not None and k1_alone is not None and k1_alone["launches"]:
+        roofline["alone"] = dict(k1_alone, frac=bytes_per_obj * k1_alone["object_frames_per_launch"] / (k1_alone["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                 note="the same kernel with every batch waited for before the next one is submitted (nothing of another "
+                                      "batch on the device): what the launch costs by itself; `frac` above is the figure of record")
     dominant = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])[0] if kernels else None
     d_frames = max(stats1["frames"] - stats0["frames"], 1)
 
