@@ -861,3 +861,30 @@ def test_batched_tracker_front_end_compiles_and_explains_itself(tmp_path):
     assert r.returncode == 1 and "usage: ROFT-tracker-batch --from config.cfg" in r.stderr
     r = subprocess.run([exe, "--log_root", str(tmp_path), "--object", str(tmp_path), "box"], capture_output=True, text=True)
     assert r.returncode == 1 and "--from" in r.stderr
+
+
+def test_every_facade_header_compiles_on_its_own(tmp_path):
+    """Each header of include/ROFT and include/compat is self-contained (a translation unit that includes only it compiles), with
+    warnings as errors."""
+    units = []
+    for sub in ("ROFT", "compat", "compat/BayesFilters", "compat/RobotsIO/Camera", "compat/RobotsIO/Utils", "compat/Eigen"):
+        d = os.path.join(ROOT, "include", sub)
+        for name in sorted(os.listdir(d)):
+            if os.path.isfile(os.path.join(d, name)) and (name.endswith((".h", ".hpp")) or name == "Dense"):
+                units.append(os.path.join(sub, name))
+    assert len(units) >= 40
+    src = tmp_path / "all.cpp"
+    # one translation unit per header would be 45 compiler runs; including all of them twice in every order is not needed
+    # either: each header is the FIRST include of one unit, compiled in batches
+    for k, u in enumerate(units):
+        (tmp_path / ("u%d.cpp" % k)).write_text('#include "%s"\nint unit_%d() { return 0; }\n' % (u[len("compat/"):] if u.startswith("compat/") else u, k))
+    procs = []
+    for k in range(len(units)):
+        procs.append(subprocess.Popen(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include", "compat"),
+                                       "-I", os.path.join(ROOT, "include"), str(tmp_path / ("u%d.cpp" % k))], stderr=subprocess.PIPE, text=True))
+        if len(procs) == 8 or k == len(units) - 1:
+            for j, pr in enumerate(procs):
+                err = pr.communicate()[1]
+                assert pr.returncode == 0, (units[k - len(procs) + 1 + j], err[-1500:])
+            procs = []
+    del src
