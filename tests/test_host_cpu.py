@@ -199,3 +199,43 @@ def test_metric_class_of_the_references_evaluation():
         sig_d = {k: v[1] for k, v in poses.items()}
         assert np.isclose(m.evaluate("ALL", ref_d, sig_d, None), M.auc(np.array(want_all)))
         assert 0.0 < m.evaluate("ALL", ref_d, sig_d, None) <= 100.0
+
+
+def test_results_table_tool(tmp_path, capsys):
+    """tools/evaluate_results.py on a results tree written in the reference's log format: per-object rows and the pooled ALL row,
+    the dropped velocity columns of the pose log, the pole displacement of the linear velocity, the optical-flow time added."""
+    import importlib.util
+    import json
+    from roft_amd import io
+    rng = np.random.default_rng(8)
+    results, dataset = tmp_path / "results", tmp_path / "dataset"
+    n = 30
+    for name, off in (("a", 0.01), ("b", 0.02)):
+        (results / name).mkdir(parents=True)
+        (dataset / name / "gt").mkdir(parents=True)
+        gt = np.zeros((n + 5, 7)); gt[:, :3] = rng.normal(size=(n + 5, 3)) * 0.05 + [0, 0, 0.7]; gt[:, 3:] = [0, 0, 1, 0.3]
+        np.savetxt(str(dataset / name / "gt" / "poses.txt"), gt)
+        w = rng.normal(size=(n + 5, 3)) * 0.2
+        gv = np.concatenate([rng.normal(size=(n + 5, 3)) * 0.1, w], 1)
+        np.savetxt(str(dataset / name / "gt" / "velocities.txt"), gv)
+        io.write_obj(str(dataset / name / "model.obj"), rng.normal(size=(60, 3)) * 0.04, np.array([[0, 1, 2]]))
+        est = gt[:n].copy(); est[:, 0] += off
+        np.savetxt(str(results / name / "pose_estimate.txt"), np.concatenate([np.zeros((n, 6)), est], 1))
+        # the filter reports the velocity of the point at the camera origin: v_O = v - w x r
+        vo = gv[:n].copy(); vo[:, :3] = gv[:n, :3] - np.cross(gv[:n, 3:], gt[:n, :3])
+        np.savetxt(str(results / name / "velocity_estimate.txt"), vo)
+        np.savetxt(str(results / name / "execution_times.txt"), np.stack([np.full(n, 2.0), np.zeros(n)], 1))
+    spec = importlib.util.spec_from_file_location("evaluate_results", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "evaluate_results.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    assert ev.main(["--results", str(results), "--dataset", str(dataset), "--of-ms", "3", "--json", str(tmp_path / "t.json")]) == 0
+    out = capsys.readouterr().out.strip().splitlines()
+    assert out[0].startswith("| object | rmse_cartesian_3d (cm) | rmse_angular (deg) | add (AUC %) | adi (AUC %) | rmse_linear_velocity (cm/s)")
+    assert [line.split("|")[1].strip() for line in out[2:]] == ["a", "b", "ALL"]
+    t = json.load(open(str(tmp_path / "t.json")))
+    assert np.isclose(t["rmse_cartesian_3d"]["a"], 1.0) and np.isclose(t["rmse_cartesian_3d"]["b"], 2.0)
+    assert np.isclose(t["rmse_cartesian_3d"]["ALL"], np.sqrt((1.0 + 4.0) / 2.0))
+    assert abs(t["rmse_angular"]["ALL"]) < 1e-5
+    assert t["rmse_linear_velocity"]["a"] < 1e-9 and t["rmse_angular_velocity"]["b"] < 1e-9      # the pole was moved back
+    assert t["time"]["ALL"] == 5.0 and t["excess_33_ms"]["ALL"] == 0.0
+    assert 80.0 < t["add"]["b"] < t["add"]["a"] <= 100.0 and t["adi"]["a"] >= t["add"]["a"]
