@@ -806,8 +806,9 @@ def test_batched_tracker_front_end_equals_one_tracker_per_object(tmp_path, capsy
         st = copy.copy(util.stream(720 + i, n, 2, with_gray=True))
         st.pose_meas = st.pose_meas.copy()
         st.pose_meas[0] = st.pose_meas[6]
-        root = str(tmp_path / ("seq%d" % i))
         name = "box%d" % i
+        root = str(tmp_path / "dataset" / name)            # the reference's layout: one directory per object / sequence
+        os.makedirs(root)
         mesh = io.write_sequence(root, st, name, flow_set="analytic")
         seqs.append((root, name, mesh, st))
     c = seqs[0][3].camera
@@ -844,6 +845,16 @@ def test_batched_tracker_front_end_equals_one_tracker_per_object(tmp_path, capsy
     for _, name, _, _ in seqs:
         for f in ("pose_estimate.txt", "velocity_estimate.txt"):
             assert open(str(tmp_path / "out" / name / f)).read() == open(str(tmp_path / "out_sharded" / name / f)).read(), (name, f)
+    # ... and the step after the path: the metrics table of that results tree against the sequences' ground truth
+    spec = importlib.util.spec_from_file_location("evaluate_results", os.path.join(ROOT, "tools", "evaluate_results.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    assert ev.main(["--results", str(tmp_path / "out"), "--dataset", str(tmp_path / "dataset"), "--metrics", "rmse_cartesian_3d,rmse_angular,add,adi",
+                    "--json", str(tmp_path / "table.json")]) == 0
+    table = json.load(open(str(tmp_path / "table.json")))
+    lines = capsys.readouterr().out.strip().splitlines()
+    assert [ln.split("|")[1].strip() for ln in lines[-4:]] == ["box0", "box1", "box2", "ALL"]
+    assert table["rmse_cartesian_3d"]["ALL"] < 3.0 and table["rmse_angular"]["ALL"] < 8.0 and table["adi"]["ALL"] > 80.0 and table["add"]["ALL"] > 60.0
     # the three trajectories differ from each other (the objects were not mixed up)
     a = io.read_log(str(tmp_path / "out" / "box0" / "pose_estimate.txt"))
     b = io.read_log(str(tmp_path / "out" / "box1" / "pose_estimate.txt"))
