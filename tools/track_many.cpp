@@ -18,6 +18,7 @@
 //   g++ -std=c++17 -O2 -I include/compat -I include tools/track_many.cpp -L roft_amd/csrc -lroft_hip -o ROFT-tracker-batch
 #include <cstdio>
 #include <cstring>
+#include <filesystem>
 
 #include <ConfigParser.h>
 #include <ROFT/Filters.h>
@@ -272,7 +273,9 @@ int main(int argc, char** argv)
         compat::throw_if(roft_engine_get_log_rows(engine.engine(), 0, frames, rows.data()), "roft_engine_get_log_rows");
         for (int o = 0; o < n_obj; ++o) {
             const std::string dir = log_root + "/" + tracked[o].args.name;
-            if (std::system(("mkdir -p '" + dir + "'").c_str()) != 0) throw std::runtime_error("cannot create " + dir);
+            std::error_code ec;
+            std::filesystem::create_directories(dir, ec);
+            if (ec) throw std::runtime_error("cannot create " + dir + ": " + ec.message());
             std::remove((dir + "/pose_estimate.txt").c_str());
             std::remove((dir + "/velocity_estimate.txt").c_str());
             EstimateLog log;
