@@ -1,5 +1,6 @@
-"""BASELINE.json configs #3 and #5 at their full size, through the C ABI on the GPU:
+"""BASELINE.json configs #3, #4 and #5 at their full size, through the C ABI on the GPU:
 
+ #4  the 64 objects of bench.py at 640x480 with CV_32FC2 flow, every object against the oracle;
  #3  the five Fast-YCB-sized objects -- five different extents, five different meshes -- batched in one engine at
      1280x720 with CV_16SC2 grid-4 flow (config_fast_ycb.cfg + nvof_1_slow), against the oracle's ROFTFilter;
  #5  16 objects at 1280x720 with pose re-sync and outlier rejection (the branches of ROFTFilter.cpp:313-367),
@@ -62,6 +63,26 @@ def test_config3_five_different_objects_batched_1280x720_s16():
     for o, st in enumerate(host):
         check(log, masks, o, util.run_oracle_tracker(ob, st, n), n)
     assert stats["launches"] / n < 6.0
+
+
+def test_config4_64_objects_640x480_vs_oracle():
+    """BASELINE config #4 at its full size -- the 64 objects of bench.py (same seeds, same extents), 640x480, CV_32FC2 per
+    pixel, batches of six frames over DEVICE inputs as the bench submits them -- every object against the oracle over 26 frames
+    (four mask / pose arrivals: re-sync replays and outlier tests): flow point counts, decisions, final masks, poses, twists."""
+    from oracle import binding as ob
+    n, n_obj = 26, 64
+    dev = []
+    for gid in range(n_obj):
+        scale = 0.8 + 0.4 * (((gid % 64) * 7) % 10) / 9.0
+        half = tuple(h * scale for h in synth.CRACKER_BOX_HALF_EXTENTS)
+        dev.append(synth.make_stream(4000 + gid, n, synth.Camera.shape_a(), flow_type=synth.FLOW_F32C2, half_extents=half, device="cuda"))
+    log, masks, stats = util.run_engine_logged(make_engine, dev, n, T=6)
+    n_tests = 0
+    for o, st in enumerate(dev):
+        ref = util.run_oracle_tracker(ob, host_copy(st), n)
+        check(log, masks, o, ref, n)
+        n_tests += sum(r["sel"] >= 0 for r in ref)
+    assert n_tests >= n_obj * 3
 
 
 N5_OBJECTS, N5_FRAMES, N5_PERIOD, N5_ORACLE = 16, 3000, 60, 66
