@@ -19,7 +19,10 @@ import run_baseline_configs as rb
 n_obj = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n = 14 if os.environ.get("PHASES") == "fused" else (32 if os.environ.get("PHASES") == "mask" else 12)
 dev = torch.device("cuda", 0)
-streams = [synth.make_stream(4000 + i, n, synth.Camera.shape_a(), device=dev) for i in range(n_obj)]
+# SHAPE=B FLOW=s16: 1280x720 with CV_16SC2 grid-4 flow (config_fast_ycb.cfg) instead of the metric shape
+cam = synth.Camera.shape_b() if os.environ.get("SHAPE") == "B" else synth.Camera.shape_a()
+ftype = synth.FLOW_S16C2 if os.environ.get("FLOW") == "s16" else synth.FLOW_F32C2
+streams = [synth.make_stream(4000 + i, n, cam, flow_type=ftype, device=dev) for i in range(n_obj)]
 eng = rb.make_engine(streams)
 names = ["ctrl", "plane->LDS", "popc+scan", "cand list", "gathers", "scan+write"]
 if os.environ.get("PHASES") == "feat":
