@@ -269,16 +269,13 @@ __device__ bool spd_inverse6_wave(double* M)
 constexpr int kSkfLdsN = 4096;  // measurement counts up to this keep innovations + norms in LDS (96 KB)
 constexpr int kBins = 1024;
 constexpr int kBucketCap = 256;
-constexpr int kBinsPerThread = kBins / kSkfThreads;
-static_assert(kBins % kSkfThreads == 0 && kBinsPerThread >= 1, "bucket_select2 scans kBins / kSkfThreads bins per thread");
 
 struct SkfShared {
-    double red[kSkfThreads / 64], red2[kSkfThreads / 64];
+    double red[kSkfThreads / 64];
     double acc[27][kSkfThreads / 64];
-    int hist[kBins];
+    alignas(16) int hist[kBins];
     int sel[2];
-    int wave[17];
-    int bin[2], base[2], cnt[2];
+    int cnt[2];
     double list[2][kBucketCap];
     double med[2];
     double Lm[36], Ppi[36], eta[6], xo[6];   // information matrix -> posterior covariance, prior information, ...
@@ -289,67 +286,82 @@ struct SkfShared {
 #endif
 };
 
-// Exact order statistics of ranks ra <= rb (rb - ra <= 1) of N non-negative doubles in ~5 barrier phases:
+// Exact order statistics of ranks ra <= rb (rb - ra <= 1) of N non-negative doubles in three barrier phases:
 // a monotone 1024-bin histogram over [0, 8 x mean] locates the bucket of each rank, the (few) members of that
 // bucket are collected and ranked by counting.  Returns false if a bucket holds more than kBucketCap values.
-// `my_sum`: this thread's share of the sum of the values (the caller adds them up while it computes them).
-__device__ bool bucket_select2(const double* vals, int N, int ra, int rb, SkfShared& S, double& va, double& vb, double my_sum)
+//
+// The bins cover [0, 8 x mean], what lies above goes into the last one (the mapping stays monotone, so the prefix counts
+// stay exact): the median of non-negative values is at most twice their mean, and a few gross outliers -- flow vectors
+// that lost their pixel -- do not stretch the bins until the median's bucket holds hundreds of values, as bins over
+// [min, max] did (1280x720, N ~ 3 000: the select took 11.6 of the frame's 28 us and some objects fell back to the
+// 8-pass radix select).  No pass for the extremes either: the sum comes with the values.
+//
+// bucket_select_prepare: called by every thread with its share of the sum of the values, BEFORE the barrier that
+// publishes the values.
+__device__ void bucket_select_prepare(SkfShared& S, double my_sum)
 {
-    // The bins cover [0, 8 x mean], what lies above goes into the last one (the mapping stays monotone, so the prefix counts
-    // stay exact): the median of non-negative values is at most twice their mean, and a few gross outliers -- flow vectors
-    // that lost their pixel -- do not stretch the bins until the median's bucket holds hundreds of values, as bins over
-    // [min, max] did (1280x720, N ~ 3 000: the select took 11.6 of the frame's 28 us and some objects fell back to the
-    // 8-pass radix select).  No pass for the extremes either: the sum comes with the values.
-    const double lo = 0.0;
-    double sum;
-    {   // the sum through one pair of barriers; the histogram is cleared under the same pair
-        const double ws = wave_sum_to_lane63(my_sum);
-        __syncthreads();
-        if ((threadIdx.x & 63) == 63) S.red[threadIdx.x >> 6] = ws;
-        for (int i = threadIdx.x; i < kBins; i += blockDim.x) S.hist[i] = 0;
-        if (threadIdx.x < 2) S.cnt[threadIdx.x] = 0;
-        __syncthreads();
-        sum = S.red[0];
-        for (int w = 1; w < kSkfThreads / 64; ++w) sum += S.red[w];
-    }
+    const double ws = wave_sum_to_lane63(my_sum);
+    if ((threadIdx.x & 63) == 63) S.red[threadIdx.x >> 6] = ws;
+    for (int i = threadIdx.x; i < kBins; i += blockDim.x) S.hist[i] = 0;
+    if (threadIdx.x < 2) S.cnt[threadIdx.x] = 0;
+}
+
+__device__ bool bucket_select2(const double* vals, int N, int ra, int rb, SkfShared& S, double& va, double& vb)
+{
+    double sum = S.red[0];
+    for (int w = 1; w < kSkfThreads / 64; ++w) sum += S.red[w];
     const double top = 8.0 * (sum / (double)N);
-    if (!(top > 0.0)) { va = vb = 0.0; __syncthreads(); return true; }   // all values are zero
+    if (!(top > 0.0)) { va = vb = 0.0; __syncthreads(); return true; }   // all values are zero (barrier: S.red is the caller's next)
     const double scale = (double)(kBins - 1) / top;
     for (int k = threadIdx.x; k < N; k += blockDim.x) {
-        int b = (int)((vals[k] - lo) * scale);   // monotone in vals[k]
+        int b = (int)(vals[k] * scale);   // monotone in vals[k]
         b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
         atomicAdd(&S.hist[b], 1);
     }
     __syncthreads();
-    {   // exclusive prefix over the bins, kBinsPerThread bins per thread
-        const int t = threadIdx.x;
-        int h[kBinsPerThread], sum = 0;
+    // Every wave scans the whole histogram by itself (16 consecutive bins per lane, a shuffle scan over the lane sums)
+    // and keeps the two buckets in registers: no barrier between the histogram and the collection.
+    int bin[2], base[2];
+    {
+        constexpr int kPerLane = kBins / 64;
+        static_assert(kPerLane == 16, "four int4 reads per lane");
+        const int l = threadIdx.x & 63;
+        int h[kPerLane], tot = 0;
 #pragma unroll
-        for (int i = 0; i < kBinsPerThread; ++i) { h[i] = S.hist[kBinsPerThread * t + i]; sum += h[i]; }
-        int total;
-        int pre = block_exclusive_scan(sum, S.wave, &total);
+        for (int i = 0; i < kPerLane / 4; ++i) {
+            const int4 q = *reinterpret_cast<const int4*>(&S.hist[kPerLane * l + 4 * i]);
+            h[4 * i] = q.x; h[4 * i + 1] = q.y; h[4 * i + 2] = q.z; h[4 * i + 3] = q.w;
+            tot += q.x + q.y + q.z + q.w;
+        }
+        int incl = tot;
 #pragma unroll
-        for (int i = 0; i < kBinsPerThread; ++i) {
-            for (int q = 0; q < 2; ++q) {
-                const int r = q ? rb : ra;
-                if (r >= pre && r < pre + h[i]) { S.bin[q] = kBinsPerThread * t + i; S.base[q] = pre; }
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(incl, off, 64); if (l >= off) incl += o; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r = q ? rb : ra;
+            int pre = incl - tot, mybin = 0, mybase = 0;
+            const bool mine = r >= pre && r < incl;
+#pragma unroll
+            for (int i = 0; i < kPerLane; ++i) {
+                if (r >= pre && r < pre + h[i]) { mybin = kPerLane * l + i; mybase = pre; }
+                pre += h[i];
             }
-            pre += h[i];
+            const int src = __ffsll((long long)__ballot(mine)) - 1;   // exactly one lane: 0 <= r < N = sum of the bins
+            bin[q] = __shfl(mybin, src, 64);
+            base[q] = __shfl(mybase, src, 64);
         }
     }
-    __syncthreads();
-    const int binA = S.bin[0], binB = S.bin[1];
     for (int k = threadIdx.x; k < N; k += blockDim.x) {
         const double v = vals[k];
-        int b = (int)((v - lo) * scale);
+        int b = (int)(v * scale);
         b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
-        if (b == binA) { const int p = atomicAdd(&S.cnt[0], 1); if (p < kBucketCap) S.list[0][p] = v; }
-        if (b == binB) { const int p = atomicAdd(&S.cnt[1], 1); if (p < kBucketCap) S.list[1][p] = v; }
+        if (b == bin[0]) { const int p = atomicAdd(&S.cnt[0], 1); if (p < kBucketCap) S.list[0][p] = v; }
+        if (b == bin[1]) { const int p = atomicAdd(&S.cnt[1], 1); if (p < kBucketCap) S.list[1][p] = v; }
     }
     __syncthreads();
     if (S.cnt[0] > kBucketCap || S.cnt[1] > kBucketCap) return false;
     for (int q = 0; q < 2; ++q) {
-        const int m = S.cnt[q], r = (q ? rb : ra) - S.base[q];
+        const int m = S.cnt[q], r = (q ? rb : ra) - base[q];
         if ((int)threadIdx.x < m) {
             const double v = S.list[q][threadIdx.x];
             int less = 0, eq = 0;
@@ -358,9 +370,8 @@ __device__ bool bucket_select2(const double* vals, int N, int ra, int rb, SkfSha
         }
     }
     __syncthreads();
-    va = S.med[0];
+    va = S.med[0];   // next written after the barriers of the next call
     vb = S.med[1];
-    __syncthreads();
     return true;
 }
 
@@ -394,11 +405,12 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
             qn[k] = nrm;
             qsum += nrm;
         }
+        bucket_select_prepare(S, qsum);
         __syncthreads();
         SKFTICK(2);
         const int ra = (N % 2 == 0) ? N / 2 - 1 : N / 2, rb = N / 2;
         double va, vb;
-        if (!bucket_select2(qn, N, ra, rb, S, va, vb, qsum)) {
+        if (!bucket_select2(qn, N, ra, rb, S, va, vb)) {
             // a bucket overflowed (heavily clustered values): exact 8-pass radix select instead
             va = __longlong_as_double((long long)radix_select(qn, N, ra, S.hist, S.sel));
             vb = va;
