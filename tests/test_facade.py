@@ -715,6 +715,51 @@ def test_stamped_source_facade_equals_the_oracle(tmp_path):
     assert pos == len(raw)
 
 
+REF_DUMPER_MAIN = "/root/reference/tools/nvof/dumper/src/main.cpp"
+REF_DUMPER_BIN = os.path.join(ROOT, "tests", "cpp", "_ref_build", "ROFT-of-dumper")
+
+
+def test_reference_flow_dumper_compiles_against_the_facade():
+    """tools/nvof/dumper/src/main.cpp of the reference (ROFT-of-dumper), UNMODIFIED and where it lies, against include/: the
+    executable of the step before the path.  Dev container only."""
+    if not os.path.exists(REF_DUMPER_MAIN):
+        pytest.skip("the reference checkout is not here")
+    subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(ROOT, "include", "compat"), "-I", os.path.join(ROOT, "include"), REF_DUMPER_MAIN])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("version", ["nvof1", "nvof2"])
+def test_reference_flow_dumper_runs_on_the_hip_producer(tmp_path, version):
+    """The built ROFT-of-dumper, started with the reference's nine arguments on a sequence directory: `<index>.float` for every
+    frame but the first, each file what roft_optical_flow gives for the two RGB frames (nvof1: CV_16SC2 on a grid of 4, nvof2:
+    CV_32FC2 per pixel), readable by the file-backed flow source; wrong argument counts end with the synopsis."""
+    import util
+    from roft_amd import io, ops, synth
+    if not os.path.exists(REF_DUMPER_BIN):
+        pytest.skip("tests/cpp/_ref_build/ROFT-of-dumper is built where the reference checkout is (python __graft_entry__.py)")
+    n = 5
+    st = util.stream(712, n, 2, with_gray=True)
+    root = str(tmp_path / "seq")
+    io.write_sequence(root, st, "box")
+    H, W = st.mask_gt.shape[1:]
+    out = tmp_path / "flow_out"
+    out.mkdir()
+    r = subprocess.run([REF_DUMPER_BIN, root, "txt", "png", "0", "0", str(W), str(H), version, str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Processing completed." in r.stdout
+    assert sorted(os.listdir(out)) == ["%d.float" % k for k in range(1, n)]
+    gray = [io.rgb_to_gray(io.read_png(os.path.join(root, "rgb", "%d.png" % k))) for k in range(n)]
+    for k in range(1, n):
+        want = ops.optical_flow(gray[k - 1], gray[k], flow_type=synth.FLOW_S16C2 if version == "nvof1" else synth.FLOW_F32C2)
+        valid, got = io.read_flow(str(out / ("%d.float" % k)))
+        assert valid and got.dtype == want.dtype and got.shape == want.shape, k
+        assert np.array_equal(got, want), k
+    bad = subprocess.run([REF_DUMPER_BIN, root], capture_output=True, text=True)
+    assert bad.returncode != 0 and "Synopsis: ROFT-of-dumper" in bad.stderr
+    bad = subprocess.run([REF_DUMPER_BIN, root, "txt", "png", "0", "0", str(W), str(H), "nvof3", str(out)], capture_output=True, text=True)
+    assert bad.returncode != 0 and "Invalid <nvof_version>" in bad.stderr
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("product", [1, 2])
 def test_live_flow_source_with_the_references_constructor(tmp_path, product):
