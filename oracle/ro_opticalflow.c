@@ -18,8 +18,10 @@
  *     G = sum [Ix^2, Ix Iy; Ix Iy, Iy^2](p + o);  d = 2 * d_{l+1}(p >> 1) (0 at the coarsest level)
  *     if det G > det_min, `iterations` times:  b = sum grad(p+o) * (W(p + o) - I0c(p + o));  d -= G^-1 b
  *     W = the current image warped by d with ONE pair of bilinear weights for the whole window (d is constant over
- *     it): q = p + d, q0 = floor(q), a = q - q0;  h(z) = (1-ax) I1c(z) + ax I1c(z + (1,0))  (horizontal pass),
- *     W(p + o) = (1-ay) h(q0 + o) + ay h(q0 + o + (0,1))  (vertical pass)
+ *     it): q = p + d, q0 = floor(q), a = q - q0;  h(z) = fma(ax, I1c(z + (1,0)), (1-ax) I1c(z))  (horizontal pass),
+ *     W(p + o) = fma(ay, h(q0 + o + (0,1)), (1-ay) h(q0 + o))  (vertical pass)
+ *     every accumulation of the window sums is ONE fused multiply-add per tap, s <- fma(a, b, s) (single rounding):
+ *     the form the GPU's (packed) FMA units execute; everything else is separate IEEE operations (-ffp-contract=off)
  *   output    level-0 field; CV_16SC2: sampled at the centre (4i+2, 4j+2) of each 4x4 block, round(32 d) saturated
  */
 #include "roft_oracle.h"
@@ -70,7 +72,7 @@ int ro_optical_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int l
                     for (int ox = -radius; ox <= radius; ox++) {
                         const float ix = 0.5f * (at(I0, wl, hl, x + ox + 1, y + oy) - at(I0, wl, hl, x + ox - 1, y + oy));
                         const float iy = 0.5f * (at(I0, wl, hl, x + ox, y + oy + 1) - at(I0, wl, hl, x + ox, y + oy - 1));
-                        g11 += ix * ix; g12 += ix * iy; g22 += iy * iy;
+                        g11 = fmaf(ix, ix, g11); g12 = fmaf(ix, iy, g12); g22 = fmaf(iy, iy, g22);
                     }
                 const float det = g11 * g22 - g12 * g12;
                 if (det > det_min) {
@@ -87,10 +89,10 @@ int ro_optical_flow(const uint8_t* prev, const uint8_t* cur, int W, int H, int l
                             for (int ox = -radius; ox <= radius; ox++) {
                                 const float ix = 0.5f * (at(I0, wl, hl, x + ox + 1, y + oy) - at(I0, wl, hl, x + ox - 1, y + oy));
                                 const float iy = 0.5f * (at(I0, wl, hl, x + ox, y + oy + 1) - at(I0, wl, hl, x + ox, y + oy - 1));
-                                const float top = (1.0f - ax) * at(I1, wl, hl, x0 + ox, y0 + oy) + ax * at(I1, wl, hl, x0 + ox + 1, y0 + oy);
-                                const float bot = (1.0f - ax) * at(I1, wl, hl, x0 + ox, y0 + oy + 1) + ax * at(I1, wl, hl, x0 + ox + 1, y0 + oy + 1);
-                                const float it_ = ((1.0f - ay) * top + ay * bot) - at(I0, wl, hl, x + ox, y + oy);
-                                b1 += ix * it_; b2 += iy * it_;
+                                const float top = fmaf(ax, at(I1, wl, hl, x0 + ox + 1, y0 + oy), (1.0f - ax) * at(I1, wl, hl, x0 + ox, y0 + oy));
+                                const float bot = fmaf(ax, at(I1, wl, hl, x0 + ox + 1, y0 + oy + 1), (1.0f - ax) * at(I1, wl, hl, x0 + ox, y0 + oy + 1));
+                                const float it_ = fmaf(ay, bot, (1.0f - ay) * top) - at(I0, wl, hl, x + ox, y + oy);
+                                b1 = fmaf(ix, it_, b1); b2 = fmaf(iy, it_, b2);
                             }
                         dx -= (g22 * b1 - g12 * b2) * inv;
                         dy -= (g11 * b2 - g12 * b1) * inv;

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kOfTx * kOfTy) void of_lk_kernel(OfArgs a, int l)
     for (int k = 0; k < n; ++k)
         for (int j = 0; j < n; ++j) {
             const float2 g = g0[k * gw + j];
-            g11 += g.x * g.x; g12 += g.x * g.y; g22 += g.y * g.y;
+            g11 = fmaf(g.x, g.x, g11); g12 = fmaf(g.x, g.y, g12); g22 = fmaf(g.y, g.y, g22);
         }
     const float det = g11 * g22 - g12 * g12;
     if (det > a.det_min) {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kOfTx * kOfTy) void of_lk_kernel(OfArgs a, int l)
                 for (int j = 0; j < NMAX; ++j) {
                     if (j >= n) break;
                     const float right = row[clampi(qx + j + 1, 0, w - 1)];
-                    hc[j] = (1.0f - ax) * left + ax * right;
+                    hc[j] = fmaf(ax, right, (1.0f - ax) * left);
                     left = right;
                 }
                 if (k > 0) {
@@ -136,9 +136,9 @@ __global__ __launch_bounds__(kOfTx * kOfTy) void of_lk_kernel(OfArgs a, int l)
                     for (int j = 0; j < NMAX; ++j) {
                         if (j >= n) break;
                         const int o = (k - 1) * gw + j;
-                        const float dt = ((1.0f - ay) * hp[j] + ay * hc[j]) - t0[(k - 1) * tw + j];
+                        const float dt = fmaf(ay, hc[j], (1.0f - ay) * hp[j]) - t0[(k - 1) * tw + j];
                         const float2 g = g0[o];
-                        b1 += g.x * dt; b2 += g.y * dt;
+                        b1 = fmaf(g.x, dt, b1); b2 = fmaf(g.y, dt, b2);
                     }
                 }
 #pragma unroll
