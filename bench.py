@@ -388,15 +388,21 @@ def main():
     kernels = {}
     k1_live = None
     if not args.no_kernel_timing:
-        ms, cnt = eng.timing()["flow_measure"]
+        tm = eng.timing()
+        ms, cnt = tm["flow_measure"]
         k1_live = dict(total_ms=ms, launches=cnt, avg_us=1e3 * ms / max(cnt, 1))
+        if "flow_measure_span" in tm and tm["flow_measure_span"][1]:
+            # the same launches on the device's own 100 MHz clock: first workgroup in -> last workgroup out
+            k1_live["span_avg_us"] = 1e3 * tm["flow_measure_span"][0] / tm["flow_measure_span"][1]
+            k1_live["span_launches"] = tm["flow_measure_span"][1]
         # per-kernel breakdown over the next 24 frames of the same streams (outside the timed region: a marker event
         # after every launch costs throughput)
         eng.enable_timing(2)
         run(extra_batches, extra_splits)
         eng.sync()
         for name, (ms, cnt) in eng.timing().items():
-            kernels[name] = dict(total_ms=ms, marks=cnt, avg_us=1e3 * ms / max(cnt, 1))
+            if name != "flow_measure_span":
+                kernels[name] = dict(total_ms=ms, marks=cnt, avg_us=1e3 * ms / max(cnt, 1))
         eng.enable_timing(0)
 
     if rank != 0:
@@ -710,6 +716,15 @@ def main():
                              "the memory system serves scattered sectors (measured_random_Gsectors_per_s: roft_debug_sector_rate on this box, "
                              "x 64 B = 0.4 of the streaming peak; frac_of_measured_random_sector_rate = the kernel's gathers alone against "
                              "it, the plane stream and the record writes not counted), not by streaming bandwidth")
+    if roofline is not None and k1_live is not None and k1_live.get("span_avg_us"):
+        span_s = k1_live["span_avg_us"] * 1e-6
+        roofline["kernel_span"] = dict(
+            avg_us=k1_live["span_avg_us"], launches=k1_live["span_launches"], achieved=bytes_per_launch / span_s / 1e9,
+            frac=bytes_per_launch / span_s / 1e9 / HBM_PEAK_GBS,
+            note="the same timed launches on the device's own 100 MHz clock (every workgroup leaves its start and end: first "
+                 "workgroup in -> last workgroup out), which is the duration a kernel trace reports; the HIP event pair of "
+                 "`avg_launch_us` reads 2 - 6 us more per launch (under rocprofv3 too: profiles/README.md). `frac` above stays "
+                 "on the event pair")
     if roofline is not None and k1_alone is not None and k1_alone["launches"]:
         roofline["alone"] = dict(k1_alone, frac=bytes_per_obj * k1_alone["object_frames_per_launch"] / (k1_alone["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  note="the same kernel with every batch waited for before the next one is submitted (nothing of another "

@@ -201,6 +201,7 @@ struct Arrays {
         a.ukf_chol_guard_bil = 0.0;
         a.mask_wgs = 0;
         a.dev_error = nullptr;
+        a.k1_span = nullptr;
         return ROFT_OK;
     }
 };
@@ -394,6 +395,11 @@ struct roft_engine {
     std::vector<int> tlaunches;
     std::vector<int> tmark;    // kernel id per event interval (-1 = chain start)
     std::vector<int> tstream;  // stream of each mark (0 mask chain, 1 / 3 pose lanes, 2 velocity chain, 4 upload / preparation)
+    // the flow measurement's launches on the device's own clock (timing runs): per launch and workgroup the 100 MHz wall clock at
+    // its start and end, kSpanLaunches launches between two roft_engine_get_timing() calls (later ones are not stamped)
+    static constexpr int kSpanLaunches = 64;
+    DevBuf<unsigned long long> k1_span;
+    std::vector<int> span_wgs;   // workgroups of each stamped launch
 };
 
 static inline double host_now_us()
@@ -1276,7 +1282,17 @@ static int step_batch(roft_engine* e)
         // reports it, with no marker packets around it
         hipEvent_t k1_start = nullptr, k1_stop = nullptr;
         tmark_kernel(e, "flow_measure", 2, &k1_start, &k1_stop);
-        launch_flow_measure(a, e->cfg.depth_maximum, radius, sv, k1_start, k1_stop);
+        // ... and, next to it, on the device's own clock: every workgroup leaves its start and end (first one in to last one
+        // out = the launch as the kernel trace of a profiler sees it, without the packets the event pair brings along)
+        EngineArrays ak = a;
+        if (e->timing && (int)e->span_wgs.size() < roft_engine::kSpanLaunches) {
+            const size_t per_launch = (size_t)2 * kMaxBatch * e->cfg.max_objects;
+            if (e->k1_span.p) {   // (allocated by roft_engine_enable_timing)
+                ak.k1_span = e->k1_span.p + per_launch * e->span_wgs.size();
+                e->span_wgs.push_back(a.T * a.n_obj);
+            }
+        }
+        launch_flow_measure(ak, e->cfg.depth_maximum, radius, sv, k1_start, k1_stop);
         ++launches;
         CHECK_LAUNCH("flow measurement");
     }
@@ -1476,6 +1492,7 @@ int roft_engine_enable_timing(roft_engine* e, int enable)
     if (!e) return fail(ROFT_ERR_INVALID, "null engine");
     e->timing = enable != 0;
     e->timing_level = (enable == 1) ? 1 : 2;
+    if (e->timing) HIP_TRY(e->k1_span.ensure((size_t)2 * kMaxBatch * e->cfg.max_objects * roft_engine::kSpanLaunches, true));
     return ROFT_OK;
 }
 
@@ -1509,11 +1526,39 @@ int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, 
         prev[w] = (long)i;
     }
     if (dump) fclose(dump);
+    if (!e->span_wgs.empty()) {
+        // pseudo kernel "flow_measure_span": first workgroup in -> last workgroup out of each stamped launch, 10 ns ticks
+        const size_t per_launch = (size_t)2 * kMaxBatch * e->cfg.max_objects;
+        std::vector<unsigned long long> h(per_launch * e->span_wgs.size());
+        HIP_TRY(hipMemcpy(h.data(), e->k1_span.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(e->k1_span.p, 0, h.size() * sizeof(unsigned long long)));
+        double total_us = 0.0;
+        int counted = 0;
+        for (size_t l = 0; l < e->span_wgs.size(); ++l) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int w = 0; w < e->span_wgs[l]; ++w) {
+                const unsigned long long a0 = h[l * per_launch + 2 * w], a1 = h[l * per_launch + 2 * w + 1];
+                if (a0 == 0 || a1 == 0) continue;   // (a kernel variant that does not stamp)
+                t0 = std::min(t0, a0);
+                t1 = std::max(t1, a1);
+            }
+            if (t1 > t0) { total_us += (double)(t1 - t0) * 0.01; ++counted; }
+        }
+        e->span_wgs.clear();
+        if (counted) {
+            int id = -1;
+            for (size_t i = 0; i < e->tnames_s.size(); ++i)
+                if (e->tnames_s[i] == "flow_measure_span") id = (int)i;
+            if (id < 0) { e->tnames_s.push_back("flow_measure_span"); e->tms.push_back(0.f); e->tlaunches.push_back(0); id = (int)e->tnames_s.size() - 1; }
+            e->tms[id] = (float)(total_us * 1e-3);
+            e->tlaunches[id] = counted;
+        }
+    }
     e->tmark.clear();
     e->tstream.clear();
     e->tnames.clear();
     for (auto& s : e->tnames_s) e->tnames.push_back(s.c_str());
-    *n_out = (int)nk;
+    *n_out = (int)e->tnames_s.size();
     if (names_out) *names_out = e->tnames.data();
     if (ms_out) *ms_out = e->tms.data();
     if (launches_out) *launches_out = e->tlaunches.data();

@@ -120,6 +120,18 @@ struct FlowCtrl {
     const void* flow;
 };
 
+// Timing runs (EngineArrays::k1_span): when this workgroup started and when its last wave is through, on the 100 MHz wall
+// clock all workgroups share -- the host takes the launch's span, first workgroup in to last workgroup out, from them.
+__device__ __forceinline__ void span_out(const EngineArrays& a, int slot, long long t0)
+{
+    if (!a.k1_span) return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.k1_span[2 * slot] = (unsigned long long)t0;
+        a.k1_span[2 * slot + 1] = (unsigned long long)wall_clock64();
+    }
+}
+
 // Plane words held in registers: thread t owns the PER4 consecutive 16-byte groups starting at t * PER4 (no LDS copy
 // of the plane at all).  Needs plane_words % 4 == 0 and plane_words / 4 <= PER4 * kFlowThreads.
 template <int PER4>
@@ -129,6 +141,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays
     __shared__ uint2 s_item[kCandLds];
     const int obj = blockIdx.x, slot = blockIdx.y * a.n_obj + obj;   // slot = (frame of the batch, object)
     const FrameCtrl& c = a.ctrl[slot];
+    const long long span_t0 = a.k1_span ? wall_clock64() : 0;   // (timing runs: see span_out)
 #ifdef ROFT_K1_PROFILE
     ObjState& st = a.state[obj];
 #endif
@@ -154,6 +167,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays
     }
     if (!k.vel_stage) {
         if (threadIdx.x == 0) a.npts[slot] = -1;
+        span_out(a, slot, span_t0);
         return;
     }
     int cnt = 0;
@@ -189,6 +203,7 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays
     const int n = (C <= kCandLds) ? tail(s_item) : tail(reinterpret_cast<uint2*>(a.cand + (size_t)slot * a.cand_cap));
     K1TICK(5);
     if (threadIdx.x == 0) a.npts[slot] = n;
+    span_out(a, slot, span_t0);
 }
 
 // Any plane size: the plane is staged in dynamic LDS, every thread walks a contiguous chunk of its words.
