@@ -60,7 +60,9 @@ extern "C" {
 #define ROFT_MEAS_POSE 2
 #define ROFT_MEAS_POSE_VELOCITY 3
 
-/* memory kind of image pointers handed to the engine */
+/* memory kind of image pointers handed to the engine.  ROFT_MEM_DEVICE pointers are looked up (hipPointerGetAttributes) on the
+ * first submit of an engine: a host buffer declared as device memory is refused with ROFT_ERR_INVALID instead of faulting on the
+ * GPU; later submits trust the caller (the look-up costs microseconds per pointer). */
 #define ROFT_MEM_HOST 0
 #define ROFT_MEM_DEVICE 1
 

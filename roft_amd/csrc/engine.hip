@@ -385,6 +385,7 @@ struct roft_engine {
     int completed_batches = 0, completed_frames = 0;
     int batch_end_frame[kBatchRing] = {};
     roft_engine_stats stats{};
+    bool device_pointers_checked = false;   // ROFT_MEM_DEVICE inputs are looked up once, on the first submit
     // timing
     bool timing = false;
     int timing_level = 2;   // 1: only flow_measure_kernel (two events per batch), 2: every launch group
@@ -986,6 +987,21 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
                 d_depth = in.depth;
                 d_flow = in.flow;
                 d_mask = in.mask;
+                // the first call of an engine only: a host pointer declared as device memory is a GPU page fault that takes
+                // the process down at the first kernel -- the commonest mistake of a new binding is refused here instead
+                if (!e->device_pointers_checked) {
+                    const void* ptrs[3] = {in.depth, in.flow, in.mask};
+                    static const char* const what[3] = {"depth", "flow", "mask"};
+                    for (int q = 0; q < 3; ++q) {
+                        if (!ptrs[q]) continue;
+                        hipPointerAttribute_t attr{};
+                        const hipError_t pe = hipPointerGetAttributes(&attr, ptrs[q]);
+                        if (pe != hipSuccess) (void)hipGetLastError();
+                        if (pe != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged))
+                            return fail(ROFT_ERR_INVALID, std::string("mem_kind is ROFT_MEM_DEVICE but the ") + what[q] + " pointer of object " +
+                                                              std::to_string(id) + " is not device memory (pass ROFT_MEM_HOST for host buffers)");
+                    }
+                }
                 if ((reinterpret_cast<uintptr_t>(d_mask) & 15) || (reinterpret_cast<uintptr_t>(d_flow) & 7) ||
                     (reinterpret_cast<uintptr_t>(d_depth) & 3))
                     return fail(ROFT_ERR_INVALID, "device buffers must be aligned: mask 16 B, flow 8 B, depth 4 B");
@@ -1140,6 +1156,7 @@ int roft_frames_submit(roft_engine* e, const roft_frame_input* inputs, int n_obj
     }
     e->cur_T = n_frames;
     e->submitted = true;
+    e->device_pointers_checked = true;
     return ROFT_OK;
 }
 

@@ -240,6 +240,8 @@ def test_two_engines_interleaved_in_one_process():
     mutable state between engine handles (streams, rings and device state are per engine)."""
     a = [util.stream(580, 24, scale=2, device="cuda")]
     b = [util.stream(581, 24, scale=2, flow_type=synth.FLOW_S16C2, shape="B", device="cuda")]
+    for st in a + b:   # (util.stream leaves the images on the host; this test hands device pointers over)
+        st.depth, st.flow, st.mask_gt = st.depth.cuda(), st.flow.cuda(), st.mask_gt.cuda()
     alone_a = _run_logged(a, 24)
     alone_b = _run_logged(b, 24)
     from roft_amd import _lib as L
@@ -297,3 +299,61 @@ def test_more_objects_than_the_device_has_room_for_mask_workgroups():
     streams = [util.stream(3000 + i, n, scale=4, mesh_n=6, device="cuda") for i in range(n_obj)]
     n_tests = compare(streams, n)
     assert n_tests >= n_obj          # an outlier test per object at the arrival on frame 6
+
+
+def test_roofline_kernel_is_timed_twice_and_timing_changes_nothing():
+    """roft_engine_enable_timing: the flow measurement's launches come back with their HIP event pair ("flow_measure") and on
+    the device's own clock ("flow_measure_span": first workgroup in -> last workgroup out, what bench.py's roofline.kernel_span
+    quotes) -- as many launches, a span that is positive and not longer than the event pair's figure plus the clock's
+    resolution --, the stamps change no result, and a second collection starts from zero."""
+    n = 12
+    streams = [util.stream(560 + i, n, scale=2, device="cuda") for i in range(3)]
+
+    def run(timing):
+        eng = make_engine(streams)
+        eng.enable_log(n)
+        if timing:
+            eng.enable_timing(1)
+        got = []
+        for rep in range(2 if timing else 1):
+            for k in range(rep * n // 2, (rep + 1) * n // 2) if timing else range(n):
+                frames = []
+                for st in streams:
+                    depth, flow, mask, pose = util.frame_inputs(st, k)
+                    frames.append(dict(depth=depth, flow=flow, mask=mask, pose=pose, dt=st.dt))
+                eng.submit(frames)
+                eng.step()
+            if timing:
+                got.append(eng.timing())
+        out = eng.get_log(0, n)
+        eng.close()
+        return out, got
+
+    plain, _ = run(False)
+    timed, marks = run(True)
+    for x, y in zip(plain, timed):
+        assert np.array_equal(x, y)
+    for tm in marks:
+        ms_ev, n_ev = tm["flow_measure"]
+        ms_sp, n_sp = tm["flow_measure_span"]
+        assert n_ev == n_sp == n // 2
+        assert 0.0 < ms_sp <= ms_ev + 1e-4 * n_sp, (ms_sp, ms_ev)
+
+
+def test_host_pointer_declared_as_device_memory_is_refused():
+    """The first submit of an engine looks its ROFT_MEM_DEVICE pointers up: a host buffer handed over as device memory is an
+    error with its reason, not a GPU page fault at the first kernel; the engine is usable afterwards."""
+    st = util.stream(570, 4, scale=2, device="cuda")   # (util.stream leaves the images on the host)
+    eng = make_engine([st])
+    depth, flow, mask, pose = util.frame_inputs(st, 0)
+    bad = dict(depth=depth.ctypes.data, flow=None, mask=mask.ctypes.data if mask is not None else None, pose=pose, dt=st.dt,
+               mem_kind=L.MEM_DEVICE)
+    with pytest.raises(L.RoftError) as err:
+        eng.submit([bad])
+    assert "not device memory" in str(err.value) and "depth" in str(err.value)
+    dev, dev_mask = torch.from_numpy(depth).cuda(), torch.from_numpy(mask).cuda()
+    ok = dict(depth=dev.data_ptr(), flow=None, mask=dev_mask.data_ptr(), pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE)
+    eng.submit([ok])
+    eng.step()
+    eng.sync()
+    eng.close()
