@@ -165,6 +165,8 @@ def parse():
     p.add_argument("--splits", default="", help="explicit batch sizes of the timed frames, e.g. 2,6,6,6 (must sum to --steps)")
     p.add_argument("--mask-workgroups", type=int, default=0,
                    help="roft_config::mask_workgroups_per_object (0: the engine's choice, (CUs - CUs / 4) / objects)")
+    p.add_argument("--outlier-bands", type=int, default=0,
+                   help="roft_config::outlier_bands_per_alternative (0: the engine's choice, CUs / (2 x objects))")
     p.add_argument("--no-kernel-timing", action="store_true",
                    help="do not record HIP events in the timed region and skip the per-kernel breakdown")
     return p.parse_args()
@@ -262,6 +264,7 @@ def main():
         cfg = E.default_config(cam.width, cam.height, ftype, max_objects=max_objects, device=local_rank, max_batch_frames=T)
         cfg.cam.fx, cfg.cam.fy, cfg.cam.cx, cfg.cam.cy = cam.fx, cam.fy, cam.cx, cam.cy
         cfg.mask_workgroups_per_object = args.mask_workgroups
+        cfg.outlier_bands_per_alternative = args.outlier_bands
         return cfg, E.ROFTFilterBatch(cfg)
 
     def add_objects(eng, sts):

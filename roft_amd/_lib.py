@@ -55,7 +55,8 @@ class Config(C.Structure):
                 ("flow_aided_segmentation", C.c_int), ("mask_frames_between", C.c_int),
                 ("pose_frames_between", C.c_int), ("stamped_masks", C.c_int), ("max_objects", C.c_int), ("ukf_cholesky_guard", C.c_double),
                 ("ukf_cholesky_guard_bilinear", C.c_double),
-                ("device", C.c_int), ("max_batch_frames", C.c_int), ("mask_workgroups_per_object", C.c_int)]
+                ("device", C.c_int), ("max_batch_frames", C.c_int), ("mask_workgroups_per_object", C.c_int),
+                ("outlier_bands_per_alternative", C.c_int)]
 
 
 class ObjectDesc(C.Structure):

@@ -200,6 +200,7 @@ struct Arrays {
         a.ukf_chol_guard = 0.0;
         a.ukf_chol_guard_bil = 0.0;
         a.mask_wgs = 0;
+        a.outlier_parts = 0;
         a.dev_error = nullptr;
         a.k1_span = nullptr;
         return ROFT_OK;
@@ -654,6 +655,7 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
         e->arr.a.dev_error = static_cast<int*>(dp);
     }
     e->arr.a.mask_wgs = cfg->mask_workgroups_per_object;
+    e->arr.a.outlier_parts = cfg->outlier_bands_per_alternative;
     e->arr.a.ukf_chol_guard = (cfg->ukf_cholesky_guard > 0.0) ? cfg->ukf_cholesky_guard : 0.0;
     e->arr.a.ukf_chol_guard_bil = (cfg->ukf_cholesky_guard_bilinear > 0.0) ? cfg->ukf_cholesky_guard_bilinear : 0.0;
     e->h_params.resize(cfg->max_objects);
@@ -678,6 +680,8 @@ int roft_engine_create(const roft_config* cfg, roft_engine** out)
         return fail(ROFT_ERR_INVALID, "max_batch_frames must be 0 .. ROFT_MAX_BATCH_FRAMES");
     if (cfg->mask_workgroups_per_object < 0 || cfg->mask_workgroups_per_object > 8)
         return fail(ROFT_ERR_INVALID, "mask_workgroups_per_object must be 0 (automatic) .. 8");
+    if (cfg->outlier_bands_per_alternative < 0 || cfg->outlier_bands_per_alternative > kMaxOutlierParts)
+        return fail(ROFT_ERR_INVALID, "outlier_bands_per_alternative must be 0 (automatic) .. 8");
     if ((int)(size_t)cfg->subsampling_radius <= 0) return fail(ROFT_ERR_INVALID, "subsampling_radius must be >= 1");
     const int T = std::max(cfg->max_batch_frames, 1);
     // batches in flight: enough that the host never runs out of enqueued work while it waits for the oldest one -- a

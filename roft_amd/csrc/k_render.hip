@@ -504,6 +504,7 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     (void)set_max_dynamic_lds(reinterpret_cast<const void*>(outlier_fused_kernel), (int)lds_total);
     // bands per alternative: as many workgroups as the chip has CUs to spare
     int parts = std::max(1, std::min(kMaxOutlierParts, device_cu_count() / (2 * std::max(a.n_obj, 1))));
+    if (a.outlier_parts > 0) parts = std::min(a.outlier_parts, kMaxOutlierParts);
     if (opts && opts->parts > 0) parts = std::min(opts->parts, kMaxOutlierParts);
     // (a band is a fraction of the window: request only the LDS it can need, so that other chains' workgroups fit next to it)
     const size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + parts - 1) / parts + (size_t)a.tile_w);

@@ -202,6 +202,7 @@ struct EngineArrays {
     roft_object_output* out_log;  // [log_cap][n_obj] per-frame outputs, or null
     int log_cap;
     int mask_wgs;            // roft_config::mask_workgroups_per_object (0: by the device's CU count)
+    int outlier_parts;       // roft_config::outlier_bands_per_alternative (0: by the device's CU count)
     int* dev_error;          // one word of pinned host memory (or null): ROFT_DEV_ERROR_* raised by a kernel that gave up
     unsigned long long* k1_span;  // [T][n_obj][2] of THIS launch of the flow measurement, or null: 100 MHz wall clock at which each
                                   // workgroup started and ended (timing runs only: the launch's span on the device's own clock)

@@ -39,6 +39,16 @@ def test_struct_layouts_match_header_sizes():
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
     assert sizes == [C.sizeof(L.Camera), C.sizeof(L.Flow), C.sizeof(L.Config), C.sizeof(L.ObjectDesc),
                      C.sizeof(L.FrameInput), C.sizeof(L.ObjectOutput)]
+    # (the trailing ints of roft_config share one alignment slot: a field missing from the mirror would not change the size)
+    src = ('#include <stdio.h>\n#include <stddef.h>\n#include "roft_engine.h"\nint main(){printf("%zu %zu %zu %zu\\n", offsetof(roft_config, device), '
+           'offsetof(roft_config, max_batch_frames), offsetof(roft_config, mask_workgroups_per_object), '
+           'offsetof(roft_config, outlier_bands_per_alternative));return 0;}')
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "o.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "o.c"), "-o", os.path.join(d, "o")])
+        offs = [int(x) for x in subprocess.check_output([os.path.join(d, "o")]).split()]
+    assert offs == [L.Config.device.offset, L.Config.max_batch_frames.offset, L.Config.mask_workgroups_per_object.offset,
+                    L.Config.outlier_bands_per_alternative.offset]
 
 
 def test_defaults_follow_the_reference_config():

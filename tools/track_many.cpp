@@ -4,7 +4,7 @@
 // ROFTFilter::filtering_step, so this is the same computation per object (tests/test_facade.py compares the two).
 //
 //   ROFT-tracker-batch --from config.cfg [--group::key value ...]        the reference's configuration file and overrides
-//                      --log_root DIR [--batch_frames T] [--device D] [--shard RANK WORLD]
+//                      --log_root DIR [--batch_frames T] [--outlier_bands B] [--device D] [--shard RANK WORLD]
 //                      --object SEQUENCE_DIR NAME [MESH.obj] [--object ...]
 //
 // Several GPUs: one process per GPU, each given the same object list, `--device r --shard r G`: process r tracks the r-th block
@@ -70,7 +70,7 @@ int main(int argc, char** argv)
         // ---- split the command line: what is ours, what is the configuration's
         std::vector<ObjectArgs> objects;
         std::string log_root;
-        int batch_frames = 6, device = 0, shard_rank = 0, shard_world = 1;
+        int batch_frames = 6, device = 0, shard_rank = 0, shard_world = 1, outlier_bands = 0;
         std::vector<char*> cfg_argv = {argv[0]};
         for (int i = 1; i < argc; ++i) {
             const std::string a = argv[i];
@@ -83,10 +83,11 @@ int main(int argc, char** argv)
             } else if (a == "--log_root" && i + 1 < argc) log_root = argv[++i];
             else if (a == "--batch_frames" && i + 1 < argc) batch_frames = std::atoi(argv[++i]);
             else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
+            else if (a == "--outlier_bands" && i + 1 < argc) outlier_bands = std::atoi(argv[++i]);   // roft_config::outlier_bands_per_alternative
             else if (a == "--shard" && i + 2 < argc) { shard_rank = std::atoi(argv[i + 1]); shard_world = std::atoi(argv[i + 2]); i += 2; }
             else cfg_argv.push_back(argv[i]);
         }
-        if (objects.empty() || log_root.empty()) throw std::runtime_error("usage: ROFT-tracker-batch --from config.cfg [--group::key value ...] --log_root DIR [--batch_frames T] [--device D] [--shard RANK WORLD] --object SEQUENCE_DIR NAME [MESH.obj] ...");
+        if (objects.empty() || log_root.empty()) throw std::runtime_error("usage: ROFT-tracker-batch --from config.cfg [--group::key value ...] --log_root DIR [--batch_frames T] [--outlier_bands B] [--device D] [--shard RANK WORLD] --object SEQUENCE_DIR NAME [MESH.obj] ...");
         if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) throw std::runtime_error("--shard RANK WORLD: 0 <= RANK < WORLD");
         {
             const std::size_t per = (objects.size() + (std::size_t)shard_world - 1) / (std::size_t)shard_world;
@@ -192,6 +193,7 @@ int main(int argc, char** argv)
         cfg.device = device;
         if (batch_frames < 1 || batch_frames > ROFT_MAX_BATCH_FRAMES) throw std::runtime_error("--batch_frames out of range");
         cfg.max_batch_frames = batch_frames;
+        cfg.outlier_bands_per_alternative = outlier_bands;   // (0: the engine's choice; 1 tracks long recordings of many objects ~5 % faster)
         ROFTFilterBatch engine(cfg);
         for (TrackedObject& t : tracked) {
             roft_object_desc d{};
