@@ -219,10 +219,10 @@ typedef struct {
      * ("mask chain barrier timed out"); the process is not aborted. */
     int mask_workgroups_per_object;
     /* Workgroups one alternative of an outlier test is rendered by: horizontal bands of the object's window, 1 .. 8; 0 = chosen
-     * from the device (CUs / (2 x max_objects), 2 for 64 objects on 256 CUs).  Fewer bands occupy fewer CUs for longer: with 64
-     * objects one band tracks 5 % more object-frames/s in long runs and 2.5 % fewer in a 20-frame burst.
-     * The band count enters the summation order of the likelihoods: results are bit-reproducible for a given value and may
-     * differ in the last digits between values. */
+     * by the engine: from the device (CUs / (2 x max_objects), 2 for 64 objects on 256 CUs), and half of that while the host runs
+     * ahead of the device by the whole in-flight bound, i.e. in the steady state of a long sequence (fewer bands occupy fewer CUs
+     * for longer: with 64 objects one band tracks 5 % more object-frames/s in long runs and 2.5 % fewer in a 20-frame burst,
+     * DESIGN.md section 4).  The likelihood's sums are exact (integer), so the band count changes no result. */
     int outlier_bands_per_alternative;
 } roft_config;
 

@@ -387,6 +387,7 @@ struct roft_engine {
     int batch_end_frame[kBatchRing] = {};
     roft_engine_stats stats{};
     bool device_pointers_checked = false;   // ROFT_MEM_DEVICE inputs are looked up once, on the first submit
+    bool throttled = false;   // the submit of the current batch had to wait for the in-flight bound: the device is `lead` batches behind
     // timing
     bool timing = false;
     int timing_level = 2;   // 1: only flow_measure_kernel (two events per batch), 2: every launch group
@@ -423,11 +424,16 @@ static int check_dev_error(roft_engine* e)
 }
 
 // blocks until batch b (and therefore every earlier one) has ended on the GPU
-static int wait_batch(roft_engine* e, int b)
+static int wait_batch(roft_engine* e, int b, bool* waited = nullptr)
 {
+    if (waited) *waited = false;
     if (b < e->completed_batches || b >= e->batch_counter) return ROFT_OK;
     for (int l = 0; l < kNumLin; ++l)
-        if (e->done_used[b % roft_engine::kBatchRing][l]) HIP_TRY(hipEventSynchronize(e->ev_done[b % roft_engine::kBatchRing][l]));
+        if (e->done_used[b % roft_engine::kBatchRing][l]) {
+            if (waited && hipEventQuery(e->ev_done[b % roft_engine::kBatchRing][l]) == hipErrorNotReady) *waited = true;
+            (void)hipGetLastError();   // (hipErrorNotReady is not an error of this call)
+            HIP_TRY(hipEventSynchronize(e->ev_done[b % roft_engine::kBatchRing][l]));
+        }
     e->completed_batches = b + 1;
     e->completed_frames = e->batch_end_frame[b % roft_engine::kBatchRing];
     return check_dev_error(e);
@@ -1136,7 +1142,7 @@ int roft_frames_submit(roft_engine* e, const roft_frame_input* inputs, int n_obj
     HIP_TRY(hipSetDevice(e->cfg.device));
     double hp_t = e->host_prof ? host_now_us() : 0.0;
     // bound the batches in flight (see roft_engine::lead); this also frees the batch ring slot
-    if (int rc = wait_batch(e, e->batch_counter - e->lead)) return rc;
+    if (int rc = wait_batch(e, e->batch_counter - e->lead, &e->throttled)) return rc;
     HP_MARK(e, 0, hp_t);   // time blocked on the GPU
     e->backup.resize(e->objs.size());
     for (size_t i = 0; i < e->objs.size(); ++i) e->backup[i] = e->objs[i]->s;
@@ -1362,7 +1368,13 @@ static int step_batch(roft_engine* e)
             CHECK_LAUNCH("pose chain segment");
             tmark(e, "ukf_chain", which);
             if (!last) {
-                launch_outlier(a, lin, sp, nullptr);
+                // bands per alternative: the caller's number, else by the CUs to spare -- and half of that while the host runs
+                // `lead` batches ahead of the device (a long sequence in its steady state: fewer, longer workgroups leave more
+                // CUs to the chains; 64 objects: +5 %, and -2.5 % if a 20-frame burst did the same).  The likelihood sums are
+                // exact, so the band count changes no result.
+                OutlierLaunchOpts oo;
+                if (e->cfg.outlier_bands_per_alternative == 0 && e->throttled) oo.parts = -2;   // (-d: the automatic count / d)
+                launch_outlier(a, lin, sp, nullptr, &oo);
                 ++launches;
                 CHECK_LAUNCH("outlier rejection");
                 tmark(e, "outlier_render_likelihood", which);

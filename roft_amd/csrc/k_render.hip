@@ -316,7 +316,8 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
                                                                      float* tile_dump)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ double s_err[kFusedThreads / 64], s_cnt[kFusedThreads / 64];
+    __shared__ long long s_hi[kFusedThreads / 64], s_lo[kFusedThreads / 64];
+    __shared__ int s_cnt[kFusedThreads / 64];
     __shared__ int s_box[4];
     // Workgroups are handed to the XCDs round robin by their linear index; the 2 x parts workgroups of an object read the
     // same mesh (186 KB of indices + 98 KB of vertices at the bench's 15.5 k triangles): with the grid laid out as
@@ -399,7 +400,8 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     const uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
     const float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
     const int n = st.n_feat[fslot];
-    double err = 0.0, cnt = 0.0;
+    LikelihoodSum err;
+    int cnt = 0;
     if (win_w > 0 && j1 >= j0 && i0 >= 0 && j0 >= 0) {
         const int rows = max(1, win_cap / win_w);   // (win_cap >= the target's width: a strip holds at least one row)
         for (int js = j0; js <= j1; js += rows) {
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
                     const int tj = v / d, ti = u / d;
                     if (tj < js || tj > je || ti < i0 || ti > i1) continue;
                     const uint32_t b = s_z[(tj - js) * win_w + (ti - i0)];
-                    if (b != 0x7F800000u) { err += (double)fabsf(dep[k] - __uint_as_float(b)); cnt += 1.0; }
+                    if (b != 0x7F800000u) { err.add(fabsf(dep[k] - __uint_as_float(b))); cnt += 1; }
                 }
             }
             __syncthreads();   // the next strip clears the window
@@ -477,14 +479,20 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
 #endif
         }
     }
-    for (int off = 32; off > 0; off >>= 1) { err += __shfl_down(err, off, 64); cnt += __shfl_down(cnt, off, 64); }
-    if ((tid & 63) == 0) { s_err[tid >> 6] = err; s_cnt[tid >> 6] = cnt; }
+    for (int off = 32; off > 0; off >>= 1) {
+        err.hi += __shfl_down(err.hi, off, 64);
+        err.lo += __shfl_down(err.lo, off, 64);
+        cnt += __shfl_down(cnt, off, 64);
+    }
+    if ((tid & 63) == 0) { s_hi[tid >> 6] = err.hi; s_lo[tid >> 6] = err.lo; s_cnt[tid >> 6] = cnt; }
     __syncthreads();
     if (tid == 0) {
-        double e = 0.0, n2 = 0.0;
-        for (int w = 0; w < kFusedThreads / 64; ++w) { e += s_err[w]; n2 += s_cnt[w]; }
-        pl.part_err[alt][part] = e;
-        pl.part_cnt[alt][part] = n2;
+        long long hi = 0, lo = 0;
+        int n2 = 0;
+        for (int w = 0; w < kFusedThreads / 64; ++w) { hi += s_hi[w]; lo += s_lo[w]; n2 += s_cnt[w]; }
+        pl.part_hi[alt][part] = hi;
+        pl.part_lo[alt][part] = lo;
+        pl.part_cnt[alt][part] = (double)n2;
         if (alt == 0 && part == 0) pl.n_parts = parts;
     }
 }
@@ -506,6 +514,7 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     int parts = std::max(1, std::min(kMaxOutlierParts, device_cu_count() / (2 * std::max(a.n_obj, 1))));
     if (a.outlier_parts > 0) parts = std::min(a.outlier_parts, kMaxOutlierParts);
     if (opts && opts->parts > 0) parts = std::min(opts->parts, kMaxOutlierParts);
+    if (opts && opts->parts < 0) parts = std::max(1, parts / -opts->parts);
     // (a band is a fraction of the window: request only the LDS it can need, so that other chains' workgroups fit next to it)
     const size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + parts - 1) / parts + (size_t)a.tile_w);
     const size_t lds = std::min(lds_total, (((cache ? vbytes : 0) + win_need + 15) & ~(size_t)15));

@@ -1164,8 +1164,10 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
         // no sample at all -> DBL_MAX (ROFTFilter.cpp:569-574); the gain is a bool in the reference, i.e. 1 (ROFTFilter.h:64)
         double Lk[2];
         for (int k = 0; k < 2; ++k) {
-            double e = 0.0, n2 = 0.0;
-            for (int p = 0; p < pl.n_parts; ++p) { e += pl.part_err[k][p]; n2 += pl.part_cnt[k][p]; }
+            long long hi = 0, lo = 0;
+            double n2 = 0.0;
+            for (int p = 0; p < pl.n_parts; ++p) { hi += pl.part_hi[k][p]; lo += pl.part_lo[k][p]; n2 += pl.part_cnt[k][p]; }
+            const double e = LikelihoodSum::value(hi, lo);   // the exact sum of the float terms, rounded here once
             Lk[k] = (n2 == 0.0) ? 1.7976931348623157e308 : (e / n2) / 1.0;
             if (threadIdx.x == 0) { pl.outlier_L[k] = Lk[k]; pl.outlier_cnt[k] = n2; }
         }

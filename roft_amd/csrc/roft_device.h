@@ -85,7 +85,10 @@ struct PoseLane {
     double outlier_cnt[2];
     int ukf_status;
     int n_parts;           // workgroups per alternative of the last outlier test (outlier_fused_kernel)
-    double part_err[2][kMaxOutlierParts];   // their partial sums of |depth - render| and sample counts, per alternative
+    // their partial sums of |depth - render| and sample counts, per alternative.  The sums are EXACT: every float term is
+    // split into two integers (units of 2^-32 m and 2^-64 m, LikelihoodSum below), so that the likelihood does not depend on
+    // how the samples are distributed over bands, strips, threads and waves -- the band count may follow the load
+    long long part_hi[2][kMaxOutlierParts], part_lo[2][kMaxOutlierParts];
     double part_cnt[2][kMaxOutlierParts];
 };
 
@@ -164,6 +167,21 @@ struct MaskRec {
 };
 
 // ---- launch wrappers (defined in the k_*.hip files) -------------------------------------------
+
+// Order-free sum of non-negative float terms: a term x (clamped to 256 -- metres of depth difference) is x = hi 2^-32 + lo 2^-64
+// with integers hi < 2^40, lo < 2^32, exactly for every float >= 2^-41; integer sums are associative, so any distribution of
+// the terms over threads gives the same two totals (2^19.8 terms at most: hi < 2^60, lo < 2^52).
+struct LikelihoodSum {
+    long long hi = 0, lo = 0;
+    __host__ __device__ void add(float x)
+    {
+        const double xs = fmin((double)x, 256.0) * 4294967296.0;
+        const double fl = floor(xs);
+        hi += (long long)fl;
+        lo += (long long)((xs - fl) * 4294967296.0);
+    }
+    __host__ __device__ static double value(long long hi, long long lo) { return (double)hi * (1.0 / 4294967296.0) + (double)lo * (1.0 / 4294967296.0 / 4294967296.0); }
+};
 
 struct EngineArrays {
     int n_obj;
@@ -342,7 +360,7 @@ void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nul
 // Operator-level overrides of the outlier test's launch shape (roft_render_depth / roft_outlier_test: the parity tests drive
 // the engine's kernel through every configuration); the engine passes none.
 struct OutlierLaunchOpts {
-    int parts = 0;            // horizontal bands per alternative (0: by the CUs to spare)
+    int parts = 0;            // horizontal bands per alternative (0: by the CUs to spare, -d: that count / d)
     int no_vertex_cache = 0;  // project the vertices per triangle instead of once into LDS
     int window_pixels = 0;    // cap of the LDS depth window in pixels (> 0: forces the strip path for larger windows)
     float* tile_dump = nullptr;   // [2][tile_h][tile_w], zero-filled: receives the rendered window of both alternatives

@@ -226,32 +226,23 @@ def test_mask_workgroups_per_object_changes_nothing():
             assert np.array_equal(a, b), wgs
 
 
-def test_outlier_bands_per_alternative_keep_the_decisions():
-    """roft_config::outlier_bands_per_alternative: 1 .. 8 horizontal bands per rendered alternative (or the automatic choice).
-    The rendered depths are the same pixels whatever the bands (tests/test_parity_gpu.py); the band count only changes the
-    order in which the likelihood's samples are added up: the same outlier decisions and masks, trajectories equal to
-    far below the parity tolerance, and every setting reproduces itself bit for bit."""
+def test_outlier_bands_per_alternative_change_nothing():
+    """roft_config::outlier_bands_per_alternative: 1 .. 8 horizontal bands per rendered alternative, or the engine's choice
+    (which follows the load).  The rendered depths are the same pixels whatever the bands (tests/test_parity_gpu.py) and the
+    likelihood's sums are exact integers (LikelihoodSum: tests/test_parity_gpu.py compares the likelihoods themselves across bands,
+    strips and vertex-cache settings bit for bit), so the whole log is bit for bit the same."""
     n = 26
     streams = [util.to_device(st) for st in awkward_streams(n)]
     ref = None
-    for bands in (0, 1, 2, 3, 8, 1):
+    for bands in (0, 1, 2, 3, 8):
         log, masks, _ = util.run_engine_logged(make_engine, streams, n, T=8, outlier_bands_per_alternative=bands)
         if ref is None:
             ref = (log, masks)
-            first_one = None
+            assert (log[3] >= 0).any()
             continue
-        pose, twist, npts, sel = log[0], log[1], log[2], log[3]
-        assert np.array_equal(ref[0][2], npts) and np.array_equal(ref[0][3], sel), bands
-        assert (sel >= 0).any()
-        np.testing.assert_allclose(pose, ref[0][0], rtol=0, atol=1e-9)
-        np.testing.assert_allclose(twist, ref[0][1], rtol=0, atol=1e-9)
+        for a, b in zip(ref[0], log):
+            assert np.array_equal(a, b), bands
         for a, b in zip(ref[1], masks):
             assert np.array_equal(a, b), bands
-        if bands == 1:
-            if first_one is None:
-                first_one = log
-            else:
-                for a, b in zip(first_one, log):
-                    assert np.array_equal(a, b)
     with pytest.raises(L.RoftError):
         make_engine(streams, outlier_bands_per_alternative=9)

@@ -349,8 +349,12 @@ def test_outlier_test_hot_path_kernel(oracle, shape, scale, mesh_n, div):
         t_ref = [oracle.render_depth(omesh, x2[k], q2[k], ocam, div) for k in range(2)]
         ref = [oracle.depth_likelihood(ocam, depth, mask, t_ref[k], div) for k in range(2)]
         assert (t_ref[0] > 0).sum() > 50
+        L_first = None
         for kw in shapes:
             Lv, ns, sel, tiles = ops.outlier_test(_cam(st), div, depth, mask, mesh, x2, q2, **kw)
+            # exact (integer) sums: the likelihood does not depend on bands, strips or the vertex cache, to the last bit
+            L_first = list(Lv) if L_first is None else L_first
+            assert list(Lv) == L_first, (kw, list(Lv), L_first)
             for k in range(2):
                 assert np.array_equal(tiles[k], t_ref[k]), (kw, k, int((tiles[k] != t_ref[k]).sum()))
                 assert ns[k] == ref[k][1], (kw, k)

@@ -193,7 +193,7 @@ int main(int argc, char** argv)
         cfg.device = device;
         if (batch_frames < 1 || batch_frames > ROFT_MAX_BATCH_FRAMES) throw std::runtime_error("--batch_frames out of range");
         cfg.max_batch_frames = batch_frames;
-        cfg.outlier_bands_per_alternative = outlier_bands;   // (0: the engine's choice; 1 tracks long recordings of many objects ~5 % faster)
+        cfg.outlier_bands_per_alternative = outlier_bands;   // (0: the engine's choice, which follows the load)
         ROFTFilterBatch engine(cfg);
         for (TrackedObject& t : tracked) {
             roft_object_desc d{};
