@@ -322,9 +322,13 @@ int roft_engine_get_stats(roft_engine* e, roft_engine_stats* out);
 /* HIP stream the engine enqueues on (as void*), for timing with hipEvents */
 void* roft_engine_stream(roft_engine* e);
 
-/* Kernel timing with HIP events on the engine's stream, accumulated over the steps since the last
- * roft_engine_get_timing.  enable: 0 off, 1 only flow_measure_kernel (two event records per frame, what
- * bench.py keeps on inside its timed region), 2 every launch group (adds ~10 event records per frame).
+/* Kernel timing with HIP events on the engine's streams, accumulated over the steps since the last
+ * roft_engine_get_timing.  enable: 0 off, 1 only flow_measure_kernel (a start / stop event pair bound to its dispatch, what
+ * bench.py keeps on inside its timed region), 2 every launch group (adds ~10 event records per batch).
+ * With timing on, the flow measurement's launches (the first 64 between two roft_engine_get_timing calls) are also timed
+ * on the device's own 100 MHz clock -- every workgroup leaves its start and end, the entry "flow_measure_span" is first
+ * workgroup in -> last workgroup out, the duration a kernel trace reports.  roft_engine_enable_timing creates its events
+ * and sends one event-paired dispatch down the velocity stream before it returns (call it outside a timed region).
  * names/ms arrays are owned by the engine. */
 int roft_engine_enable_timing(roft_engine* e, int enable);
 int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, const float** ms_out,
