@@ -239,3 +239,31 @@ def test_results_table_tool(tmp_path, capsys):
     assert t["rmse_linear_velocity"]["a"] < 1e-9 and t["rmse_angular_velocity"]["b"] < 1e-9      # the pole was moved back
     assert t["time"]["ALL"] == 5.0 and t["excess_33_ms"]["ALL"] == 0.0
     assert 80.0 < t["add"]["b"] < t["add"]["a"] <= 100.0 and t["adi"]["a"] >= t["add"]["a"]
+
+
+def test_batch_planners_cover_the_frames_once_and_end_with_the_pose_arrivals():
+    """roft_amd.engine.aligned_batches (the batches a recorded sequence is cut into: each ends with a pose-arrival frame where
+    a batch can hold a period) and bench.py's split_batches: every frame exactly once, in order, no batch above T; the
+    driver's shape (5 warm-up + 20 timed frames, T = 8, arrivals every 6 frames) is 2, 6, 6, 6."""
+    import importlib.util
+    from roft_amd import engine as E
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_planner", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert [t for _, t in E.aligned_batches(5, 25, 8, 6)] == [2, 6, 6, 6]
+    assert [t for _, t in E.aligned_batches(0, 5, 8, 6)] == [1, 4]
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        first = int(rng.integers(0, 40)); last = first + int(rng.integers(1, 90)); T = int(rng.integers(1, 9))
+        period = int(rng.integers(1, 13)); phase = int(rng.integers(0, period))
+        for plan in (E.aligned_batches(first, last, T, period, phase), bench.split_batches(first, last, T), bench.split_batches(first, last, T, ramp=True)):
+            k = first
+            for k0, t in plan:
+                assert k0 == k and 1 <= t <= T
+                k += t
+            assert k == last
+        plan = E.aligned_batches(first, last, T, period, phase)
+        if period <= T:
+            for k0, t in plan[:-1]:   # (the last batch ends where the frames end)
+                assert (k0 + t - 1) % period == phase, (first, last, T, period, phase, plan)
