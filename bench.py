@@ -339,6 +339,10 @@ def main():
 
     barrier = parallel.barrier
     if args.rehearsal_ms > 0:
+        # The scratch engines run on the very streams -- hardware queues -- the timed run will use: the engine created above
+        # hands its stream set back first (the library keeps a process's stream sets and gives the first free one to the next
+        # engine), and the engine of the timed run is created after the rehearsal.
+        eng.close()
         t_w = time.perf_counter()
         while True:
             _c, scratch = new_engine(n_obj)
@@ -350,6 +354,9 @@ def main():
             scratch.close()
             if (time.perf_counter() - t_w) * 1e3 >= args.rehearsal_ms:
                 break
+        cfg, eng = new_engine(n_obj)
+        add_objects(eng, streams)
+        eng.enable_log(n_frames)
     if args.clock_warm_ms > 0:
         # not tracker work and not timed: brings the device out of its idle power state (see --clock-warm-ms)
         # (a GEMM for the shader clock, large copies for the memory / fabric clocks: the tracker's kernels are bound by
@@ -373,9 +380,16 @@ def main():
     stats0 = eng.stats()
     barrier()
     torch.cuda.synchronize()
+    # the host thread has just slept in the waits above: a few milliseconds of spinning bring its core back to its working
+    # clock before the 1.4 ms window in which it enqueues ~50 launches (one run in twenty showed the host side of those launches
+    # four to five times slower than the others)
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < 3e-3:
+        pass
     t0 = time.perf_counter()
     run(timed_batches, timed_splits)
     host_enqueue = time.perf_counter() - t0   # host side of the loop (frame programs + launches), GPU still running
+    host_cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1
     eng.sync()
     gathered = None
     if world > 1:
@@ -744,6 +758,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
+        "host_state": {"cpu": host_cpu, "loadavg_1min": os.getloadavg()[0], "cpus_online": os.cpu_count()},
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
