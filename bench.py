@@ -190,8 +190,39 @@ def split_batches(first, last, T, ramp=False):
     return out
 
 
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process (torch.distributed.run, one rank
+    per GPU, rendezvous on 127.0.0.1) before this process has imported torch or touched a GPU, relay the child's output
+    (rank 0's JSON line) and exit with its code -- never exec.  Under a launcher (WORLD_SIZE set) the world size must be
+    the one --gpus states: a silent mismatch would print a line whose n_gpus is not what the caller asked for."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks; start it with "
+                             "--nproc-per-node %d (or drop the launcher: `python bench.py --gpus %d` starts the ranks itself)\n"
+                             % (args.gpus, ws, args.gpus, args.gpus))
+            raise SystemExit(2)
+        return
+    if args.gpus <= 1:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+    try:
+        rc = child.wait()
+    except KeyboardInterrupt:
+        child.terminate()
+        rc = child.wait()
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    self_launch(args, sys.argv[1:])
     import torch
     import torch.distributed as dist
     from roft_amd import _lib as L
@@ -203,6 +234,10 @@ def main():
     # (several ranks on cuda:0 over gloo); the driver's multi-GPU runs use LOCAL_RANK and RCCL.
     dev_index = int(os.environ.get("ROFT_BENCH_DEVICE", local_rank))
     backend = os.environ.get("ROFT_BENCH_BACKEND", "nccl")
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d, this node shows %d (one rank per GPU; ROFT_BENCH_DEVICE=0 "
+                         "ROFT_BENCH_BACKEND=gloo puts every rank on GPU 0 to exercise the N > 1 path on a one-GPU box)"
+                         % (rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if backend == "nccl":
@@ -242,21 +277,31 @@ def main():
 
     # ---- synthetic streams, generated on the GPU and left resident in HBM
     t_gen = time.time()
-    streams = []
-    for gid in my_objects:
-        seed = 4000 + gid  # stream seed = 1000 * config + global object index
-        scale = 0.8 + 0.4 * (((gid % 64) * 7) % 10) / 9.0
-        half = tuple(h * scale for h in synth.CRACKER_BOX_HALF_EXTENTS)
-        streams.append(synth.make_stream(seed, n_frames, cam, flow_type=ftype, half_extents=half, device=dev))
-    scene = None
-    if args.shared_scene:
-        # one scene for every object of every rank: all ranks build the same stream (masks, poses and the mesh stay local),
-        # but only the ingest rank keeps its images -- the others receive them batch by batch (parallel.broadcast_frames)
-        scene = synth.make_stream(4000, n_frames, cam, flow_type=ftype, device=dev)
-        streams = [scene] * n_obj
-        if world > 1 and rank != 0:
-            scene.depth.zero_()
-            scene.flow.zero_()
+
+    def make_streams(seed_base, n_fr, zero_remote=True):
+        """The rank's objects' streams: stream seed = seed_base + global object index (seed_base 4000 = 1000 x config #4:
+        the workload; other bases: same shapes and object models, different motion, noise and images)."""
+        if args.shared_scene:
+            # one scene for every object of every rank: all ranks build the same stream (masks, poses and the mesh stay
+            # local), but only the ingest rank keeps its images -- the others receive them batch by batch (broadcast_frames)
+            sc = synth.make_stream(seed_base, n_fr, cam, flow_type=ftype, device=dev)
+            if world > 1 and rank != 0 and zero_remote:
+                sc.depth.zero_()
+                sc.flow.zero_()
+            return [sc] * n_obj, sc
+        out = []
+        for gid in my_objects:
+            scale = 0.8 + 0.4 * (((gid % 64) * 7) % 10) / 9.0
+            half = tuple(h * scale for h in synth.CRACKER_BOX_HALF_EXTENTS)
+            out.append(synth.make_stream(seed_base + gid, n_fr, cam, flow_type=ftype, half_extents=half, device=dev))
+        return out, None
+
+    streams, scene = make_streams(4000, n_frames)
+    # The rehearsal (below) tracks a DISJOINT stream set of the same shapes (seeds + 1000): no frame of the timed region has
+    # been read by anything in this process when the clock starts -- a tracker sees each frame once.
+    rehearsal_streams = None
+    if args.rehearsal_ms > 0:
+        rehearsal_streams, _rs = make_streams(5000, n_timed_end, zero_remote=False)   # (nothing broadcasts in the rehearsal)
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
 
@@ -285,16 +330,24 @@ def main():
         return dict(depth=src["depth"][k].data_ptr(), flow=src["flow"][k].data_ptr() if st.flow_valid[k] else None,
                     mask=src["mask"][mi].data_ptr() if mi >= 0 else None, pose=pose, dt=st.dt, mem_kind=kind)
 
-    host = None
-    if args.host_inputs:   # pinned host copies of the streams: the boundary then pays the PCIe transfer
-        host = [dict(depth=st.depth.cpu().pin_memory(), flow=st.flow.cpu().pin_memory(), mask=st.mask_gt.cpu().pin_memory())
-                for st in streams]
+    def host_copies(sts):   # pinned host copies of the streams: the boundary then pays the PCIe transfer
+        if not args.host_inputs:
+            return None
+        seen = {}
+        for st in sts:
+            if id(st) not in seen:
+                seen[id(st)] = dict(depth=st.depth.cpu().pin_memory(), flow=st.flow.cpu().pin_memory(), mask=st.mask_gt.cpu().pin_memory())
+        return [seen[id(st)] for st in sts]
 
-    def build(k0, t):
+    host = host_copies(streams)
+
+    def build(k0, t, sts=None, hst=None):
+        sts = streams if sts is None else sts
+        hst = host if sts is streams else hst
         frames_list = []
         for k in range(k0, k0 + t):
-            frames_list.append([frame_dict(st, k, host[o] if host else dict(depth=st.depth, flow=st.flow, mask=st.mask_gt),
-                                           L.MEM_HOST if host else L.MEM_DEVICE) for o, st in enumerate(streams)])
+            frames_list.append([frame_dict(st, k, hst[o] if hst else dict(depth=st.depth, flow=st.flow, mask=st.mask_gt),
+                                           L.MEM_HOST if hst else L.MEM_DEVICE) for o, st in enumerate(sts)])
         return eng.build_batch(frames_list)
 
     period = int(cfg.pose_frames_between)
@@ -342,18 +395,23 @@ def main():
         # The scratch engines run on the very streams -- hardware queues -- the timed run will use: the engine created above
         # hands its stream set back first (the library keeps a process's stream sets and gives the first free one to the next
         # engine), and the engine of the timed run is created after the rehearsal.
+        # The rehearsal tracks OTHER streams (seeds + 1000: same shapes, same batch cuts): every frame of the warm-up and of
+        # the timed region is read for the first time by the run that is timed.
+        reh_host = host_copies(rehearsal_streams)
+        reh_batches = [build(k0, t, rehearsal_streams, reh_host) for k0, t in warm_splits + timed_splits]
         eng.close()
         t_w = time.perf_counter()
         while True:
             _c, scratch = new_engine(n_obj)
-            add_objects(scratch, streams)
-            for arr, _keep, t in warm_batches + timed_batches:
+            add_objects(scratch, rehearsal_streams)
+            for arr, _keep, t in reh_batches:
                 scratch.submit_batch_raw(arr, t)
                 scratch.step()
             scratch.sync()
             scratch.close()
             if (time.perf_counter() - t_w) * 1e3 >= args.rehearsal_ms:
                 break
+        del reh_batches, reh_host
         cfg, eng = new_engine(n_obj)
         add_objects(eng, streams)
         eng.enable_log(n_frames)
@@ -375,6 +433,22 @@ def main():
     eng.sync()
     torch.cuda.synchronize()
     bcast_bytes[0] = 0
+    plan = None
+    if world > 1:
+        # Nothing of the exchange happens for the first time inside the window: the shard sizes are exchanged here, once, and
+        # one all-gather of the timed region's shape (and, for a shared scene, one broadcast of a batch's shape) runs before
+        # the clock starts -- the first collective of a process builds its communicator's channels and can cost more than
+        # the whole window.
+        plan = parallel.gather_plan(n_obj, (args.steps, 19), red_dev)
+        parallel.gather_records(torch.zeros((n_obj, args.steps, 19), dtype=torch.float64), red_dev, plan)
+        if scene is not None:
+            t_max = max(t for _k0, t in timed_splits)
+            dummy = [torch.zeros_like(scene.depth[:t_max]), torch.zeros_like(scene.flow[:t_max])]
+            if backend != "nccl":
+                dummy = [d.cpu() for d in dummy]
+            parallel.broadcast_frames(dummy, src=0)
+            del dummy
+        torch.cuda.synchronize()
     if not args.no_kernel_timing:
         eng.enable_timing(1)   # a start/stop HIP event pair on the roofline kernel's own dispatch, nothing else
     stats0 = eng.stats()
@@ -395,7 +469,7 @@ def main():
     if world > 1:
         # the only exchange of the job: every rank's per-object result rows (pose 13 | twist 6 per object-frame)
         rows = torch.from_numpy(eng.get_log_rows(args.warmup, args.steps)).transpose(0, 1).contiguous()   # [obj, frame, 19]
-        gathered = parallel.gather_records(rows, red_dev)
+        gathered = parallel.gather_records(rows, red_dev, plan)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -600,14 +674,19 @@ def main():
             torch.cuda.synchronize()
             return time.perf_counter() - t1
         # (the device has idled through the CPU baseline and the host work above: no clock warm-up precedes this run)
+        # fresh frames as well: a third stream set (seeds + 2000, same shapes) that nothing has read before this run
+        cold_streams, _cs = make_streams(6000, n_timed_end, zero_remote=False)
+        torch.cuda.synchronize()
         time.sleep(1.0)
         _c, e2 = new_engine(n_obj)
-        add_objects(e2, streams)
-        dt_cold = timed_sequence(e2, streams, args.warmup, args.steps)
+        add_objects(e2, cold_streams)
+        dt_cold = timed_sequence(e2, cold_streams, args.warmup, args.steps)
         e2.close()
+        del cold_streams
         value_cold = dict(value=n_obj * args.steps / dt_cold, ms_per_step=1e3 * dt_cold / args.steps, host_enqueue_ms_per_step=1e3 * cold_host[0] / args.steps,
-                          note="the timed sequence again on a fresh engine after the device has idled (CPU baseline, host "
-                               "work, 1 s sleep) and WITHOUT the --clock-warm-ms load: what a short burst from an idle GPU gets")
+                          note="a timed sequence of the same shape on a fresh engine and on FRESH frames (a third stream set, seeds "
+                               "+ 2000, read by nothing before) after the device has idled (CPU baseline, host work, 1 s sleep), "
+                               "no rehearsal of any kind: what a short burst from an idle GPU gets")
         # the roofline kernel with the device to itself: the same frames, every batch waited for before the next one is
         # submitted (its launch then overlaps nothing but the tail of its own batch's mask chain)
         _c, e3 = new_engine(n_obj)
@@ -765,6 +844,13 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "inputs": "host (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
+        "timed_frames_first_touch": True,
+        "method": {"rehearsal_ms": args.rehearsal_ms,
+                   "rehearsal_streams": "disjoint from the timed ones (seeds + 1000, same shapes and batch cuts)" if args.rehearsal_ms > 0 else None,
+                   "host_spin_ms_before_window": 3.0,
+                   "batch_cuts": "explicit --splits" if args.splits else ("full batches" if args.no_align else "batches end with the pose-arrival frame"),
+                   "note": "no frame of the warm-up or of the timed region is read by anything in this process before the run that "
+                           "is timed reads it; the W warm-up steps run on the timed engine right before the window"},
         "config": {"workload": "BASELINE config #4: %dx%d, %s flow grid %d, %d objects in total, %s "
                                "(sharded by object, no data-path collective; result rows all-gathered over RCCL at N > 1), "
                                "masks+poses at 5 fps with 6-frame delay, flow-aided masks, re-sync and outlier rejection on, "

@@ -60,9 +60,11 @@ extern "C" {
 #define ROFT_MEAS_POSE 2
 #define ROFT_MEAS_POSE_VELOCITY 3
 
-/* memory kind of image pointers handed to the engine.  ROFT_MEM_DEVICE pointers are looked up (hipPointerGetAttributes) on the
- * first submit of an engine: a host buffer declared as device memory is refused with ROFT_ERR_INVALID instead of faulting on the
- * GPU; later submits trust the caller (the look-up costs microseconds per pointer). */
+/* memory kind of image pointers handed to the engine.  ROFT_MEM_DEVICE: memory the GPU can address as it is -- device or
+ * managed memory, or pinned host memory that is mapped into the device's address space at the same address (hipHostMalloc,
+ * hipHostRegister: zero-copy reads over the bus).  The pointers are looked up (hipPointerGetAttributes) on the first submit of
+ * an engine: unregistered, pageable host memory declared as device memory is refused with ROFT_ERR_INVALID instead of
+ * faulting on the GPU; later submits trust the caller (the look-up costs microseconds per pointer). */
 #define ROFT_MEM_HOST 0
 #define ROFT_MEM_DEVICE 1
 

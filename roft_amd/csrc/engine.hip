@@ -1004,12 +1004,21 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
                     static const char* const what[3] = {"depth", "flow", "mask"};
                     for (int q = 0; q < 3; ++q) {
                         if (!ptrs[q]) continue;
+                        // device or managed memory, or host memory the GPU can address as it is (hipHostMalloc / hipHostRegister:
+                        // pinned and mapped -- zero-copy over the bus); unregistered pageable memory is what is refused
                         hipPointerAttribute_t attr{};
                         const hipError_t pe = hipPointerGetAttributes(&attr, ptrs[q]);
                         if (pe != hipSuccess) (void)hipGetLastError();
-                        if (pe != hipSuccess || (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged))
+                        bool usable = pe == hipSuccess && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+                        if (!usable && pe == hipSuccess && attr.type == hipMemoryTypeHost) {
+                            void* dp = nullptr;
+                            usable = hipHostGetDevicePointer(&dp, const_cast<void*>(ptrs[q]), 0) == hipSuccess && dp == ptrs[q];
+                            if (!usable) (void)hipGetLastError();
+                        }
+                        if (!usable)
                             return fail(ROFT_ERR_INVALID, std::string("mem_kind is ROFT_MEM_DEVICE but the ") + what[q] + " pointer of object " +
-                                                              std::to_string(id) + " is not device memory (pass ROFT_MEM_HOST for host buffers)");
+                                                              std::to_string(id) + " is neither device memory nor pinned, mapped host memory "
+                                                              "(pass ROFT_MEM_HOST for ordinary host buffers)");
                     }
                 }
                 if ((reinterpret_cast<uintptr_t>(d_mask) & 15) || (reinterpret_cast<uintptr_t>(d_flow) & 7) ||
@@ -1523,6 +1532,10 @@ void* roft_engine_stream(roft_engine* e) { return e ? (void*)e->stream : nullptr
 int roft_engine_enable_timing(roft_engine* e, int enable)
 {
     if (!e) return fail(ROFT_ERR_INVALID, "null engine");
+    // (the engine's device, not whatever device is current on this thread: the span buffer, the events and the priming
+    //  dispatch below belong to it -- and nothing of a batch in flight may see the timing state change under it)
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (int rc = roft_sync(e)) return rc;
     e->timing = enable != 0;
     e->timing_level = (enable == 1) ? 1 : 2;
     if (e->timing) {

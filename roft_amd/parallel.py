@@ -65,20 +65,42 @@ def broadcast_frames(tensors, src=0):
         dist.broadcast(t, src=src)
 
 
-def gather_records(records, device="cpu"):
+class GatherPlan:
+    """What an all-gather of per-rank record blocks needs to know about the other ranks, exchanged ONCE (outside any timed
+    region): every rank's number of rows (the block partition may be uneven) and the padded receive buffers."""
+
+    def __init__(self, counts, row_shape, device):
+        self.counts = [int(c) for c in counts]
+        self.row_shape = tuple(int(x) for x in row_shape)
+        self.device = device
+        self.pad = max(self.counts) if self.counts else 0
+        self.send = torch.zeros((self.pad,) + self.row_shape, dtype=torch.float64, device=device)
+        self.recv = [torch.empty_like(self.send) for _ in self.counts]
+
+
+def gather_plan(n_local, row_shape, device="cpu"):
+    """Exchanges the shard sizes (one small all-gather + a host read-back: do this before the clock starts) and allocates the
+    buffers of later gather_records(..., plan=...) calls for records of shape [n_local, *row_shape]."""
+    if not dist.is_initialized():
+        return GatherPlan([n_local], row_shape, device)
+    world = dist.get_world_size()
+    n = torch.tensor([int(n_local)], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n)
+    return GatherPlan([int(c.item()) for c in counts], row_shape, device)
+
+
+def gather_records(records, device="cpu", plan=None):
     """All-gather [n_local, ...] float64 records (19 doubles per object-frame in the reference's logs) along the first
-    axis; the shards may differ in n_local (block partition of an object count the ranks do not divide)."""
+    axis; the shards may differ in n_local (block partition of an object count the ranks do not divide).  With a `plan`
+    (gather_plan) the call is ONE collective on preallocated buffers and no host synchronisation -- what a timed region
+    should contain; without one the shard sizes are exchanged first."""
     records = records.to(device=device, dtype=torch.float64).contiguous()
     if not dist.is_initialized():
         return records
-    world = dist.get_world_size()
-    n = torch.tensor([records.shape[0]], dtype=torch.int64, device=device)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
-    pad = max(counts)
-    buf = torch.zeros((pad,) + tuple(records.shape[1:]), dtype=torch.float64, device=device)
-    buf[:records.shape[0]] = records
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    return torch.cat([o[:c] for o, c in zip(out, counts)], 0)
+    if plan is None:
+        plan = gather_plan(records.shape[0], records.shape[1:], device)
+    assert tuple(records.shape[1:]) == plan.row_shape and records.shape[0] <= plan.pad, (records.shape, plan.row_shape, plan.pad)
+    plan.send[:records.shape[0]] = records
+    dist.all_gather(plan.recv, plan.send)
+    return torch.cat([o[:c] for o, c in zip(plan.recv, plan.counts)], 0)

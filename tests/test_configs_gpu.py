@@ -133,3 +133,25 @@ def test_config5_full_length_properties(config5_streams, monkeypatch):
     print('config5 position error vs GT: median %.4f p99 %.4f max %.4f; outlier tests %d rejected %d' % (np.median(err), np.quantile(err, 0.99), err.max(), (sel >= 0).sum(), (sel == 1).sum()))
     assert np.median(err) < 0.02 and np.quantile(err, 0.99) < 0.10
     assert stats["frames"] == n and stats["launches"] / n < 4.0
+
+
+def test_cholesky_guard_defaults_stay_inside_the_parity_tolerance(config5_streams):
+    """roft_config::ukf_cholesky_guard / ukf_cholesky_guard_bilinear are PARITY parameters, not only throughput knobs: while
+    they hold, the sigma points come from the Cholesky factor where the reference (bfl) draws them from U sqrt(S), which shows
+    in fourth-order terms of the unscented transform only (roft_engine.h).  At the SHIPPED defaults the trajectories of
+    configs #3 and #5 over their first 600 frames must stay within 1e-9 (m, m/s, rad/s, quaternion components) of the run
+    with the guard at 0 -- always the eigen-decomposition, the reference's square root -- with every flow point count and
+    every outlier decision identical.  A change of the defaults that drifts past the stated tolerance fails here."""
+    from roft_amd import engine as E
+    d = E.default_config(1280, 720, synth.FLOW_S16C2)
+    assert d.ukf_cholesky_guard > 0.0 and d.ukf_cholesky_guard_bilinear > 0.0     # the defaults are what is pinned
+    n = 600
+    cfg3 = [shape_b_stream(3000 + i, i, period=N5_PERIOD, n_schedule=n) for i in range(5)]
+    for name, sts in (("#3", cfg3), ("#5", config5_streams)):
+        a, _ma, _ = util.run_engine_logged(make_engine, sts, n, T=6)
+        b, _mb, _ = util.run_engine_logged(make_engine, sts, n, T=6, ukf_cholesky_guard=0.0, ukf_cholesky_guard_bilinear=0.0)
+        assert np.array_equal(a[2], b[2]), name                     # N of the velocity stage
+        assert np.array_equal(a[3], b[3]), name                     # outlier decisions
+        gap = max(np.abs(a[0] - b[0]).max(), np.abs(a[1] - b[1]).max())
+        print("config %s: max |default guard - eigen| over %d frames x %d objects = %.3g" % (name, n, len(sts), gap))
+        assert gap <= 1e-9, (name, gap)

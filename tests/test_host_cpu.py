@@ -267,3 +267,22 @@ def test_batch_planners_cover_the_frames_once_and_end_with_the_pose_arrivals():
         if period <= T:
             for k0, t in plan[:-1]:   # (the last batch ends where the frames end)
                 assert (k0 + t - 1) % period == phase, (first, last, T, period, phase, plan)
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """`--gpus N` is a statement about the job: under a launcher whose WORLD_SIZE differs bench.py exits non-zero with the
+    reason (before it imports torch) instead of printing a line whose n_gpus is not what the caller asked for."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "WORLD_SIZE=2" in r.stderr and "--gpus 4" in r.stderr
+    assert r.stdout.strip() == ""
+
+
+def test_bench_gpus_n_starts_its_own_ranks_and_relays_their_exit_code():
+    """`python bench.py --gpus 2` without a launcher starts torch.distributed.run itself (a child process, two ranks).  Here,
+    without a GPU, both ranks stop at their device check: the parent relays the failure and the reason reaches stderr."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs GPU" in r.stderr and "rank 1" in r.stderr

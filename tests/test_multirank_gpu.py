@@ -15,12 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def run_bench(tmp_path, n_ranks, tag, port, extra=()):
+def run_bench(tmp_path, n_ranks, tag, port, extra=(), launcher=True):
     out = str(tmp_path / ("rows_%s.npy" % tag))
     args = ["bench.py", "--gpus", str(n_ranks), "--steps", "14", "--warmup", "4", "--objects", "5", "--no-cpu-baseline",
             "--pcie-frames", "0", "--no-extras", "--no-kernel-timing", "--rehearsal-ms", "0", "--dump-rows", out] + list(extra)
     env = dict(os.environ, ROFT_BENCH_DEVICE="0", ROFT_BENCH_BACKEND="gloo")
-    if n_ranks > 1:
+    if n_ranks > 1 and launcher:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
                "--master-addr", "127.0.0.1", "--master-port", str(port)] + args
     else:
@@ -52,3 +52,21 @@ def test_shared_scene_broadcast_delivers_the_ingest_ranks_frames(tmp_path):
     assert one["shared_scene"]["broadcast_MB_per_step"] == 0.0
     assert np.array_equal(rows1, rows2)
     assert np.array_equal(rows2[0], rows2[4])                      # the same scene and object model for every tracker
+
+
+def test_gpus_n_without_a_launcher_starts_the_ranks_itself(tmp_path):
+    """`python bench.py --gpus 2`, no torch.distributed.run around it: bench.py starts the two ranks as a child process (before
+    it touches the GPU), relays rank 0's line -- n_gpus 2, the block partition, the gathered rows of both ranks."""
+    env_clean = {k: os.environ[k] for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK") if k in os.environ}
+    for k in env_clean:
+        del os.environ[k]
+    try:
+        two, rows2 = run_bench(tmp_path, 2, "self", 0, launcher=False)
+    finally:
+        os.environ.update(env_clean)
+    assert two["n_gpus"] == 2 and two["config"]["ranks"] == 2
+    assert two["config"]["objects_total"] == 5 and two["config"]["objects_per_gpu"] == 3
+    assert two["timed_frames_first_touch"] is True
+    assert rows2.shape == (5, 14, 19) and np.isfinite(rows2).all()
+    one, rows1 = run_bench(tmp_path, 1, "self1", 0)
+    assert np.array_equal(rows1, rows2)
