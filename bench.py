@@ -450,7 +450,9 @@ def main():
             del dummy
         torch.cuda.synchronize()
     if not args.no_kernel_timing:
-        eng.enable_timing(1)   # a start/stop HIP event pair on the roofline kernel's own dispatch, nothing else
+        # a start/stop HIP event pair on the roofline kernel's own dispatch, nothing else (ROFT_BENCH_FULL_TIMING=1: a mark after
+        # every launch group of the timed region -- with ROFT_DUMP_MARKS=<file> the profiler-free timeline of the run)
+        eng.enable_timing(2 if os.environ.get("ROFT_BENCH_FULL_TIMING") == "1" else 1)
     stats0 = eng.stats()
     barrier()
     torch.cuda.synchronize()
@@ -748,7 +750,7 @@ def main():
         # HBM traffic of this kernel: a separate rocprofv3 --pmc pass of this same command, committed under profiles/
         # (see profiles/README.md for the gfx950 counting caveats); only quoted when the workload matches that pass
         traffic, traffic_raw, traffic_source = None, None, None
-        for tag in ("r03", "r02"):
+        for tag in ("r04", "r03", "r02"):
             pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_k1.json" % tag)
             if not os.path.exists(pmc_path):
                 continue
@@ -825,6 +827,54 @@ def main():
         roofline["alone"] = dict(k1_alone, frac=bytes_per_obj * k1_alone["object_frames_per_launch"] / (k1_alone["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  note="the same kernel with every batch waited for before the next one is submitted (nothing of another "
                                       "batch on the device): what the launch costs by itself; `frac` above is the figure of record")
+    # ---- the other kernels of the path, priced (SURVEY 8d "other kernels -- reported"): declared bytes per launch group, the
+    #      duration of the group in the 24 frames behind the timed region (HIP event marks, all chains running), GB/s, and the
+    #      HBM bytes of the same kernels from the committed --pmc passes (FETCH_SIZE / WRITE_SIZE per dispatch)
+    roofline_other = None
+    if kernels:
+        e_b = 8 if ftype == synth.FLOW_F32C2 else 4
+        plane_b = cam.width * cam.height // 8
+        mask_px_o = float(np.mean([float((st.mask_gt[:n_timed_end] > 0).sum().item()) / max(n_timed_end, 1) for st in streams]))
+        n_feat = mask_px_o / 2.0
+        flows_per_frame = (period - 1 + min(period, 6)) / float(period) if period > 0 else 1.0   # one flow per frame, `period` on the frame a mask arrives
+        nv = float(np.mean([st.mesh[0].shape[0] for st in streams]))
+        nt = float(np.mean([st.mesh[1].shape[0] for st in streams]))
+        declared = {
+            # source plane (both candidates are fetched: the last propagated mask and the delivered one) + flow at the mask's
+            # pixels + the zeroed slot of the frame after + the OR flush (read-modify-write of the touched words)
+            "mask_frames": dict(per="object-frame", bytes=2 * plane_b + e_b * mask_px_o * flows_per_frame / (g * g) + plane_b + mask_px_o / 2.0,
+                                mark="mask_chain", frames_per_group=float(np.mean([t for _k0, t in extra_splits])) if extra_splits else 1.0),
+            # plane + one depth sample per feature + the (pixel, depth) list written
+            "features": dict(per="object and pose frame", bytes=plane_b + 4 * n_feat + 8 * n_feat, mark="features", frames_per_group=1.0),
+            # per alternative: vertices + triangle indices + the feature list
+            "outlier_fused": dict(per="object and test", bytes=2 * (12 * nv + 12 * nt + 8 * n_feat), mark="outlier_render_likelihood", frames_per_group=1.0),
+        }
+        pmc = {}
+        for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+            path = os.path.join(ROOT, "profiles", "r04_pmc_%s.csv" % cname)
+            if os.path.exists(path):
+                import csv as _csv
+                for r in _csv.DictReader(open(path)):
+                    pmc[(r["kernel"].split("::")[-1].split("<")[0], cname)] = (float(r["mean_value_per_dispatch"]) * 1024.0, int(r["dispatches"]))
+        kmap = {"mask_frames": "mask_frame_kernel", "features": "features_kernel", "outlier_fused": "outlier_fused_kernel"}
+        roofline_other = {}
+        for name, dsc in declared.items():
+            mk = kernels.get(dsc["mark"])
+            ent = dict(declared_bytes=dsc["bytes"], per=dsc["per"])
+            if mk and mk["marks"]:
+                group_bytes = dsc["bytes"] * n_obj * dsc["frames_per_group"]
+                ent.update(avg_us_per_launch_group=mk["avg_us"], launch_groups=mk["marks"], declared_bytes_per_launch_group=group_bytes,
+                           achieved_GBs=group_bytes / (mk["avg_us"] * 1e-6) / 1e9, frac_of_hbm_peak=group_bytes / (mk["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
+            for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+                if (kmap[name], cname) in pmc:
+                    ent[cname.lower() + "_bytes_per_dispatch"] = pmc[(kmap[name], cname)][0]
+            roofline_other[name] = ent
+        roofline_other["note"] = ("declared = algorithmic bytes of the kernel (DESIGN.md section 5); durations = HIP event marks around the launch "
+                                  "group in the frames behind the timed region, all chains running (mask_frames: the T frame kernels of a batch + "
+                                  "mask_general); fetch / write = profiles/r04_pmc_{FETCH,WRITE}_SIZE.csv (separate rocprofv3 --pmc passes, bytes "
+                                  "per dispatch: one frame of all objects for mask_frame_kernel).  None of these kernels is bandwidth-bound: they "
+                                  "are chains of dependent round trips over a few hundred KB per object (latency), the rasteriser is bound by "
+                                  "VALU issue on its CU; the CU x us budget of the pipeline is profiles/r04_cu_budget.csv")
     dominant = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])[0] if kernels else None
     d_frames = max(stats1["frames"] - stats0["frames"], 1)
 
@@ -867,6 +917,7 @@ def main():
         "launches_per_frame": (stats1["launches"] - stats0["launches"]) / d_frames,
         "event_ops_per_frame": (stats1["event_ops"] - stats0["event_ops"]) / d_frames,
         "roofline": roofline,
+        "roofline_other": roofline_other,
         "cpu_baseline": cpu,
         "cpu_baseline_multicore": cpu_multi,
         "speedup_vs_cpu_1core": (value / cpu["value"]) if cpu else None,
@@ -881,8 +932,9 @@ def main():
         "adds_vs_cpu_ref_mm": ({"mean": 1e3 * float(adds_cpu.mean()), "max": 1e3 * float(adds_cpu.max())}
                                if adds_cpu is not None else None),
         "rmse_vs_gt": rmse,
-        "pipeline": "three HIP streams per engine (mask / velocity / pose chains), one persistent per-object kernel per chain "
-                    "and batch, up to 5 batches in flight",
+        "pipeline": "four HIP streams per engine (mask frames / velocity chain / two pose lanes): one mask kernel per frame (small "
+                    "workgroups, nothing persistent), one per-object kernel per batch for the velocity filter and per segment for a pose "
+                    "lane, twists handed from the velocity filter to the lanes frame by frame in bursts, up to 5 batches in flight",
         "kernels_post_run_breakdown": kernels,
         "dominant_kernel": dominant,
         "stream_generation_s": t_gen,

@@ -212,13 +212,13 @@ typedef struct {
     /* largest number of frames one roft_frames_submit may carry (1 .. ROFT_MAX_BATCH_FRAMES; 0 means 1).  Sizes the
      * engine's rings and, for zero-copy DEVICE inputs, the retention window (roft_engine_retain_frames). */
     int max_batch_frames;
-    /* Workgroups one object's mask propagation is spread over inside the persistent mask chain kernel (1..8; 0 = chosen
-     * from the device: (3/4 of its CUs) / max_objects).  With more than one, the workgroups of an object meet at a barrier
-     * in device memory between two frames, which needs all of them -- mask_workgroups_per_object x n_objects, each filling
-     * a CU -- resident at the same time.  That holds for one engine on a device of its own; several engines or processes
-     * running on ONE device at once should set 1 (no barrier).  A barrier that cannot complete is abandoned after ~2 s:
-     * the batch's results are invalid and the next roft_sync / roft_get_* / roft_frames_submit returns ROFT_ERR_DEVICE
-     * ("mask chain barrier timed out"); the process is not aborted. */
+    /* Bands (workgroups) the mask bit plane of an object is split over in the kernel that propagates the masks of one frame
+     * (1..8; 0 = chosen by the engine: bands of ~20 image rows, a third of that on frames that deliver a mask).  A band is a
+     * small workgroup -- four waves, a few KB of LDS -- that lives for one frame: nothing is persistent and no workgroup ever
+     * waits for another one, so any number of engines and processes may share a device.  The propagation is an order-free OR:
+     * the number of bands changes no bit of the masks (tests/test_batch_gpu.py).  (Rounds 2 - 3 walked a batch in one
+     * persistent kernel whose workgroups met at a barrier in device memory and had to be resident together; the value then
+     * had to be 1 for engines sharing a device.) */
     int mask_workgroups_per_object;
     /* Workgroups one alternative of an outlier test is rendered by: horizontal bands of the object's window, 1 .. 8; 0 = chosen
      * by the engine: from the device (CUs / (2 x max_objects), 2 for 64 objects on 256 CUs), and half of that while the host runs

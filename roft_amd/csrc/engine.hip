@@ -155,11 +155,12 @@ struct Arrays {
     DevBuf<double> norms;
     DevBuf<int> npts;
     DevBuf<MaskRec> mrec;
-    DevBuf<unsigned> mask_sync, mask_general;
+    DevBuf<unsigned> mask_general;
     DevBuf<uint32_t> feat_pix;
     DevBuf<float> feat_depth;
     DevBuf<uint32_t> zbuf;
     DevBuf<roft_object_output> log;
+    DevBuf<unsigned long long> skf_started;
 
     int alloc(int n_obj, int T, const DevCamera& cam, const DevFlowFmt& ffmt, int radius)
     {
@@ -178,7 +179,6 @@ struct Arrays {
         HIP_TRY(ctrl.ensure((size_t)n_obj * T, true));
         HIP_TRY(planes.ensure((size_t)n_obj * kPlaneSlotsTotal * 2 * a.plane_words, true));
         HIP_TRY(mrec.ensure((size_t)2 * n_obj * (kMaxBatch + 1), true));   // two tables (batch parity)
-        HIP_TRY(mask_sync.ensure((size_t)2 * n_obj, true));
         HIP_TRY(mask_general.ensure(n_obj, true));
         HIP_TRY(map.ensure((size_t)n_obj * npix, true));
         HIP_TRY(cand.ensure((size_t)n_obj * T * a.cand_cap));
@@ -190,7 +190,7 @@ struct Arrays {
         HIP_TRY(zbuf.ensure((size_t)2 * a.tile_w * a.tile_h));   // operator level only (roft_depth_likelihood)
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
         a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.mrec = mrec.p;
-        a.mask_sync = mask_sync.p; a.mask_general = mask_general.p;
+        a.mask_general = mask_general.p;
         a.mrec_carry = mrec.p; a.slot_new = kSlotNew; a.slot_prev0 = -1; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
         a.zbuf = zbuf.p;
         a.out_log = nullptr;
@@ -203,6 +203,9 @@ struct Arrays {
         a.outlier_parts = 0;
         a.dev_error = nullptr;
         a.k1_span = nullptr;
+        HIP_TRY(skf_started.ensure(1, true));
+        a.skf_started = nullptr;   // (the batched engine sets it; the operator level runs its kernels one after the other)
+        a.handoff = 0;
         return ROFT_OK;
     }
 };
@@ -231,7 +234,7 @@ void clear_ctrl(FrameCtrl& c)
 // writes the device copy, so the control blocks of a batch travel in-order on the compute queue instead of
 // through an SDMA copy with its cross-engine signalling.
 // Control blocks of a batch: pinned host staging -> device, and the reset of what the batch's mask chain accumulates
-// into (ingest counters, barrier arrivals) on the way.  (a.ctrl, a.mrec, a.mask_sync: this batch's.)
+// into (ingest counters, the bits of the frames left to mask_general_kernel) on the way.  (a.ctrl, a.mrec: this batch's.)
 __global__ void ctrl_upload_kernel(const uint4* __restrict__ src, EngineArrays a, size_t n16)
 {
     uint4* dst = reinterpret_cast<uint4*>(a.ctrl);
@@ -388,6 +391,13 @@ struct roft_engine {
     roft_engine_stats stats{};
     bool device_pointers_checked = false;   // ROFT_MEM_DEVICE inputs are looked up once, on the first submit
     bool throttled = false;   // the submit of the current batch had to wait for the in-flight bound: the device is `lead` batches behind
+    // Frame-granular hand-over velocity filter -> pose lanes (EngineArrays::handoff).  handoff_mode: 0 never, 1 while the host is
+    // not throttled by the in-flight bound (bursts: the pipeline is filling or draining and latency is what counts), 2 always.
+    int handoff_mode = 1;
+    bool feat_dep_in_batch = false;        // an outlier test of the batch reads features buffered by a frame of the same batch
+    unsigned long long skf_total = 0;      // velocity-filter workgroups launched so far (the value the lanes' gates wait for)
+    bool vel_used[kBatchRing] = {};        // the batch's velocity chain ended with ev_vel (wait_batch waits for it as well)
+    std::vector<int> feat_batch;           // [objects][kFeatRing] batch that last wrote each feature set (-1: none)
     // timing
     bool timing = false;
     int timing_level = 2;   // 1: only flow_measure_kernel (two events per batch), 2: every launch group
@@ -417,9 +427,9 @@ static int check_dev_error(roft_engine* e)
 {
     const int code = e->dev_error ? *reinterpret_cast<volatile int*>(e->dev_error) : 0;
     if (code == 0) return ROFT_OK;
-    if (code == ROFT_DEV_ERROR_MASK_BARRIER)
-        return fail(ROFT_ERR_DEVICE, "mask chain barrier timed out: the workgroups of an object never became resident together "
-                                     "(several engines on one device? set roft_config::mask_workgroups_per_object = 1)");
+    if (code == ROFT_DEV_ERROR_TWIST_WAIT)
+        return fail(ROFT_ERR_DEVICE, "a pose lane waited two seconds for a twist of the velocity filter it runs next to and gave up "
+                                     "(frame-granular hand-over; ROFT_HANDOFF=0 disables it): the results of the batch are invalid");
     return fail(ROFT_ERR_DEVICE, "a kernel reported error " + std::to_string(code));
 }
 
@@ -428,6 +438,12 @@ static int wait_batch(roft_engine* e, int b, bool* waited = nullptr)
 {
     if (waited) *waited = false;
     if (b < e->completed_batches || b >= e->batch_counter) return ROFT_OK;
+    // (with the frame-granular hand-over a pose lane can end before the features kernel behind the velocity filter does)
+    if (e->vel_used[b % roft_engine::kBatchRing]) {
+        if (waited && hipEventQuery(e->ev_vel[b % roft_engine::kBatchRing]) == hipErrorNotReady) *waited = true;
+        (void)hipGetLastError();
+        HIP_TRY(hipEventSynchronize(e->ev_vel[b % roft_engine::kBatchRing]));
+    }
     for (int l = 0; l < kNumLin; ++l)
         if (e->done_used[b % roft_engine::kBatchRing][l]) {
             if (waited && hipEventQuery(e->ev_done[b % roft_engine::kBatchRing][l]) == hipErrorNotReady) *waited = true;
@@ -516,39 +532,49 @@ int roft_engine_destroy(roft_engine* e);
 struct StreamSet {
     hipStream_t mask = nullptr, vel = nullptr, pose[kNumLin] = {nullptr, nullptr}, up = nullptr;
     int device = 0;
-    bool priorities = true, busy = false;
-    bool parked = false;   // its busy streams share a hardware queue: kept alive (it shifts the runtime's round robin), never handed out
-    int conflicts = 0;     // pairs of busy streams on one hardware queue when the set was created
+    bool priorities = true;
+    bool in_use = false;   // handed to an engine
+    bool parked = false;   // its busy streams share a hardware queue: kept alive (it shifts the runtime's round robin), handed out only
+                           // when the device's cap of sets is reached
+    int conflicts = 0;     // pairs of busy streams on one hardware queue when the set was created (-1: not probed)
 };
 static std::mutex g_stream_mu;
 static std::vector<StreamSet*> g_stream_sets;
+constexpr int kMaxStreamSetsPerDevice = 12;   // 60 streams: what a process ever creates per device, however many engines it builds
 
 // Microseconds until a one-workgroup kernel on `b` completes while `a` is placing a grid three times the size of the device
-// (one 150 KB-LDS workgroup per CU at a time, 100 us each): ~15 when the streams have hardware queues of their own, >= 80
-// when the runtime mapped them onto ONE queue -- b's packet then waits until a's dispatch has been placed completely.
+// (one 150 KB-LDS workgroup per CU at a time, 100 us each): the host's launch + wait latency (~15) when the streams have
+// hardware queues of their own, >= 100 more when the runtime mapped them onto ONE queue -- b's packet then waits until a's
+// dispatch has been placed completely.  a == nullptr: the same without the blocker (the base line of this host, now).
 static double probe_pair_us(hipStream_t a, hipStream_t b, int* flag)
 {
-    (void)hipStreamSynchronize(a);
+    if (a) (void)hipStreamSynchronize(a);
     (void)hipStreamSynchronize(b);
     const double t0 = host_now_us();
-    hipLaunchKernelGGL(probe_blocker_kernel, dim3(3 * device_cu_count()), dim3(64), 150 * 1024, a, 10000ll);
+    if (a) hipLaunchKernelGGL(probe_blocker_kernel, dim3(3 * device_cu_count()), dim3(64), 150 * 1024, a, 10000ll);
     hipLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, b, flag);
     (void)hipStreamSynchronize(b);
     const double dt = host_now_us() - t0;
-    (void)hipStreamSynchronize(a);
+    if (a) (void)hipStreamSynchronize(a);
     return dt;
 }
 
-// number of pairs among the four busy chains' streams (pose lanes, velocity, mask) that share a hardware queue
+// number of pairs among the four busy chains' streams (pose lanes, velocity, mask) that share a hardware queue.  The
+// threshold follows the host: the best of three launches of the one-workgroup kernel alone is the base line (a loaded host
+// core reads 30 - 40 us where an idle one reads 12), a pair counts as sharing a queue at base line + 60 us (the blocker
+// holds a shared queue for >= 100 us) in both of two tries.
 static int stream_conflicts(const StreamSet* s, int* flag)
 {
     hipStream_t st[4] = {s->pose[0], s->pose[1], s->vel, s->mask};
+    double base = 1e30;
+    for (int i = 0; i < 3; ++i) base = std::min(base, probe_pair_us(nullptr, st[i], flag));
+    const double thr = base + 60.0;
     int n = 0;
     for (int a = 0; a < 4; ++a)
         for (int b = a + 1; b < 4; ++b) {
             double us = probe_pair_us(st[a], st[b], flag);
-            if (us >= 50.0) us = std::min(us, probe_pair_us(st[a], st[b], flag));   // (a slow host call is not a conflict)
-            if (us >= 50.0) ++n;
+            if (us >= thr) us = std::min(us, probe_pair_us(st[a], st[b], flag));   // (a slow host call is not a conflict)
+            if (us >= thr) ++n;
         }
     return n;
 }
@@ -559,17 +585,21 @@ static int create_stream_set(int device, bool priorities, StreamSet** out)
     s->device = device;
     s->priorities = priorities;
     // Priorities (measured): the velocity chain -- short kernels every other chain waits for -- high, the
-    // mask chain -- 192 whole-CU workgroups that would starve everybody -- low, the pose lanes in between.  The lanes spend
+    // mask chain low, the pose lanes in between.  The lanes spend
     // most of a short run WAITING for events of the velocity chain; with the lanes on the high-priority queues (rounds 1 and
     // 2) the 20-frame run of the driver tracked 10 % slower (8.4e5 against 9.3e5 object-frames/s), longer runs the same.
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (!priorities) greatest = least;
     const int normal = (least + greatest) / 2;
+    // (ROFT_PRIO=<lane 0><lane 1><velocity><mask>, each h | n | l: experiments)
+    int pr[4] = {normal, normal, greatest, least};
+    if (const char* pe = getenv("ROFT_PRIO"))
+        for (int i = 0; i < 4 && pe[i]; ++i) pr[i] = pe[i] == 'h' ? greatest : (pe[i] == 'l' ? least : normal);
     hipError_t err = hipSuccess;
-    for (int l = 0; l < kNumLin && err == hipSuccess; ++l) err = hipStreamCreateWithPriority(&s->pose[l], hipStreamNonBlocking, normal);
-    if (err == hipSuccess) err = hipStreamCreateWithPriority(&s->vel, hipStreamNonBlocking, greatest);
-    if (err == hipSuccess) err = hipStreamCreateWithPriority(&s->mask, hipStreamNonBlocking, least);
+    for (int l = 0; l < kNumLin && err == hipSuccess; ++l) err = hipStreamCreateWithPriority(&s->pose[l], hipStreamNonBlocking, pr[l]);
+    if (err == hipSuccess) err = hipStreamCreateWithPriority(&s->vel, hipStreamNonBlocking, pr[2]);
+    if (err == hipSuccess) err = hipStreamCreateWithPriority(&s->mask, hipStreamNonBlocking, pr[3]);
     if (err == hipSuccess) err = hipStreamCreateWithFlags(&s->up, hipStreamNonBlocking);
     if (err != hipSuccess) { delete s; return fail(ROFT_ERR_DEVICE, std::string("stream creation: ") + hipGetErrorString(err)); }
     *out = s;
@@ -583,33 +613,61 @@ static int create_stream_set(int device, bool priorities, StreamSet** out)
 // object-frames/s with three streams created ahead of the engine's, 7.7e5 for the third engine of a process.  So a new set is
 // probed (stream_conflicts, ~3 ms), and while two of its busy streams share a queue the set is parked -- its streams stay
 // alive and shift the round robin -- and another one is created (at most four times; the least bad one is used then).
+// The probe measures time on a device it assumes idle: it is skipped while another engine of this process has work in flight
+// on the device (that engine would read as conflicts on every pair, and would see the probe's whole-device blocker grids in
+// its pipeline) and with ROFT_NO_STREAM_PROBE=1.  A process never holds more than kMaxStreamSetsPerDevice sets per device: beyond
+// that, free sets -- parked ones included, least conflicts first -- are handed out again.
 static int acquire_streams(int device, bool priorities, StreamSet** out)
 {
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    for (StreamSet* s : g_stream_sets)
-        if (!s->busy && s->device == device && s->priorities == priorities) { s->busy = true; *out = s; return ROFT_OK; }
-    const char* np = getenv("ROFT_NO_STREAM_PROBE");
-    const bool probe = !(np && np[0] == '1');
-    DevBuf<int> flag;
-    if (probe) {
-        HIP_TRY(flag.ensure(1));
-        HIP_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(probe_blocker_kernel), 150 * 1024));
+    int n_dev = 0;
+    bool other_busy = false;   // another engine of this process has work in flight on the device
+    for (StreamSet* s : g_stream_sets) {
+        if (s->device != device) continue;
+        ++n_dev;
+        if (!s->in_use) continue;
+        for (hipStream_t q : {s->pose[0], s->pose[1], s->vel, s->mask, s->up})
+            if (hipStreamQuery(q) != hipSuccess) other_busy = true;
+        (void)hipGetLastError();   // (hipErrorNotReady is an answer, not an error)
     }
-    StreamSet* best = nullptr;
-    int best_conflicts = 1 << 30;
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (StreamSet* s : g_stream_sets)
+        if (!s->in_use && !s->parked && s->device == device && s->priorities == priorities) { s->in_use = true; *out = s; return ROFT_OK; }
+    if (n_dev >= kMaxStreamSetsPerDevice) {
+        StreamSet* best = nullptr;
+        for (StreamSet* s : g_stream_sets)
+            if (!s->in_use && s->device == device && s->priorities == priorities && (!best || s->conflicts < best->conflicts)) best = s;
+        if (best) { best->in_use = true; *out = best; return ROFT_OK; }
+    }
+    const char* np = getenv("ROFT_NO_STREAM_PROBE");
+    const bool probe = !(np && np[0] == '1') && !other_busy && n_dev < kMaxStreamSetsPerDevice;
+    if (!probe) {
         StreamSet* s = nullptr;
         if (int rc = create_stream_set(device, priorities, &s)) return rc;
-        const int c = probe ? stream_conflicts(s, flag.p) : 0;
+        s->conflicts = -1;
+        s->in_use = true;
+        g_stream_sets.push_back(s);
+        *out = s;
+        return ROFT_OK;
+    }
+    DevBuf<int> flag;
+    HIP_TRY(flag.ensure(1));
+    HIP_TRY(set_max_dynamic_lds(reinterpret_cast<const void*>(probe_blocker_kernel), 150 * 1024));
+    StreamSet* best = nullptr;
+    int best_conflicts = 1 << 30;
+    for (int attempt = 0; attempt < 4 && n_dev < kMaxStreamSetsPerDevice; ++attempt, ++n_dev) {
+        StreamSet* s = nullptr;
+        if (int rc = create_stream_set(device, priorities, &s)) return rc;
+        const int c = stream_conflicts(s, flag.p);
         s->conflicts = c;
+        if (getenv("ROFT_STREAM_DEBUG")) std::fprintf(stderr, "[roft streams] device %d attempt %d: %d conflicting pairs\n", device, attempt, c);
         if (c < best_conflicts) { best = s; best_conflicts = c; }
-        s->busy = true;                 // parked unless chosen below
-        s->parked = true;
+        s->parked = true;               // unless chosen below
         g_stream_sets.push_back(s);
         if (c == 0) break;
     }
     (void)hipGetLastError();
     best->parked = false;
+    best->in_use = true;
     *out = best;
     return ROFT_OK;
 }
@@ -617,7 +675,7 @@ static int acquire_streams(int device, bool priorities, StreamSet** out)
 static void release_streams(StreamSet* s)
 {
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    if (s) s->busy = false;
+    if (s) s->in_use = false;
 }
 
 static int engine_setup(roft_engine* e, const roft_config* cfg)
@@ -666,6 +724,8 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
     e->arr.a.ukf_chol_guard_bil = (cfg->ukf_cholesky_guard_bilinear > 0.0) ? cfg->ukf_cholesky_guard_bilinear : 0.0;
     e->h_params.resize(cfg->max_objects);
     e->staging.resize(e->retain);
+    if (const char* hm = getenv("ROFT_HANDOFF")) e->handoff_mode = atoi(hm);
+    e->feat_batch.assign((size_t)cfg->max_objects * kFeatRing, -1);
     const char* hpf = getenv("ROFT_HOST_PROF");
     e->host_prof = hpf && hpf[0] == '1';
     return ROFT_OK;
@@ -1126,7 +1186,10 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
             o.last_touch[o.cur_slot] = b;
             if (c.outlier_step >= 0)
                 max_outliers[c.lane] = std::max(max_outliers[c.lane], ++n_outliers[(size_t)id * kNumLin + c.lane]);
+            if (c.outlier_step >= 0 && c.feat_read >= 0 && c.feat_read != c.feat_write &&
+                e->feat_batch[(size_t)id * kFeatRing + c.feat_read] == b) e->feat_dep_in_batch = true;
             if (c.feat_write >= 0) {
+                e->feat_batch[(size_t)id * kFeatRing + c.feat_write] = b;
                 e->any_feat = true;
                 // a feature set is re-used only when the batch that read or wrote it last has ended
                 const int last = o.feat_use[c.feat_write];
@@ -1156,6 +1219,7 @@ int roft_frames_submit(roft_engine* e, const roft_frame_input* inputs, int n_obj
     e->backup.resize(e->objs.size());
     for (size_t i = 0; i < e->objs.size(); ++i) e->backup[i] = e->objs[i]->s;
     e->any_feat = e->any_feat_now = e->had_uploads = false;
+    e->feat_dep_in_batch = false;
     e->new_mask_frames = 0;
     const int rc = submit_frames(e, inputs, n_objects, n_frames);
     HP_MARK(e, 1, hp_t);
@@ -1261,7 +1325,6 @@ static int step_batch(roft_engine* e)
         a.mrec_carry = e->prev_T > 0 ? base + (1 - par) * table + (size_t)e->prev_T * a.n_obj : a.mrec;
         a.slot_new = kSlotNew + par * kMaxBatch;
         a.slot_prev0 = (e->frame_counter + kPlaneSlots - 1) % kPlaneSlots;   // (submit_frames: slot_prev of every object)
-        a.mask_sync = e->arr.mask_sync.p + (size_t)par * a.n_obj;
     }
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
 
@@ -1287,7 +1350,7 @@ static int step_batch(roft_engine* e)
     HP_MARK(e, 3, hp_t);
     // ---- mask chain: every object's masks frame after frame
     tmark(e, nullptr, 0);
-    launches += launch_mask_chain(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, s,
+    launches += launch_mask_chain(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, e->new_mask_frames, s,
                                   (multi && !full) ? e->ev_mask[slot] : nullptr);
     CHECK_LAUNCH("mask chain");
     tmark(e, "mask_chain", 0);
@@ -1333,6 +1396,17 @@ static int step_batch(roft_engine* e)
         CHECK_LAUNCH("flow measurement");
     }
     const bool feat_last = feat_on_vel && e->any_feat;
+    // Frame-granular hand-over to the pose lanes: their kernels are released when every workgroup of this velocity filter is
+    // resident and take each twist when its tag appears (k_skf.hip / k_ukf.hip), instead of starting behind the filter's last
+    // frame and the features kernel.  Not when an outlier test of the batch reads features buffered by this very batch (they
+    // are extracted behind the filter), not on one stream, and -- by default -- only while the host is not throttled by the
+    // in-flight bound: a lane that waits inside its kernel holds the CU it waits on, which a full pipeline cannot spare.
+    const bool handoff = multi && T > 1 && e->handoff_mode > 0 && !(e->handoff_mode == 1 && e->throttled) &&
+                         !e->feat_dep_in_batch && !e->any_feat_now && e->arr.skf_started.p != nullptr;
+    a.handoff = handoff ? 1 : 0;
+    a.skf_started = e->arr.skf_started.p;
+    e->skf_total += (unsigned long long)a.n_obj;
+    e->vel_used[slot] = multi;
     launch_skf_chain(a, e->cfg.flow_weighting, sv, (multi && !full && !feat_last) ? e->ev_vel[slot] : nullptr);
     ++launches;
     CHECK_LAUNCH("velocity filter chain");
@@ -1361,7 +1435,10 @@ static int step_batch(roft_engine* e)
         }
         if (!e->lin_any[lin]) continue;
         const int which = lin == 0 ? 1 : 3;
-        if (multi) {
+        if (multi && handoff) {
+            HIP_TRY(hipStreamWaitValue64(sp, e->arr.skf_started.p, e->skf_total, hipStreamWaitValueGte, ~0ull));
+            ++evops;
+        } else if (multi) {
             HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[slot], 0));
             ++evops;
             // The pose chain reads mask-chain products only through the feature ring.  With one-frame batches the set an
@@ -1891,7 +1968,7 @@ int roft_mask_propagate(uint8_t* mask, int W, int H, const roft_flow* flows, int
     c.arr.a.mrec_carry = c.arr.mrec.p;   // row 0: rec0[0]
     launch_mask_reset(c.arr.a, c.stream);
     launch_mask_ingest(c.arr.a, 0, c.stream);
-    launch_mask_chain(c.arr.a, frames_between, 1, c.stream);
+    launch_mask_chain(c.arr.a, frames_between, 1, 1u, c.stream);
     HIP_TRY(c.b2.ensure(npix));
     launch_planes_to_mask(c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 0), c.arr.a.planes + plane_offset(c.arr.a, 0, 0, 1),
                           (int)npix, c.b2.p, c.stream);
@@ -2201,6 +2278,8 @@ extern "C" int roft_debug_get_dbg(roft_engine* e, int id, long long out[32])
     hipError_t err = hipMemcpy(st, e->arr.state.p + id, sizeof(ObjState), hipMemcpyDeviceToHost);
     if (err == hipSuccess) std::memcpy(out, st->dbg, sizeof(long long) * 32);
     delete st;
+    // (read and clear: the stamps of the frame kernels are maxima over their workgroups)
+    if (err == hipSuccess) err = hipMemset(reinterpret_cast<char*>(e->arr.state.p + id) + offsetof(ObjState, dbg), 0, sizeof(long long) * 32);
     return err == hipSuccess ? ROFT_OK : ROFT_ERR_DEVICE;
 }
 

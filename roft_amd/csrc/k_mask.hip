@@ -9,22 +9,22 @@
 //   nz  = raw value != 0  (what cv::findNonZero sees inside the OF-aided source)
 //   obj = raw value  > 1  (what every consumer sees after the threshold)
 // The mask of frame k is the source of frame k+1: the recursion is sequential per object and frame.  Per frame of a
-// batch the chain is mask_ingest_kernel on the frames that deliver masks (u8 -> planes, counts), then ONE launch of
-// mask_chain_kernel that walks the frames:
+// batch: mask_ingest_kernel on the frames that deliver masks (u8 -> planes, counts), then ONE launch of mask_frame_kernel per
+// frame:
 //  * binary masks (no pixel of value 1, i.e. nz == obj -- decided on the device at ingest): every source pixel carries
-//    the same value, so the reference's "later writer wins" map + remap is an order-free OR of the target bits.  S
-//    workgroups per object (grid S x n_obj, S * n_obj ~ the CU count) each walk a share of the source's 64-pixel groups,
-//    OR into an LDS plane of their own (W*H/8 bytes, LDS atomics) and flush its non-zero words with global atomicOr into
-//    the destination, which the frame before left zeroed.  No map, no gather; only the obj plane of a
-//    binary mask is written and read.
-//  * general masks ({0, 1, 255}): mask_general_kernel, one persistent workgroup per object at the end of the batch,
+//    the same value, so the reference's "later writer wins" map + remap is an order-free OR of the target bits.  Many small
+//    workgroups per object (grid Q x n_obj, four waves each) walk a band of the source's 64-pixel groups, OR into an LDS
+//    window around the band (LDS atomics) and flush its non-zero words with global atomicOr into the destination, which
+//    the frame before left zeroed.  No map, no gather; only the obj plane of a binary mask is written and read.
+//  * general masks ({0, 1, 255}): mask_general_kernel, one workgroup per object at the end of the batch,
 //    handles the frames whose source is not binary: the winner among the sources of a target is the one with the LARGEST
 //    linear index = an atomicMax on a W*H int32 map whose zero value doubles as "unmapped -> sample mask(0,0)" exactly
 //    like the zero-initialised cv::Mat map (:237); the gather reads every entry inside the targets' bounding box with
 //    an atomic exchange (read + clear), so the map is never memset and never read through a stale L1 line.
-// The per-frame decisions (mode, source, flow count, binary or not) are made once, by the chain kernel, and recorded in
+// The per-frame decisions (mode, source, flow count, binary or not) are made by the frame kernels and recorded in
 // MaskRec rows that carry the state from frame to frame and from batch to batch.
 #include <algorithm>
+#include <cstdlib>
 
 #include "roft_device.h"
 
@@ -142,15 +142,23 @@ void launch_mask_reset(const EngineArrays& a, hipStream_t s)
     hipLaunchKernelGGL(mask_reset_kernel, dim3(((a.T + 1) * a.n_obj + 255) / 256), dim3(256), 0, s, a);
 }
 
-// ---- mask chain ------------------------------------------------------------------------------------
-constexpr int kMaskThreads = 1024;
-constexpr int kMaskWaves = kMaskThreads / 64;
+// ---- mask frames -----------------------------------------------------------------------------------
+// One launch per frame of the batch (mask_frame_kernel), many small workgroups per object, NOTHING persistent: the mask
+// of frame t is the source of frame t + 1, and the kernel boundary between two frames is the hand-over -- plain loads and
+// stores, no barrier in memory among workgroups, no co-residency requirement, no watchdog.  (Rounds 2 - 3 walked the T
+// frames of a batch in ONE persistent launch of 3 x n_obj workgroups of 16 waves that met at a barrier in memory after every
+// frame: each of them filled the register file of its CU for the whole batch -- 192 of 256 CUs held by a latency-bound
+// kernel, half of the chip's CU time, DESIGN.md section 5.  A workgroup here is four waves with a few KB of LDS: it fits
+// next to the filters' workgroups and is gone after a few microseconds.)
+constexpr int kFrameThreads = 256;
+constexpr int kFrameWaves = kFrameThreads / 64;
 // (64-pixel groups whose walks through the flows are in flight together in one wave -- chase_groups' NCH: a pixel's
 //  walk is a chain of dependent loads, the chains of different groups are independent)
 
 struct MaskShared {
     int bbox[4];
     int n_list;
+    unsigned long long w00[2];        // word 0 of the two candidate source planes (mask(0,0): hpp:214-215)
     const void* flows[kMaxFlowHist];
 };
 
@@ -186,12 +194,29 @@ __device__ __forceinline__ int trunc_clamped(float x)
 }
 
 #define ROFT_GLOBAL __attribute__((address_space(1)))
-// Walks of the source pixels of one frame.  `list` (LDS) holds the non-empty 64-pixel groups of the source plane as
+
+// Where the target bits of a workgroup go: an LDS window of plane words [off, off + words) -- the rows of the workgroup's
+// source groups and a margin above and below --, and, for the few pixels that fly further, the destination plane itself.
+struct OrTarget {
+    ROFT_LDS uint32_t* win;     // LDS window (workgroup-uniform address)
+    int off, words;             // first plane word of the window, its length
+    uint32_t* dst;              // destination obj plane in HBM (zeroed by the frame before)
+    __device__ __forceinline__ void hit(int tp) const
+    {
+        const int wi = (tp >> 5) - off;
+        const uint32_t bit = 1u << (tp & 31);
+        if ((unsigned)wi < (unsigned)words) (void)__hip_atomic_fetch_or(win + wi, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else (void)__hip_atomic_fetch_or(dst + (tp >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+// Walks of the source pixels of one frame.  `list` (LDS) holds non-empty 64-pixel groups of the source plane as
 // (row << 16 | column) of their first pixel -- the division by the image width is done once per group by the list
-// pass, one group per thread, instead of by every wave that walks the group; wave w owns entries w, w + 16, ... (the object's rows spread over all waves), prefetches the plane
-// words of up to 64 of them with one load (lane i <-> the wave's i-th entry) and chases them NCH at a time: the
-// flow reads of a wave are row-contiguous (64 x 8 B).  A surviving pixel is handed to `hit(target, x, y, source)`.
-// One CU walks a whole object, so the instruction count per pixel and flow matters as much as the load latency:
+// pass, one group per thread, instead of by every wave that walks the group; wave w of the NW waves owns entries w, w + NW,
+// ... (the object's rows spread over all waves), keeps the plane words of up to 64 of them in its lanes (lane i <-> the
+// wave's i-th entry) and chases them NCH at a time: the flow reads of a wave are row-contiguous (64 x 8 B).  A surviving
+// pixel is handed to `hit(target, x, y, source)`.
+// The instruction count per pixel and flow matters as much as the load latency:
 //  * per-group work (row / column of the group) is wave-uniform;
 //  * a pixel that is not set, or left the image, carries t_x = NaN from then on -- NaN survives every flow addition and
 //    converts to "out of the image", so there is no per-walk activity flag to keep (and a NaN flow drops the pixel the
@@ -199,7 +224,7 @@ __device__ __forceinline__ int trunc_clamped(float x)
 //  * the float -> int conversions are clamps; MODE 2: grid 1 and scale 1 (CV_32FC2), the flow element of a pixel is
 //    the pixel itself; MODE 1: grid and scale are powers of two, the divisions are exact reciprocal multiplies;
 //    MODE 0: true divisions.
-template <int FT, int NCH, int MODE, class Hit>
+template <int FT, int NCH, int MODE, int NW, class Hit>
 __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plane2_, const uint32_t* list, int n_list,
                                              int n_flows, bool clear00, const void* const* flows, Hit hit,
                                              const uint2* words = nullptr)
@@ -208,8 +233,8 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const ROFT_GLOBAL uint2* plane2 = (const ROFT_GLOBAL uint2*)plane2_;
     const float nan = __uint_as_float(0x7FC00000u);
-    for (int e0 = wave; e0 < n_list; e0 += kMaskWaves * 64) {
-        const int my_e = e0 + lane * kMaskWaves;
+    for (int e0 = wave; e0 < n_list; e0 += NW * 64) {
+        const int my_e = e0 + lane * NW;
         uint32_t my_yx = 0u;
         uint2 mine = make_uint2(0u, 0u);
         if (my_e < n_list) {
@@ -218,9 +243,7 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
                 mine = words[my_e];
             } else {
                 const int my_grp = (int)(((my_yx >> 16) * (uint32_t)W + (my_yx & 0xFFFFu)) >> 6);
-                // (agent-coherent: inside the chain kernel the word may come from a workgroup on another XCD)
-                const unsigned long long w = __hip_atomic_load((const ROFT_GLOBAL unsigned long long*)(plane2 + my_grp),
-                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w = *(const ROFT_GLOBAL unsigned long long*)(plane2 + my_grp);
                 mine = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
             }
         }
@@ -300,13 +323,13 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
 
 // One flow (every frame between two mask deliveries: mode 1): the walk of a pixel is a single step from an integer
 // position, so nothing but the loaded flow elements has to stay in registers while the loads are in flight -- two
-// VGPRs per group -- and ALL groups of a wave (about a dozen at 64 objects) go out in one round: the frame pays one
+// VGPRs per group -- and ALL groups of a wave (about a dozen) go out in one round: the frame pays one
 // memory latency for its flow.  Position, bit and target are (re)computed when the data is back.  Same arithmetic as
 // chase_groups with n_flows == 1, operation by operation.  Needs the plane words of the listed groups in LDS (`words`).
 constexpr int kSingleWalks = 12;   // groups per wave whose flow loads are in flight together (16: slower, register pressure)
-template <int FT, int MODE>
+template <int FT, int MODE, int NW>
 __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* list_, const uint2* words_, int n_list, bool clear00,
-                                            const void* flow, ROFT_LDS uint32_t* tgt)
+                                            const void* flow, const OrTarget tgt)
 {
     constexpr int NCH = kSingleWalks;
     // (LDS pointers as such: through generic pointers every read of the list is a flat load, and a flat load waits for
@@ -321,11 +344,11 @@ __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* li
     const ROFT_GLOBAL unsigned char* fl = (const ROFT_GLOBAL unsigned char*)(
         ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fl_bits >> 32)) << 32) |
         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fl_bits));
-    for (int e0 = wave; e0 < n_list; e0 += NCH * kMaskWaves) {
+    for (int e0 = wave; e0 < n_list; e0 += NCH * NW) {
         uint2 raw[NCH];
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
-            const int e = e0 + u * kMaskWaves;
+            const int e = e0 + u * NW;
             raw[u] = make_uint2(0u, 0u);
             if (e < n_list) {   // (wave-uniform)
                 const uint32_t yx = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[e]);
@@ -348,7 +371,7 @@ __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* li
         }
 #pragma unroll
         for (int u = 0; u < NCH; ++u) {
-            const int e = e0 + u * kMaskWaves;
+            const int e = e0 + u * NW;
             if (e < n_list) {
                 const uint32_t yx = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[e]);
                 unsigned long long bits = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)words[2 * e + 1]) << 32) |
@@ -365,41 +388,31 @@ __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* li
                 if (MODE == 1) { dx *= g.inv_scale; dy *= g.inv_scale; }
                 const float t_x = (float)px + dx, t_y = (float)py + dy;
                 const int ix = trunc_clamped(t_x), iy = trunc_clamped(t_y);
-                if (((bits >> lane) & 1ull) && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) {
-                    const int tp = iy * W + ix;
-                    (void)__hip_atomic_fetch_or(tgt + (tp >> 5), 1u << (tp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                if (((bits >> lane) & 1ull) && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) tgt.hit(iy * W + ix);
             }
         }
     }
 }
 
-// binary source: OR-scatter into the LDS plane.  kBinaryWalks walks in flight per wave: a workgroup's share of an object
-// is about a dozen groups per wave, so all their flow reads go out together and the frame pays ONE memory latency per
-// flow instead of one per eight groups.
+// binary source: OR-scatter of the listed groups' pixels.  kBinaryWalks walks in flight per wave.
 constexpr int kBinaryWalks = 8;
-template <int FT>
-__device__ __noinline__ void propagate_binary(ChaseGeo g, const uint2* plane2, const uint32_t* list, int n_list, int n_flows,
-                                              bool clear00, const void* const* flows, uint32_t* s_tgt, const uint2* words)
+template <int FT, int NW>
+__device__ __forceinline__ void propagate_binary(ChaseGeo g, const uint2* plane2, const uint32_t* list, int n_list, int n_flows,
+                                                 bool clear00, const void* const* flows, const OrTarget tgt, const uint2* words)
 {
-    // (workgroup-uniform LDS address into a scalar register: arguments of a function arrive in vector registers)
-    ROFT_LDS uint32_t* const tgt = (ROFT_LDS uint32_t*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane(
-        (int)(uint32_t)(uintptr_t)(ROFT_LDS uint32_t*)s_tgt);
     if (n_flows == 1 && words && g.mode != 0) {
-        if (g.mode == 2) walk_single<FT, 2>(g, list, words, n_list, clear00, flows[0], tgt);
-        else walk_single<FT, 1>(g, list, words, n_list, clear00, flows[0], tgt);
+        if (g.mode == 2) walk_single<FT, 2, NW>(g, list, words, n_list, clear00, flows[0], tgt);
+        else walk_single<FT, 1, NW>(g, list, words, n_list, clear00, flows[0], tgt);
         return;
     }
-    auto hit = [tgt](int tp, int, int, int) {
-        (void)__hip_atomic_fetch_or(tgt + (tp >> 5), 1u << (tp & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-    if (g.mode == 2) chase_groups<FT, kBinaryWalks, 2>(g, plane2, list, n_list, n_flows, clear00, flows, hit, words);
-    else if (g.mode == 1) chase_groups<FT, kBinaryWalks, 1>(g, plane2, list, n_list, n_flows, clear00, flows, hit, words);
-    else chase_groups<FT, 4, 0>(g, plane2, list, n_list, n_flows, clear00, flows, hit, words);
+    auto hit = [tgt](int tp, int, int, int) { tgt.hit(tp); };
+    if (g.mode == 2) chase_groups<FT, kBinaryWalks, 2, NW>(g, plane2, list, n_list, n_flows, clear00, flows, hit, words);
+    else if (g.mode == 1) chase_groups<FT, kBinaryWalks, 1, NW>(g, plane2, list, n_list, n_flows, clear00, flows, hit, words);
+    else chase_groups<FT, 4, 0, NW>(g, plane2, list, n_list, n_flows, clear00, flows, hit, words);
 }
 
 // general source: map of the winning (largest) source index per target + the targets' bounding box (LDS bbox[4])
-template <int FT>
+template <int FT, int NW>
 __device__ __noinline__ void propagate_general(ChaseGeo g, const uint2* plane2, const uint32_t* list, int n_list, int n_flows,
                                                bool clear00, const void* const* flows, int32_t* map, int* s_bbox)
 {
@@ -409,9 +422,9 @@ __device__ __noinline__ void propagate_general(ChaseGeo g, const uint2* plane2, 
         bx0 = min(bx0, ix); bx1 = max(bx1, ix);
         by0 = min(by0, iy); by1 = max(by1, iy);
     };
-    if (g.mode == 2) chase_groups<FT, 4, 2>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
-    else if (g.mode == 1) chase_groups<FT, 4, 1>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
-    else chase_groups<FT, 4, 0>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
+    if (g.mode == 2) chase_groups<FT, 4, 2, NW>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
+    else if (g.mode == 1) chase_groups<FT, 4, 1, NW>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
+    else chase_groups<FT, 4, 0, NW>(g, plane2, list, n_list, n_flows, clear00, flows, hit);
     for (int off = 32; off > 0; off >>= 1) {
         bx0 = min(bx0, __shfl_xor(bx0, off, 64)); by0 = min(by0, __shfl_xor(by0, off, 64));
         bx1 = max(bx1, __shfl_xor(bx1, off, 64)); by1 = max(by1, __shfl_xor(by1, off, 64));
@@ -440,30 +453,6 @@ __device__ __forceinline__ void plane_fill(uint32_t* d, uint32_t v, size_t n_wor
         for (size_t i = threadIdx.x; i < n_words / 2; i += blockDim.x) reinterpret_cast<uint2*>(d)[i] = make_uint2(v, v);
 }
 
-// The same through agent-coherent accesses (sc1: write-through stores, loads that miss the caches above the coherence
-// point), 8 bytes at a time: what the workgroups of an object, spread over XCDs with an L2 each, exchange INSIDE the
-// persistent chain kernel goes through these and through atomics only -- no cache write-back / invalidate per frame.
-__device__ __forceinline__ unsigned long long coh_load64(const void* p)
-{
-    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ void coh_store64(void* p, unsigned long long v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-__device__ __forceinline__ void plane_copy_coherent(uint32_t* d, const uint32_t* s, size_t n_words)
-{
-    for (size_t i = threadIdx.x; i < n_words / 2; i += blockDim.x) coh_store64(d + 2 * i, coh_load64(s + 2 * i));
-}
-
-__device__ __forceinline__ void plane_fill_coherent(uint32_t* d, uint32_t v, size_t n_words)
-{
-    const unsigned long long vv = ((unsigned long long)v << 32) | v;
-    for (size_t i = threadIdx.x; i < n_words / 2; i += blockDim.x) coh_store64(d + 2 * i, vv);
-}
-
 // The decisions of frame t (ImageSegmentationOFAidedSource::step_frame, hpp:169-226) from the state after frame t-1.
 __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskRec& cur, int new_slot, const FrameCtrl& c,
                                                 int frames_between, int flow_aided)
@@ -485,188 +474,141 @@ __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskR
     return r;
 }
 
-// Barrier among the nq workgroups of one object inside the persistent chain kernel: `counter` (zeroed by the control block
-// upload of the batch) counts arrivals, `target` = nq * (barriers so far + 1).  What the workgroups exchange goes through
-// agent-coherent accesses (sc1 stores / loads, device-scope atomics): a thread only has to wait for its own stores and
-// atomics to be acknowledged before the workgroup arrives.  In two halves, so that what a workgroup can do for the next
-// frame without the others' results -- control block, decisions, zeroing -- runs while the arrivals travel: arrive (one
-// atomic by thread 0) ... wait (thread 0 polls).
-// FORWARD PROGRESS: the poll ends only if the object's other workgroups run, i.e. the nq * n_obj workgroups of the launch
-// must become resident together.  HIP promises no dispatch order; what the launch relies on is (i) nq * n_obj <= the CUs
-// the launch may fill (launch_mask_chain: three quarters of the device's CUs, one workgroup fills a CU's register file;
-// nq = 1, no barrier at all, when that cannot hold), (ii) the hardware dispatching the workgroups of ONE launch in
-// order and (iii) no kernel of the other chains ever waiting for this one while it holds CUs.  Several engines -- or
-// processes -- running mask chains on one device at once can break (i); therefore the poll is bounded: after ~2 s the
-// workgroup raises EngineArrays::dev_error (pinned host memory: the host turns it into ROFT_ERR_DEVICE at its next
-// synchronisation, roft_engine.h) and leaves the kernel, and so does every workgroup that sees the flag raised.
-__device__ __forceinline__ void object_arrive(unsigned* counter)
-{
-    __builtin_amdgcn_s_waitcnt(0);   // every store / atomic of this thread acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// returns false when the barrier was abandoned (dev_error raised)
-__device__ __forceinline__ bool object_wait(unsigned* counter, unsigned target, int* dev_error, int* s_ok)
-{
-    if (threadIdx.x == 0) {
-        const long long t0 = wall_clock64();
-        int ok = 1;
-        unsigned spins = 0;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 1023u) == 0u) {   // ~ every 50 us: somebody else gave up, or two seconds have passed (100 MHz clock)
-                const bool raised = dev_error && __hip_atomic_load(dev_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0;
-                if (raised || wall_clock64() - t0 > 200000000ll) {
-                    if (dev_error && !raised) __hip_atomic_store(dev_error, ROFT_DEV_ERROR_MASK_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    ok = 0;
-                    break;
-                }
-            }
-        }
-        *s_ok = ok;
-    }
-    __syncthreads();
-    return *s_ok != 0;
-}
-
-// The binary-mask chain of a batch: ONE launch walks the T frames.  grid: (S, n_obj).  Workgroup q of an object owns
-// the 64-pixel groups q, q + S, ... of the source and the words [q, q+1) * plane_words / S of the planes it copies /
-// fills / zeroes; the S workgroups of an object meet at a barrier in memory (object_arrive / object_wait) between two frames (the mask of frame t is
-// the source of frame t + 1), objects never wait for each other.
-// dynamic LDS: [plane_words] OR target | list of this workgroup's non-empty groups [| their plane words]
+// Frame t of the batch, binary masks.  grid: (Q, n_obj).  Workgroup q of an object owns the 64-pixel groups
+// [q, q + 1) * grp_per_wg of the source plane (a band of image rows) and the same share of the planes it copies / fills /
+// zeroes.  It ORs the targets of its pixels into an LDS window -- the band's rows and `margin` rows above and below;
+// the few pixels that fly further go to the destination plane directly -- and flushes the window's non-zero words with
+// atomicOr into the destination, which the frame before left zeroed (bands overlap in their margins: an order-free OR).
+// Every workgroup of an object makes the same decisions from the same two records; workgroup 0 leaves the record of the
+// frame for the next one.  Frames whose source is three-valued are left to mask_general_kernel (bit t of mask_general).
+// dynamic LDS: [win_cap words] window | [kFrameThreads] list | [kFrameThreads] plane words of the listed groups
 #ifdef ROFT_MASK_PROFILE
-#define MTICK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 4) { long long _t = wall_clock64(); a.state[blockIdx.y].dbg[blockIdx.x * 8 + (i)] += _t - m_t0; m_t0 = _t; } } while (0)
+// absolute 100 MHz stamps per object: dbg[8] = 2^62 - earliest workgroup start, dbg[i] = latest workgroup passing phase i (atomicMax both)
+#define MTICK(i) do { __syncthreads(); if (threadIdx.x == 0) atomicMax((unsigned long long*)&a.state[blockIdx.y].dbg[(i)], (unsigned long long)wall_clock64()); } while (0)
 #else
 #define MTICK(i) do {} while (0)
 #endif
 
 template <int FT>
-__global__ __launch_bounds__(kMaskThreads) void mask_chain_kernel(EngineArrays a, int frames_between, int flow_aided,
-                                                                  int list_cap, int keep_words)
+__global__ __launch_bounds__(kFrameThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided, int grp_per_wg, int margin, int win_cap)
 {
 #ifdef ROFT_MASK_PROFILE
-    long long m_t0 = wall_clock64();
-    if (threadIdx.x < 8 && blockIdx.x < 4) a.state[blockIdx.y].dbg[blockIdx.x * 8 + threadIdx.x] = 0;
+    if (threadIdx.x == 0) atomicMax((unsigned long long*)&a.state[blockIdx.y].dbg[8], (unsigned long long)((1ll << 62) - wall_clock64()));
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ MaskShared S;
-    uint32_t* s_tgt = reinterpret_cast<uint32_t*>(smem);
-    uint32_t* s_list = reinterpret_cast<uint32_t*>(smem + ((a.plane_words * 4 + 15) & ~(size_t)15));
-    const int obj = blockIdx.y, q = blockIdx.x, nq = gridDim.x;
-    // plane words of the listed groups (behind the list, when the launch reserved the room)
-    uint2* s_words = keep_words ? reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(s_list) + (((size_t)list_cap * 4 + 15) & ~(size_t)15))
-                                : nullptr;
-    const int W = a.cam.W, H = a.cam.H, n_grp = (W * H) >> 6;
-    const int tid = threadIdx.x, lane = tid & 63;
     __shared__ FrameCtrl s_c;
-    __shared__ int s_barrier_ok;
     __shared__ MaskRec s_rec[2];   // [0] state after the frame before (frame 0: the carry), [1] this frame's counters
     static_assert(sizeof(MaskRec) == 32, "two 16-byte loads per record");
-    // share of the plane words of this workgroup, in 16-byte units when the planes are 16-byte aligned
-    const int unit = (a.plane_words & 3) ? 2 : 4;
-    const int n_units = (int)(a.plane_words / unit);
-    const int u0 = (int)((long long)n_units * q / nq) * unit, u1 = (int)((long long)n_units * (q + 1) / nq) * unit;
+    uint32_t* s_win = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* s_list = s_win + win_cap;
+    uint2* s_words = reinterpret_cast<uint2*>(s_list + kFrameThreads);
+    const int obj = blockIdx.y, q = blockIdx.x;
+    const int W = a.cam.W, H = a.cam.H, wpr = a.cam.wpr, n_grp = (W * H) >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g0 = q * grp_per_wg, g1 = min(n_grp, g0 + grp_per_wg);
+    // the band's rows + margin = the LDS window
+    const int r_lo = max(0, (g0 * 64) / W - margin), r_hi = min(H - 1, (g1 * 64 - 1) / W + margin);
+    const int win_off = r_lo * wpr, win_words = min(win_cap, (r_hi - r_lo + 1) * wpr);
+    // ---- one round trip: control block, the two records, and (speculatively) this thread's group word of BOTH planes the
+    //      frame can read -- the last propagated mask (ring slot slot_prev0 + t inside the engine) and the mask delivered
+    //      with the frame (slot_new + t; stale but valid memory when none was delivered)
+    stage_ctrl(&s_c, frame_ctrl(a, t, obj));
+    if (tid >= 128 && tid < 132) {
+        const int k = tid - 128;   // 0, 1: the state after the frame before; 2, 3: this frame's counters
+        const MaskRec* prev = (t == 0) ? a.mrec_carry + obj : a.mrec + (size_t)t * a.n_obj + obj;
+        reinterpret_cast<uint4*>(s_rec)[k] = (k >= 2) ? reinterpret_cast<const uint4*>(a.mrec + (size_t)(t + 1) * a.n_obj + obj)[k & 1]
+                                                      : reinterpret_cast<const uint4*>(prev)[k & 1];
+    }
+    const int guess_prev = a.slot_prev0 >= 0 ? (a.slot_prev0 + t) % kPlaneSlots : -1, guess_new = a.slot_new + t;
+    const ROFT_GLOBAL unsigned long long* pl_prev = guess_prev >= 0 ? (const ROFT_GLOBAL unsigned long long*)(a.planes + plane_offset(a, obj, guess_prev, 1)) : nullptr;
+    const ROFT_GLOBAL unsigned long long* pl_new = (const ROFT_GLOBAL unsigned long long*)(a.planes + plane_offset(a, obj, guess_new, 1));
+    unsigned long long w_prev = 0ull, w_new = 0ull;
+    if (g0 + tid < g1) {
+        if (pl_prev) w_prev = pl_prev[g0 + tid];
+        w_new = pl_new[g0 + tid];
+    }
+    if (tid == 192) { S.w00[0] = pl_prev ? pl_prev[0] : 0ull; S.w00[1] = pl_new[0]; }
+    for (int i = tid; i < win_words; i += kFrameThreads) s_win[i] = 0u;
+    if (tid == 0) S.n_list = 0;
+    __syncthreads();
+    MTICK(4);
+    const FrameCtrl& c = s_c;
+    const MaskRec r = decide_frame(s_rec[0], s_rec[1], a.slot_new + t, c, frames_between, flow_aided);
+    if (q == 0 && tid == 0) a.mrec[(size_t)(t + 1) * a.n_obj + obj] = r;   // (every workgroup computes the same record)
+    if (tid < kMaxFlowHist) S.flows[tid] = (tid < r.n_flows) ? c.flow[tid] : nullptr;
+    MTICK(0);
+    // the obj plane of the NEXT frame's slot zeroed for that frame's OR flush (nobody reads that slot any more: its last
+    // user is kPlaneSlots frames back)
+    const size_t sh0 = (size_t)2 * g0, sh_n = (size_t)2 * (g1 - g0);   // this workgroup's share of a plane, in words
+    plane_fill(a.planes + plane_offset(a, obj, (c.slot_cur + 1) % kPlaneSlots, 1) + sh0, 0u, sh_n);
+    const uint32_t* src = a.planes + plane_offset(a, obj, r.src_slot, 1);
+    uint32_t* dst = a.planes + plane_offset(a, obj, c.slot_cur, 1);
+    if (!r.src_binary) {
+        if (q == 0 && tid == 0) atomicOr(&a.mask_general[obj], 1u << t);   // three-valued source: mask_general_kernel
+        return;
+    }
+    if (r.mode == 0) {
+        plane_copy(dst + sh0, src + sh0, sh_n);
+        return;
+    }
+    const bool from_guess = r.src_slot == guess_prev || r.src_slot == guess_new;
+    const unsigned long long w00 = from_guess ? S.w00[r.src_slot == guess_new ? 1 : 0] : *reinterpret_cast<const unsigned long long*>(src);
+    if (r.mode == 2 && (w00 & 1ull)) {
+        // mask(0,0) set in a new-mask frame: every target, mapped or not, samples a set pixel
+        plane_fill(dst + sh0, ~0u, sh_n);
+        return;
+    }
     const ChaseGeo geo = make_chase_geo(a.cam, a.ffmt);
-    unsigned n_barriers = 0, general = 0u;
-    // What a frame needs before it can read its source: control block and state records -> LDS with one load per thread,
-    // the decisions, the obj plane of the NEXT frame's slot zeroed for that frame's OR flush (nobody reads that slot
-    // any more: its last user is kPlaneSlots frames back), the LDS plane zeroed.  Runs between the arrival at the
-    // barrier behind the frame before and the wait for the others.
-    auto prologue = [&](int t) -> MaskRec {
-        stage_ctrl(&s_c, frame_ctrl(a, t, obj));
-        if (tid >= 128 && tid < 132) {
-            const int k = tid - 128;   // 0, 1: the carry (first frame only; later the record of the frame before); 2, 3: this frame's
-            if (k >= 2)
-                reinterpret_cast<uint4*>(s_rec)[k] = reinterpret_cast<const uint4*>(a.mrec + (size_t)(t + 1) * a.n_obj + obj)[k & 1];
-            else if (t == 0)
-                reinterpret_cast<uint4*>(s_rec)[k] = reinterpret_cast<const uint4*>(a.mrec_carry + obj)[k & 1];
+    OrTarget tgt;
+    tgt.win = (ROFT_LDS uint32_t*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(ROFT_LDS uint32_t*)s_win);
+    tgt.off = win_off;
+    tgt.words = win_words;
+    tgt.dst = dst;
+    // this workgroup's non-empty groups -> list (any order: the scatter is order-free), kFrameThreads groups at a time, then
+    // their walks
+    const uint2* plane2 = reinterpret_cast<const uint2*>(src);
+    for (int c0 = g0; c0 < g1; c0 += kFrameThreads) {
+        const int g = c0 + tid;
+        unsigned long long ww = 0ull;
+        if (g < g1) {
+            if (c0 == g0 && from_guess) ww = (r.src_slot == guess_new) ? w_new : w_prev;
+            else ww = *reinterpret_cast<const unsigned long long*>(plane2 + g);
         }
-        plane_fill(s_tgt, 0u, a.plane_words);
-        __syncthreads();
-        const MaskRec r = decide_frame(s_rec[0], s_rec[1], a.slot_new + t, s_c, frames_between, flow_aided);
-        MTICK(0);
-        if (q == 0 && tid == 0) a.mrec[(size_t)(t + 1) * a.n_obj + obj] = r;   // (every workgroup computes the same record)
-        plane_fill_coherent(a.planes + plane_offset(a, obj, (s_c.slot_cur + 1) % kPlaneSlots, 1) + u0, 0u, (size_t)(u1 - u0));
-        if (tid < kMaxFlowHist) S.flows[tid] = (tid < r.n_flows) ? s_c.flow[tid] : nullptr;
-        if (tid == 0) S.n_list = 0;
+        if (c0 > g0) {
+            __syncthreads();   // the walks of the chunk before have read the list
+            if (tid == 0) S.n_list = 0;
+            __syncthreads();
+        }
+        const bool ne = ww != 0ull;
+        const unsigned long long b = __ballot(ne);
+        int base = 0;
+        if (lane == 0 && b) base = atomicAdd(&S.n_list, __popcll(b));
+        base = __shfl(base, 0, 64);
+        if (ne) {
+            const int e = base + __popcll(b & ((1ull << lane) - 1ull));
+            const int p0 = g * 64, y0 = p0 / W;
+            s_list[e] = ((uint32_t)y0 << 16) | (uint32_t)(p0 - y0 * W);
+            s_words[e] = make_uint2((uint32_t)ww, (uint32_t)(ww >> 32));
+        }
         __syncthreads();
         MTICK(1);
-        return r;
-    };
-    MaskRec r = prologue(0);
-    for (int t = 0; t < a.T; ++t) {
-        const FrameCtrl& c = s_c;
-        const uint32_t* src = a.planes + plane_offset(a, obj, r.src_slot, 1);
-        uint32_t* dst = a.planes + plane_offset(a, obj, c.slot_cur, 1);
-        if (!r.src_binary) {
-            general |= 1u << t;   // three-valued source: mask_general_kernel
-        } else if (r.mode == 0) {
-            plane_copy_coherent(dst + u0, src + u0, (size_t)(u1 - u0));
-        } else if (r.mode == 2 && (src[0] & 1u)) {
-            // mask(0,0) set in a new-mask frame: every target, mapped or not, samples a set pixel
-            plane_fill_coherent(dst + u0, ~0u, (size_t)(u1 - u0));
-        } else {
-            // This workgroup's non-empty 64-pixel groups of the source (g = q + nq i) -> list (any order: the scatter
-            // is order-free), then their walks; in chunks of list_cap groups when the LDS next to the plane cannot list
-            // the whole share at once (a 1280x720 plane with one workgroup per object).
-            const uint2* plane2 = reinterpret_cast<const uint2*>(src);
-            const int share = (n_grp - q + nq - 1) / nq;
-            for (int c0 = 0; c0 < share; c0 += list_cap) {
-                if (c0 > 0) {
-                    __syncthreads();   // the walks of the chunk before have read the list
-                    if (tid == 0) S.n_list = 0;
-                    __syncthreads();
-                }
-                const int c1 = min(share, c0 + list_cap);
-                for (int i0 = c0; i0 < c1; i0 += kMaskThreads) {
-                    const int i = i0 + tid, g = q + nq * i;
-                    bool ne = false;
-                    uint2 w = make_uint2(0u, 0u);
-                    if (i < c1) {
-                        const unsigned long long ww = coh_load64(plane2 + g);
-                        w = make_uint2((uint32_t)ww, (uint32_t)(ww >> 32));
-                        ne = ww != 0ull;
-                    }
-                    const unsigned long long b = __ballot(ne);
-                    int base = 0;
-                    if (lane == 0 && b) base = atomicAdd(&S.n_list, __popcll(b));
-                    base = __shfl(base, 0, 64);
-                    if (ne) {
-                        const int e = base + __popcll(b & ((1ull << lane) - 1ull));
-                        const int p0 = g * 64, y0 = p0 / W;
-                        s_list[e] = ((uint32_t)y0 << 16) | (uint32_t)(p0 - y0 * W);
-                        if (s_words) s_words[e] = w;
-                    }
-                }
-                __syncthreads();
-                MTICK(2);
-                propagate_binary<FT>(geo, plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, s_tgt, s_words);
-            }
-            __syncthreads();
-            MTICK(3);
-            // flush: the non-zero words of this workgroup's plane into the (zeroed) destination
-            for (int i = tid; i < (int)a.plane_words; i += kMaskThreads) {
-                const uint32_t v = s_tgt[i];
-                if (v) atomicOr(&dst[i], v);
-            }
-            MTICK(4);
-        }
-        if (t + 1 == a.T) {
-            if (q == 0 && tid == 0) a.mask_general[obj] = general;
-            break;
-        }
-        // the next frame reads this frame's planes and ORs into the slot zeroed by this frame's prologue
-        if (nq > 1) object_arrive(a.mask_sync + obj);
-        else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }   // (one workgroup, one CU: its L1 is written through)
-        if (tid == 0) s_rec[0] = r;   // (the staging barrier of the prologue publishes it)
-        r = prologue(t + 1);
-        if (nq > 1 && !object_wait(a.mask_sync + obj, (unsigned)nq * ++n_barriers, a.dev_error, &s_barrier_ok)) return;
-        MTICK(5);
+        propagate_binary<FT, kFrameWaves>(geo, plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, tgt, s_words);
     }
+    __syncthreads();
+    MTICK(2);
+    // flush: the non-zero words of the window into the (zeroed) destination
+    for (int i = tid; i < win_words; i += kFrameThreads) {
+        const uint32_t v = s_win[i];
+        if (v) atomicOr(&dst[win_off + i], v);
+    }
+    MTICK(3);
 }
 
-// One persistent workgroup per object at the end of the batch's mask chain: the frames whose source is three-valued.
+constexpr int kMaskThreads = 256;   // (idle on binary masks -- every mask the reference's sources deliver: four waves find room anywhere)
+constexpr int kMaskWaves = kMaskThreads / 64;
+// One workgroup per object at the end of the batch's mask frames: the frames whose source is three-valued.
 // dynamic LDS: list of the non-empty groups
 template <int FT>
 __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays a)
@@ -677,7 +619,8 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
     const int obj = blockIdx.x;
     const int W = a.cam.W, H = a.cam.H, npix = W * H, n_grp = npix >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
-    const unsigned todo = a.mask_general[obj];   // (almost always 0: every mask the reference's sources deliver is binary)
+    const unsigned todo = a.mask_general[obj];
+    if (!todo) return;   // (almost always 0: every mask the reference's sources deliver is binary)
     for (int t = 0; t < a.T; ++t) {
         if (!((todo >> t) & 1u)) continue;
         const MaskRec r = a.mrec[(size_t)(t + 1) * a.n_obj + obj];
@@ -711,7 +654,7 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
             }
             __syncthreads();
             int32_t* map = a.map + (size_t)obj * npix;
-            propagate_general<FT>(make_chase_geo(a.cam, a.ffmt), plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, map, S.bbox);
+            propagate_general<FT, kMaskWaves>(make_chase_geo(a.cam, a.ffmt), plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, map, S.bbox);
             __syncthreads();
             const int bx0 = S.bbox[0], by0 = S.bbox[1], bx1 = S.bbox[2], by1 = S.bbox[3];
             // every 64-pixel output group: constant background outside the box, map samples inside
@@ -738,43 +681,49 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
     }
 }
 
-int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s, hipEvent_t stop)
+int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s, hipEvent_t stop)
 {
-    const size_t n_grp = (size_t)a.cam.W * a.cam.H / 64;
-    // Workgroups per object: the walks are latency-bound on one CU, so an object is spread over several (at most 8).  A
-    // workgroup of 16 waves with 128 registers per thread fills the register file of its CU, and it stays for the whole
-    // batch: a quarter of the device's CUs is left to the per-object chains of the other streams (the pose and velocity
-    // filters need a nearly empty CU each) -- measured at 64 objects on 256 CUs: 3 workgroups per object +4 %
-    // object-frames/s over 4, and the flow measurement's launch no longer waits for CUs.  All S * n_obj workgroups must be
-    // resident together (the barrier of object_wait): S = 1, no barrier, when three quarters of the CUs cannot hold two per
-    // object.  roft_config::mask_workgroups_per_object overrides the choice (clamped to what fits).
-    const int cus = device_cu_count(), n_obj = a.n_obj > 0 ? a.n_obj : 1;
-    const int fit = (cus - cus / 4) / n_obj;
-    int S = a.mask_wgs > 0 ? std::min(a.mask_wgs, std::max(cus / n_obj, 1)) : fit;
-    S = S < 1 ? 1 : (S > 8 ? 8 : S);
-    const size_t lds_plane = (a.plane_words * 4 + 15) & ~(size_t)15;
-    // list of a workgroup's groups next to its plane (4 B per group), their plane words behind it (8 B) if the CU's LDS
-    // has the room; a share that does not fit even the list is walked in chunks
-    const size_t lds_cap = 160 * 1024 - 4096;
-    size_t list_cap = (n_grp + S - 1) / S;
-    const int keep_words = lds_plane + ((list_cap * 4 + 15) & ~(size_t)15) + list_cap * 8 <= lds_cap ? 1 : 0;
-    if (lds_plane + ((list_cap * 4 + 15) & ~(size_t)15) > lds_cap) list_cap = ((lds_cap - lds_plane) / 4) & ~(size_t)3;
-    const size_t lds_step = lds_plane + ((list_cap * 4 + 15) & ~(size_t)15) + (keep_words ? list_cap * 8 : 0);
-    const size_t lds_gen = (n_grp * 4 + 15) & ~(size_t)15;
+    const int n_grp = a.cam.W * a.cam.H / 64;
+    // Groups per workgroup.  Automatic: ~3 image rows' worth of pixels more than a band of 16 rows at 640 pixels -- a workgroup
+    // inside the object then lists a few dozen non-empty groups, a dozen per wave, whose flow reads go out in ONE round
+    // (walk_single) -- and a third of that on frames that deliver a mask (the schedule tells the host which: the new mask is
+    // chased through up to 30 flows, a chain of dependent reads per group).  roft_config::mask_workgroups_per_object = S > 0
+    // splits the plane into exactly S bands instead (1: one workgroup walks the whole object, chunk by chunk).
+    static const int rows_env = getenv("ROFT_MASK_ROWS") ? atoi(getenv("ROFT_MASK_ROWS")) : 0;           // (experiments)
+    static const int rows_new_env = getenv("ROFT_MASK_ROWS_NEW") ? atoi(getenv("ROFT_MASK_ROWS_NEW")) : 0;
+    const int rows_auto = rows_env > 0 ? rows_env : 20, rows_auto_new = rows_new_env > 0 ? rows_new_env : 6;
+    auto per_for = [&](bool fresh) {
+        if (a.mask_wgs > 0) return (n_grp + a.mask_wgs - 1) / a.mask_wgs;
+        const int per = std::max(1, (fresh ? rows_auto_new : rows_auto) * a.cam.W / 64);
+        return std::min(per, n_grp);
+    };
+    const size_t lds_cap = 160 * 1024 - 4096;   // (the kernel's static LDS -- control block, records, flow pointers -- is ~1.3 KB)
     {
-        const int cap = 160 * 1024 - 4096;   // (the kernel's static LDS -- control block, records, flow pointers -- is ~1.2 KB)
-        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_chain_kernel<ROFT_FLOW_S16C2>), cap);
-        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_chain_kernel<ROFT_FLOW_F32C2>), cap);
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_frame_kernel<ROFT_FLOW_S16C2>), (int)lds_cap);
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_frame_kernel<ROFT_FLOW_F32C2>), (int)lds_cap);
     }
     int launches = 0;
     const bool s16 = a.ffmt.type == ROFT_FLOW_S16C2;
-    if (s16)
-        hipLaunchKernelGGL(mask_chain_kernel<ROFT_FLOW_S16C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a,
-                           frames_between, flow_aided, (int)list_cap, keep_words);
-    else
-        hipLaunchKernelGGL(mask_chain_kernel<ROFT_FLOW_F32C2>, dim3(S, a.n_obj), dim3(kMaskThreads), (uint32_t)lds_step, s, a,
-                           frames_between, flow_aided, (int)list_cap, keep_words);
-    ++launches;
+    for (int t = 0; t < a.T; ++t) {
+        const bool fresh = (new_mask_frames >> t) & 1u;
+        const int per = per_for(fresh);
+        // LDS window: the band's rows + a margin of rows above and below (pixels that fly further are ORed into the
+        // destination plane directly): 16 rows for one flow step, 48 when a new mask is chased through several
+        const int margin = fresh ? 48 : 16;
+        const size_t fixed = (size_t)kFrameThreads * 12;
+        size_t win_cap = ((size_t)std::min(a.cam.H, (per * 64 + a.cam.W - 1) / a.cam.W + 1 + 2 * margin) * a.cam.wpr + 1) & ~(size_t)1;
+        win_cap = std::min(win_cap, ((lds_cap - fixed) / 4) & ~(size_t)1);
+        const size_t lds = win_cap * 4 + fixed;
+        const dim3 grid((n_grp + per - 1) / per, a.n_obj);
+        if (s16)
+            hipLaunchKernelGGL(mask_frame_kernel<ROFT_FLOW_S16C2>, grid, dim3(kFrameThreads), (uint32_t)lds, s, a, t, frames_between, flow_aided,
+                               per, margin, (int)win_cap);
+        else
+            hipLaunchKernelGGL(mask_frame_kernel<ROFT_FLOW_F32C2>, grid, dim3(kFrameThreads), (uint32_t)lds, s, a, t, frames_between, flow_aided,
+                               per, margin, (int)win_cap);
+        ++launches;
+    }
+    const size_t lds_gen = ((size_t)n_grp * 4 + 15) & ~(size_t)15;
     if (s16)
         hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_S16C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, stop, 0, a);
     else

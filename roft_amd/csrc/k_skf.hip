@@ -529,6 +529,26 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
     return S.sel[0];
 }
 
+// The twist of a frame -> the ring slot a pose lane reads it from.  The lane may be running NEXT to this kernel (frame-granular
+// hand-over, EngineArrays::handoff), on a CU of another XCD with an L2 of its own: the six values go out as agent-coherent
+// stores (threads 0 .. 5 of wave 0), the wave waits until they are acknowledged, then thread 0 publishes the tag -- no cache
+// write-back, no fence.
+__device__ __forceinline__ void publish_twist_value(ObjState& st, int slot, int i, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(&st.twist_hist[slot][i]), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void publish_twist_tag(ObjState& st, int slot, int frame_idx)
+{
+    if (threadIdx.x < 64) {   // wave 0: the wave that stored the values
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __builtin_amdgcn_s_waitcnt(0);   // every store of this wave acknowledged
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if (threadIdx.x == 0) __hip_atomic_store(&st.twist_tag[slot], frame_idx + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // One workgroup per object walks the frames of the batch: the velocity belief of frame k is the prior of frame k+1,
 // so the recursion is sequential per object; the flow records of all frames are already there (flow_measure_kernel).
 #ifndef PRIO_SKF
@@ -546,6 +566,8 @@ __global__ __launch_bounds__(kSkfThreads) void skf_chain_kernel(EngineArrays a, 
     const int obj = blockIdx.x;
     ObjState& st = a.state[obj];
     const ObjParams& prm = a.params[obj];
+    // resident: the pose lanes of the batch may be released next to this kernel (they only ever wait for workgroups that run)
+    if (threadIdx.x == 0 && a.skf_started) (void)__hip_atomic_fetch_add(a.skf_started, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (int t = 0; t < a.T; ++t) {
         const int slot = t * a.n_obj + obj;
         stage_ctrl(&s_c, a.ctrl[slot]);   // (the barrier at the end of the previous frame precedes this overwrite)
@@ -561,13 +583,14 @@ __global__ __launch_bounds__(kSkfThreads) void skf_chain_kernel(EngineArrays a, 
         if (N < 3) {
             if (threadIdx.x < 6) {
                 const double v = st.v_mean[threadIdx.x];
-                st.twist_hist[c.twist_slot][threadIdx.x] = v;
+                publish_twist_value(st, c.twist_slot, threadIdx.x, v);
                 if (row) row->twist[threadIdx.x] = v;
             }
             if (threadIdx.x == 0) {
                 st.skf_status = (N <= 0) ? 1 : 2;
-                if (row) { row->n_flow_points = n_pts; row->outlier_selected = -1; }
+                if (row) row->n_flow_points = n_pts;
             }
+            publish_twist_tag(st, c.twist_slot, c.frame_idx);
             __syncthreads();
             continue;
         }
@@ -591,7 +614,7 @@ __global__ __launch_bounds__(kSkfThreads) void skf_chain_kernel(EngineArrays a, 
         if (threadIdx.x < 6) {
             const double v = (rc == 0) ? S.xo[threadIdx.x] : s_x[threadIdx.x];
             if (rc == 0) st.v_mean[threadIdx.x] = v;
-            st.twist_hist[c.twist_slot][threadIdx.x] = v;
+            publish_twist_value(st, c.twist_slot, threadIdx.x, v);
             if (row) row->twist[threadIdx.x] = v;
         }
         if (threadIdx.x == 0) {
@@ -599,8 +622,9 @@ __global__ __launch_bounds__(kSkfThreads) void skf_chain_kernel(EngineArrays a, 
 #ifdef ROFT_SKF_PROFILE
             for (int i = 0; i < 9; ++i) st.dbg[i] = S.dbg[i];
 #endif
-            if (row) { row->n_flow_points = n_pts; row->outlier_selected = -1; }
+            if (row) row->n_flow_points = n_pts;   // (row->outlier_selected belongs to the pose lane that walks the frame)
         }
+        publish_twist_tag(st, c.twist_slot, c.frame_idx);
         __syncthreads();   // the belief written here is the next frame's prior (same workgroup)
     }
 }

@@ -1066,9 +1066,31 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
     if (lane < 13) L.mean[lane] = src.mean[lane];
     static_assert(offsetof(ObjParams, R_q) == 21 * sizeof(double), "L.par mirrors the head of ObjParams");
     if (lane >= 160 && lane < 184) L.par[lane - 160] = reinterpret_cast<const double*>(&prm)[lane - 160];
-    if (lane >= 192 && lane < 205) {
+    if (lane >= 192) {   // wave 3
         const int i = lane - 192;
-        L.meas[i] = (i < 6) ? st.twist_hist[sd.twist_slot][i] : ((i < 9) ? c.pose_x[i - 6] : c.pose_q[i - 9]);
+        if (a.handoff) {
+            // The velocity filter of this batch may still be running (frame-granular hand-over): wait for the tag of the twist
+            // -- frame index + 1 of the latest frame <= this one whose twist lives in the slot -- and read the six values with
+            // agent-coherent loads (they were written through; nothing of them may come from this XCD's L2).
+            const int want = c.frame_idx - ((c.frame_idx - sd.twist_slot) & (kTwistRing - 1)) + 1;
+            if (lane == 192) {
+                const long long t0 = wall_clock64();
+                unsigned spins = 0;
+                while (__hip_atomic_load(&st.twist_tag[sd.twist_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 4095u) == 0u && wall_clock64() - t0 > 200000000ll) {   // two seconds (100 MHz): give up
+                        if (a.dev_error) __hip_atomic_store(a.dev_error, ROFT_DEV_ERROR_TWIST_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                }
+            }
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            if (i < 6) L.meas[i] = __longlong_as_double((long long)__hip_atomic_load(
+                reinterpret_cast<const unsigned long long*>(&st.twist_hist[sd.twist_slot][i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        } else if (i < 6) {
+            L.meas[i] = st.twist_hist[sd.twist_slot][i];
+        }
+        if (i >= 6 && i < 13) L.meas[i] = (i < 9) ? c.pose_x[i - 6] : c.pose_q[i - 9];
     }
     __syncthreads();
 
@@ -1208,7 +1230,10 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
             __syncthreads();
         }
         const FrameCtrl& c = s_c;
-        if (step == 0 && threadIdx.x == 0) pl.outlier_selected = -1;  // set again by outlier_kernel if it runs
+        if (step == 0 && threadIdx.x == 0) {
+            pl.outlier_selected = -1;  // set again by the decision behind an outlier test
+            if (roft_object_output* row0 = log_row(a, c, obj)) row0->outlier_selected = -1;
+        }
         if (step >= c.n_steps) { ++t; step = 0; continue; }
 #ifdef ROFT_UKF_WALL
         const long long w_s0 = wall_clock64();

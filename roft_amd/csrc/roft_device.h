@@ -97,6 +97,9 @@ struct ObjState {
     double v_cov[36];
     PoseBelief belief[kNumBelief];
     double twist_hist[kTwistRing][6];
+    // frame index + 1 of the twist a ring slot holds, published by the velocity filter AFTER the six values (agent-coherent
+    // stores, tag last): the frame-granular hand-over to a pose lane that runs next to it (EngineArrays::handoff)
+    int twist_tag[kTwistRing];
     PoseLane lane[kNumLin];
     int n_flow_points;     // N of the velocity stage of the last frame (-1: did not run)
     int n_feat[kFeatRing]; // buffered outlier-rejection samples (rank-even mask pixels) per feature ring slot
@@ -201,8 +204,8 @@ struct EngineArrays {
     int slot_new;            // plane slots receiving the masks ingested by this batch: slot_new + frame of the batch
     int slot_prev0;          // ring slot of the mask BEFORE frame 0 of the batch (frame t reads slot_prev0 + t, mod the ring:
                              // the flow measurement starts its plane loads without waiting for the control block), -1: unknown
-    unsigned* mask_sync;     // [n_obj] arrivals at the barriers among an object's workgroups inside mask_chain_kernel
-    unsigned* mask_general;  // [n_obj] bit t: frame t of the batch is left to mask_general_kernel (three-valued source)
+    unsigned* mask_general;  // [n_obj] bit t: frame t of the batch is left to mask_general_kernel (three-valued source);
+                             // zeroed with the batch's counters (mask_reset_tables), set by the frame kernels
     int32_t* map;            // [n_obj][W*H] scatter map of the general (non-binary) mask path, all-zero between frames
     FlowRec* cand;           // [T][n_obj][cand_cap] candidate scratch
     FlowRec* recs;           // [T][n_obj][cand_cap] kept flow records
@@ -219,14 +222,21 @@ struct EngineArrays {
     double ukf_chol_guard_bil;  // roft_config::ukf_cholesky_guard_bilinear
     roft_object_output* out_log;  // [log_cap][n_obj] per-frame outputs, or null
     int log_cap;
-    int mask_wgs;            // roft_config::mask_workgroups_per_object (0: by the device's CU count)
+    int mask_wgs;            // roft_config::mask_workgroups_per_object (0: bands of ~20 image rows)
     int outlier_parts;       // roft_config::outlier_bands_per_alternative (0: by the device's CU count)
     int* dev_error;          // one word of pinned host memory (or null): ROFT_DEV_ERROR_* raised by a kernel that gave up
+    // Frame-granular hand-over velocity filter -> pose lanes: the lanes' kernels of a batch are released by
+    // the command processor as soon as every workgroup of the batch's velocity filter is resident (skf_started, a running
+    // count the host waits on with hipStreamWaitValue64) and take each twist when its tag appears, instead of starting behind
+    // the filter's last frame.  0: the lanes run behind the velocity chain's completion event (tags are still published).
+    int handoff;
+    unsigned long long* skf_started;   // running count of velocity-filter workgroups that have started (or null)
     unsigned long long* k1_span;  // [T][n_obj][2] of THIS launch of the flow measurement, or null: 100 MHz wall clock at which each
                                   // workgroup started and ended (timing runs only: the launch's span on the device's own clock)
 };
 
-constexpr int ROFT_DEV_ERROR_MASK_BARRIER = 1;   // mask_chain_kernel: an object's workgroups never became resident together
+constexpr int ROFT_DEV_ERROR_TWIST_WAIT = 2;     // ukf_chain_kernel: a twist it was told to wait for was not published within two seconds
+constexpr int ROFT_DEV_ERROR_MASK_BARRIER = 1;   // (rounds 2 - 3: the persistent mask chain's barrier in memory; no kernel raises it any more)
 
 #define ROFT_LDS __attribute__((address_space(3)))
 
@@ -318,7 +328,7 @@ __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, i
 
 // frame t's new masks -> plane slot slot_new + t, their pixel counts -> mrec row t + 1 (zeroed before: mask_reset_tables)
 void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s, hipEvent_t stop = nullptr);
-// Zeroes what the ingest kernels and the chain accumulate into: the counters of mrec rows 1 .. T and mask_sync.
+// Zeroes what the ingest kernels and the frame kernels accumulate into: the counters of mrec rows 1 .. T and mask_general.
 // (Inside the engine the control block upload kernel does this; the operator-level entry points call it.)
 void launch_mask_reset(const EngineArrays& a, hipStream_t s);
 __device__ inline void mask_reset_tables(const EngineArrays& a, size_t i)   // thread i of a grid of >= (T + 1) * n_obj threads
@@ -328,13 +338,14 @@ __device__ inline void mask_reset_tables(const EngineArrays& a, size_t i)   // t
         r.new_count = 0;
         r.new_ones = 0;
     } else if (i < (size_t)(a.T + 1) * a.n_obj) {
-        a.mask_sync[i - (size_t)a.T * a.n_obj] = 0u;
+        a.mask_general[i - (size_t)a.T * a.n_obj] = 0u;
     }
 }
-// Mask chain of the batch (after the reset and the ingest of its new masks): one persistent kernel that walks the frames
-// of the batch (binary masks) and one persistent kernel for the frames of objects with three-valued masks.  Returns the
-// number of launches.
-int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, hipStream_t s, hipEvent_t stop = nullptr);
+// Mask chain of the batch (after the reset and the ingest of its new masks): one launch per frame (binary masks; many small
+// workgroups per object, nothing persistent) and one kernel for the frames of objects with three-valued masks.
+// new_mask_frames: bit t = some object receives a mask in frame t (those frames are split finer).  Returns the number of
+// launches.
+int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s, hipEvent_t stop = nullptr);
 void launch_planes_to_mask(const uint32_t* nz, const uint32_t* ob, int npix, uint8_t* mask, hipStream_t s);
 // `stop` / `start` (optional): HIP events bound to the kernel's own dispatch (hipExtLaunchKernelGGL) -- they complete
 // with the kernel, without the extra barrier packet and host call of a hipEventRecord behind it.

@@ -191,9 +191,9 @@ def test_shared_scene_host_inputs_are_uploaded_once():
 
 
 def test_mask_chain_result_independent_of_workgroups_per_object():
-    """The mask chain spreads an object over S = (256 - 64) / n_obj workgroups (at most 8, at least 1) that meet at a
-    barrier in memory between frames: 8 objects -> S = 8, 64 -> 3, 200 -> 1 (no barrier).  The same eight streams
-    tracked alone and as the first eight of 64 / 200 objects give the same rows and masks bit for bit."""
+    """The mask frames of 8, 64 and 200 objects (grids of 24 x n_obj small workgroups per frame, several rounds of the device at
+    200): the same eight streams tracked alone and as the first eight of 64 / 200 objects give the same rows and masks bit
+    for bit."""
     n = 22
     base = [util.to_device(clone(util.stream(740 + i, n, scale=2, pose_drop_prob=0.2 if i == 3 else 0.03, device="cuda")))
             for i in range(8)]
@@ -210,8 +210,8 @@ def test_mask_chain_result_independent_of_workgroups_per_object():
 
 
 def test_mask_workgroups_per_object_changes_nothing():
-    """roft_config::mask_workgroups_per_object: one workgroup per object (no barrier in memory), a few, or the automatic
-    choice -- the propagation is an order-free OR, so the whole trajectory is bit for bit the same."""
+    """roft_config::mask_workgroups_per_object: one band (workgroup) per object and frame, a few, or the automatic choice (bands
+    of ~20 image rows) -- the propagation is an order-free OR, so the whole trajectory is bit for bit the same."""
     n = 20
     streams = [util.to_device(st) for st in awkward_streams(n)]
     ref = None

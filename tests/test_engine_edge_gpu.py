@@ -292,9 +292,9 @@ def test_busy_streams_of_every_engine_have_hardware_queues_of_their_own():
 
 
 def test_more_objects_than_the_device_has_room_for_mask_workgroups():
-    """200 objects (not a multiple of eight, more than the 192 CUs the mask chain may take): one mask workgroup per object, no
-    barrier in memory, several rounds of every kernel's grid -- every object against the oracle, masks included, through a
-    pose arrival with its re-sync replay and outlier test."""
+    """200 objects (not a multiple of eight, more workgroups per launch than the device holds at once): several rounds of every
+    kernel's grid -- every object against the oracle, masks included, through a pose arrival with its re-sync replay and
+    outlier test."""
     n_obj, n = 200, 8
     streams = [util.stream(3000 + i, n, scale=4, mesh_n=6, device="cuda") for i in range(n_obj)]
     n_tests = compare(streams, n)
@@ -350,10 +350,37 @@ def test_host_pointer_declared_as_device_memory_is_refused():
                mem_kind=L.MEM_DEVICE)
     with pytest.raises(L.RoftError) as err:
         eng.submit([bad])
-    assert "not device memory" in str(err.value) and "depth" in str(err.value)
+    assert "neither device memory nor pinned" in str(err.value) and "depth" in str(err.value)
     dev, dev_mask = torch.from_numpy(depth).cuda(), torch.from_numpy(mask).cuda()
     ok = dict(depth=dev.data_ptr(), flow=None, mask=dev_mask.data_ptr(), pose=pose, dt=st.dt, mem_kind=L.MEM_DEVICE)
     eng.submit([ok])
     eng.step()
     eng.sync()
     eng.close()
+
+
+def test_pinned_host_memory_is_read_in_place_as_device_input():
+    """Pinned, mapped host memory (hipHostMalloc / hipHostRegister: what torch's pin_memory() allocates) handed over as
+    ROFT_MEM_DEVICE is read in place over the bus -- only the sectors the kernels touch cross it, nothing is uploaded -- under the
+    retention contract of DEVICE inputs; the trajectory equals the one tracked from HBM-resident copies bit for bit."""
+    n = 14
+    st = util.stream(571, n, scale=2, device="cuda")
+    dev = util.to_device(st)
+    ref, ref_masks, _ = util.run_engine_logged(make_engine, [dev], n, T=1)
+    import copy
+    pin = copy.copy(st)
+    pin.depth, pin.flow, pin.mask_gt = st.depth.pin_memory(), st.flow.pin_memory(), st.mask_gt.pin_memory()
+    assert pin.depth.is_pinned() and not pin.depth.is_cuda
+    eng = make_engine([pin])
+    eng.enable_log(n)
+    h2d0 = eng.stats()["h2d_bytes"]
+    for k in range(n):
+        eng.submit([util.device_frame(pin, k)])       # mem_kind = MEM_DEVICE, pointers into the pinned host tensors
+        eng.step()
+    log = eng.get_log(0, n)
+    assert eng.stats()["h2d_bytes"] == h2d0           # nothing was staged
+    masks = [eng.mask(0)]
+    eng.close()
+    for a, b in zip(ref, log):
+        assert np.array_equal(a, b)
+    assert np.array_equal(ref_masks[0], masks[0])
