@@ -15,7 +15,9 @@
 #include <cstddef>
 #include <cstdint>
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <deque>
 #include <fstream>
 #include <memory>
@@ -29,6 +31,42 @@
 #include <vector>
 
 #include "../roft_engine.h"
+
+// Image-sized buffers of the stand-in matrix types live in pinned, device-mapped host memory when the library finds a device
+// (roft_host_alloc, roft_engine.h section 2b): ROFT::ROFTFilter then hands them to the engine as they are -- the kernels read the
+// few hundred KB of a frame they need in place, nothing is staged or uploaded -- and smaller buffers in ordinary memory.
+// (weak references: a program that uses only the stand-in types and does not link libroft_hip.so -- a log writer, a file
+//  converter -- still links; its buffers are ordinary memory then)
+#pragma weak roft_host_alloc
+#pragma weak roft_host_free
+#pragma weak roft_host_is_pinned
+namespace ROFT {
+namespace compat {
+template <class T>
+struct ImageAllocator {
+    using value_type = T;
+    static constexpr std::size_t kPinFrom = (std::size_t)64 << 10;   // bytes
+    ImageAllocator() = default;
+    template <class U> ImageAllocator(const ImageAllocator<U>&) {}
+    T* allocate(std::size_t n)
+    {
+        const std::size_t bytes = n * sizeof(T);
+        if (bytes >= kPinFrom && roft_host_alloc)
+            if (void* p = roft_host_alloc(bytes)) return static_cast<T*>(p);
+        void* p = std::malloc(bytes ? bytes : 1);
+        if (!p) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, std::size_t n)
+    {
+        if (n * sizeof(T) >= kPinFrom && roft_host_is_pinned && roft_host_is_pinned(p)) roft_host_free(p);
+        else std::free(p);
+    }
+    template <class U> bool operator==(const ImageAllocator<U>&) const { return true; }
+    template <class U> bool operator!=(const ImageAllocator<U>&) const { return false; }
+};
+}  // namespace compat
+}  // namespace ROFT
 
 #ifndef ROFT_HAVE_REAL_DEPENDENCIES
 
@@ -60,22 +98,27 @@ private:
     std::size_t n_;
 };
 
+// A dense row-major matrix with Eigen's value semantics.  The storage is shared between copies and detached by the first
+// mutating access (copy on write): a depth image travels from the camera through CameraMeasurement::measure()'s tuple to the
+// filter without being copied three times per frame, and the pointer the engine reads stays the one the file was read into.
 template <class S>
 class DenseMatrix {
+    using Store = std::vector<S, ROFT::compat::ImageAllocator<S>>;
+
 public:
     DenseMatrix() = default;
-    DenseMatrix(const VectorBlock<S>& b) : r_(b.size()), c_(1), d_(b.size())
+    DenseMatrix(const VectorBlock<S>& b) : r_(b.size()), c_(1), d_(std::make_shared<Store>(b.size()))
     {
-        for (std::size_t i = 0; i < d_.size(); ++i) d_[i] = b(i);
+        for (std::size_t i = 0; i < d_->size(); ++i) (*d_)[i] = b(i);
     }
     VectorBlock<S> head(std::size_t n) { return block(0, n); }
-    VectorBlock<S> tail(std::size_t n) { return block(d_.size() - n, n); }
+    VectorBlock<S> tail(std::size_t n) { return block(size() - n, n); }
     VectorBlock<S> segment(std::size_t i, std::size_t n) { return block(i, n); }
     template <int N> VectorBlock<S> head() { return block(0, N); }
-    template <int N> VectorBlock<S> tail() { return block(d_.size() - N, N); }
+    template <int N> VectorBlock<S> tail() { return block(size() - N, N); }
     template <int N> VectorBlock<S> segment(std::size_t i) { return block(i, N); }
-    DenseMatrix(std::size_t r, std::size_t c) : r_(r), c_(c), d_(r * c, S(0)) {}
-    explicit DenseMatrix(std::size_t n) : r_(n), c_(1), d_(n, S(0)) {}
+    DenseMatrix(std::size_t r, std::size_t c) : r_(r), c_(c), d_(std::make_shared<Store>(r * c, S(0))) {}
+    explicit DenseMatrix(std::size_t n) : r_(n), c_(1), d_(std::make_shared<Store>(n, S(0))) {}
     static DenseMatrix Zero(std::size_t r, std::size_t c = 1) { return DenseMatrix(r, c); }
     static DenseMatrix Identity(std::size_t r, std::size_t c)
     {
@@ -83,14 +126,14 @@ public:
         for (std::size_t i = 0; i < r && i < c; ++i) m(i, i) = S(1);
         return m;
     }
-    void resize(std::size_t r, std::size_t c = 1) { r_ = r; c_ = c; d_.assign(r * c, S(0)); }
+    void resize(std::size_t r, std::size_t c = 1) { r_ = r; c_ = c; d_ = std::make_shared<Store>(r * c, S(0)); }
     std::size_t rows() const { return r_; }
     std::size_t cols() const { return c_; }
-    std::size_t size() const { return d_.size(); }
-    S& operator()(std::size_t i, std::size_t j = 0) { return d_[i * c_ + j]; }
-    const S& operator()(std::size_t i, std::size_t j = 0) const { return d_[i * c_ + j]; }
-    S* data() { return d_.data(); }
-    const S* data() const { return d_.data(); }
+    std::size_t size() const { return d_ ? d_->size() : 0; }
+    S& operator()(std::size_t i, std::size_t j = 0) { return own()[i * c_ + j]; }
+    const S& operator()(std::size_t i, std::size_t j = 0) const { return (*d_)[i * c_ + j]; }
+    S* data() { return size() ? own().data() : nullptr; }
+    const S* data() const { return d_ ? d_->data() : nullptr; }
     DenseMatrix transpose() const
     {
         DenseMatrix m(c_, r_);
@@ -101,19 +144,26 @@ public:
     // diag(v) of a vector, as `v.asDiagonal()` is used in the reference's constructors
     DenseMatrix asDiagonal() const
     {
-        DenseMatrix m(d_.size(), d_.size());
-        for (std::size_t i = 0; i < d_.size(); ++i) m(i, i) = d_[i];
+        DenseMatrix m(size(), size());
+        for (std::size_t i = 0; i < size(); ++i) m(i, i) = (*d_)[i];
         return m;
     }
 
 private:
+    // the storage for writing: detached from the copies that share it
+    Store& own()
+    {
+        if (!d_) d_ = std::make_shared<Store>();
+        else if (d_.use_count() > 1) d_ = std::make_shared<Store>(*d_);
+        return *d_;
+    }
     VectorBlock<S> block(std::size_t i, std::size_t n)
     {
-        if (i + n > d_.size() || (r_ != 1 && c_ != 1)) throw std::runtime_error("Eigen stand-in: block outside of the vector");
-        return VectorBlock<S>(d_.data() + i, n);
+        if (i + n > size() || (r_ != 1 && c_ != 1)) throw std::runtime_error("Eigen stand-in: block outside of the vector");
+        return VectorBlock<S>(own().data() + i, n);
     }
     std::size_t r_ = 0, c_ = 0;
-    std::vector<S> d_;
+    std::shared_ptr<Store> d_;
 };
 template <class S>
 VectorBlock<S>& VectorBlock<S>::operator=(const DenseMatrix<S>& v)
@@ -223,7 +273,7 @@ struct Vec2s { short v[2]; short operator()(int i) const { return v[i]; } };
 class Mat {
 public:
     Mat() = default;
-    Mat(int rows, int cols, int type) : rows(rows), cols(cols), type_(type), buf_(std::make_shared<std::vector<unsigned char>>((std::size_t)rows * cols * elem(type), 0)) { data = buf_->data(); }
+    Mat(int rows, int cols, int type) : rows(rows), cols(cols), type_(type), buf_(std::make_shared<Store>((std::size_t)rows * cols * elem(type), 0)) { data = buf_->data(); }
     // wraps caller memory (no ownership), like cv::Mat(rows, cols, type, void*)
     Mat(int rows, int cols, int type, void* external) : rows(rows), cols(cols), data(static_cast<unsigned char*>(external)), type_(type) {}
     int type() const { return type_; }
@@ -244,7 +294,8 @@ public:
 private:
     static std::size_t elem(int type) { return type == CV_32FC2 ? 8 : (type == CV_16SC2 ? 4 : (type == CV_8UC3 ? 3 : 1)); }
     int type_ = CV_8UC1;
-    std::shared_ptr<std::vector<unsigned char>> buf_;
+    using Store = std::vector<unsigned char, ROFT::compat::ImageAllocator<unsigned char>>;
+    std::shared_ptr<Store> buf_;
 };
 
 }  // namespace cv

@@ -256,13 +256,20 @@ private:
     long first_ = 0, cursor_ = -1;
 };
 
+// microseconds the file-backed sources of this process spent loading since the counter was last taken (the filter's
+// ROFT_FILTER_TIMING report: the whole milliseconds below are the reference's resolution)
+inline double& loading_us_counter() { static double us = 0.0; return us; }
+inline double take_loading_us() { const double v = loading_us_counter(); loading_us_counter() = 0.0; return v; }
+
 // wall-clock milliseconds a callable took (the data-loading times the filter subtracts from its execution time)
 template <class F>
 double milliseconds_of(F&& f)
 {
     const auto started = std::chrono::steady_clock::now();
     f();
-    return (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - started).count();
+    const auto d = std::chrono::steady_clock::now() - started;
+    loading_us_counter() += std::chrono::duration<double, std::micro>(d).count();
+    return (double)std::chrono::duration_cast<std::chrono::milliseconds>(d).count();
 }
 
 // rows of doubles of a text file: `skip_rows` leading rows and `skip_cols` leading columns dropped, rows with fewer than
@@ -353,7 +360,7 @@ public:
         }
         std::fclose(in);
         if (!ok) std::cout << "DatasetCamera::depth. Error: cannot load depth data of frame " << path << std::endl;
-        return {ok, d};
+        return {ok, std::move(d)};
     }
     std::pair<bool, cv::Mat> rgb(const bool&) override
     {

@@ -24,9 +24,8 @@ public:
     {
         const long item = compat::delayed_item(head_, first_, period_, late_);
         if (item < 0) return {false, cv::Mat()};
-        const auto started = std::chrono::steady_clock::now();
-        std::pair<bool, cv::Mat> delivered = read_file((std::size_t)item);
-        loading_ms_ = (double)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - started).count();
+        std::pair<bool, cv::Mat> delivered;
+        loading_ms_ = compat::milliseconds_of([&] { delivered = read_file((std::size_t)item); });
         return delivered;
     }
     void reset_data_loading_time() override { loading_ms_ = 0.0; }

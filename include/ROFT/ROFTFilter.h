@@ -11,6 +11,8 @@
 // cpp:396-446) are served when set, so the tail of src/roft/src/main.cpp:393-424 compiles against this class as it is.
 #pragma once
 
+#include <deque>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -133,7 +135,16 @@ public:
         if (enable_log) measurement_log_.enable_log(log_path, log_prefix);
     }
 
-    virtual ~ROFTFilter() { if (engine_) roft_engine_destroy(engine_); }
+    virtual ~ROFTFilter()
+    {
+        // ROFT_FILTER_TIMING=1: what the integer milliseconds of `execution_times` (the reference's resolution, cpp:463) hide
+        if (std::getenv("ROFT_FILTER_TIMING") && timed_frames_ > 0)
+            std::printf("ROFTFilter: %ld frames, %.1f us per frame outside data loading (submit + step + state read-back: %.1f us; polling the "
+                        "sources: %.1f us), %s inputs\n", timed_frames_, exec_us_ / timed_frames_, engine_us_ / timed_frames_,
+                        sources_us_ / timed_frames_, in_place_frames_ == timed_frames_ ? "in-place (pinned)" : "staged (HOST)");
+        if (engine_) roft_engine_destroy(engine_);
+        held_.clear();
+    }
     ROFTFilter(const ROFTFilter&) = delete;
     ROFTFilter& operator=(const ROFTFilter&) = delete;
 
@@ -194,6 +205,7 @@ protected:
         }
         const double rgbd_load_time = ms_since(time0);
         const auto std_time_0 = clock::now();   // start_time_count(): the RGB-D loading time is excluded (cpp:267-270)
+        (void)compat::take_loading_us();
         bool valid = false;
         bfl::Data cam_data;
         std::tie(valid, cam_data) = camera_->measure();
@@ -222,25 +234,44 @@ protected:
         in.depth = depth.data();
         in.flow = valid_flow ? flow.data : nullptr;
         in.mask = new_mask ? mask.data : nullptr;
-        in.mem_kind = ROFT_MEM_HOST;
+        // Images that live in the library's pinned, device-mapped pool (the stand-in matrix types allocate image-sized buffers
+        // there: Compat.h) are handed over as they are and read in place over the bus -- a frame costs the few hundred KB the
+        // kernels touch instead of a 5.5 MB upload; this filter keeps them alive for the engine's retention window (below).
+        static const bool staged_only = std::getenv("ROFT_FACADE_STAGED") != nullptr;   // (A/B: force the HOST upload path)
+        const bool in_place = !staged_only && roft_host_is_pinned(in.depth) && (!in.flow || roft_host_is_pinned(in.flow)) && (!in.mask || roft_host_is_pinned(in.mask));
+        in.mem_kind = in_place ? ROFT_MEM_DEVICE : ROFT_MEM_HOST;
         if (cfg_.use_pose && pose_measurement_->freeze(false)) {
             last_pose_ = pose_measurement_->transform();
             in.pose_valid = 1;
             for (int i = 0; i < 3; ++i) in.pose_x[i] = last_pose_.translation()[i];
             for (int i = 0; i < 4; ++i) in.pose_q[i] = last_pose_.quaternion()[i];
         }
+        const auto eng_t0 = clock::now();
+        sources_us_ += std::chrono::duration<double, std::micro>(eng_t0 - std_time_0).count() - compat::loading_us_counter();
         compat::throw_if(roft_frame_submit(engine_, &in, 1), "ROFTFilter::filtering_step");
         compat::throw_if(roft_step(engine_), "ROFTFilter::filtering_step");
         compat::throw_if(roft_get_state(engine_, 0, p_corr_belief_.mean().data(), p_corr_belief_.covariance().data(), v_corr_belief_.mean().data(),
                                         v_corr_belief_.covariance().data()), "ROFTFilter::filtering_step");
         compat::throw_if(roft_get_outputs(engine_, &out_, 1), "ROFTFilter::filtering_step");
         ++frames_;
+        engine_us_ += std::chrono::duration<double, std::micro>(clock::now() - eng_t0).count();
+        if (in_place) {
+            ++in_place_frames_;
+            // (depth of frame k is read again by frame k + 1, a flow by the masks chased through it for up to
+            //  mask_frames_between frames: roft_engine_retain_frames)
+            held_.push_back(Held{cam_data, valid_flow ? flow : cv::Mat(), new_mask ? mask : cv::Mat()});
+            while ((int)held_.size() > roft_engine_retain_frames(engine_) + 1) held_.pop_front();
+        }
         // stop_time_count(): what follows is "for debugging purposes only" (cpp:369-384); the time the sources spent
         // loading data from disk is taken out of the execution time and reported next to the RGB-D loading time
         double exec_time = ms_since(std_time_0);
+        const double exec_us_now = std::chrono::duration<double, std::micro>(clock::now() - std_time_0).count();
+        const double loading_us = compat::take_loading_us();
         const double load_time = flow_source_->get_data_loading_time() + segmentation_source_->get_data_loading_time();
         segmentation_source_->reset_data_loading_time();
         exec_time -= load_time;
+        exec_us_ += exec_us_now - loading_us;   // (the sources report their loading time in whole milliseconds, like the reference's)
+        ++timed_frames_;
 
         // `pose_estimate` = v w x axis angle, `velocity_estimate` = v_O w, `execution_times` (cpp:386-394, 448-451)
         Eigen::VectorXd p_mean(13), v_mean(6), execution_time(2);
@@ -330,6 +361,11 @@ private:
     std::vector<float> verts_;
     std::vector<std::int32_t> tris_;
     roft_engine* engine_ = nullptr;
+    // frames handed to the engine in place (pinned pool): camera tuple (depth), flow and mask of the retention window
+    struct Held { bfl::Data cam; cv::Mat flow, mask; };
+    std::deque<Held> held_;
+    double exec_us_ = 0.0, engine_us_ = 0.0, sources_us_ = 0.0;
+    long timed_frames_ = 0, in_place_frames_ = 0;
     roft_object_output out_{};
     const double sample_time_;
     double last_camera_stamp_ = -1;

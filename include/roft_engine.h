@@ -336,6 +336,19 @@ int roft_engine_enable_timing(roft_engine* e, int enable);
 int roft_engine_get_timing(roft_engine* e, int* n_out, const char*** names_out, const float** ms_out,
                            const int** launches_out);
 
+/* ---- (2b) pinned host memory for images that are read in place ---------------------------------------------------- *
+ * Image buffers handed over as ROFT_MEM_HOST are copied to the device by the submit call: every byte of depth, flow and mask
+ * crosses the bus although the kernels read a few hundred KB of a frame (the pixels of the object's mask).  Buffers that live in
+ * pinned, device-mapped host memory can be handed over as ROFT_MEM_DEVICE instead -- under the retention contract of DEVICE
+ * inputs (roft_frame_input) -- and are then read in place: only the sectors the kernels touch cross the bus and nothing is
+ * staged.  roft_host_alloc returns such memory from a pool (blocks are recycled by size; the first allocation of a size pins
+ * pages, ~0.1 ms per MB), NULL when there is no device or the allocation fails: use ordinary memory and ROFT_MEM_HOST then.
+ * The class facade (include/ROFT/Compat.h) allocates its image-sized buffers this way and ROFT::ROFTFilter keeps the frames of
+ * the retention window alive, so the reference's executable reads its images from disk straight into memory the GPU reads. */
+void* roft_host_alloc(size_t bytes);
+void roft_host_free(void* p);              /* p from roft_host_alloc; NULL is ignored */
+int roft_host_is_pinned(const void* p);    /* 1 when p lies inside a live block of the pool */
+
 /* ---- (3) optical-flow producer (replaces the reference's NVIDIA-hardware flow source) ---------------- *
  * ROFT consumes pre-computed flow frames produced by cv::cuda::NvidiaOpticalFlow_{1_0,2_0}
  * (src/roft-lib/src/ImageOpticalFlowNVOF.cpp:100-159, tools/nvof/dumper/src/main.cpp:40-146).  MI355X has no

@@ -95,6 +95,7 @@ ABI_SYMBOLS = [
     "roft_engine_get_timing", "roft_default_of_params", "roft_optical_flow", "roft_flow_producer_create",
     "roft_flow_producer_destroy", "roft_flow_producer_run", "roft_flow_producer_sync", "roft_flow_producer_stream",
     "roft_debug_plan", "roft_debug_get_dbg", "roft_debug_probe_streams", "roft_debug_sector_rate",
+    "roft_host_alloc", "roft_host_free", "roft_host_is_pinned",
 ]
 
 
@@ -166,9 +167,14 @@ def lib():
     L.roft_flow_producer_sync.argtypes = [vp]
     L.roft_flow_producer_stream.restype = vp
     L.roft_flow_producer_stream.argtypes = [vp]
+    L.roft_host_alloc.restype = vp
+    L.roft_host_alloc.argtypes = [C.c_size_t]
+    L.roft_host_free.restype = None
+    L.roft_host_free.argtypes = [vp]
+    L.roft_host_is_pinned.argtypes = [vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
-        if name not in ("roft_last_error_string", "roft_engine_stream", "roft_flow_producer_stream"):
+        if name not in ("roft_last_error_string", "roft_engine_stream", "roft_flow_producer_stream", "roft_host_alloc", "roft_host_free"):
             f.restype = C.c_int
     _lib = L
     return L

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -466,6 +467,81 @@ int roft_device_count(void)
     return n;
 }
 
+// ---- pinned host memory pool (roft_engine.h section 2b) ----
+namespace {
+struct HostPool {
+    std::mutex mu;
+    std::map<uintptr_t, size_t> live;                       // blocks handed out: start -> bytes
+    std::map<size_t, std::vector<void*>> spare;             // recycled blocks by size
+    size_t spare_bytes = 0;
+};
+HostPool& host_pool() { static HostPool* p = new HostPool(); return *p; }   // (never destroyed: buffers of static objects may outlive main)
+constexpr size_t kHostPoolGranule = (size_t)64 << 10;
+constexpr size_t kHostPoolSpareCap = (size_t)512 << 20;   // recycled bytes kept before blocks go back to the runtime
+}  // namespace
+
+void* roft_host_alloc(size_t bytes)
+{
+    if (bytes == 0) return nullptr;
+    static const int n_dev = roft_device_count();
+    if (n_dev <= 0) return nullptr;
+    const size_t sz = (bytes + kHostPoolGranule - 1) / kHostPoolGranule * kHostPoolGranule;
+    HostPool& hp = host_pool();
+    {
+        std::lock_guard<std::mutex> lk(hp.mu);
+        auto it = hp.spare.find(sz);
+        if (it != hp.spare.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            hp.spare_bytes -= sz;
+            hp.live[reinterpret_cast<uintptr_t>(p)] = sz;
+            return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, sz, hipHostMallocMapped | hipHostMallocPortable) != hipSuccess || !p) { (void)hipGetLastError(); return nullptr; }
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || dp != p) {   // (must be addressable by the GPU at the same address)
+        (void)hipGetLastError();
+        (void)hipHostFree(p);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(hp.mu);
+    hp.live[reinterpret_cast<uintptr_t>(p)] = sz;
+    return p;
+}
+
+void roft_host_free(void* p)
+{
+    if (!p) return;
+    HostPool& hp = host_pool();
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> lk(hp.mu);
+        auto it = hp.live.find(reinterpret_cast<uintptr_t>(p));
+        if (it == hp.live.end()) return;
+        sz = it->second;
+        hp.live.erase(it);
+        if (hp.spare_bytes + sz <= kHostPoolSpareCap) {
+            hp.spare[sz].push_back(p);
+            hp.spare_bytes += sz;
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
+int roft_host_is_pinned(const void* p)
+{
+    if (!p) return 0;
+    HostPool& hp = host_pool();
+    std::lock_guard<std::mutex> lk(hp.mu);
+    auto it = hp.live.upper_bound(reinterpret_cast<uintptr_t>(p));
+    if (it == hp.live.begin()) return 0;
+    --it;
+    return reinterpret_cast<uintptr_t>(p) < it->first + it->second ? 1 : 0;
+}
+
 int roft_default_config(roft_config* c, int width, int height, int flow_type)
 {
     if (!c) return fail(ROFT_ERR_INVALID, "null config");
@@ -593,14 +669,14 @@ static int create_stream_set(int device, bool priorities, StreamSet** out)
     if (!priorities) greatest = least;
     const int normal = (least + greatest) / 2;
     // (ROFT_PRIO=<lane 0><lane 1><velocity><mask>, each h | n | l: experiments)
-    int pr[4] = {normal, normal, greatest, least};
+    int pr[5] = {normal, normal, greatest, least, normal};
     if (const char* pe = getenv("ROFT_PRIO"))
-        for (int i = 0; i < 4 && pe[i]; ++i) pr[i] = pe[i] == 'h' ? greatest : (pe[i] == 'l' ? least : normal);
+        for (int i = 0; i < 5 && pe[i]; ++i) pr[i] = pe[i] == 'h' ? greatest : (pe[i] == 'l' ? least : normal);
     hipError_t err = hipSuccess;
     for (int l = 0; l < kNumLin && err == hipSuccess; ++l) err = hipStreamCreateWithPriority(&s->pose[l], hipStreamNonBlocking, pr[l]);
     if (err == hipSuccess) err = hipStreamCreateWithPriority(&s->vel, hipStreamNonBlocking, pr[2]);
     if (err == hipSuccess) err = hipStreamCreateWithPriority(&s->mask, hipStreamNonBlocking, pr[3]);
-    if (err == hipSuccess) err = hipStreamCreateWithFlags(&s->up, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipStreamCreateWithPriority(&s->up, hipStreamNonBlocking, pr[4]);
     if (err != hipSuccess) { delete s; return fail(ROFT_ERR_DEVICE, std::string("stream creation: ") + hipGetErrorString(err)); }
     *out = s;
     return ROFT_OK;
