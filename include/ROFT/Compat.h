@@ -65,6 +65,11 @@ struct ImageAllocator {
     template <class U> bool operator==(const ImageAllocator<U>&) const { return true; }
     template <class U> bool operator!=(const ImageAllocator<U>&) const { return false; }
 };
+
+// microseconds the file-backed sources of this process spent loading since the counter was last taken (ROFTFilter's
+// ROFT_FILTER_TIMING report; the sources themselves report whole milliseconds, the reference's resolution: CompatIO.h)
+inline double& loading_us_counter() { static double us = 0.0; return us; }
+inline double take_loading_us() { const double v = loading_us_counter(); loading_us_counter() = 0.0; return v; }
 }  // namespace compat
 }  // namespace ROFT
 

@@ -256,11 +256,6 @@ private:
     long first_ = 0, cursor_ = -1;
 };
 
-// microseconds the file-backed sources of this process spent loading since the counter was last taken (the filter's
-// ROFT_FILTER_TIMING report: the whole milliseconds below are the reference's resolution)
-inline double& loading_us_counter() { static double us = 0.0; return us; }
-inline double take_loading_us() { const double v = loading_us_counter(); loading_us_counter() = 0.0; return v; }
-
 // wall-clock milliseconds a callable took (the data-loading times the filter subtracts from its execution time)
 template <class F>
 double milliseconds_of(F&& f)

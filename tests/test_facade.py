@@ -890,6 +890,46 @@ def test_batched_tracker_front_end_equals_one_tracker_per_object(tmp_path, capsy
     for _, name, _, _ in seqs:
         for f in ("pose_estimate.txt", "velocity_estimate.txt"):
             assert open(str(tmp_path / "out" / name / f)).read() == open(str(tmp_path / "out_sharded" / name / f)).read(), (name, f)
+    # the native exchange of a multi-GPU job (--gather, built with rccl.h): every process's result rows through an ncclAllGather,
+    # process 0 writes the logs of ALL objects.  One process (a communicator of one rank) always works; two processes on the ONE
+    # GPU of this box are what RCCL may refuse ("Duplicate GPU detected"): then only the refusal is checked -- on a node every
+    # process has a GPU of its own (--device r --shard r G).
+    exe_rccl = str(tmp_path / "ROFT-tracker-batch-rccl")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-DROFT_WITH_RCCL", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           "-I", os.path.join(ROOT, "include", "compat"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "track_many.cpp"), "-o", exe_rccl, "-L", CSRC, "-lroft_hip", "-Wl,-rpath," + CSRC,
+                           "-L/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    g1 = [a if a != str(tmp_path / "out") else str(tmp_path / "out_gather1") for a in args] + ["--gather", str(tmp_path / "id1")]
+    r = subprocess.run([exe_rccl] + g1, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rows all-gathered over RCCL, logs of 3 objects written" in r.stdout, r.stdout[-800:] + r.stderr[-800:]
+    for _, name, _, _ in seqs:
+        for f in ("pose_estimate.txt", "velocity_estimate.txt"):
+            assert open(str(tmp_path / "out" / name / f)).read() == open(str(tmp_path / "out_gather1" / name / f)).read(), (name, f)
+    procs = []
+    for rank in range(2):
+        g2 = [a if a != str(tmp_path / "out") else str(tmp_path / "out_gather2") for a in args] + ["--device", "0", "--shard", str(rank), "2", "--gather", str(tmp_path / "id2")]
+        procs.append(subprocess.Popen([exe_rccl] + g2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    import time as _time
+    t_end = _time.time() + 240
+    while _time.time() < t_end and any(p_.poll() is None for p_ in procs):
+        if any(p_.poll() not in (None, 0) for p_ in procs):      # one process gave up: the other one waits for it in vain
+            _time.sleep(2.0)
+            break
+        _time.sleep(0.2)
+    for p_ in procs:
+        if p_.poll() is None:
+            p_.kill()
+    outs = [p_.communicate() for p_ in procs]
+    if all(p_.returncode == 0 for p_ in procs):
+        assert "logs of 3 objects written" in outs[0][0]
+        for _, name, _, _ in seqs:
+            for f in ("pose_estimate.txt", "velocity_estimate.txt"):
+                assert open(str(tmp_path / "out" / name / f)).read() == open(str(tmp_path / "out_gather2" / name / f)).read(), (name, f)
+        print("two processes on one GPU: RCCL all-gather ok")
+    else:
+        msg = " ".join(o[1] for o in outs)
+        assert "ncclCommInitRank" in msg or "ncclAllGather" in msg, msg[-1500:]     # refused by RCCL itself, with its reason
+        print("two processes on one GPU refused by RCCL: " + msg.strip().splitlines()[-1][:200])
     # ... and the step after the path: the metrics table of that results tree against the sequences' ground truth
     spec = importlib.util.spec_from_file_location("evaluate_results", os.path.join(ROOT, "tools", "evaluate_results.py"))
     ev = importlib.util.module_from_spec(spec)

@@ -3,7 +3,7 @@
 # gpurun_out/<tag>/ (copy the ones to keep into profiles/ with the tag as prefix).   usage: bash tools/collect_profiles.sh [tag]
 set -x
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
@@ -25,6 +25,30 @@ for n in (8, 16, 32, 64, 128, 256):
                     kernels=d["kernels_post_run_breakdown"]))
 json.dump(dict(what="python bench.py --steps 60 --warmup 12 --objects N (one MI355X): the per-GPU load of config #4 sharded over 8 / 4 / 2 / 1 GPUs is 8 / 16 / 32 / 64 objects", runs=out), sys.stdout, indent=1)
 PY
+# ... and the same points in the DRIVER's shape (--steps 20 --warmup 5): what a strong-scaling run of config #4 over 8 / 4 / 2 / 1 GPUs puts on one GPU
+python - > $O/object_sweep_20.json <<PY
+import json, subprocess, sys
+out = []
+for n in (8, 16, 32, 64):
+    vals = []
+    for rep in range(3):
+        r = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--objects", str(n), "--no-cpu-baseline", "--pcie-frames", "0", "--no-extras"],
+                           capture_output=True, text=True, timeout=600)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        vals.append(d["value"])
+    out.append(dict(objects=n, values=vals, median=sorted(vals)[1], frames_per_sec_per_object=sorted(vals)[1] / n, ms_per_step=d["ms_per_step"]))
+json.dump(dict(what="python bench.py --steps 20 --warmup 5 --objects N (one MI355X), three runs each", runs=out), sys.stdout, indent=1)
+PY
+# the reference's executable over this engine: microseconds per frame at 1280x720, images read in place / staged
+timeout 600 python tools/tracker_timing.py 120 --out $O/tracker_timing.json > /dev/null 2>> $O/bench.err
+# profiler-free timelines (HIP event marks after every launch group): the driver-shaped window and the steady state
+rm -f $O/marks_20.txt $O/marks_240.txt
+ROFT_BENCH_FULL_TIMING=1 ROFT_DUMP_MARKS=$O/marks_20.txt ROFT_BENCH_EXTRA_FRAMES=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-frames 0 --no-extras > /dev/null 2>> $O/bench.err
+python tools/marks_timeline.py $O/marks_20.txt --list > $O/marks_timeline_20.txt
+ROFT_BENCH_FULL_TIMING=1 ROFT_DUMP_MARKS=$O/marks_240.txt ROFT_BENCH_EXTRA_FRAMES=0 timeout 300 python bench.py --steps 240 --warmup 16 --no-cpu-baseline --pcie-frames 0 --no-extras > /dev/null 2>> $O/bench.err
+python tools/marks_timeline.py $O/marks_240.txt --from 4000 --to 9000 > $O/marks_timeline_240.txt
+python tools/marks_timeline.py $O/marks_240.txt --from 6000 --to 7400 --list | tail -n +16 >> $O/marks_timeline_240.txt
+rm -f $O/marks_20.txt $O/marks_240.txt
 # the N > 1 code path executed: two ranks on this one GPU over gloo (the driver's multi-GPU runs use one GPU per rank and RCCL)
 ROFT_BENCH_DEVICE=0 ROFT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2ranks_one_gpu_gloo.json 2>> $O/bench.err
 ROFT_BENCH_DEVICE=0 ROFT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 20 --warmup 5 --shared-scene > $O/bench_2ranks_one_gpu_gloo_shared_scene.json 2>> $O/bench.err
@@ -45,6 +69,9 @@ python3 $R/tools/prof_summary.py stats $O/stats1/*/*kernel_stats.csv $O/bench_ke
 rm -rf $O/stats1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python3 $R/bench.py --steps 48 --warmup 7 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
 python3 $R/tools/prof_summary.py stats $O/stats2/*/*kernel_stats.csv $O/bench_kernel_stats_48.csv
+# CU x us budget of that run (48 timed + 7 warm-up + 24 breakdown frames x 64 objects; footprints: profiles/${TAG}_kernel_resources.csv,
+# made without a GPU by tools/kernel_resources.sh)
+[ -f $R/profiles/${TAG}_kernel_resources.csv ] && python3 $R/tools/cu_budget.py $O/stats2/*/*kernel_trace.csv $R/profiles/${TAG}_kernel_resources.csv $((64 * 55)) > $O/cu_budget.csv
 rm -rf $O/stats2
 # HBM traffic, one counter per pass (FETCH_SIZE and WRITE_SIZE do not fit one pass); every launch of the roofline kernel
 # covers 8 frames x 64 objects in this run (24 timed frames after 8 warm-up frames, batches of 8)

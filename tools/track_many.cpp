@@ -8,7 +8,11 @@
 //                      --object SEQUENCE_DIR NAME [MESH.obj] [--object ...]
 //
 // Several GPUs: one process per GPU, each given the same object list, `--device r --shard r G`: process r tracks the r-th block
-// of ceil(n / G) objects (the partition of roft_amd/parallel.py) -- no process talks to another.
+// of ceil(n / G) objects (the partition of roft_amd/parallel.py) -- no process talks to another while tracking.
+// `--gather ID_FILE` (built with -DROFT_WITH_RCCL): the one exchange a job needs, natively -- at the end every process hands its
+// per-object result rows (19 doubles per object-frame: pose 13 | twist 6, what ROFTFilter logs) to an ncclAllGather over
+// RCCL / xGMI and process 0 writes the logs of ALL objects; the ncclUniqueId travels through ID_FILE (process 0 writes it, the
+// others wait for it: no MPI, no launcher beyond starting the G processes).
 //
 // Per object: camera / flow / mask / pose sources exactly as main.cpp:327-381 builds them from the configuration, rooted at
 // SEQUENCE_DIR (`pose_dataset.path` is taken relative to it), the initial pose = the first row of its pose file
@@ -16,9 +20,17 @@
 // velocity_estimate.txt in the format of the reference's logs.
 //
 //   g++ -std=c++17 -O2 -I include/compat -I include tools/track_many.cpp -L roft_amd/csrc -lroft_hip -o ROFT-tracker-batch
+//   ... -DROFT_WITH_RCCL -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include ... -L/opt/rocm/lib -lrccl -lamdhip64     (with --gather)
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <filesystem>
+#include <thread>
+
+#ifdef ROFT_WITH_RCCL
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+#endif
 
 #include <ConfigParser.h>
 #include <ROFT/Filters.h>
@@ -56,6 +68,76 @@ struct FrameBuffers {
     cv::Mat flow, mask;
 };
 
+#ifdef ROFT_WITH_RCCL
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define NCCL_OK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) throw std::runtime_error(std::string(#x) + ": " + ncclGetErrorString(r_)); } while (0)
+
+// The result rows of every process -> every process (ncclAllGather over RCCL): shard sizes first (the block partition may be
+// uneven and sequences may differ in length), then the rows in blocks padded to the largest shard.  Returns, per rank, its
+// (objects, frames, rows[frames][objects][19]).
+struct ShardRows { long n_obj = 0, frames = 0; std::vector<double> rows; };
+std::vector<ShardRows> gather_rows(const std::string& id_file, int rank, int world, int device, long n_obj, long frames, const std::vector<double>& rows)
+{
+    HIP_OK(hipSetDevice(device));
+    ncclUniqueId id;
+    if (rank == 0) {
+        NCCL_OK(ncclGetUniqueId(&id));
+        const std::string tmp = id_file + ".tmp";
+        std::FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
+        std::fclose(f);
+        std::filesystem::rename(tmp, id_file);
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            std::FILE* f = std::fopen(id_file.c_str(), "rb");
+            if (f) {
+                const bool ok = std::fread(&id, sizeof(id), 1, f) == 1;
+                std::fclose(f);
+                if (ok) break;
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) throw std::runtime_error("no ncclUniqueId in " + id_file + " after 120 s");
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    ncclComm_t comm;
+    NCCL_OK(ncclCommInitRank(&comm, world, id, rank));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+    // shard sizes
+    long long mine[2] = {n_obj, frames};
+    long long *d_mine = nullptr, *d_all = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&d_mine), sizeof(mine)));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&d_all), sizeof(mine) * world));
+    HIP_OK(hipMemcpy(d_mine, mine, sizeof(mine), hipMemcpyHostToDevice));
+    NCCL_OK(ncclAllGather(d_mine, d_all, 2, ncclInt64, comm, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    std::vector<long long> all(2 * (size_t)world);
+    HIP_OK(hipMemcpy(all.data(), d_all, sizeof(mine) * world, hipMemcpyDeviceToHost));
+    size_t pad = 1;
+    for (int r = 0; r < world; ++r) pad = std::max(pad, (size_t)(all[2 * r] * all[2 * r + 1] * 19));
+    // rows
+    double *d_send = nullptr, *d_recv = nullptr;
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&d_send), sizeof(double) * pad));
+    HIP_OK(hipMalloc(reinterpret_cast<void**>(&d_recv), sizeof(double) * pad * world));
+    HIP_OK(hipMemset(d_send, 0, sizeof(double) * pad));
+    if (!rows.empty()) HIP_OK(hipMemcpy(d_send, rows.data(), sizeof(double) * rows.size(), hipMemcpyHostToDevice));
+    NCCL_OK(ncclAllGather(d_send, d_recv, pad, ncclDouble, comm, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    std::vector<ShardRows> out((size_t)world);
+    for (int r = 0; r < world; ++r) {
+        out[r].n_obj = (long)all[2 * r];
+        out[r].frames = (long)all[2 * r + 1];
+        out[r].rows.resize((size_t)(out[r].n_obj * out[r].frames * 19));
+        if (!out[r].rows.empty()) HIP_OK(hipMemcpy(out[r].rows.data(), d_recv + pad * (size_t)r, sizeof(double) * out[r].rows.size(), hipMemcpyDeviceToHost));
+    }
+    for (void* p : {(void*)d_mine, (void*)d_all, (void*)d_send, (void*)d_recv}) (void)hipFree(p);
+    (void)hipStreamDestroy(stream);
+    NCCL_OK(ncclCommDestroy(comm));
+    return out;
+}
+#endif
+
 std::string join(const std::string& root, const std::string& rel)
 {
     if (!rel.empty() && rel.front() == '/') return rel;
@@ -69,7 +151,7 @@ int main(int argc, char** argv)
     try {
         // ---- split the command line: what is ours, what is the configuration's
         std::vector<ObjectArgs> objects;
-        std::string log_root;
+        std::string log_root, gather_id_file;
         int batch_frames = 6, device = 0, shard_rank = 0, shard_world = 1, outlier_bands = 0;
         std::vector<char*> cfg_argv = {argv[0]};
         for (int i = 1; i < argc; ++i) {
@@ -85,15 +167,21 @@ int main(int argc, char** argv)
             else if (a == "--device" && i + 1 < argc) device = std::atoi(argv[++i]);
             else if (a == "--outlier_bands" && i + 1 < argc) outlier_bands = std::atoi(argv[++i]);   // roft_config::outlier_bands_per_alternative
             else if (a == "--shard" && i + 2 < argc) { shard_rank = std::atoi(argv[i + 1]); shard_world = std::atoi(argv[i + 2]); i += 2; }
+            else if (a == "--gather" && i + 1 < argc) gather_id_file = argv[++i];
             else cfg_argv.push_back(argv[i]);
         }
         if (objects.empty() || log_root.empty()) throw std::runtime_error("usage: ROFT-tracker-batch --from config.cfg [--group::key value ...] --log_root DIR [--batch_frames T] [--outlier_bands B] [--device D] [--shard RANK WORLD] --object SEQUENCE_DIR NAME [MESH.obj] ...");
         if (shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) throw std::runtime_error("--shard RANK WORLD: 0 <= RANK < WORLD");
+#ifndef ROFT_WITH_RCCL
+        if (!gather_id_file.empty()) throw std::runtime_error("--gather needs a build with -DROFT_WITH_RCCL (rccl.h / librccl)");
+#endif
+        const std::vector<ObjectArgs> all_objects = objects;   // (process 0 of a --gather job writes every object's logs)
         {
             const std::size_t per = (objects.size() + (std::size_t)shard_world - 1) / (std::size_t)shard_world;
             const std::size_t lo = std::min(objects.size(), per * (std::size_t)shard_rank), hi = std::min(objects.size(), lo + per);
             objects = std::vector<ObjectArgs>(objects.begin() + (long)lo, objects.begin() + (long)hi);
-            if (objects.empty()) { std::printf("tracked 0 objects over 0 frames\n"); return EXIT_SUCCESS; }
+            if (objects.empty() && gather_id_file.empty()) { std::printf("tracked 0 objects over 0 frames\n"); return EXIT_SUCCESS; }
+            if (objects.empty()) throw std::runtime_error("--gather: every process needs at least one object (fewer processes than objects)");
         }
         ConfigParser conf((int)cfg_argv.size(), cfg_argv.data());
 
@@ -273,8 +361,9 @@ int main(int argc, char** argv)
         // ---- logs in the reference's format (ROFTFilter.cpp:386-394 through bfl::Logger)
         std::vector<double> rows((std::size_t)frames * n_obj * 19);
         compat::throw_if(roft_engine_get_log_rows(engine.engine(), 0, frames, rows.data()), "roft_engine_get_log_rows");
+        auto write_logs = [&](const std::vector<double>& rows, int n_obj, int frames, const ObjectArgs* names) {
         for (int o = 0; o < n_obj; ++o) {
-            const std::string dir = log_root + "/" + tracked[o].args.name;
+            const std::string dir = log_root + "/" + names[o].name;
             std::error_code ec;
             std::filesystem::create_directories(dir, ec);
             if (ec) throw std::runtime_error("cannot create " + dir + ": " + ec.message());
@@ -294,6 +383,25 @@ int main(int argc, char** argv)
                 log.logger(p.transpose(), v.transpose());
             }
         }
+        };
+#ifdef ROFT_WITH_RCCL
+        if (!gather_id_file.empty()) {
+            const std::vector<ShardRows> shards = gather_rows(gather_id_file, shard_rank, shard_world, device, n_obj, frames, rows);
+            long total = 0;
+            if (shard_rank == 0) {
+                const std::size_t per = (all_objects.size() + (std::size_t)shard_world - 1) / (std::size_t)shard_world;
+                for (int r = 0; r < shard_world; ++r) {
+                    write_logs(shards[r].rows, (int)shards[r].n_obj, (int)shards[r].frames, all_objects.data() + per * (std::size_t)r);
+                    total += shards[r].n_obj;
+                }
+                std::remove(gather_id_file.c_str());
+            }
+            std::printf("tracked %d objects over %d frames (process %d of %d; rows all-gathered over RCCL%s)\n", n_obj, frames, shard_rank, shard_world,
+                        shard_rank == 0 ? (", logs of " + std::to_string(total) + " objects written").c_str() : "");
+            return EXIT_SUCCESS;
+        }
+#endif
+        write_logs(rows, n_obj, frames, objects.data());
         std::printf("tracked %d objects over %d frames\n", n_obj, frames);
         return EXIT_SUCCESS;
     } catch (const std::exception& e) {
