@@ -429,10 +429,11 @@ def main():
                 wc.copy_(wb)
             torch.cuda.synchronize()
         del wa, wb, wc
-    run(warm_batches, warm_splits)
-    eng.sync()
-    torch.cuda.synchronize()
-    bcast_bytes[0] = 0
+    # Everything that is not the W warm-up steps happens BEFORE them, so that the timed window follows the warm-up steps as
+    # closely as the contract's barrier + synchronize allow (~0.1 ms of device idle time instead of the milliseconds of round 3's
+    # order, after which the first kernels of the window ran at the clocks of an idle device): the exchange's set-up, the timing
+    # machinery, the host thread's spin.
+    spin_late = os.environ.get("ROFT_BENCH_SPIN_LATE") == "1"   # (A/B against round 3's order)
     plan = None
     if world > 1:
         # Nothing of the exchange happens for the first time inside the window: the shard sizes are exchanged here, once, and
@@ -453,15 +454,27 @@ def main():
         # a start/stop HIP event pair on the roofline kernel's own dispatch, nothing else (ROFT_BENCH_FULL_TIMING=1: a mark after
         # every launch group of the timed region -- with ROFT_DUMP_MARKS=<file> the profiler-free timeline of the run)
         eng.enable_timing(2 if os.environ.get("ROFT_BENCH_FULL_TIMING") == "1" else 1)
+
+    def host_spin():
+        # a few milliseconds of spinning bring the host thread's core to its working clock before the window in which it enqueues
+        # ~70 launches in a millisecond (one run in twenty showed the host side of those launches four to five times slower)
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < 3e-3:
+            pass
+    barrier()
+    if not spin_late:
+        host_spin()
+    run(warm_batches, warm_splits)
+    eng.sync()
+    torch.cuda.synchronize()
+    if not args.no_kernel_timing:
+        eng.timing()   # (the marks of the warm-up steps are not the timed region's)
+    bcast_bytes[0] = 0
     stats0 = eng.stats()
     barrier()
     torch.cuda.synchronize()
-    # the host thread has just slept in the waits above: a few milliseconds of spinning bring its core back to its working
-    # clock before the 1.4 ms window in which it enqueues ~50 launches (one run in twenty showed the host side of those launches
-    # four to five times slower than the others)
-    t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < 3e-3:
-        pass
+    if spin_late:
+        host_spin()
     t0 = time.perf_counter()
     run(timed_batches, timed_splits)
     host_enqueue = time.perf_counter() - t0   # host side of the loop (frame programs + launches), GPU still running
@@ -902,7 +915,7 @@ def main():
         "timed_frames_first_touch": True,
         "method": {"rehearsal_ms": args.rehearsal_ms,
                    "rehearsal_streams": "disjoint from the timed ones (seeds + 1000, same shapes and batch cuts)" if args.rehearsal_ms > 0 else None,
-                   "host_spin_ms_before_window": 3.0,
+                   "host_spin_ms": 3.0, "host_spin": "before the W warm-up steps (the window follows them behind one barrier + synchronize)",
                    "batch_cuts": "explicit --splits" if args.splits else ("full batches" if args.no_align else "batches end with the pose-arrival frame"),
                    "note": "no frame of the warm-up or of the timed region is read by anything in this process before the run that "
                            "is timed reads it; the W warm-up steps run on the timed engine right before the window"},

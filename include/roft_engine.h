@@ -397,6 +397,10 @@ int roft_debug_probe_streams(roft_engine* e, double out[25]);
  * of a 2 GiB scratch buffer, best of four launches -- the roofline of a gather-bound kernel such as the flow measurement (its
  * depth and flow samples are one sector each).  Allocates and frees 2 GiB of device memory; ~30 ms. */
 int roft_debug_sector_rate(int device, double* sectors_per_second);
+/* (100 MHz ticks, workgroups) per kernel the workgroups spent resident on the device since the last call, read and cleared; order:
+ * mask_frame, mask_ingest, mask_general, flow_measure, skf_chain, features, ukf_chain, outlier_fused.  Only filled by libraries
+ * built with -DROFT_RESIDENCY (tools/residency_budget.py: the CU x us budget of the pipeline). */
+int roft_debug_get_residency(roft_engine* e, unsigned long long out[32]);
 /* phase counters of one object's last kernels (only filled by libraries built with a -DROFT_*_PROFILE switch) */
 int roft_debug_get_dbg(roft_engine* e, int obj_id, long long out[32]);
 

@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "roft_engine_get_timing", "roft_default_of_params", "roft_optical_flow", "roft_flow_producer_create",
     "roft_flow_producer_destroy", "roft_flow_producer_run", "roft_flow_producer_sync", "roft_flow_producer_stream",
     "roft_debug_plan", "roft_debug_get_dbg", "roft_debug_probe_streams", "roft_debug_sector_rate",
-    "roft_host_alloc", "roft_host_free", "roft_host_is_pinned",
+    "roft_host_alloc", "roft_host_free", "roft_host_is_pinned", "roft_debug_get_residency",
 ]
 
 
@@ -173,6 +173,8 @@ def lib():
     L.roft_host_free.argtypes = [vp]
     L.roft_host_is_pinned.argtypes = [vp]
     for name in ABI_SYMBOLS:
+        if name.startswith("roft_debug_") and not hasattr(L, name):
+            continue   # (an older build loaded through ROFT_LIB_SO for an A/B run: diagnostics only; tests/test_abi_cpu.py checks the in-tree library has them all)
         f = getattr(L, name)
         if name not in ("roft_last_error_string", "roft_engine_stream", "roft_flow_producer_stream", "roft_host_alloc", "roft_host_free"):
             f.restype = C.c_int

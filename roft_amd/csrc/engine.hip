@@ -161,7 +161,7 @@ struct Arrays {
     DevBuf<float> feat_depth;
     DevBuf<uint32_t> zbuf;
     DevBuf<roft_object_output> log;
-    DevBuf<unsigned long long> skf_started;
+    DevBuf<unsigned long long> skf_started, residency;
 
     int alloc(int n_obj, int T, const DevCamera& cam, const DevFlowFmt& ffmt, int radius)
     {
@@ -205,6 +205,8 @@ struct Arrays {
         a.dev_error = nullptr;
         a.k1_span = nullptr;
         HIP_TRY(skf_started.ensure(1, true));
+        HIP_TRY(residency.ensure(32, true));
+        a.residency = residency.p;
         a.skf_started = nullptr;   // (the batched engine sets it; the operator level runs its kernels one after the other)
         a.handoff = 0;
         return ROFT_OK;
@@ -468,6 +470,7 @@ int roft_device_count(void)
 }
 
 // ---- pinned host memory pool (roft_engine.h section 2b) ----
+extern "C++" {
 namespace {
 struct HostPool {
     std::mutex mu;
@@ -479,6 +482,7 @@ HostPool& host_pool() { static HostPool* p = new HostPool(); return *p; }   // (
 constexpr size_t kHostPoolGranule = (size_t)64 << 10;
 constexpr size_t kHostPoolSpareCap = (size_t)512 << 20;   // recycled bytes kept before blocks go back to the runtime
 }  // namespace
+}  // extern "C++"
 
 void* roft_host_alloc(size_t bytes)
 {
@@ -801,6 +805,9 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
     e->h_params.resize(cfg->max_objects);
     e->staging.resize(e->retain);
     if (const char* hm = getenv("ROFT_HANDOFF")) e->handoff_mode = atoi(hm);
+    // A tool that lets only ONE kernel run at a time (rocprofv3 --pmc: counter collection serialises the dispatches) cannot run a
+    // lane next to the velocity filter it waits for -- the runtime's stream-wait itself is a kernel that spins: off under it.
+    else if (getenv("ROCPROF_COUNTER_COLLECTION")) e->handoff_mode = 0;
     e->feat_batch.assign((size_t)cfg->max_objects * kFeatRing, -1);
     const char* hpf = getenv("ROFT_HOST_PROF");
     e->host_prof = hpf && hpf[0] == '1';
@@ -2357,6 +2364,16 @@ extern "C" int roft_debug_get_dbg(roft_engine* e, int id, long long out[32])
     // (read and clear: the stamps of the frame kernels are maxima over their workgroups)
     if (err == hipSuccess) err = hipMemset(reinterpret_cast<char*>(e->arr.state.p + id) + offsetof(ObjState, dbg), 0, sizeof(long long) * 32);
     return err == hipSuccess ? ROFT_OK : ROFT_ERR_DEVICE;
+}
+
+// Diagnostics: (100 MHz ticks, workgroups) the workgroups of each kernel spent resident since the last call -- ResidencyKernel
+// order, only filled by libraries built with -DROFT_RESIDENCY (tools/residency_budget.py)
+extern "C" int roft_debug_get_residency(roft_engine* e, unsigned long long out[32])
+{
+    if (!e || !out) return ROFT_ERR_INVALID;
+    if (roft_sync(e) != ROFT_OK) return ROFT_ERR_DEVICE;
+    if (hipMemcpy(out, e->arr.residency.p, sizeof(unsigned long long) * 32, hipMemcpyDeviceToHost) != hipSuccess) return ROFT_ERR_DEVICE;
+    return hipMemset(e->arr.residency.p, 0, sizeof(unsigned long long) * 32) == hipSuccess ? ROFT_OK : ROFT_ERR_DEVICE;
 }
 
 // Diagnostics (roft_engine.h section 4): which of the engine's HIP streams delay each other at the dispatch level.  out[a * 5

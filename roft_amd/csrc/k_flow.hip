@@ -137,6 +137,7 @@ __device__ __forceinline__ void span_out(const EngineArrays& a, int slot, long l
 template <int PER4>
 __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays a, double depth_max, int radius)
 {
+    ROFT_RESIDENT(a, RK_FLOW_MEASURE);
     __shared__ int s_wave[16];
     __shared__ uint2 s_item[kCandLds];
     const int obj = blockIdx.x, slot = blockIdx.y * a.n_obj + obj;   // slot = (frame of the batch, object)

@@ -108,6 +108,7 @@ __device__ __forceinline__ void ingest_group(const uint4* src, int g, uint2* nz,
 // grid: (ceil(W*H/64/256), n_obj); frame t of the batch
 __global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a, int t)
 {
+    ROFT_RESIDENT(a, RK_MASK_INGEST);
     const int obj = blockIdx.y;
     const FrameCtrl& c = frame_ctrl(a, t, obj);
     if (!c.has_new_mask) return;
@@ -496,6 +497,7 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
 #ifdef ROFT_MASK_PROFILE
     if (threadIdx.x == 0) atomicMax((unsigned long long*)&a.state[blockIdx.y].dbg[8], (unsigned long long)((1ll << 62) - wall_clock64()));
 #endif
+    ROFT_RESIDENT(a, RK_MASK_FRAME);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ MaskShared S;
     __shared__ FrameCtrl s_c;
@@ -619,6 +621,7 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
     const int obj = blockIdx.x;
     const int W = a.cam.W, H = a.cam.H, npix = W * H, n_grp = npix >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
+    ROFT_RESIDENT(a, RK_MASK_GENERAL);
     const unsigned todo = a.mask_general[obj];
     if (!todo) return;   // (almost always 0: every mask the reference's sources deliver is binary)
     for (int t = 0; t < a.T; ++t) {

@@ -39,6 +39,7 @@ constexpr int kFeatThreads = 1024;
 
 __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
 {
+    ROFT_RESIDENT(a, RK_FEATURES);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_wave[16];
     __shared__ int s_chunk[kFeatThreads];
@@ -315,6 +316,7 @@ constexpr int kFusedThreads = 1024;
 __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArrays a, int lin, int vcache_cap, int win_cap, int parts,
                                                                      float* tile_dump)
 {
+    ROFT_RESIDENT(a, RK_OUTLIER);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ long long s_hi[kFusedThreads / 64], s_lo[kFusedThreads / 64];
     __shared__ int s_cnt[kFusedThreads / 64];

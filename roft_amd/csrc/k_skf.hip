@@ -556,6 +556,7 @@ __device__ __forceinline__ void publish_twist_tag(ObjState& st, int slot, int fr
 #endif
 __global__ __launch_bounds__(kSkfThreads) void skf_chain_kernel(EngineArrays a, int reweight)
 {
+    ROFT_RESIDENT(a, RK_SKF_CHAIN);
     __shared__ SkfShared S;
     __shared__ double s_x[6];
     __shared__ double s_P[36];

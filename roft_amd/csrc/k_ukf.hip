@@ -1146,6 +1146,7 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
 {
     // static LDS on purpose: with `extern __shared__` the compiler re-reads the dynamic-LDS base address from a
     // table in global memory inside every Jacobi round (two dependent global loads per round)
+    ROFT_RESIDENT(a, RK_UKF_CHAIN);
     __shared__ UkfLds L;
     __shared__ unsigned s_mine;
     // A pose step is one long chain of dependent instructions on four waves; the CU it runs on is shared with the wide

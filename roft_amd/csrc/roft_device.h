@@ -231,9 +231,29 @@ struct EngineArrays {
     // the filter's last frame.  0: the lanes run behind the velocity chain's completion event (tags are still published).
     int handoff;
     unsigned long long* skf_started;   // running count of velocity-filter workgroups that have started (or null)
+    unsigned long long* residency;     // [16][2] (100 MHz ticks, workgroups) a kernel's workgroups spent resident: only written by
+                                       // libraries built with -DROFT_RESIDENCY (tools/residency_budget.py)
     unsigned long long* k1_span;  // [T][n_obj][2] of THIS launch of the flow measurement, or null: 100 MHz wall clock at which each
                                   // workgroup started and ended (timing runs only: the launch's span on the device's own clock)
 };
+
+// CU residency accounting (-DROFT_RESIDENCY builds only): every workgroup adds the time between its first instruction and the end
+// of its thread 0 to its kernel's counter -- what a workgroup really occupies its share of a CU for, early exits included.
+enum ResidencyKernel { RK_MASK_FRAME = 0, RK_MASK_INGEST, RK_MASK_GENERAL, RK_FLOW_MEASURE, RK_SKF_CHAIN, RK_FEATURES, RK_UKF_CHAIN, RK_OUTLIER, RK_COUNT };
+#ifdef ROFT_RESIDENCY
+struct ResidencyTimer {
+    unsigned long long* p;
+    long long t0;
+    __device__ ResidencyTimer(unsigned long long* base, int kid) : p(base ? base + 2 * kid : nullptr), t0(wall_clock64()) {}
+    __device__ ~ResidencyTimer()
+    {
+        if (p && threadIdx.x == 0) { atomicAdd(p, (unsigned long long)(wall_clock64() - t0)); atomicAdd(p + 1, 1ull); }
+    }
+};
+#define ROFT_RESIDENT(a, kid) ResidencyTimer roft_resident_timer_((a).residency, (kid))
+#else
+#define ROFT_RESIDENT(a, kid) do {} while (0)
+#endif
 
 constexpr int ROFT_DEV_ERROR_TWIST_WAIT = 2;     // ukf_chain_kernel: a twist it was told to wait for was not published within two seconds
 constexpr int ROFT_DEV_ERROR_MASK_BARRIER = 1;   // (rounds 2 - 3: the persistent mask chain's barrier in memory; no kernel raises it any more)
