@@ -327,7 +327,10 @@ __device__ __forceinline__ void chase_groups(const ChaseGeo g, const uint2* plan
 // VGPRs per group -- and ALL groups of a wave (about a dozen) go out in one round: the frame pays one
 // memory latency for its flow.  Position, bit and target are (re)computed when the data is back.  Same arithmetic as
 // chase_groups with n_flows == 1, operation by operation.  Needs the plane words of the listed groups in LDS (`words`).
-constexpr int kSingleWalks = 12;   // groups per wave whose flow loads are in flight together (16: slower, register pressure)
+#ifndef ROFT_SINGLE_WALKS
+#define ROFT_SINGLE_WALKS 12
+#endif
+constexpr int kSingleWalks = ROFT_SINGLE_WALKS;   // groups per wave whose flow loads are in flight together
 template <int FT, int MODE, int NW>
 __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* list_, const uint2* words_, int n_list, bool clear00,
                                             const void* flow, const OrTarget tgt)

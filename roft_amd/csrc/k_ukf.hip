@@ -913,8 +913,16 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
         }
         quat_boxplus(L.mean + 9, d + 9, q);
         // input deviations of the state dof rows: bfl recomputes them from the sigma points, (mean + d) - mean and
-        // log(exp(d) q q^-1) -- which is d again, to the last bit or two
-        for (int i = 0; i < 12; ++i) L.X[i * kCols + lane] = d[i];
+        // log(exp(d) q q^-1) -- which is d again, to the last bit or two, as long as the rotation offset is shorter than pi;
+        // beyond that the shortest-arc logarithm wraps and d does not: recompute it the way bfl does
+        for (int i = 0; i < 9; ++i) L.X[i * kCols + lane] = d[i];
+        if (d[9] * d[9] + d[10] * d[10] + d[11] * d[11] < 9.0) {   // |d_rot| < 3 < pi
+            for (int i = 9; i < 12; ++i) L.X[i * kCols + lane] = d[i];
+        } else {
+            double dq[3];
+            quat_diff(q, L.mean + 9, dq);
+            for (int i = 0; i < 3; ++i) L.X[(9 + i) * kCols + lane] = dq[i];
+        }
 
         int row = 0;
         if (has_vel) {

@@ -286,6 +286,31 @@ def test_ukf_wide_sigma_clusters_take_the_general_paths(oracle):
         np.testing.assert_allclose(P1, P0, rtol=0, atol=UKF_ATOL)
 
 
+def test_ukf_correct_sigma_rotations_beyond_pi(oracle):
+    """Rotational standard deviations of ~0.9 rad: sigma rotations of sqrt(18) x that, well beyond pi.  The input deviation of
+    such a column is what bfl computes from the sigma point -- the shortest-arc logarithm of q_sigma q_mean^-1, which wraps --
+    and not the drawn offset itself (the shortcut k_ukf.hip takes below pi): cross covariance and gain follow the oracle."""
+    rng = np.random.default_rng(91)
+    rp = [1e-3] * 3 + [1e-4] * 3
+    rv = [0.1] * 3 + [1e-4] * 3
+    wrapped = 0
+    for i in range(4):
+        mean, P = _random_belief(rng, scale=1e-3)
+        P[9:, 9:] += np.eye(3) * (0.8 + 0.1 * i)                      # var(theta) ~ 0.8 .. 1.1 rad^2
+        wrapped += int(np.sqrt(18 * np.linalg.eigvalsh(P[9:, 9:]).max()) > np.pi)
+        q = mean[9:] + rng.normal(size=4) * 0.05
+        pose = np.concatenate([mean[6:9] + rng.normal(size=3) * 0.01, q / np.linalg.norm(q)])
+        for mtype, meas, rd in ((L.MEAS_POSE, pose, rp), (L.MEAS_POSE_VELOCITY, np.concatenate([rng.normal(size=6) * 0.3, pose]), rv + rp)):
+            rc0, m0, P0 = oracle.ukf_correct(mean, P, mtype, meas, rd)
+            rc1, m1, P1 = ops.ukf_correct(mean, P, mtype, meas, rd)
+            assert rc0 == rc1
+            # (1e-6: a cluster this wide is ill-conditioned -- the two eigen square roots agree to ~1e-8 here; taking the drawn
+            #  offset for the wrapped deviation is an error of order 1)
+            np.testing.assert_allclose(m1, m0, rtol=0, atol=1e-6)
+            np.testing.assert_allclose(P1, P0, rtol=0, atol=1e-6)
+    assert wrapped == 4
+
+
 def test_ukf_correct_no_measurement(oracle):
     rng = np.random.default_rng(2)
     mean, P = _random_belief(rng)
