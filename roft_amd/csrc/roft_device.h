@@ -239,7 +239,8 @@ struct EngineArrays {
 
 // CU residency accounting (-DROFT_RESIDENCY builds only): every workgroup adds the time between its first instruction and the end
 // of its thread 0 to its kernel's counter -- what a workgroup really occupies its share of a CU for, early exits included.
-enum ResidencyKernel { RK_MASK_FRAME = 0, RK_MASK_INGEST, RK_MASK_GENERAL, RK_FLOW_MEASURE, RK_SKF_CHAIN, RK_FEATURES, RK_UKF_CHAIN, RK_OUTLIER, RK_COUNT };
+enum ResidencyKernel { RK_MASK_FRAME = 0, RK_MASK_INGEST, RK_MASK_GENERAL, RK_FLOW_MEASURE, RK_SKF_CHAIN, RK_FEATURES, RK_UKF_CHAIN, RK_OUTLIER,
+                       RK_MASK_FRAME_EMPTY /* the workgroups of mask_frame_kernel that found no pixel in their band (counted here INSTEAD of RK_MASK_FRAME) */, RK_COUNT };
 #ifdef ROFT_RESIDENCY
 struct ResidencyTimer {
     unsigned long long* p;
@@ -249,10 +250,13 @@ struct ResidencyTimer {
     {
         if (p && threadIdx.x == 0) { atomicAdd(p, (unsigned long long)(wall_clock64() - t0)); atomicAdd(p + 1, 1ull); }
     }
+    __device__ void rekind(unsigned long long* base, int kid) { if (base) p = base + 2 * kid; }
 };
 #define ROFT_RESIDENT(a, kid) ResidencyTimer roft_resident_timer_((a).residency, (kid))
+#define ROFT_RESIDENT_AS(a, kid) roft_resident_timer_.rekind((a).residency, (kid))
 #else
 #define ROFT_RESIDENT(a, kid) do {} while (0)
+#define ROFT_RESIDENT_AS(a, kid) do {} while (0)
 #endif
 
 constexpr int ROFT_DEV_ERROR_TWIST_WAIT = 2;     // ukf_chain_kernel: a twist it was told to wait for was not published within two seconds

@@ -59,13 +59,14 @@ plane = cam.width * cam.height // 8
 # (kernel, threads per workgroup, dynamic LDS bytes of the launch at 640x480)
 shapes = [("mask_frame_kernel<13>", 256, 4240 + 3072), ("mask_ingest_kernel", 256, 0), ("mask_general_kernel<13>", 256, 19200),
           ("flow_measure_kernel<3>", 1024, 0), ("skf_chain_kernel", 512, 0), ("features_kernel", 1024, plane), ("ukf_chain_kernel", 256, 0),
-          ("outlier_fused_kernel", 1024, 98576 + 4 * (320 * 240 // 1 + 320))]
+          ("outlier_fused_kernel", 1024, 98576 + 4 * (320 * 240 // 1 + 320)),
+          ("mask_frame_kernel<13> (bands without a pixel)", 256, 4240 + 3072)]
 w = csv.writer(sys.stdout)
 w.writerow(["kernel", "workgroups", "resident_us_total", "mean_resident_us_per_workgroup", "cu_share_of_one_workgroup", "cu_us_per_object_frame"])
 total = 0.0
 for kid, (name, threads, dyn_lds) in enumerate(shapes):
     ticks, wgs = buf[2 * kid], buf[2 * kid + 1]
-    k = res.get(name) or res.get(name.split("<")[0])
+    k = res.get(name.split(" (")[0]) or res.get(name.split("<")[0])
     waves_per_simd = max(1.0, threads / 64.0 / 4.0)
     regs = (int(k["vgprs"] or 0) + int(k["agprs"] or 0) + 7) // 8 * 8
     lds = min(160.0 * 1024.0, float(k["static_lds_bytes"] or 0) + dyn_lds)
