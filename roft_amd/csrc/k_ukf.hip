@@ -1058,7 +1058,16 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
 __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj, int step, const UtTable& ut, UkfLds& L)
 {
     ObjState& st = a.state[obj];
-    const StepDesc sd = c.steps[step];
+    // (field by field into registers: a copy of the struct, whose arrays the correction loop indexes, would live in scratch memory
+    //  -- a store and a dependent load through the vector memory path at the head of every step)
+    struct {
+        int op, src, do_predict, n_corr, type0, type1, dst0, dst1, twist_slot;
+    } sd;
+    {
+        const StepDesc& d = c.steps[step];
+        sd.op = d.op; sd.src = d.src; sd.do_predict = d.do_predict; sd.n_corr = d.n_corr;
+        sd.type0 = d.type[0]; sd.type1 = d.type[1]; sd.dst0 = d.dst[0]; sd.dst1 = d.dst[1]; sd.twist_slot = d.twist_slot;
+    }
     if (!sd.op) return;
     const ObjParams& prm = a.params[obj];
     const int lane = threadIdx.x;
@@ -1110,11 +1119,11 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
         if (lane < 13) pr.mean[lane] = L.mean[lane];
     }
     if (sd.n_corr == 0) {
-        PoseBelief& d = st.belief[sd.dst[0]];
+        PoseBelief& d = st.belief[sd.dst0];
         for (int i = lane; i < 144; i += kUkfThreads) d.cov[i] = L.cov[i];
         if (lane < 13) d.mean[lane] = L.mean[lane];
         if (roft_object_output* row = log_row(a, c, obj))
-            if (lane < 13 && sd.dst[0] == cur) row->pose[lane] = L.mean[lane];
+            if (lane < 13 && sd.dst0 == cur) row->pose[lane] = L.mean[lane];
         return;
     }
     TICK(L, 6);
@@ -1124,7 +1133,7 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
     TICK(L, 7);
     int status = 0;
     for (int k = 0; k < sd.n_corr; ++k) {
-        const int rc = ukf_correct(L, sd.type[k], ut, &st.belief[sd.dst[k]]);
+        const int rc = ukf_correct(L, k == 0 ? sd.type0 : sd.type1, ut, &st.belief[k == 0 ? sd.dst0 : sd.dst1]);
         status |= rc << (4 * k);
         __syncthreads();
     }
