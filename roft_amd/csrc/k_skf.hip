@@ -240,6 +240,16 @@ __device__ unsigned long long radix_select(const double* vals, int N, int rank, 
 // entry: six sweeps (Gauss-Jordan without pivoting -- the pivots of an SPD matrix are its positive Schur
 // complements), then the lower triangle is overwritten by the upper one so that the result is exactly symmetric.
 // Every lane of the wave must call; returns (wave-uniform) false if a pivot is not positive.
+// 1 / d from the hardware seed (v_rcp_f64, ~24 bits) and two Newton steps: full double accuracy in a third of the dependent
+// instructions of an IEEE division -- these reciprocals sit on the one-wave chain of the frame (pivots, scales)
+__device__ __forceinline__ double skf_rcp(double d)
+{
+    double x = __builtin_amdgcn_rcp(d);
+    x = fma(fma(-d, x, 1.0), x, x);
+    x = fma(fma(-d, x, 1.0), x, x);
+    return x;
+}
+
 __device__ bool spd_inverse6_wave(double* M)
 {
     const int l = threadIdx.x & 63;
@@ -251,7 +261,7 @@ __device__ bool spd_inverse6_wave(double* M)
     for (int k = 0; k < 6; ++k) {
         const double d = M[k * 7], rk = M[k * 6 + j], ck = M[i * 6 + k];
         if (!(d > 0.0)) ok = false;
-        const double inv = 1.0 / d;          // one division per sweep; the four cases are selects, not branches
+        const double inv = skf_rcp(d);       // one reciprocal per sweep; the four cases are selects, not branches
         const double scaled = a * inv;
         const double swept = a - ck * (rk * inv);
         a = (i == k) ? ((j == k) ? inv : scaled) : ((j == k) ? -scaled : swept);
@@ -436,10 +446,11 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
             weighted = true;
             double m = 0.0;
             __syncthreads();   // every thread has read the norms (the sum above): they make room for the likelihoods
+            const double ib = skf_rcp(b), half_ib = 0.5 * ib;
             for (int j = threadIdx.x; j < N; j += blockDim.x) {
                 const double e0 = ein[2 * j], e1 = ein[2 * j + 1];
                 const double nj = sqrt(e0 * e0 + e1 * e1);
-                double l = 1.0 / (2 * b) * exp(-fabs(nj - mi) / b);
+                double l = half_ib * exp(-fabs(nj - mi) * ib);
                 if (l < 1e-6) l = 1e-6;
                 qn[j] = l;     // (read back by the same thread in the accumulation below: same j -> same thread)
                 m = fmax(m, l);
@@ -454,6 +465,7 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
 #pragma unroll
     for (int i = 0; i < 32; ++i) acc[i] = 0.0;
     const double ir0 = 1.0 / r_flow[0], ir1 = 1.0 / r_flow[1];
+    const double ilmax = weighted ? skf_rcp(lmax) : 1.0;
     for (int j = threadIdx.x; j < N; j += blockDim.x) {
         double h[12], y[2];
         acc_in.get(j, h, y);
@@ -468,7 +480,7 @@ __device__ int skf_core(const Acc& acc_in, int N, const double x[6], const doubl
             e1 = -(p1 - y[1]);
         }
         double l = 1.0;
-        if (weighted) l = qn[j] / lmax;
+        if (weighted) l = qn[j] * ilmax;
         const double w0 = l * ir0, w1 = l * ir1;
         int t = 0;
 #pragma unroll

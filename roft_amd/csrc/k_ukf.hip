@@ -78,12 +78,23 @@ __device__ __forceinline__ void half_angle(double n, double& sin_over_n, double&
 
 __device__ __forceinline__ void quat_boxplus(const double q[4], const double r[3], double o[4])
 {
-    const double n = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    // (the polynomials of half_angle need only n^2: no square root on the small-angle path, which is the chain's)
+    const double n2 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
     double s, c;
-    half_angle(n, s, c);   // n = 0 gives (0.5, 1): the identity rotation, as the reference's branch does
+    if (n2 < 0.25) {
+        const double x = 0.25 * n2;
+        s = 0.5 * (1.0 + x * (-1.0 / 6.0 + x * (1.0 / 120.0 + x * (-1.0 / 5040.0 + x * (1.0 / 362880.0 +
+                   x * (-1.0 / 39916800.0 + x * (1.0 / 6227020800.0)))))));
+        c = 1.0 + x * (-0.5 + x * (1.0 / 24.0 + x * (-1.0 / 720.0 + x * (1.0 / 40320.0 + x * (-1.0 / 3628800.0 +
+            x * (1.0 / 479001600.0 + x * (-1.0 / 87178291200.0)))))));
+    } else {
+        half_angle(sqrt(n2), s, c);   // (n = 0 gives (0.5, 1) above: the identity rotation, as the reference's branch does)
+    }
     const double qr[4] = {c, s * r[0], s * r[1], s * r[2]};
     quat_mul(qr, q, o);
 }
+
+__device__ __forceinline__ double fast_rcp(double d);
 
 __device__ __forceinline__ void quat_diff(const double a[4], const double b[4], double o[3])
 {
@@ -96,11 +107,13 @@ __device__ __forceinline__ void quat_diff(const double a[4], const double b[4], 
     // rotation vector = (2 atan2(n, |p0|) / n) p_vec.  With t = n / |p0| this is (2 / |p0|) (atan t / t) p_vec, and for
     // t^2 <= 0.01 (angles below 0.2 rad) nine terms of the alternating series give atan t / t to 5e-20: no square
     // root, no atan2
-    const double t2 = n2 / (p[0] * p[0]);
+    // (one reciprocal -- hardware seed + two Newton steps, below -- instead of two IEEE divisions one after the other)
+    const double ip0 = fast_rcp(fabs(p[0]));
+    const double t2 = n2 * (ip0 * ip0);
     if (t2 <= 0.01) {
         const double at = 1.0 + t2 * (-1.0 / 3.0 + t2 * (1.0 / 5.0 + t2 * (-1.0 / 7.0 + t2 * (1.0 / 9.0 + t2 * (-1.0 / 11.0 +
                           t2 * (1.0 / 13.0 + t2 * (-1.0 / 15.0 + t2 * (1.0 / 17.0))))))));
-        k = sgn * 2.0 * at / fabs(p[0]);
+        k = sgn * 2.0 * at * ip0;
     } else {
         const double n = sqrt(n2);
         if (n == 0.0) { o[0] = o[1] = o[2] = 0.0; return; }
