@@ -676,7 +676,7 @@ __device__ void sigma_perturbation(int col, int r, double sc, bool noise_eig, do
 // sqrt(d_j)) -- no eigenvalue gap in any denominator -- so S = V (D^1/2 + X1 + X2) satisfies S S' = cov up to
 // O(E^3), and S equals the exact U sqrt(Lambda) times an orthogonal matrix within O(E) of the identity: the sigma
 // set the reference draws, to rounding.
-__device__ __noinline__ void decompose_state_cov(UkfLds& L, double* warm, int* warm_age)
+__device__ __forceinline__ void decompose_state_cov(UkfLds& L, double* warm, int* warm_age)
 {
     const int tid = threadIdx.x;
     const int age = warm ? *warm_age : 0;
