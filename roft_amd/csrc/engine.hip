@@ -1484,7 +1484,10 @@ static int step_batch(roft_engine* e)
     // frame and the features kernel.  Not when an outlier test of the batch reads features buffered by this very batch (they
     // are extracted behind the filter), not on one stream, and -- by default -- only while the host is not throttled by the
     // in-flight bound: a lane that waits inside its kernel holds the CU it waits on, which a full pipeline cannot spare.
-    const bool handoff = multi && T > 1 && e->handoff_mode > 0 && !(e->handoff_mode == 1 && e->throttled) &&
+    // ... unless the device has CUs to spare anyway (at most one object per eight CUs: 32 on an MI355X -- measured: always handing
+    // over is worth +4 - 6 % at 8 and 32 objects in 60-step runs, +1 - 2 % in the steady state at 32, -1 % at 64).
+    const bool cus_to_spare = 8 * a.n_obj <= device_cu_count();
+    const bool handoff = multi && T > 1 && e->handoff_mode > 0 && !(e->handoff_mode == 1 && e->throttled && !cus_to_spare) &&
                          !e->feat_dep_in_batch && !e->any_feat_now && e->arr.skf_started.p != nullptr;
     a.handoff = handoff ? 1 : 0;
     a.skf_started = e->arr.skf_started.p;
