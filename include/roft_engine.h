@@ -401,6 +401,11 @@ int roft_debug_sector_rate(int device, double* sectors_per_second);
  * mask_frame, mask_ingest, mask_general, flow_measure, skf_chain, features, ukf_chain, outlier_fused.  Only filled by libraries
  * built with -DROFT_RESIDENCY (tools/residency_budget.py: the CU x us budget of the pipeline). */
 int roft_debug_get_residency(roft_engine* e, unsigned long long out[32]);
+/* How the workgroups of one alternative of an outlier test share its work, for every test launched by this process from now on:
+ * 1 = they split its TRIANGLES (windows merged in memory, the last workgroup scores; rows as well when the window does not fit
+ * the LDS in one piece), 0 = they split only the ROWS of its window, -1 = the library's choice (1).  The results do not depend
+ * on it (tests/test_parity_gpu.py). */
+int roft_debug_outlier_split(int mode);
 /* phase counters of one object's last kernels (only filled by libraries built with a -DROFT_*_PROFILE switch) */
 int roft_debug_get_dbg(roft_engine* e, int obj_id, long long out[32]);
 

@@ -95,7 +95,7 @@ ABI_SYMBOLS = [
     "roft_engine_get_timing", "roft_default_of_params", "roft_optical_flow", "roft_flow_producer_create",
     "roft_flow_producer_destroy", "roft_flow_producer_run", "roft_flow_producer_sync", "roft_flow_producer_stream",
     "roft_debug_plan", "roft_debug_get_dbg", "roft_debug_probe_streams", "roft_debug_sector_rate",
-    "roft_host_alloc", "roft_host_free", "roft_host_is_pinned", "roft_debug_get_residency",
+    "roft_host_alloc", "roft_host_free", "roft_host_is_pinned", "roft_debug_get_residency", "roft_debug_outlier_split",
 ]
 
 

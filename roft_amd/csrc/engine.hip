@@ -160,6 +160,24 @@ struct Arrays {
     DevBuf<uint32_t> feat_pix;
     DevBuf<float> feat_depth;
     DevBuf<uint32_t> zbuf;
+    DevBuf<uint32_t> zmerge;   // merge slabs of the outlier test (EngineArrays::zmerge)
+    DevBuf<int> zcount;
+    // (re)allocates the merge slabs for n objects and tiles of tpix pixels: enough for the automatic band count at any number of
+    // objects up to n (objects * bands <= max(n, CUs / 2)); a caller who asks for more bands than that gets the row split
+    int ensure_zmerge(int n, size_t tpix)
+    {
+        const size_t slabs = std::max<size_t>((size_t)n, std::min<size_t>((size_t)n * kMaxOutlierParts, (size_t)std::max(device_cu_count() / 2, 1)));
+        const size_t need = (size_t)kNumLin * slabs * 2 * tpix;
+        if (need > zmerge.n || !zmerge.p || tpix != a.zmerge_stride || slabs != a.zmerge_slabs) {
+            HIP_TRY(zmerge.ensure(need));
+            a.zmerge_stride = tpix;
+            a.zmerge_slabs = slabs;
+        }
+        HIP_TRY(zcount.ensure((size_t)kNumLin * n * 2 * kMaxOutlierParts, true));
+        a.zmerge = zmerge.p;
+        a.zcount = zcount.p;
+        return ROFT_OK;
+    }
     DevBuf<roft_object_output> log;
     DevBuf<unsigned long long> skf_started, residency;
 
@@ -189,6 +207,7 @@ struct Arrays {
         HIP_TRY(feat_pix.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
         HIP_TRY(feat_depth.ensure((size_t)n_obj * kFeatRing * a.feat_cap));
         HIP_TRY(zbuf.ensure((size_t)2 * a.tile_w * a.tile_h));   // operator level only (roft_depth_likelihood)
+        if (int rc = ensure_zmerge(n_obj, (size_t)a.tile_w * a.tile_h)) return rc;
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
         a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.mrec = mrec.p;
         a.mask_general = mask_general.p;
@@ -2179,6 +2198,7 @@ static int op_outlier(const roft_camera* cam, int divider, const float* depth, c
     a.tile_w = cam->width / divider;
     a.tile_h = cam->height / divider;
     const size_t npix = (size_t)cam->width * cam->height, tpix = (size_t)a.tile_w * a.tile_h;
+    if (int rc = c.arr.ensure_zmerge(1, tpix)) return rc;
     auto restore = [&]() {   // default tile geometry of this context
         a.cam = make_cam(*cam);
         a.tile_w = cam->width / a.cam.divider;
@@ -2371,6 +2391,12 @@ extern "C" int roft_debug_get_dbg(roft_engine* e, int id, long long out[32])
 
 // Diagnostics: (100 MHz ticks, workgroups) the workgroups of each kernel spent resident since the last call -- ResidencyKernel
 // order, only filled by libraries built with -DROFT_RESIDENCY (tools/residency_budget.py)
+extern "C" int roft_debug_outlier_split(int mode)
+{
+    roft::set_outlier_split(mode);
+    return ROFT_OK;
+}
+
 extern "C" int roft_debug_get_residency(roft_engine* e, unsigned long long out[32])
 {
     if (!e || !out) return ROFT_ERR_INVALID;

@@ -17,6 +17,7 @@
 //    a compact (pixel, depth) list indexed by rank/2, so the likelihood is a dense reduction over
 //    ~N_mask/2 samples and the frame itself need not be retained.
 #include <algorithm>
+#include <atomic>
 
 #include "plane_rank.h"
 
@@ -301,9 +302,16 @@ __global__ __launch_bounds__(kOutlierThreads) void outlier_kernel(EngineArrays a
 // projected per triangle.  The per-pixel arithmetic is raster_projected's, whatever the strips, bands and the vertex cache: the depths are bit-identical
 // to oracle/ro_render.c in every configuration (tests/test_parity_gpu.py drives this kernel through roft_render_depth and
 // roft_outlier_test).
-// With few objects an alternative is shared by `parts` workgroups: each takes a horizontal band of the window (walks all
-// triangles, draws the rows of its band, sums the features that fall into it) and leaves its partial sums; the pose
-// chain segment that follows adds them up in band order and decides.
+// With CUs to spare an alternative is shared by `parts` workgroups, as R bands of the window's rows x G groups of its
+// triangles (round 4; R G = parts, R = the fewest bands that fit the LDS in one piece -- 1 for most objects).  The G workgroups of
+// a band each draw THEIR triangles (runs of 64, dealt out in turn) into a window of their own, write it through to a slab in
+// memory (agent-coherent stores, EngineArrays::zmerge), count themselves in; the one that arrives last reads the other slabs
+// back (agent-coherent loads), keeps the nearest depth per pixel -- the same minimum, so the same bits, as one window would
+// hold -- and scores the band.  Every band leaves its partial sums; the pose chain segment that follows adds them up in band
+// order and decides.  (G = 1: the row split of rounds 2 - 3, every workgroup walks all triangles; the launch falls back to it
+// when the slabs do not cover objects x parts, roft_debug_outlier_split(0) forces it.)  The launch lasts as long as its slowest
+// workgroup, which in the row split is the middle band of the largest object (49 - 56 us of triangles at 8 and 16 objects against
+// 25 - 30 with the triangles dealt out: 60 - 66 -> 45 - 46 us per launch).
 // grid: (2 alternatives x parts, n_obj).  dynamic LDS: [3 * vcache_cap floats] | [win_cap z values]
 constexpr int kFusedThreads = 1024;
 // phase stamps (-DROFT_FUSED_PROFILE; PHASES=fused tools/k1_phase_profile.py): 100 MHz ticks -> ObjState::dbg[alt * 8 + phase]
@@ -314,13 +322,14 @@ constexpr int kFusedThreads = 1024;
 #endif
 
 __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArrays a, int lin, int vcache_cap, int win_cap, int parts,
-                                                                     float* tile_dump)
+                                                                     int split_tris, float* tile_dump)
 {
     ROFT_RESIDENT(a, RK_OUTLIER);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ long long s_hi[kFusedThreads / 64], s_lo[kFusedThreads / 64];
     __shared__ int s_cnt[kFusedThreads / 64];
     __shared__ int s_box[4];
+    __shared__ int s_last;
     // Workgroups are handed to the XCDs round robin by their linear index; the 2 x parts workgroups of an object read the
     // same mesh (186 KB of indices + 98 KB of vertices at the bench's 15.5 k triangles): with the grid laid out as
     // [group of 8 objects][workgroup of the object][object within the group] they share one XCD and one L2.
@@ -390,10 +399,23 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     //  left or above the target contribute lower bound 0, vertices right or below it the upper bound w - 1 / h - 1)
     UTICK(0);
     const int i0 = min(s_box[0], tw - 1), i1 = s_box[2];
-    // this workgroup's band of the window's rows
+    // The `parts` workgroups of the alternative share its work as R bands of the window's rows x G groups of its triangles
+    // (R G = parts).  Rows only (G = 1): every workgroup walks all triangles and draws the rows of its band.  With triangle
+    // groups, the G workgroups of a band each draw their share of the triangles into a window of their own, the windows are
+    // merged in memory and the workgroup that arrives last scores the band: R is the smallest divisor of `parts` whose bands
+    // fit the LDS in one piece (1 for most objects: set-up and walk are divided by `parts`, nothing is done twice but the
+    // projection).  Every workgroup of the alternative sees the same box and decides alike.
     int j0 = min(s_box[1], th - 1), j1 = s_box[3];
-    if (j1 >= j0 && parts > 1) {
-        const int rows_all = j1 - j0 + 1, b0 = j0 + (int)((long long)rows_all * part / parts), b1 = j0 + (int)((long long)rows_all * (part + 1) / parts) - 1;
+    int R = parts;
+    if (split_tris && parts > 1 && i1 >= i0 && j1 >= j0 && i0 >= 0 && j0 >= 0) {
+        const long long w_all = i1 - i0 + 1, rows_all = j1 - j0 + 1;
+        for (R = 1; R < parts; ++R)
+            if (parts % R == 0 && ((rows_all + R - 1) / R) * w_all <= (long long)win_cap) break;
+    }
+    const int G = parts / R, band = part / G, grp = part % G;
+    const bool split = G > 1;
+    if (j1 >= j0 && R > 1) {
+        const int rows_all = j1 - j0 + 1, b0 = j0 + (int)((long long)rows_all * band / R), b1 = j0 + (int)((long long)rows_all * (band + 1) / R) - 1;
         j0 = b0;
         j1 = b1;
     }
@@ -416,16 +438,21 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
                 (void)__hip_atomic_fetch_min(zw + ((j - js) * win_w + (i - i0)), __float_as_uint(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             constexpr int kTB = 8;   // triangles per thread whose vertex indices are fetched together
-            for (int tb = tid; tb < nt; tb += kTB * kFusedThreads) {
+            // (split: the triangles are dealt out to the workgroups of the alternative in runs of 64 -- one run per wave and
+            //  fetch, so the index loads stay coalesced and neighbouring runs, which cost alike, go to different workgroups)
+            const int stride = G, first = grp;
+            auto tri_of = [=](int slot) { return ((slot >> 6) * stride + first) * 64 + (slot & 63); };   // slot: this workgroup's own numbering
+            const int n_slots = split ? ((nt + 63) / 64 + stride - 1 - first) / stride * 64 : nt;        // (its runs; the last one may be short)
+            for (int tb = tid; tb < n_slots; tb += kTB * kFusedThreads) {
               int idx[kTB][3];
 #pragma unroll
               for (int k = 0; k < kTB; ++k) {
-                  const int32_t* tri = prm.tris + (size_t)3 * min(tb + k * kFusedThreads, nt - 1);
+                  const int32_t* tri = prm.tris + (size_t)3 * min(tri_of(min(tb + k * kFusedThreads, n_slots - 1)), nt - 1);
                   idx[k][0] = tri[0]; idx[k][1] = tri[1]; idx[k][2] = tri[2];
               }
 #pragma unroll
               for (int k = 0; k < kTB; ++k) {
-                if (tb + k * kFusedThreads >= nt) break;
+                if (tb + k * kFusedThreads >= n_slots || tri_of(tb + k * kFusedThreads) >= nt) break;
                 const int v0 = idx[k][0], v1 = idx[k][1], v2 = idx[k][2];
                 float x0, y0, z0, x1, y1, z1, x2, y2, z2;
                 if (cached) {
@@ -442,6 +469,46 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
             }
             __syncthreads();
             UTICK(2);
+            if (split) {
+                // This workgroup's window -> its slab in memory, written through (agent-coherent stores: the workgroups of an
+                // alternative may sit on different XCDs, each behind an L2 of its own); the workgroup that arrives last reads all
+                // slabs back with agent-coherent loads, keeps the nearest depth of every pixel and goes on alone: dump, samples,
+                // sums.  No atomics on the pixels, nothing to clear afterwards: every slab is rewritten whole by the next test.
+                const size_t slab0 = (((size_t)lin * a.zmerge_slabs + (size_t)obj * parts + (size_t)band * G) * 2 + alt) * a.zmerge_stride;   // the band's first slab
+                uint32_t* mine = a.zmerge + slab0 + (size_t)grp * 2 * a.zmerge_stride;
+                int* arrivals = a.zcount + (((size_t)lin * a.n_obj + obj) * 2 + alt) * kMaxOutlierParts + band;
+                for (int i = tid; i < npx; i += kFusedThreads)
+                    __hip_atomic_store(&mine[i], s_z[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                __builtin_amdgcn_s_waitcnt(0);   // every store of this wave acknowledged
+                __atomic_signal_fence(__ATOMIC_SEQ_CST);
+                __syncthreads();
+                if (tid == 0) {
+                    const int before = __hip_atomic_fetch_add(arrivals, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_last = (before == G - 1) ? 1 : 0;
+                    if (before == G - 1) __hip_atomic_store(arrivals, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                if (!s_last) return;
+                // (agent-coherent loads, a pixel's G - 1 of them in flight together: as atomic loads the compiler waits for each one)
+                static_assert(kMaxOutlierParts <= 8, "eight slabs per pixel");
+                const uint32_t* others = a.zmerge + slab0;
+                const size_t slab_step = 2 * a.zmerge_stride;
+                for (int i = tid; i < npx; i += kFusedThreads) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        v[p] = 0x7F800000u;
+                        if (p < G && p != grp) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[p]) : "v"(others + (size_t)p * slab_step + i) : "memory");
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+                    uint32_t m = s_z[i];
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) m = min(m, v[p]);
+                    s_z[i] = m;
+                }
+                __syncthreads();
+            }
             // operator level (roft_render_depth / roft_outlier_test): the strip of the window as this workgroup drew it ->
             // the caller's (zero-filled) render tile of the alternative, 0 = background as the reference reads it back
             if (tile_dump) {
@@ -492,12 +559,16 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
         long long hi = 0, lo = 0;
         int n2 = 0;
         for (int w = 0; w < kFusedThreads / 64; ++w) { hi += s_hi[w]; lo += s_lo[w]; n2 += s_cnt[w]; }
-        pl.part_hi[alt][part] = hi;
-        pl.part_lo[alt][part] = lo;
-        pl.part_cnt[alt][part] = (double)n2;
-        if (alt == 0 && part == 0) pl.n_parts = parts;
+        // (one workgroup per band gets here -- with triangle groups the one that merged the band -- with the sums of its rows)
+        pl.part_hi[alt][band] = hi;
+        pl.part_lo[alt][band] = lo;
+        pl.part_cnt[alt][band] = (double)n2;
+        if (band == 0) pl.n_parts[alt] = R;
     }
 }
+
+static std::atomic<int> g_outlier_split{-1};   // roft_debug_outlier_split
+void set_outlier_split(int mode) { g_outlier_split.store(mode < 0 ? -1 : (mode ? 1 : 0), std::memory_order_relaxed); }
 
 void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t stop, const OutlierLaunchOpts* opts)
 {
@@ -517,14 +588,21 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     if (a.outlier_parts > 0) parts = std::min(a.outlier_parts, kMaxOutlierParts);
     if (opts && opts->parts > 0) parts = std::min(opts->parts, kMaxOutlierParts);
     if (opts && opts->parts < 0) parts = std::max(1, parts / -opts->parts);
+    // Several workgroups per alternative share its TRIANGLES (R bands x G triangle groups, decided per alternative inside the
+    // kernel from the size of its window: see there) unless the caller asks for rows only.
+    static const int split_env = getenv("ROFT_OUTLIER_SPLIT") ? atoi(getenv("ROFT_OUTLIER_SPLIT")) : -1;   // (experiments)
+    const int forced = g_outlier_split.load(std::memory_order_relaxed) >= 0 ? g_outlier_split.load(std::memory_order_relaxed) : split_env;
+    int split = (opts && opts->split >= 0) ? opts->split : (forced >= 0 ? forced : 1);
+    if (parts <= 1 || !a.zmerge || (size_t)a.n_obj * parts > a.zmerge_slabs) split = 0;
     // (a band is a fraction of the window: request only the LDS it can need, so that other chains' workgroups fit next to it)
-    const size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + parts - 1) / parts + (size_t)a.tile_w);
+    const int lds_parts = split ? 1 : parts;
+    const size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + lds_parts - 1) / lds_parts + (size_t)a.tile_w);
     const size_t lds = std::min(lds_total, (((cache ? vbytes : 0) + win_need + 15) & ~(size_t)15));
     win_cap = std::min(win_cap, (int)((lds - (cache ? vbytes : 0)) / 4));
     // (operator level: a smaller window forces the strip path)
     if (opts && opts->window_pixels > 0) win_cap = std::max(a.tile_w, std::min(win_cap, opts->window_pixels));
     hipExtLaunchKernelGGL(outlier_fused_kernel, dim3(2 * parts * ((a.n_obj + 7) / 8) * 8), dim3(kFusedThreads), (uint32_t)lds, s, nullptr, stop, 0, a, lin,
-                          vcache_cap, win_cap, parts, opts ? opts->tile_dump : nullptr);
+                          vcache_cap, win_cap, parts, split, opts ? opts->tile_dump : nullptr);
 }
 
 void launch_outlier_only(const EngineArrays& a, hipStream_t s)

@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
         for (int k = 0; k < 2; ++k) {
             long long hi = 0, lo = 0;
             double n2 = 0.0;
-            for (int p = 0; p < pl.n_parts; ++p) { hi += pl.part_hi[k][p]; lo += pl.part_lo[k][p]; n2 += pl.part_cnt[k][p]; }
+            for (int p = 0; p < pl.n_parts[k]; ++p) { hi += pl.part_hi[k][p]; lo += pl.part_lo[k][p]; n2 += pl.part_cnt[k][p]; }
             const double e = LikelihoodSum::value(hi, lo);   // the exact sum of the float terms, rounded here once
             Lk[k] = (n2 == 0.0) ? 1.7976931348623157e308 : (e / n2) / 1.0;
             if (threadIdx.x == 0) { pl.outlier_L[k] = Lk[k]; pl.outlier_cnt[k] = n2; }

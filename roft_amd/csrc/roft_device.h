@@ -84,7 +84,7 @@ struct PoseLane {
     double outlier_L[2];
     double outlier_cnt[2];
     int ukf_status;
-    int n_parts;           // workgroups per alternative of the last outlier test (outlier_fused_kernel)
+    int n_parts[2];        // partial sums each alternative of the last outlier test left (outlier_fused_kernel)
     // their partial sums of |depth - render| and sample counts, per alternative.  The sums are EXACT: every float term is
     // split into two integers (units of 2^-32 m and 2^-64 m, LikelihoodSum below), so that the likelihood does not depend on
     // how the samples are distributed over bands, strips, threads and waves -- the band count may follow the load
@@ -214,6 +214,13 @@ struct EngineArrays {
     uint32_t* feat_pix;      // [n_obj][kFeatRing][feat_cap] buffered feature pixel (v << 16 | u)
     float* feat_depth;       // [n_obj][kFeatRing][feat_cap]
     uint32_t* zbuf;          // [2][tile_h*tile_w] float bits, +inf = empty: z-buffers of the operator-level likelihood
+    // Outlier test with the TRIANGLES of an alternative split over several workgroups (k_render.hip): every workgroup leaves its
+    // window in a slab of its own, [lane][zmerge_slabs: object * parts + part][alternative][zmerge_stride] float bits, zcount
+    // counts the arrivals and the workgroup that arrives last merges the slabs.
+    uint32_t* zmerge;
+    int* zcount;             // [lane][object][alternative][band], zero between two tests
+    size_t zmerge_stride;    // >= tile_w * tile_h
+    size_t zmerge_slabs;     // slabs per lane (>= objects * workgroups per alternative, else the rows are split instead)
     int cand_cap, feat_cap;
     size_t plane_words;      // wpr*H
     int tile_w, tile_h;
@@ -399,9 +406,11 @@ struct OutlierLaunchOpts {
     int no_vertex_cache = 0;  // project the vertices per triangle instead of once into LDS
     int window_pixels = 0;    // cap of the LDS depth window in pixels (> 0: forces the strip path for larger windows)
     float* tile_dump = nullptr;   // [2][tile_h][tile_w], zero-filled: receives the rendered window of both alternatives
+    int split = -1;           // several workgroups per alternative share its TRIANGLES (1) or only its window's rows (0); -1: the default (triangles)
 };
 // render + likelihood of the pending tests of a lane (the decision is the first thing the next pose chain segment does)
 void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t stop = nullptr, const OutlierLaunchOpts* opts = nullptr);
+void set_outlier_split(int mode);   // process-wide override of OutlierLaunchOpts::split (-1: none)
 void launch_outlier_only(const EngineArrays& a, hipStream_t s);  // operator level: likelihood + decision on filled z-buffers
 
 // multiProcessorCount of the calling thread's current device (cached per device ordinal; 256 on MI355X)

@@ -146,10 +146,17 @@ def depth_likelihood(cam, depth, mask, tile, divider):
     return Lv.value, ns.value
 
 
-def outlier_test(cam, divider, depth, mask, mesh, x2, q2, bands=0, vertex_cache=True, window_pixels=0, tiles=True):
+def outlier_test(cam, divider, depth, mask, mesh, x2, q2, bands=0, vertex_cache=True, window_pixels=0, tiles=True, split=None):
     """ROFTFilter::pick_best_alternative (ROFTFilter.cpp:467-621) on the engine's own kernels (features_kernel,
     outlier_fused_kernel, the deciding pose chain segment).  x2 (2, 3), q2 (2, 4): the two alternatives.
+    split: the workgroups of an alternative share its triangles (True) / the rows of its window (False); None: the library's choice.
     Returns (L[2], samples[2], selected, tiles (2, H/d, W/d) or None)."""
+    if split is not None:
+        L.check(L.lib().roft_debug_outlier_split(1 if split else 0))
+        try:
+            return outlier_test(cam, divider, depth, mask, mesh, x2, q2, bands, vertex_cache, window_pixels, tiles)
+        finally:
+            L.lib().roft_debug_outlier_split(-1)
     depth = np.ascontiguousarray(depth, np.float32)
     mask = np.ascontiguousarray(mask, np.uint8)
     x2, q2 = _f64(np.asarray(x2).reshape(6)), _f64(np.asarray(q2).reshape(8))

@@ -344,8 +344,9 @@ def test_render_depth_bit_exact(oracle, scale, mesh_n):
 
 
 # The engine's own outlier test (features_kernel -> outlier_fused_kernel -> deciding pose chain segment), one object, in
-# every launch shape the engine can choose: 1 / 2 / 8 horizontal bands per alternative, the whole window in LDS or strips
-# of a few rows, projected vertices cached in LDS or re-projected per triangle.  Render: bit exact against
+# every launch shape the engine can choose: 1 ... 8 workgroups per alternative sharing its triangles (windows merged in memory)
+# and / or the rows of its window, the whole window in LDS or strips of a few rows, projected vertices cached in LDS or
+# re-projected per triangle.  Render: bit exact against
 # oracle/ro_render.c; likelihood: same samples, LIK_RTOL; decision identical.
 @pytest.mark.parametrize("shape,scale,mesh_n,div", [("A", 1, 36, 2), ("B", 1, 24, 4), ("A", 2, 12, 2)])
 def test_outlier_test_hot_path_kernel(oracle, shape, scale, mesh_n, div):
@@ -368,8 +369,12 @@ def test_outlier_test_hot_path_kernel(oracle, shape, scale, mesh_n, div):
         # alternative 1 off screen: no sample -> DBL_MAX, alternative 0 kept
         (np.stack([st.gt.x[0], st.gt.x[0] + [50.0, 0.0, 0.0]]), np.stack([q0, q0]), 0),
     ]
+    # (several workgroups per alternative share its TRIANGLES and merge their windows in memory -- and the rows of its window as
+    #  well when it does not fit the LDS in one piece (window_pixels) -- or only its rows (split=False): both ways for 2 ... 8)
     shapes = [dict(bands=1), dict(bands=2), dict(bands=8), dict(bands=0), dict(bands=1, window_pixels=3 * tw),
-              dict(bands=2, window_pixels=tw), dict(bands=1, vertex_cache=False), dict(bands=8, vertex_cache=False, window_pixels=2 * tw)]
+              dict(bands=2, window_pixels=tw), dict(bands=1, vertex_cache=False), dict(bands=8, vertex_cache=False, window_pixels=2 * tw),
+              dict(bands=8, split=False), dict(bands=8, split=True), dict(bands=4), dict(bands=4, split=False), dict(bands=2, split=True),
+              dict(bands=8, split=True, vertex_cache=False), dict(bands=4, split=True, window_pixels=tw), dict(bands=3, split=True)]
     for x2, q2, want_sel in cases:
         t_ref = [oracle.render_depth(omesh, x2[k], q2[k], ocam, div) for k in range(2)]
         ref = [oracle.depth_likelihood(ocam, depth, mask, t_ref[k], div) for k in range(2)]
@@ -425,7 +430,8 @@ def test_render_and_outlier_test_on_a_mesh_of_the_reference(oracle):
         t_ref = [oracle.render_depth(omesh, x2[k], q2[k], ocam, div) for k in range(2)]
         ref = [oracle.depth_likelihood(ocam, depth, mask, t_ref[k], div) for k in range(2)]
         tw = cam.width // div
-        for kw in (dict(bands=1), dict(bands=2), dict(bands=8), dict(bands=0), dict(bands=2, window_pixels=tw), dict(bands=1, vertex_cache=False)):
+        for kw in (dict(bands=1), dict(bands=2), dict(bands=8), dict(bands=0), dict(bands=2, window_pixels=tw), dict(bands=1, vertex_cache=False),
+                   dict(bands=8, split=False), dict(bands=2, split=True), dict(bands=5, split=True)):
             Lv, ns, sel, tiles = ops.outlier_test(dcam, div, depth, mask, mesh, x2, q2, **kw)
             for k in range(2):
                 assert np.array_equal(tiles[k], t_ref[k]), (kw, k, int((tiles[k] != t_ref[k]).sum()))
