@@ -246,3 +246,14 @@ def test_outlier_bands_per_alternative_change_nothing():
             assert np.array_equal(a, b), bands
     with pytest.raises(L.RoftError):
         make_engine(streams, outlier_bands_per_alternative=9)
+    # ... and whether the workgroups of an alternative share its triangles (windows merged through memory by the last one to
+    # arrive: the default) or only the rows of its window
+    try:
+        for split in (0, 1):
+            L.check(L.lib().roft_debug_outlier_split(split))
+            for bands in (0, 4):
+                log, masks, _ = util.run_engine_logged(make_engine, streams, n, T=8, outlier_bands_per_alternative=bands)
+                for a, b in zip(ref[0], log):
+                    assert np.array_equal(a, b), (split, bands)
+    finally:
+        L.lib().roft_debug_outlier_split(-1)
