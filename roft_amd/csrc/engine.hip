@@ -1429,6 +1429,15 @@ static int step_batch(roft_engine* e)
         a.slot_prev0 = (e->frame_counter + kPlaneSlots - 1) % kPlaneSlots;   // (submit_frames: slot_prev of every object)
     }
     static_assert(sizeof(FrameCtrl) % 16 == 0, "FrameCtrl is copied in 16-byte units");
+    // Frame-granular hand-over to the pose lanes (below) -- and, with CUs to spare (at most one object per eight CUs), lanes that
+    // do not even wait for the velocity filter to be resident: they start behind the batch's control blocks and take every twist
+    // when its tag appears, so the first segment of a re-sync (the pose step, which reads a twist of six frames ago) and its
+    // outlier test run next to the batch's mask frames instead of behind them.
+    const bool cus_to_spare = 8 * a.n_obj <= device_cu_count();
+    const bool handoff = multi && T > 1 && e->handoff_mode > 0 && !(e->handoff_mode == 1 && e->throttled && !cus_to_spare) &&
+                         !e->feat_dep_in_batch && !e->any_feat_now && e->arr.skf_started.p != nullptr;
+    static const int early_env = getenv("ROFT_EARLY_LANES") ? atoi(getenv("ROFT_EARLY_LANES")) : 1;   // (experiments)
+    const bool early_lanes = handoff && cus_to_spare && early_env != 0;
 
     // ---- control blocks of the batch -> device (+ reset of the mask chain's counters), ingest of the masks delivered
     //      with the batch (tables and ingest slots of this batch's parity: the carry of the chain before stays readable).
@@ -1441,7 +1450,7 @@ static int step_batch(roft_engine* e)
         // Events that complete with a kernel (hipExtLaunchKernelGGL stop events) cost neither the barrier packet nor
         // the host call of a hipEventRecord behind it.
         hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
-                              nullptr, (multi && T == 1) ? e->ev_ctrl[slot] : nullptr, 0,
+                              nullptr, (multi && (T == 1 || early_lanes)) ? e->ev_ctrl[slot] : nullptr, 0,
                               reinterpret_cast<const uint4*>(e->stage[slot]), a, n16);
         ++launches;
     }
@@ -1504,10 +1513,7 @@ static int step_batch(roft_engine* e)
     // are extracted behind the filter), not on one stream, and -- by default -- only while the host is not throttled by the
     // in-flight bound: a lane that waits inside its kernel holds the CU it waits on, which a full pipeline cannot spare.
     // ... unless the device has CUs to spare anyway (at most one object per eight CUs: 32 on an MI355X -- measured: always handing
-    // over is worth +4 - 6 % at 8 and 32 objects in 60-step runs, +1 - 2 % in the steady state at 32, -1 % at 64).
-    const bool cus_to_spare = 8 * a.n_obj <= device_cu_count();
-    const bool handoff = multi && T > 1 && e->handoff_mode > 0 && !(e->handoff_mode == 1 && e->throttled && !cus_to_spare) &&
-                         !e->feat_dep_in_batch && !e->any_feat_now && e->arr.skf_started.p != nullptr;
+    // over is worth +4 - 6 % at 8 and 32 objects in 60-step runs, +1 - 2 % in the steady state at 32, -1 % at 64): `handoff` above.
     a.handoff = handoff ? 1 : 0;
     a.skf_started = e->arr.skf_started.p;
     e->skf_total += (unsigned long long)a.n_obj;
@@ -1540,7 +1546,14 @@ static int step_batch(roft_engine* e)
         }
         if (!e->lin_any[lin]) continue;
         const int which = lin == 0 ? 1 : 3;
-        if (multi && handoff) {
+        if (multi && early_lanes) {
+            // behind the batch's control blocks, and behind the velocity chain of the batch BEFORE (its features kernel: the sets
+            // this batch's outlier tests read were buffered there or earlier)
+            HIP_TRY(hipStreamWaitEvent(sp, e->ev_ctrl[slot], 0));
+            ++evops;
+            const int pb = e->batch_counter - 1;
+            if (pb >= e->completed_batches && pb >= 0 && e->vel_used[pb % R]) { HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[pb % R], 0)); ++evops; }
+        } else if (multi && handoff) {
             HIP_TRY(hipStreamWaitValue64(sp, e->arr.skf_started.p, e->skf_total, hipStreamWaitValueGte, ~0ull));
             ++evops;
         } else if (multi) {
