@@ -1437,7 +1437,7 @@ static int step_batch(roft_engine* e)
     const bool handoff = multi && T > 1 && e->handoff_mode > 0 && !(e->handoff_mode == 1 && e->throttled && !cus_to_spare) &&
                          !e->feat_dep_in_batch && !e->any_feat_now && e->arr.skf_started.p != nullptr;
     static const int early_env = getenv("ROFT_EARLY_LANES") ? atoi(getenv("ROFT_EARLY_LANES")) : 1;   // (experiments)
-    const bool early_lanes = handoff && cus_to_spare && early_env != 0;
+    const bool early_lanes = handoff && cus_to_spare && !e->throttled && early_env != 0;   // (bursts: in the steady state a lane is behind anyway, and at 1280x720 the early tests cost 3 %)
 
     // ---- control blocks of the batch -> device (+ reset of the mask chain's counters), ingest of the masks delivered
     //      with the batch (tables and ingest slots of this batch's parity: the carry of the chain before stays readable).
