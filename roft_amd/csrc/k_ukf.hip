@@ -538,12 +538,47 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane)   // src_
     return __hiloint2double(hi, lo);
 }
 
+// lane SRC of every row of 16 lanes -> all lanes of the row: DPP row_newbcast (gfx90a+).  Two 32-bit DPP moves per double: no
+// SGPR round trip and no hazard wait states as with v_readlane (two of them + an s_nop per use).  (v_fmac_f64_dpp takes the
+// control directly -- one instruction per update -- and is no faster: measured, DESIGN.md App. A.)
+template <int SRC>
+__device__ __forceinline__ double rowbcast_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), 0x150 + SRC, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), 0x150 + SRC, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+
+template <int M, int J, int K>
+__device__ __forceinline__ void chol_update(double (&a)[M], double lij)
+{
+    if constexpr (K < M) {
+        a[K] = fma(-lij, rowbcast_f64<K>(lij), a[K]);
+        chol_update<M, J, K + 1>(a, lij);
+    }
+}
+
+template <int M, int J>
+__device__ __forceinline__ void chol_columns(double (&a)[M], double (&rinv)[M], int& ok, int lane)
+{
+    if constexpr (J < M) {
+        const double d = rowbcast_f64<J>(a[J]);   // A_jj - sum_k<j L_jk^2
+        if (!(d > 0.0)) ok = 0;
+        const double r = fast_rsqrt(d);
+        rinv[J] = r;
+        const double lij = (lane == J) ? d * r : a[J] * r;
+        a[J] = lij;
+        chol_update<M, J, J + 1>(a, lij);
+        chol_columns<M, J + 1>(a, rinv, ok, lane);
+    }
+}
+
 // Cholesky factor of the SPD M x M matrix A (ld M) into the lower triangle of Lc (ld M; the strict upper triangle
 // is left untouched) + reciprocal diagonal.  Called by the whole workgroup; the work is done by lanes 0..M-1 of
 // wave 0, lane = row, the row lives in registers and the column being eliminated is broadcast with v_readlane
 // (no LDS round trip inside the factorisation).  Returns false if A is not positive definite.
 template <int M>
-__device__ bool cholesky_rows(const double* A, double* Lc, double* inv_diag, UkfLds& L)
+__device__ __forceinline__ bool cholesky_rows(const double* A, double* Lc, double* inv_diag, UkfLds& L)
 {
     const int lane = threadIdx.x;
     if (lane < 64) {
@@ -552,17 +587,8 @@ __device__ bool cholesky_rows(const double* A, double* Lc, double* inv_diag, Ukf
         for (int k = 0; k < M; ++k) a[k] = (lane < M) ? A[lane * M + k] : 0.0;
         double rinv[M];
         int ok = 1;
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            const double d = readlane_f64(a[j], j);   // A_jj - sum_k<j L_jk^2
-            if (!(d > 0.0)) ok = 0;
-            const double r = fast_rsqrt(d);
-            rinv[j] = r;
-            const double lij = (lane == j) ? d * r : a[j] * r;
-            a[j] = lij;
-#pragma unroll
-            for (int k = j + 1; k < M; ++k) a[k] = fma(-lij, readlane_f64(lij, k), a[k]);
-        }
+        static_assert(M <= 16, "the rows of the matrix sit in one DPP row of 16 lanes");
+        chol_columns<M, 0>(a, rinv, ok, lane);
         if (lane < M) {
 #pragma unroll
             for (int k = 0; k < M; ++k) if (k <= lane) Lc[lane * M + k] = a[k];
