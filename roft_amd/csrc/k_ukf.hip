@@ -531,13 +531,6 @@ __device__ void weighted_outer(const double* A, int ra, const double* B, int rb,
     }
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int src_lane)   // src_lane: compile-time constant
-{
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
 // lane SRC of every row of 16 lanes -> all lanes of the row: DPP row_newbcast (gfx90a+).  Two 32-bit DPP moves per double: no
 // SGPR round trip and no hazard wait states as with v_readlane (two of them + an s_nop per use).  (v_fmac_f64_dpp takes the
 // control directly -- one instruction per update -- and is no faster: measured, DESIGN.md App. A.)
@@ -575,7 +568,7 @@ __device__ __forceinline__ void chol_columns(double (&a)[M], double (&rinv)[M], 
 
 // Cholesky factor of the SPD M x M matrix A (ld M) into the lower triangle of Lc (ld M; the strict upper triangle
 // is left untouched) + reciprocal diagonal.  Called by the whole workgroup; the work is done by lanes 0..M-1 of
-// wave 0, lane = row, the row lives in registers and the column being eliminated is broadcast with v_readlane
+// wave 0, lane = row, the row lives in registers and the column being eliminated is broadcast over the row of 16 lanes by DPP row_newbcast
 // (no LDS round trip inside the factorisation).  Returns false if A is not positive definite.
 template <int M>
 __device__ __forceinline__ bool cholesky_rows(const double* A, double* Lc, double* inv_diag, UkfLds& L)
