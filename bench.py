@@ -12,6 +12,14 @@ delayed masks and poses, pose re-sync, depth-render outlier rejection).  One "st
 = ROFTFilter::filtering_step x n_objects; frames are handed to the engine in batches of --batch frames
 (roft_frames_submit).  Inputs (depth, flow, masks) are resident in HBM before the timed region; the PCIe-inclusive rates
 (HOST inputs) are measured in the same run and reported beside `value`, never as it.
+
+Round 5: the timed region is run --windows times (default 5) in one invocation, every time on a FRESH engine and a FRESH,
+disjoint stream set (W warm-up steps, barrier + synchronize, exactly K timed steps, synchronize + barrier, max over ranks), with
+no timing machinery of any kind inside it; `value` is the MEDIAN window (a real run: its ms_per_step, host time and batch
+trace are the top-level ones), `runs` lists all of them.  A 20-step window is 1.3 ms of GPU time in which one host thread
+enqueues ~70 launches: one window can be hit by anything that happens on the box in that millisecond, five cannot.  The
+roofline kernel is timed (HIP event pair on its own dispatch + device clock span) in one MORE window of the same shape,
+`instrumented_window`, which is never `value`.
 """
 import argparse
 import json
@@ -168,7 +176,10 @@ def parse():
     p.add_argument("--outlier-bands", type=int, default=0,
                    help="roft_config::outlier_bands_per_alternative (0: the engine's choice, CUs / (2 x objects))")
     p.add_argument("--no-kernel-timing", action="store_true",
-                   help="do not record HIP events in the timed region and skip the per-kernel breakdown")
+                   help="skip the instrumented window (roofline kernel's event pair) and the per-kernel breakdown behind it")
+    p.add_argument("--windows", type=int, default=5,
+                   help="timed windows per invocation (each: fresh engine, fresh disjoint stream set, W warm-up + K timed steps); "
+                        "`value` is the median window")
     return p.parse_args()
 
 
@@ -233,6 +244,10 @@ def main():
     # ROFT_BENCH_DEVICE / ROFT_BENCH_BACKEND exist only to exercise the N > 1 code path on a one-GPU box
     # (several ranks on cuda:0 over gloo); the driver's multi-GPU runs use LOCAL_RANK and RCCL.
     dev_index = int(os.environ.get("ROFT_BENCH_DEVICE", local_rank))
+    if "ROFT_BENCH_DEVICE" in os.environ and world > 1:
+        # several PROCESSES on one GPU: an engine counts the CUs its early pose lanes may occupy over its own objects only
+        # (engine.hip, early_lanes) -- off, the lanes then wait for velocity-filter workgroups that are resident
+        os.environ.setdefault("ROFT_EARLY_LANES", "0")
     backend = os.environ.get("ROFT_BENCH_BACKEND", "nccl")
     if dev_index >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d needs GPU %d, this node shows %d (one rank per GPU; ROFT_BENCH_DEVICE=0 "
@@ -258,29 +273,32 @@ def main():
     n_obj = len(my_objects)
     if n_obj == 0:
         raise SystemExit("bench.py: rank %d owns no object (%d objects over %d ranks)" % (rank, total_obj, world))
-    n_extra = 0 if args.no_kernel_timing else int(os.environ.get("ROFT_BENCH_EXTRA_FRAMES", "24"))   # frames after the timed region for the per-kernel breakdown
+    n_windows = max(1, args.windows)
+    n_extra = 0 if args.no_kernel_timing else int(os.environ.get("ROFT_BENCH_EXTRA_FRAMES", "24"))   # frames behind the instrumented window: per-kernel breakdown
     n_timed_end = args.warmup + args.steps
-    n_frames = n_timed_end + n_extra
+    n_frames = n_timed_end   # frames of a window's stream set (the instrumented set carries n_extra more)
     cam = synth.Camera.shape_a() if args.shape == "A" else synth.Camera.shape_b()
     ftype = synth.FLOW_F32C2 if args.flow == "f32" else synth.FLOW_S16C2
 
-    # The streams stay resident in HBM for the whole run (depth 4 B + mask 1 B per pixel, flow per grid cell): refuse a
-    # K + W that cannot fit instead of running the box out of memory.
+    # The streams of a window stay resident in HBM while it runs (depth 4 B + mask 1 B per pixel, flow per grid cell); at most
+    # four sets are alive at once (window 0's for the accuracy figures, the running window's, the rehearsal's, the instrumented
+    # one): refuse a K + W that cannot fit instead of running the box out of memory.
     g = 1 if args.flow == "f32" else 4
     flow_frame_bytes = (cam.width // g) * (cam.height // g) * (8 if args.flow == "f32" else 4)
     per_frame = cam.width * cam.height * 5 + flow_frame_bytes
-    need = per_frame * n_frames * n_obj
+    need = per_frame * (4 * n_timed_end + n_extra) * n_obj
     free_b, _total_b = torch.cuda.mem_get_info(dev)
     if need > 0.8 * free_b:
-        raise SystemExit("bench.py: %d frames x %d objects of synthetic input need %.0f GB of HBM, %.0f GB are free; "
-                         "lower --steps / --warmup / --objects" % (n_frames, n_obj, need / 1e9, free_b / 1e9))
+        raise SystemExit("bench.py: %d frames x %d objects of synthetic input (x 4 sets) need %.0f GB of HBM, %.0f GB are free; "
+                         "lower --steps / --warmup / --objects" % (n_timed_end, n_obj, need / 1e9, free_b / 1e9))
 
     # ---- synthetic streams, generated on the GPU and left resident in HBM
-    t_gen = time.time()
+    gen_s = [0.0]
 
     def make_streams(seed_base, n_fr, zero_remote=True):
         """The rank's objects' streams: stream seed = seed_base + global object index (seed_base 4000 = 1000 x config #4:
         the workload; other bases: same shapes and object models, different motion, noise and images)."""
+        t_g = time.time()
         if args.shared_scene:
             # one scene for every object of every rank: all ranks build the same stream (masks, poses and the mesh stay
             # local), but only the ingest rank keeps its images -- the others receive them batch by batch (broadcast_frames)
@@ -288,22 +306,17 @@ def main():
             if world > 1 and rank != 0 and zero_remote:
                 sc.depth.zero_()
                 sc.flow.zero_()
+            torch.cuda.synchronize()
+            gen_s[0] += time.time() - t_g
             return [sc] * n_obj, sc
         out = []
         for gid in my_objects:
             scale = 0.8 + 0.4 * (((gid % 64) * 7) % 10) / 9.0
             half = tuple(h * scale for h in synth.CRACKER_BOX_HALF_EXTENTS)
             out.append(synth.make_stream(seed_base + gid, n_fr, cam, flow_type=ftype, half_extents=half, device=dev))
+        torch.cuda.synchronize()
+        gen_s[0] += time.time() - t_g
         return out, None
-
-    streams, scene = make_streams(4000, n_frames)
-    # The rehearsal (below) tracks a DISJOINT stream set of the same shapes (seeds + 1000): no frame of the timed region has
-    # been read by anything in this process when the clock starts -- a tracker sees each frame once.
-    rehearsal_streams = None
-    if args.rehearsal_ms > 0:
-        rehearsal_streams, _rs = make_streams(5000, n_timed_end, zero_remote=False)   # (nothing broadcasts in the rehearsal)
-    torch.cuda.synchronize()
-    t_gen = time.time() - t_gen
 
     def new_engine(max_objects):
         cfg = E.default_config(cam.width, cam.height, ftype, max_objects=max_objects, device=local_rank, max_batch_frames=T)
@@ -320,10 +333,6 @@ def main():
                 d.p_mean0[i] = m0[i]
             eng.add_object(d, *st.mesh)
 
-    cfg, eng = new_engine(n_obj)
-    add_objects(eng, streams)
-    eng.enable_log(n_frames)
-
     def frame_dict(st, k, src, kind):
         mi = st.mask_delivery[k]
         pose = (st.pose_meas[k, :3], st.pose_meas[k, 3:]) if st.pose_valid[k] else None
@@ -339,26 +348,22 @@ def main():
                 seen[id(st)] = dict(depth=st.depth.cpu().pin_memory(), flow=st.flow.cpu().pin_memory(), mask=st.mask_gt.cpu().pin_memory())
         return [seen[id(st)] for st in sts]
 
-    host = host_copies(streams)
-
-    def build(k0, t, sts=None, hst=None):
-        sts = streams if sts is None else sts
-        hst = host if sts is streams else hst
+    def build(eng, k0, t, sts, hst=None):
         frames_list = []
         for k in range(k0, k0 + t):
             frames_list.append([frame_dict(st, k, hst[o] if hst else dict(depth=st.depth, flow=st.flow, mask=st.mask_gt),
                                            L.MEM_HOST if hst else L.MEM_DEVICE) for o, st in enumerate(sts)])
         return eng.build_batch(frames_list)
 
-    period = int(cfg.pose_frames_between)
+    cfg0 = E.default_config(cam.width, cam.height, ftype)
+    period = int(cfg0.pose_frames_between)
 
-    def plan(first, last, ramp=False):
+    def plan_batches(first, last, ramp=False):
         if args.no_align or period <= 0:
             return split_batches(first, last, T, ramp=ramp)
         return E.aligned_batches(first, last, T, period)
 
-    warm_splits = plan(0, args.warmup)
-    warm_batches = [build(k0, t) for k0, t in warm_splits]
+    warm_splits = plan_batches(0, args.warmup)
     if args.splits:
         sizes = [int(x) for x in args.splits.split(",")]
         if sum(sizes) != args.steps or max(sizes) > T or min(sizes) < 1:
@@ -366,14 +371,12 @@ def main():
         starts = np.cumsum([args.warmup] + sizes[:-1])
         timed_splits = list(zip([int(x) for x in starts], sizes))
     else:
-        timed_splits = plan(args.warmup, n_timed_end, ramp=not args.no_ramp)
-    timed_batches = [build(k0, t) for k0, t in timed_splits]
-    extra_splits = plan(n_timed_end, n_frames)
-    extra_batches = [build(k0, t) for k0, t in extra_splits]
+        timed_splits = plan_batches(args.warmup, n_timed_end, ramp=not args.no_ramp)
+    extra_splits = plan_batches(n_timed_end, n_timed_end + n_extra)
 
     bcast_bytes = [0]
 
-    def run(batches, splits=None):
+    def run(eng, batches, splits=None, scene=None):
         for i, (arr, _keep, t) in enumerate(batches):
             if scene is not None and world > 1 and splits is not None:
                 k0 = splits[i][0]
@@ -392,33 +395,26 @@ def main():
 
     barrier = parallel.barrier
     if args.rehearsal_ms > 0:
-        # The scratch engines run on the very streams -- hardware queues -- the timed run will use: the engine created above
-        # hands its stream set back first (the library keeps a process's stream sets and gives the first free one to the next
-        # engine), and the engine of the timed run is created after the rehearsal.
-        # The rehearsal tracks OTHER streams (seeds + 1000: same shapes, same batch cuts): every frame of the warm-up and of
-        # the timed region is read for the first time by the run that is timed.
-        reh_host = host_copies(rehearsal_streams)
-        reh_batches = [build(k0, t, rehearsal_streams, reh_host) for k0, t in warm_splits + timed_splits]
-        eng.close()
+        # Process warm-up, once, before the first window: scratch engines track a DISJOINT stream set (seeds 20000 +) of the
+        # same shapes and batch cuts -- kernels loaded, allocations sized, the device out of its idle power state under the
+        # tracker's own load.  No frame of any window is read by it.
+        reh_streams, _rs = make_streams(20000, n_timed_end, zero_remote=False)   # (nothing broadcasts in the rehearsal)
+        reh_host = host_copies(reh_streams)
         t_w = time.perf_counter()
         while True:
             _c, scratch = new_engine(n_obj)
-            add_objects(scratch, rehearsal_streams)
-            for arr, _keep, t in reh_batches:
-                scratch.submit_batch_raw(arr, t)
+            add_objects(scratch, reh_streams)
+            for k0, t in warm_splits + timed_splits:
+                arr, _keep, tt = build(scratch, k0, t, reh_streams, reh_host)
+                scratch.submit_batch_raw(arr, tt)
                 scratch.step()
             scratch.sync()
             scratch.close()
             if (time.perf_counter() - t_w) * 1e3 >= args.rehearsal_ms:
                 break
-        del reh_batches, reh_host
-        cfg, eng = new_engine(n_obj)
-        add_objects(eng, streams)
-        eng.enable_log(n_frames)
+        del reh_streams, reh_host
     if args.clock_warm_ms > 0:
         # not tracker work and not timed: brings the device out of its idle power state (see --clock-warm-ms)
-        # (a GEMM for the shader clock, large copies for the memory / fabric clocks: the tracker's kernels are bound by
-        #  memory latency)
         wa = torch.randn(4096, 4096, device=dev, dtype=torch.float32)
         wb = torch.empty(256 << 20, device=dev, dtype=torch.uint8)
         wc = torch.empty_like(wb)
@@ -429,31 +425,23 @@ def main():
                 wc.copy_(wb)
             torch.cuda.synchronize()
         del wa, wb, wc
-    # Everything that is not the W warm-up steps happens BEFORE them, so that the timed window follows the warm-up steps as
-    # closely as the contract's barrier + synchronize allow (~0.1 ms of device idle time instead of the milliseconds of round 3's
-    # order, after which the first kernels of the window ran at the clocks of an idle device): the exchange's set-up, the timing
-    # machinery, the host thread's spin.
-    spin_late = os.environ.get("ROFT_BENCH_SPIN_LATE") == "1"   # (A/B against round 3's order)
-    plan = None
+    gplan = None
     if world > 1:
-        # Nothing of the exchange happens for the first time inside the window: the shard sizes are exchanged here, once, and
+        # Nothing of the exchange happens for the first time inside a window: the shard sizes are exchanged here, once, and
         # one all-gather of the timed region's shape (and, for a shared scene, one broadcast of a batch's shape) runs before
-        # the clock starts -- the first collective of a process builds its communicator's channels and can cost more than
-        # the whole window.
-        plan = parallel.gather_plan(n_obj, (args.steps, 19), red_dev)
-        parallel.gather_records(torch.zeros((n_obj, args.steps, 19), dtype=torch.float64), red_dev, plan)
-        if scene is not None:
+        # any clock starts -- the first collective of a process builds its communicator's channels and can cost more than
+        # a whole window.
+        gplan = parallel.gather_plan(n_obj, (args.steps, 19), red_dev)
+        parallel.gather_records(torch.zeros((n_obj, args.steps, 19), dtype=torch.float64), red_dev, gplan)
+        if args.shared_scene:
             t_max = max(t for _k0, t in timed_splits)
-            dummy = [torch.zeros_like(scene.depth[:t_max]), torch.zeros_like(scene.flow[:t_max])]
+            dummy = [torch.zeros((t_max, cam.height, cam.width), dtype=torch.float32, device=dev),
+                     torch.zeros((t_max, cam.height // g, cam.width // g, 2), dtype=torch.float32 if args.flow == "f32" else torch.int16, device=dev)]
             if backend != "nccl":
                 dummy = [d.cpu() for d in dummy]
             parallel.broadcast_frames(dummy, src=0)
             del dummy
         torch.cuda.synchronize()
-    if not args.no_kernel_timing:
-        # a start/stop HIP event pair on the roofline kernel's own dispatch, nothing else (ROFT_BENCH_FULL_TIMING=1: a mark after
-        # every launch group of the timed region -- with ROFT_DUMP_MARKS=<file> the profiler-free timeline of the run)
-        eng.enable_timing(2 if os.environ.get("ROFT_BENCH_FULL_TIMING") == "1" else 1)
 
     def host_spin():
         # a few milliseconds of spinning bring the host thread's core to its working clock before the window in which it enqueues
@@ -461,55 +449,165 @@ def main():
         t_spin = time.perf_counter()
         while time.perf_counter() - t_spin < 3e-3:
             pass
-    barrier()
-    if not spin_late:
-        host_spin()
-    run(warm_batches, warm_splits)
-    eng.sync()
-    torch.cuda.synchronize()
-    if not args.no_kernel_timing:
-        eng.timing()   # (the marks of the warm-up steps are not the timed region's)
-    bcast_bytes[0] = 0
-    stats0 = eng.stats()
-    barrier()
-    torch.cuda.synchronize()
-    if spin_late:
-        host_spin()
-    t0 = time.perf_counter()
-    run(timed_batches, timed_splits)
-    host_enqueue = time.perf_counter() - t0   # host side of the loop (frame programs + launches), GPU still running
-    host_cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1
-    eng.sync()
-    gathered = None
-    if world > 1:
-        # the only exchange of the job: every rank's per-object result rows (pose 13 | twist 6 per object-frame)
-        rows = torch.from_numpy(eng.get_log_rows(args.warmup, args.steps)).transpose(0, 1).contiguous()   # [obj, frame, 19]
-        gathered = parallel.gather_records(rows, red_dev, plan)
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = parallel.max_over_ranks(elapsed, red_dev)
-    stats1 = eng.stats()
 
+    def timed_window(seed_base, instrument=0, extra=0):
+        """One timed region on a fresh engine and a fresh stream set: W warm-up steps, barrier + synchronize, EXACTLY K timed
+        steps, engine sync (+ the all-gather of the result rows at N > 1), synchronize + barrier, max over ranks.  instrument:
+        roft_engine_enable_timing level (0 for every window that can become `value`).  Returns the record of the window and
+        what the caller keeps (engine, streams, gathered rows)."""
+        sts, scene = make_streams(seed_base, n_timed_end + extra)
+        hst = host_copies(sts)
+        cfg, eng = new_engine(n_obj)
+        add_objects(eng, sts)
+        eng.enable_log(n_timed_end + extra)
+        warm_b = [build(eng, k0, t, sts, hst) for k0, t in warm_splits]
+        timed_b = [build(eng, k0, t, sts, hst) for k0, t in timed_splits]
+        if instrument:
+            eng.enable_timing(instrument)
+        barrier()
+        host_spin()
+        run(eng, warm_b, warm_splits, scene)
+        eng.sync()
+        torch.cuda.synchronize()
+        if instrument:
+            eng.timing()   # (the marks of the warm-up steps are not the timed region's)
+        bcast_bytes[0] = 0
+        stats0 = eng.stats()
+        nb0 = stats0["batches"]
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        t0_us = time.clock_gettime(time.CLOCK_MONOTONIC) * 1e6   # (the engine's batch trace is on this clock: std::chrono::steady_clock)
+        run(eng, timed_b, timed_splits, scene)
+        host_enqueue = time.perf_counter() - t0   # host side of the loop (frame programs + launches), GPU still running
+        host_cpu = os.sched_getcpu() if hasattr(os, "sched_getcpu") else -1
+        eng.sync()
+        gathered = None
+        if world > 1:
+            # the only exchange of the job: every rank's per-object result rows (pose 13 | twist 6 per object-frame)
+            rows = torch.from_numpy(eng.get_log_rows(args.warmup, args.steps)).transpose(0, 1).contiguous()   # [obj, frame, 19]
+            gathered = parallel.gather_records(rows, red_dev, gplan)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed_own = time.perf_counter() - t0
+        elapsed = parallel.max_over_ranks(elapsed_own, red_dev)
+        stats1 = eng.stats()
+        trace = [b for b in eng.batch_trace() if b["batch"] >= nb0]
+        rec = {
+            "value": total_obj * args.steps / elapsed,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "elapsed_ms": 1e3 * elapsed,
+            "elapsed_ms_this_rank": 1e3 * elapsed_own,
+            "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
+            "host_cpu": host_cpu,
+            "loadavg_1min": os.getloadavg()[0],
+            "seed_base": seed_base,
+            "launches_per_frame": (stats1["launches"] - stats0["launches"]) / max(stats1["frames"] - stats0["frames"], 1),
+            "event_ops_per_frame": (stats1["event_ops"] - stats0["event_ops"]) / max(stats1["frames"] - stats0["frames"], 1),
+            # per batch of the window: the engine's scheduling decisions (a function of the batch index), the host's time in
+            # the submit and step calls, and when the host saw the batch complete, relative to the start of the window
+            "batches": [dict(frames=b["frames"], steady=b["steady"], throttled=b["throttled"], handoff=b["handoff"],
+                             early_lanes=b["early_lanes"], outlier_parts_halved=b["outlier_parts_halved"], launches=b["launches"],
+                             submit_us=round(b["submit_us"], 1), wait_us=round(b["wait_us"], 1), step_us=round(b["step_us"], 1),
+                             submitted_at_ms=round((b["t_submit_us"] - t0_us) * 1e-3, 4),
+                             done_at_ms=round((b["t_done_us"] - t0_us) * 1e-3, 4) if b["t_done_us"] else None) for b in trace],
+        }
+        return rec, dict(eng=eng, streams=sts, scene=scene, host=hst, gathered=gathered, cfg=cfg, bcast=bcast_bytes[0])
+
+    # ---- the timed windows
+    windows = []
+    keep0 = None
+    for w in range(n_windows):
+        rec, keep = timed_window(4000 + 1000 * w)
+        windows.append(rec)
+        if w == 0:
+            keep0 = keep   # window 0 tracks the canonical streams (seeds 4000 +): accuracy figures, --dump-rows
+        else:
+            keep["eng"].close()
+            del keep
+    order = sorted(range(n_windows), key=lambda i: windows[i]["value"])
+    med = windows[order[(n_windows - 1) // 2]]   # the median window (the lower one of an even count): a run that happened
+    value = med["value"]
+    eng, streams, scene, host, gathered, cfg = (keep0[k] for k in ("eng", "streams", "scene", "host", "gathered", "cfg"))
+    bcast_total = keep0["bcast"]
+
+    # ---- one more window of the same shape WITH the roofline kernel's event pair (never `value`), and behind it the
+    #      per-kernel breakdown over the next frames of the same streams (a marker event after every launch group)
     kernels = {}
     k1_live = None
+    inst = None
     if not args.no_kernel_timing:
-        tm = eng.timing()
+        inst, keep_i = timed_window(4000 + 1000 * n_windows, instrument=(2 if os.environ.get("ROFT_BENCH_FULL_TIMING") == "1" else 1), extra=n_extra)
+        e_i = keep_i["eng"]
+        tm = e_i.timing()
         ms, cnt = tm["flow_measure"]
         k1_live = dict(total_ms=ms, launches=cnt, avg_us=1e3 * ms / max(cnt, 1))
         if "flow_measure_span" in tm and tm["flow_measure_span"][1]:
             # the same launches on the device's own 100 MHz clock: first workgroup in -> last workgroup out
             k1_live["span_avg_us"] = 1e3 * tm["flow_measure_span"][0] / tm["flow_measure_span"][1]
             k1_live["span_launches"] = tm["flow_measure_span"][1]
-        # per-kernel breakdown over the next 24 frames of the same streams (outside the timed region: a marker event
-        # after every launch costs throughput)
-        eng.enable_timing(2)
-        run(extra_batches, extra_splits)
-        eng.sync()
-        for name, (ms, cnt) in eng.timing().items():
-            if name != "flow_measure_span":
-                kernels[name] = dict(total_ms=ms, marks=cnt, avg_us=1e3 * ms / max(cnt, 1))
-        eng.enable_timing(0)
+        if n_extra > 0:
+            e_i.enable_timing(2)
+            extra_b = [build(e_i, k0, t, keep_i["streams"], keep_i["host"]) for k0, t in extra_splits]
+            run(e_i, extra_b, extra_splits, keep_i["scene"])
+            e_i.sync()
+            for name, (ms, cnt) in e_i.timing().items():
+                if name != "flow_measure_span":
+                    kernels[name] = dict(total_ms=ms, marks=cnt, avg_us=1e3 * ms / max(cnt, 1))
+            e_i.enable_timing(0)
+        npts_inst = e_i.get_log(0, n_timed_end)[2]
+        inst_streams = keep_i["streams"]
+        e_i.close()
+        del keep_i
+
+    # ---- accuracy of window 0 (the canonical streams): ADD-S vs ground truth for EVERY object of every rank, ADD-S vs the CPU
+    #      reference path on a sample that holds objects of every rank
+    pose_log, twist_log, npts_log, sel_log = eng.get_log(0, n_timed_end)
+    pts_cache = {}
+    rng = np.random.default_rng(0)
+
+    def model_points(st):
+        key = st.half_extents
+        if key not in pts_cache:
+            v = st.mesh[0].astype(np.float64)
+            pts_cache[key] = v[rng.choice(len(v), 500, replace=False)]
+        return pts_cache[key]
+
+    sl = slice(args.warmup, n_timed_end)
+    adds_gt_local = []
+    for o in range(n_obj):
+        st = streams[o]
+        est = np.concatenate([pose_log[:, o, 6:9], pose_log[:, o, 9:13]], 1)
+        gt = np.concatenate([st.gt.x, st.gt.q], 1)
+        adds_gt_local.append(metrics.trajectory_adds(est[sl], gt[sl], model_points(st)))
+    n_sample = min(args.cpu_sample_objects, n_obj)
+    # ADD-S vs the CPU path at N > 1: every rank runs the oracle on its first ceil(sample / world) objects (25 frames of one
+    # object are 40 ms of one core) -- untimed: `cpu_baseline` is an N = 1 measurement
+    adds_cpu_local = None
+    if world > 1 and not args.no_cpu_baseline:
+        from oracle import binding as ob
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import util
+        adds_cpu_local = []
+        for o in range(min(n_obj, max(1, -(-args.cpu_sample_objects // world)))):
+            st = streams[o]
+            ref = util.run_oracle_tracker(ob, st, n_timed_end)
+            ref_pose = np.stack([np.concatenate([r["pose"][6:9], r["pose"][9:13]]) for r in ref])
+            est = np.concatenate([pose_log[:, o, 6:9], pose_log[:, o, 9:13]], 1)
+            adds_cpu_local.append(metrics.trajectory_adds(est[:n_timed_end], ref_pose, model_points(st)))
+    ranks_info = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        mine = dict(rank=rank, local_rank=local_rank, device=dev_index, device_name=props.name,
+                    device_uuid=str(getattr(props, "uuid", "")), objects=n_obj, first_object=int(my_objects[0]),
+                    adds_gt=[a.tolist() for a in adds_gt_local],
+                    adds_cpu=[a.tolist() for a in adds_cpu_local] if adds_cpu_local is not None else None,
+                    windows_ms_this_rank=[w_["elapsed_ms_this_rank"] for w_ in windows])
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        seen = torch.ones(1, device=red_dev)
+        dist.all_reduce(seen)   # one contribution per rank that is really in the communicator
+        ranks_info = dict(all=allr, seen=int(seen.item()))
 
     if rank != 0:
         eng.close()
@@ -518,7 +616,6 @@ def main():
             dist.destroy_process_group()
         return
 
-    value = total_obj * args.steps / elapsed
     if gathered is not None:
         assert tuple(gathered.shape) == (total_obj, args.steps, 19), gathered.shape
     if args.dump_rows:
@@ -530,29 +627,14 @@ def main():
         args.pcie_frames = 0
         args.no_extras = True
 
-    # ---- accuracy: ADD-S vs ground truth and vs the CPU reference path on the sampled objects
-    pose_log, twist_log, npts_log, sel_log = eng.get_log(0, n_frames)
-    pts_cache = {}
-    rng = np.random.default_rng(0)
-
-    def model_points(st):
-        key = st.half_extents
-        if key not in pts_cache:
-            v = st.mesh[0].astype(np.float64)
-            pts_cache[key] = v[rng.choice(len(v), 500, replace=False)]
-        return pts_cache[key]
-
-    n_sample = min(args.cpu_sample_objects, n_obj)
-    adds_gt = []
-    for o in range(n_sample):
-        st = streams[o]
-        est = np.concatenate([pose_log[:, o, 6:9], pose_log[:, o, 9:13]], 1)
-        gt = np.concatenate([st.gt.x, st.gt.q], 1)
-        adds_gt.append(metrics.trajectory_adds(est[args.warmup:n_timed_end], gt[args.warmup:n_timed_end], model_points(st)))
-    adds_gt = np.concatenate(adds_gt)
-    # RMSE metrics of evaluation/metrics.py on the same sample (position cm, orientation deg, velocities with the
+    if ranks_info is not None:
+        adds_gt = np.concatenate([np.asarray(a) for r in ranks_info["all"] for a in r["adds_gt"]])
+        adds_gt_objects = sum(len(r["adds_gt"]) for r in ranks_info["all"])
+    else:
+        adds_gt = np.concatenate(adds_gt_local)
+        adds_gt_objects = n_obj
+    # RMSE metrics of evaluation/metrics.py on this rank's sample (position cm, orientation deg, velocities with the
     # pole moved to the object, evaluate.py:514-521)
-    sl = slice(args.warmup, n_timed_end)
     est_x = np.concatenate([pose_log[sl, o, 6:9] for o in range(n_sample)])
     est_q = np.concatenate([pose_log[sl, o, 9:13] for o in range(n_sample)])
     gt_x = np.concatenate([streams[o].gt.x[sl] for o in range(n_sample)])
@@ -562,7 +644,6 @@ def main():
     rmse = {"position_cm": metrics.rmse_cartesian_3d(gt_x, est_x), "orientation_deg": metrics.rmse_angular(gt_q, est_q),
             "linear_velocity_cm_s": metrics.rmse_linear_velocity(gt_tw[:, :3], est_tw[:, :3]),
             "angular_velocity_deg_s": metrics.rmse_angular_velocity(gt_tw[:, 3:], est_tw[:, 3:])}
-
     cpu = None
     cpu_multi = None
     adds_cpu = None
@@ -611,10 +692,13 @@ def main():
     #      (i) one depth + flow + mask stream per object; (ii) the shared-scene form of config #4: every
     #      object points at the same depth and flow image, which the engine uploads once per frame.
     pcie = None
-    if args.pcie_frames > 0 and n_frames >= T + 2:
+    # (on the longest stream set of the run: the instrumented window's, W + K + 24 frames, else window 0's)
+    long_streams = inst_streams if (inst is not None and not args.shared_scene) else streams
+    n_long = int(long_streams[0].depth.shape[0])
+    if args.pcie_frames > 0 and n_long >= T + 2:
         def pcie_leg(shared, in_place=False):
-            n_run = min(n_frames, T + args.pcie_frames)
-            sts = [streams[0]] * n_obj if shared else streams
+            n_run = min(n_long, T + args.pcie_frames)
+            sts = [long_streams[0]] * n_obj if shared else long_streams
             src = {}
             for st in (sts[:1] if shared else sts):
                 src[id(st)] = dict(depth=st.depth[:n_run].cpu().pin_memory(), flow=st.flow[:n_run].cpu().pin_memory(),
@@ -695,7 +779,7 @@ def main():
             return time.perf_counter() - t1
         # (the device has idled through the CPU baseline and the host work above: no clock warm-up precedes this run)
         # fresh frames as well: a third stream set (seeds + 2000, same shapes) that nothing has read before this run
-        cold_streams, _cs = make_streams(6000, n_timed_end, zero_remote=False)
+        cold_streams, _cs = make_streams(30000, n_timed_end, zero_remote=False)
         torch.cuda.synchronize()
         time.sleep(1.0)
         _c, e2 = new_engine(n_obj)
@@ -704,9 +788,9 @@ def main():
         e2.close()
         del cold_streams
         value_cold = dict(value=n_obj * args.steps / dt_cold, ms_per_step=1e3 * dt_cold / args.steps, host_enqueue_ms_per_step=1e3 * cold_host[0] / args.steps,
-                          note="a timed sequence of the same shape on a fresh engine and on FRESH frames (a third stream set, seeds "
-                               "+ 2000, read by nothing before) after the device has idled (CPU baseline, host work, 1 s sleep), "
-                               "no rehearsal of any kind: what a short burst from an idle GPU gets")
+                          note="a timed sequence of the same shape on a fresh engine and on FRESH frames (one more stream set, seeds "
+                               "30000 +, read by nothing before) after the device has idled (CPU baseline, host work, 1 s sleep), "
+                               "no rehearsal of any kind and nothing of this shape run for seconds: what a short burst from an idle GPU gets")
         # the roofline kernel with the device to itself: the same frames, every batch waited for before the next one is
         # submitted (its launch then overlaps nothing but the tail of its own batch's mask chain)
         _c, e3 = new_engine(n_obj)
@@ -723,12 +807,12 @@ def main():
         k1_alone = dict(avg_launch_us=1e3 * ms_alone / max(n_alone, 1), launches=n_alone,
                         object_frames_per_launch=n_obj * (args.warmup + args.steps) / max(n_alone, 1))
         # live: ROFTFilter::filtering_step followed by a reader of the estimate, one object, nothing in flight across frames
-        n_live = min(n_frames, 72)
+        n_live = min(n_long, 72)
         cfg1 = E.default_config(cam.width, cam.height, ftype, max_objects=1, device=local_rank, max_batch_frames=1)
         cfg1.cam.fx, cfg1.cam.fy, cfg1.cam.cx, cfg1.cam.cy = cam.fx, cam.fy, cam.cx, cam.cy
         e1 = E.ROFTFilterBatch(cfg1)
-        add_objects(e1, streams[:1])
-        st = streams[0]
+        add_objects(e1, long_streams[:1])
+        st = long_streams[0]
         ins = [e1.build_inputs([frame_dict(st, k, dict(depth=st.depth, flow=st.flow, mask=st.mask_gt), L.MEM_DEVICE)]) for k in range(n_live)]
         lat = np.zeros(n_live)
         for k in range(n_live):
@@ -753,10 +837,10 @@ def main():
         plane_bytes = cam.width * cam.height // 8
         # algorithmic bytes per object-frame with tile culling declared: the obj bit plane
         # (the whole mask, 1 bit/px) + one depth and one flow sample per candidate + the kept records
-        nl = npts_log[args.warmup:n_timed_end]
+        nl = npts_inst[args.warmup:n_timed_end]   # (of the instrumented window: the launches that were timed)
         ran = nl >= 0
         # mask pixels of the frame the measurement reads (the previous frame's propagated mask ~ its ground-truth mask)
-        mask_px = np.mean([float((st.mask_gt[max(args.warmup - 1, 0):n_timed_end - 1] > 0).sum().item()) / args.steps for st in streams])
+        mask_px = np.mean([float((st.mask_gt[max(args.warmup - 1, 0):n_timed_end - 1] > 0).sum().item()) / args.steps for st in inst_streams])
         cand = mask_px / float(int(cfg.subsampling_radius))
         n_kept = float(np.mean(nl[ran])) if ran.any() else 0.0
         bytes_per_obj = plane_bytes + cand * (4 + e) + n_kept * 20
@@ -894,7 +978,13 @@ def main():
                                   "are chains of dependent round trips over a few hundred KB per object (latency), the rasteriser is bound by "
                                   "VALU issue on its CU; the CU x us budget of the pipeline is profiles/r04_cu_budget.csv")
     dominant = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])[0] if kernels else None
-    d_frames = max(stats1["frames"] - stats0["frames"], 1)
+    vals = sorted(w_["value"] for w_ in windows)
+    # accuracy at N > 1 (window 0): ADD-S vs the CPU path over a sample with objects of EVERY rank
+    if ranks_info is not None and all(r["adds_cpu"] is not None for r in ranks_info["all"]):
+        adds_cpu = np.concatenate([np.asarray(a) for r in ranks_info["all"] for a in r["adds_cpu"]])
+        adds_cpu_objects = [len(r["adds_cpu"]) for r in ranks_info["all"]]
+    else:
+        adds_cpu_objects = [n_sample] if adds_cpu is not None else None
 
     out = {
         "metric": "tracker frames/sec per object (640x480) + ADD-S vs CPU ref",
@@ -903,22 +993,36 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
-        "host_enqueue_ms_per_step": 1e3 * host_enqueue / args.steps,
-        "host_state": {"cpu": host_cpu, "loadavg_1min": os.getloadavg()[0], "cpus_online": os.cpu_count()},
+        "ms_per_step": med["ms_per_step"],
         "higher_is_better": True,
         "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
+        # ---- how `value` came about: every window of this invocation (value = the median one), and the median window's own
+        #      host time, host state and batch trace, so that a slow run explains itself
+        "value_is": "median of %d timed windows of exactly %d steps each (fresh engine + fresh disjoint stream set per window, no "
+                    "timing instrumentation inside)" % (n_windows, args.steps),
+        "runs": [w_["value"] for w_ in windows],
+        "value_min": vals[0],
+        "value_max": vals[-1],
+        "value_first_window": windows[0]["value"],
+        "host_enqueue_ms_per_step": med["host_enqueue_ms_per_step"],
+        "host_state": {"cpu": med["host_cpu"], "loadavg_1min": med["loadavg_1min"], "cpus_online": os.cpu_count()},
+        "batches": med["batches"],
+        "windows": windows,
+        "instrumented_window": inst,
         "inputs": "host (PCIe-inclusive)" if args.host_inputs else "resident in HBM",
         "timed_frames_first_touch": True,
-        "method": {"rehearsal_ms": args.rehearsal_ms,
-                   "rehearsal_streams": "disjoint from the timed ones (seeds + 1000, same shapes and batch cuts)" if args.rehearsal_ms > 0 else None,
-                   "host_spin_ms": 3.0, "host_spin": "before the W warm-up steps (the window follows them behind one barrier + synchronize)",
+        "method": {"windows": n_windows, "rehearsal_ms": args.rehearsal_ms,
+                   "rehearsal_streams": "disjoint from every window's (seeds 20000 +, same shapes and batch cuts), once, before the first window" if args.rehearsal_ms > 0 else None,
+                   "window_streams": "window i: seeds %s + object index (window 0 = the canonical streams of config #4, SURVEY 8d); instrumented window: %d +"
+                                     % (" / ".join(str(4000 + 1000 * i) for i in range(n_windows)), 4000 + 1000 * n_windows),
+                   "host_spin_ms": 3.0, "host_spin": "before the W warm-up steps of every window (the window follows them behind one barrier + synchronize)",
                    "batch_cuts": "explicit --splits" if args.splits else ("full batches" if args.no_align else "batches end with the pose-arrival frame"),
-                   "note": "no frame of the warm-up or of the timed region is read by anything in this process before the run that "
-                           "is timed reads it; the W warm-up steps run on the timed engine right before the window"},
+                   "scheduling": "a function of the batch index since the engine was last idle (roft_batch_trace::steady), not of host timing",
+                   "note": "no frame of a window is read by anything in this process before the window reads it; the W warm-up steps "
+                           "run on the window's engine right before its timed steps; nothing records an event inside a window"},
         "config": {"workload": "BASELINE config #4: %dx%d, %s flow grid %d, %d objects in total, %s "
                                "(sharded by object, no data-path collective; result rows all-gathered over RCCL at N > 1), "
                                "masks+poses at 5 fps with 6-frame delay, flow-aided masks, re-sync and outlier rejection on, "
@@ -928,12 +1032,22 @@ def main():
                                 "%d per GPU" % n_obj if args.scaling == "strong" else "%d per GPU (weak scaling)" % n_obj, T),
                    "objects_per_gpu": n_obj, "objects_total": total_obj, "width": cam.width, "height": cam.height,
                    "batch_frames": T, "timed_batches": [t for _k0, t in timed_splits], "ranks": world, "backend": backend},
-        "shared_scene": ({"broadcast_MB_per_step": bcast_bytes[0] / args.steps / 1e6, "ingest_rank": 0,
+        # ---- N > 1: who was there (one entry per rank of the communicator), what each owned, and each rank's OWN time per window
+        #      (before the max over ranks) -- a SCALE line can be checked against the per-GPU points of the object sweep
+        "ranks": ({"world_size": world, "ranks_seen_by_all_reduce": ranks_info["seen"],
+                   "objects_per_gpu": [r["objects"] for r in ranks_info["all"]],
+                   "first_object_of_rank": [r["first_object"] for r in ranks_info["all"]],
+                   "devices": [dict(rank=r["rank"], local_rank=r["local_rank"], device=r["device"], name=r["device_name"], uuid=r["device_uuid"]) for r in ranks_info["all"]],
+                   "window_ms_per_rank": [r["windows_ms_this_rank"] for r in ranks_info["all"]],
+                   "per_gpu_rate_of_the_median_window": value / world,
+                   "note": "per_gpu_rate = value / n_gpus: what ONE GPU tracks with objects_per_gpu objects -- compare with the N = 1 run at --objects <that number> (profiles/*object_sweep_20.json)"}
+                  if ranks_info is not None else None),
+        "shared_scene": ({"broadcast_MB_per_step": bcast_total / args.steps / 1e6, "ingest_rank": 0,
                           "note": "every object of every rank tracks in one camera stream; rank 0's depth + flow frames are "
                                   "broadcast batch by batch inside the timed region"} if args.shared_scene else None),
-        "frames_per_sec_per_object": args.steps / elapsed,
-        "launches_per_frame": (stats1["launches"] - stats0["launches"]) / d_frames,
-        "event_ops_per_frame": (stats1["event_ops"] - stats0["event_ops"]) / d_frames,
+        "frames_per_sec_per_object": 1e3 / med["ms_per_step"],
+        "launches_per_frame": med["launches_per_frame"],
+        "event_ops_per_frame": med["event_ops_per_frame"],
         "roofline": roofline,
         "roofline_other": roofline_other,
         "cpu_baseline": cpu,
@@ -948,8 +1062,9 @@ def main():
         "value_cold": value_cold["value"] if value_cold else None,
         "cold_run": value_cold,
         "live_latency": live,
-        "adds_vs_gt_mm": {"mean": 1e3 * float(adds_gt.mean()), "auc": metrics.auc(adds_gt)},
-        "adds_vs_cpu_ref_mm": ({"mean": 1e3 * float(adds_cpu.mean()), "max": 1e3 * float(adds_cpu.max())}
+        "adds_vs_gt_mm": {"mean": 1e3 * float(adds_gt.mean()), "auc": metrics.auc(adds_gt), "objects": adds_gt_objects,
+                          "note": "window 0 (the canonical streams), every object of every rank"},
+        "adds_vs_cpu_ref_mm": ({"mean": 1e3 * float(adds_cpu.mean()), "max": 1e3 * float(adds_cpu.max()), "objects_per_rank": adds_cpu_objects}
                                if adds_cpu is not None else None),
         "rmse_vs_gt": rmse,
         "pipeline": "four HIP streams per engine (mask frames / velocity chain / two pose lanes): one mask kernel per frame (small "
@@ -957,7 +1072,7 @@ def main():
                     "lane, twists handed from the velocity filter to the lanes frame by frame in bursts, up to 5 batches in flight",
         "kernels_post_run_breakdown": kernels,
         "dominant_kernel": dominant,
-        "stream_generation_s": t_gen,
+        "stream_generation_s": gen_s[0],
     }
     print(json.dumps(out))
     eng.close()

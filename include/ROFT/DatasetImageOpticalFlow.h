@@ -40,6 +40,7 @@ public:
     float get_scaling_factor() const override { return scale_; }
     double get_data_loading_time() const override { return loading_ms_; }
     int get_matrix_type() const override { return type_; }
+    bool flow_buffers_are_immutable() const override { return true; }   // (read_flow returns a new matrix per file)
     std::tuple<bool, cv::Mat> flow(const bool&) override { return std::make_tuple(frame_.first, frame_.second); }
 
 private:

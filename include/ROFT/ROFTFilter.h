@@ -229,6 +229,13 @@ protected:
         if (new_mask) last_mask_ = mask.clone();
         if (!mask_received_) return;   // the segmentation is not available yet: nothing to filter (cpp:291)
 
+        // The engine keeps REFERRING to a flow handed over in place -- a delayed mask is chased through the flows of the frames
+        // since it was taken -- so the buffer must hold this frame's flow for as long as the filter holds it (held_).  A source
+        // that does not promise that (one flow matrix rewritten every frame: cv::Mat copies share the buffer), or whose buffer is
+        // one the filter already holds, is copied here, once, as the reference's OF-aided source clones the flows it buffers
+        // (ImageSegmentationOFAidedSource.hpp:200-209).  Depth needs no such care: the matrix type of the camera tuple is
+        // copy-on-write (Compat.h); a mask is read once, by the step below, before the source can touch it again.
+        if (valid_flow && (!flow_source_->flow_buffers_are_immutable() || holds_buffer(flow.data))) flow = flow.clone();
         roft_frame_input in{};
         in.dt = elapsed;
         in.depth = depth.data();
@@ -364,6 +371,12 @@ private:
     // frames handed to the engine in place (pinned pool): camera tuple (depth), flow and mask of the retention window
     struct Held { bfl::Data cam; cv::Mat flow, mask; };
     std::deque<Held> held_;
+    bool holds_buffer(const void* p) const
+    {
+        for (const Held& h : held_)
+            if (p && (h.flow.data == p || h.mask.data == p)) return true;
+        return false;
+    }
     double exec_us_ = 0.0, engine_us_ = 0.0, sources_us_ = 0.0;
     long timed_frames_ = 0, in_place_frames_ = 0;
     roft_object_output out_{};

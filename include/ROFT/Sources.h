@@ -142,6 +142,12 @@ public:
     virtual std::size_t get_grid_size() const = 0;      // a flow frame is per pixel or per grid x grid block
     virtual float get_scaling_factor() const = 0;       // values of a flow frame are pixels times this factor
     virtual int get_matrix_type() const = 0;            // CV_32FC2 or CV_16SC2
+    // (not in the reference's interface) true: every flow() frame lives in a buffer of its own that this source never writes
+    // again -- ROFT::ROFTFilter may then hand the buffer to the engine as it is and keep referring to it for the frames the flow
+    // stays in use (cv::Mat shares its buffer between copies and is NOT copy-on-write).  The default is the safe answer for a
+    // source the filter knows nothing about: the filter then works on a copy of its own, as the reference's OF-aided source
+    // does (`flow.clone()`, ImageSegmentationOFAidedSource.hpp:200-209).
+    virtual bool flow_buffers_are_immutable() const { return false; }
 };
 
 // Same interface as the reference's ImageOpticalFlowNVOF (set_rgb / step_frame / flow / get_grid_size /
@@ -185,6 +191,9 @@ public:
             flow_in_ = false;
             return false;
         }
+        // a buffer of its own for every frame (the pool recycles blocks by size): a consumer that still holds the last frame's
+        // cv::Mat -- the filter keeps flows referenced for as long as a mask can be chased through them -- keeps its content
+        flow_ = cv::Mat(h_ / (int)get_grid_size(), w_ / (int)get_grid_size(), get_matrix_type());
         compat::throw_if(roft_optical_flow(last_.data(), gray, w_, h_, &prm_, get_matrix_type() == CV_16SC2 ? ROFT_FLOW_S16C2 : ROFT_FLOW_F32C2,
                                            flow_.data), "ImageOpticalFlowHIP::step_frame");
         last_.assign(gray, gray + n);
@@ -197,6 +206,7 @@ public:
     std::size_t get_grid_size() const override { return product_ == Product::NVOF_1_0 ? 4 : 1; }
     float get_scaling_factor() const override { return product_ == Product::NVOF_1_0 ? 32.0f : 1.0f; }
     int get_matrix_type() const override { return product_ == Product::NVOF_1_0 ? CV_16SC2 : CV_32FC2; }
+    bool flow_buffers_are_immutable() const override { return true; }   // (step_frame allocates)
     roft_of_params& parameters() { return prm_; }
 
 private:

@@ -162,6 +162,11 @@ int roft_depth_likelihood(const roft_camera* cam, const float* depth, const uint
 int roft_outlier_test(const roft_camera* cam, int divider, const float* depth, const uint8_t* mask, const roft_mesh* mesh,
                       const double x[6], const double q[8], int bands, int vertex_cache, int window_pixels, double L_out[2],
                       long samples_out[2], int* selected_out, float* tiles_out);
+/* The same with the way the workgroups of an alternative share its work chosen FOR THIS CALL: split 1 = its triangles (windows
+ * merged through memory), 0 = only the rows of its window, -1 = the library's choice.  No result depends on it. */
+int roft_outlier_test_split(const roft_camera* cam, int divider, const float* depth, const uint8_t* mask, const roft_mesh* mesh,
+                            const double x[6], const double q[8], int bands, int vertex_cache, int window_pixels, int split,
+                            double L_out[2], long samples_out[2], int* selected_out, float* tiles_out);
 
 /* ---- (2) batched engine --------------------------------------------------------------------- */
 
@@ -321,6 +326,27 @@ typedef struct {
 } roft_engine_stats;
 int roft_engine_get_stats(roft_engine* e, roft_engine_stats* out);
 
+/* What the engine decided for, and the host spent on, each of the last batches (a ring of 64): a slow run explains itself.
+ * The scheduling mode of a batch is a function of the batch INDEX alone: `steady` = at least <batches in flight> batches have
+ * been stepped since the engine was last idle (creation / roft_sync / anything that reads results); bursts release the pose
+ * lanes early (`handoff`, `early_lanes`) and spread an outlier test over all the CUs to spare, steady batches halve that
+ * (`outlier_parts_halved`).  `throttled` is the MEASURED counterpart (the submit call had to wait for the in-flight bound) and
+ * steers nothing.  Times: host steady clock in microseconds; t_done_us is when the HOST observed the batch complete (inside a
+ * later submit call or roft_sync, which waits for the batches one by one in order), 0 while it has not. */
+typedef struct {
+    int batch;                 /* index since roft_engine_create */
+    int frames;
+    int steady, throttled, handoff, early_lanes, outlier_parts_halved;
+    int launches, event_ops;   /* enqueued by roft_step for this batch */
+    double t_submit_us;        /* entry of roft_frames_submit */
+    double submit_us;          /* inside roft_frames_submit (frame programs, uploads) ... */
+    double wait_us;            /* ... of which blocked on the in-flight bound */
+    double step_us;            /* inside roft_step (launches) */
+    double t_done_us;
+} roft_batch_trace;
+/* the last min(capacity, 64, batches so far) batches, oldest first */
+int roft_engine_get_batch_trace(roft_engine* e, roft_batch_trace* out, int capacity, int* n_out);
+
 /* HIP stream the engine enqueues on (as void*), for timing with hipEvents */
 void* roft_engine_stream(roft_engine* e);
 
@@ -401,7 +427,9 @@ int roft_debug_sector_rate(int device, double* sectors_per_second);
  * mask_frame, mask_ingest, mask_general, flow_measure, skf_chain, features, ukf_chain, outlier_fused.  Only filled by libraries
  * built with -DROFT_RESIDENCY (tools/residency_budget.py: the CU x us budget of the pipeline). */
 int roft_debug_get_residency(roft_engine* e, unsigned long long out[32]);
-/* How the workgroups of one alternative of an outlier test share its work, for every test launched by this process from now on:
+/* (A/B experiments on a whole engine only -- process-wide, so not for a process whose threads run other engines; a single
+ * operator-level test takes the choice as an argument: roft_outlier_test_split.)
+ * How the workgroups of one alternative of an outlier test share its work, for every test launched by this process from now on:
  * 1 = they split its TRIANGLES (windows merged in memory, the last workgroup scores; rows as well when the window does not fit
  * the LDS in one piece), 0 = they split only the ROWS of its window, -1 = the library's choice (1).  The results do not depend
  * on it (tests/test_parity_gpu.py). */

@@ -79,6 +79,13 @@ class EngineStats(C.Structure):
                 ("event_ops", C.c_longlong), ("h2d_bytes", C.c_longlong)]
 
 
+class BatchTrace(C.Structure):
+    _fields_ = [("batch", C.c_int), ("frames", C.c_int), ("steady", C.c_int), ("throttled", C.c_int), ("handoff", C.c_int),
+                ("early_lanes", C.c_int), ("outlier_parts_halved", C.c_int), ("launches", C.c_int), ("event_ops", C.c_int),
+                ("t_submit_us", C.c_double), ("submit_us", C.c_double), ("wait_us", C.c_double), ("step_us", C.c_double),
+                ("t_done_us", C.c_double)]
+
+
 class ObjectOutput(C.Structure):
     _fields_ = [("pose", C.c_double * 13), ("twist", C.c_double * 6), ("n_flow_points", C.c_int),
                 ("outlier_selected", C.c_int), ("outlier_L", C.c_double * 2)]
@@ -88,11 +95,11 @@ class ObjectOutput(C.Structure):
 ABI_SYMBOLS = [
     "roft_last_error_string", "roft_device_count", "roft_flow_measurement", "roft_kf_predict",
     "roft_skf_correct", "roft_skf_correct_points", "roft_mask_propagate", "roft_pose_process_noise", "roft_ukf_predict",
-    "roft_ukf_correct", "roft_render_depth", "roft_depth_likelihood", "roft_outlier_test", "roft_default_config",
+    "roft_ukf_correct", "roft_render_depth", "roft_depth_likelihood", "roft_outlier_test", "roft_outlier_test_split", "roft_default_config",
     "roft_default_object", "roft_engine_create", "roft_engine_destroy", "roft_object_add",
     "roft_frame_submit", "roft_frames_submit", "roft_engine_retain_frames", "roft_engine_get_stats", "roft_step", "roft_sync", "roft_get_state", "roft_get_outputs", "roft_get_mask",
     "roft_engine_enable_log", "roft_engine_get_log", "roft_engine_get_log_rows", "roft_engine_stream", "roft_engine_enable_timing",
-    "roft_engine_get_timing", "roft_default_of_params", "roft_optical_flow", "roft_flow_producer_create",
+    "roft_engine_get_timing", "roft_engine_get_batch_trace", "roft_default_of_params", "roft_optical_flow", "roft_flow_producer_create",
     "roft_flow_producer_destroy", "roft_flow_producer_run", "roft_flow_producer_sync", "roft_flow_producer_stream",
     "roft_debug_plan", "roft_debug_get_dbg", "roft_debug_probe_streams", "roft_debug_sector_rate",
     "roft_host_alloc", "roft_host_free", "roft_host_is_pinned", "roft_debug_get_residency", "roft_debug_outlier_split",
@@ -137,6 +144,8 @@ def lib():
     L.roft_render_depth.argtypes = [C.POINTER(Mesh), vp, vp, C.POINTER(Camera), C.c_int, vp]
     L.roft_depth_likelihood.argtypes = [C.POINTER(Camera), vp, vp, vp, C.c_int, dp, C.POINTER(C.c_long)]
     L.roft_outlier_test.argtypes = [C.POINTER(Camera), C.c_int, vp, vp, C.POINTER(Mesh), vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, ip, vp]
+    L.roft_outlier_test_split.argtypes = [C.POINTER(Camera), C.c_int, vp, vp, C.POINTER(Mesh), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, ip, vp]
+    L.roft_engine_get_batch_trace.argtypes = [vp, C.POINTER(BatchTrace), C.c_int, ip]
     L.roft_default_config.argtypes = [C.POINTER(Config), C.c_int, C.c_int, C.c_int]
     L.roft_default_object.argtypes = [C.POINTER(ObjectDesc)]
     L.roft_engine_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]

@@ -412,7 +412,20 @@ struct roft_engine {
     int batch_end_frame[kBatchRing] = {};
     roft_engine_stats stats{};
     bool device_pointers_checked = false;   // ROFT_MEM_DEVICE inputs are looked up once, on the first submit
-    bool throttled = false;   // the submit of the current batch had to wait for the in-flight bound: the device is `lead` batches behind
+    bool throttled = false;   // MEASURED, diagnostics only (roft_batch_trace): the submit of the current batch had to wait for the in-flight bound
+    // Scheduling mode of a batch, a function of the batch INDEX alone (round 5; rounds 3 - 4 keyed it on `throttled`, a host
+    // timing, so that the launch graph itself differed from run to run): a batch is "steady" when at least `lead` batches have
+    // been stepped since the engine was last idle (creation, roft_sync and everything that calls it), i.e. from the batch on
+    // whose submit call may have to wait for the in-flight bound.  Bursts (fewer batches between two syncs) favour latency:
+    // lanes released early, outlier tests on all the CUs to spare; steady batches favour occupancy.
+    int idle_mark = 0;        // batch_counter when the engine was last known idle
+    bool steady = false;      // mode of the batch being stepped
+    bool alone_on_device = true;   // no other engine of this process held a stream set on the device when this one was created
+    bool wait_value_ok = true;     // hipDeviceAttributeCanUseStreamWaitValue
+    // trace of the last kTraceRing batches (roft_engine_get_batch_trace)
+    static constexpr int kTraceRing = 64;
+    roft_batch_trace trace[kTraceRing] = {};
+    double cur_submit_t0 = 0.0, cur_submit_us = 0.0, cur_wait_us = 0.0;
     // Frame-granular hand-over velocity filter -> pose lanes (EngineArrays::handoff).  handoff_mode: 0 never, 1 while the host is
     // not throttled by the in-flight bound (bursts: the pipeline is filling or draining and latency is what counts), 2 always.
     int handoff_mode = 1;
@@ -472,6 +485,10 @@ static int wait_batch(roft_engine* e, int b, bool* waited = nullptr)
             (void)hipGetLastError();   // (hipErrorNotReady is not an error of this call)
             HIP_TRY(hipEventSynchronize(e->ev_done[b % roft_engine::kBatchRing][l]));
         }
+    {
+        roft_batch_trace& tr = e->trace[b % roft_engine::kTraceRing];
+        if (tr.batch == b && tr.t_done_us == 0.0) tr.t_done_us = host_now_us();
+    }
     e->completed_batches = b + 1;
     e->completed_frames = e->batch_end_frame[b % roft_engine::kBatchRing];
     return check_dev_error(e);
@@ -777,6 +794,15 @@ static void release_streams(StreamSet* s)
     if (s) s->in_use = false;
 }
 
+// true when no other engine of this process holds a stream set on the device of `mine`
+static bool alone_on_device(const StreamSet* mine)
+{
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    for (const StreamSet* s : g_stream_sets)
+        if (s != mine && s->in_use && s->device == mine->device) return false;
+    return true;
+}
+
 static int engine_setup(roft_engine* e, const roft_config* cfg)
 {
     constexpr int R = roft_engine::kBatchRing;
@@ -823,6 +849,36 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
     e->arr.a.ukf_chol_guard_bil = (cfg->ukf_cholesky_guard_bilinear > 0.0) ? cfg->ukf_cholesky_guard_bilinear : 0.0;
     e->h_params.resize(cfg->max_objects);
     e->staging.resize(e->retain);
+    {
+        int can = 0;
+        if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, cfg->device) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        e->wait_value_ok = can != 0;   // (without it the lanes run behind the velocity chain's event)
+    }
+    // Nothing of a batch may happen for the first time inside a caller's timed region: every event of the batch ring has
+    // completed one dispatch on the stream that will carry it (the first use of an event as a kernel's stop event takes a signal
+    // from the runtime's pool -- a host call of its own kind), and every stream has queued a wait on an event and on a value.
+    if (e->multi) {
+        int* flag = reinterpret_cast<int*>(e->arr.skf_started.p);   // (a word that stays 0 until the first batch; the probe kernel writes 1 ... reset below)
+        for (int i = 0; i < R; ++i) {
+            hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->stream, nullptr, e->ev_ctrl[i], 0, flag);
+            hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->stream, nullptr, e->ev_mask[i], 0, flag);
+            hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->stream, nullptr, e->ev_feat[i], 0, flag);
+            HIP_TRY(hipStreamWaitEvent(e->vel_stream, e->ev_mask[i], 0));
+            hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->vel_stream, nullptr, e->ev_vel[i], 0, flag);
+            for (int l = 0; l < kNumLin; ++l) {
+                HIP_TRY(hipStreamWaitEvent(e->pose_stream[l], (i & 1) ? e->ev_vel[i] : e->ev_ctrl[i], 0));
+                hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->pose_stream[l], nullptr, e->ev_done[i][l], 0, flag);
+            }
+            HIP_TRY(hipEventRecord(e->ev_up[i], e->up_stream));
+        }
+        HIP_TRY(hipGetLastError());
+        for (hipStream_t q : {e->stream, e->vel_stream, e->pose_stream[0], e->pose_stream[1], e->up_stream}) HIP_TRY(hipStreamSynchronize(q));
+        HIP_TRY(hipMemset(e->arr.skf_started.p, 0, sizeof(unsigned long long)));
+        if (e->wait_value_ok)
+            for (int l = 0; l < kNumLin; ++l)
+                HIP_TRY(hipStreamWaitValue64(e->pose_stream[l], e->arr.skf_started.p, 0ull, hipStreamWaitValueGte, ~0ull));   // (satisfied at once)
+        for (int l = 0; l < kNumLin; ++l) HIP_TRY(hipStreamSynchronize(e->pose_stream[l]));
+    }
     if (const char* hm = getenv("ROFT_HANDOFF")) e->handoff_mode = atoi(hm);
     // A tool that lets only ONE kernel run at a time (rocprofv3 --pmc: counter collection serialises the dispatches) cannot run a
     // lane next to the velocity filter it waits for -- the runtime's stream-wait itself is a kernel that spins: off under it.
@@ -1315,8 +1371,10 @@ int roft_frames_submit(roft_engine* e, const roft_frame_input* inputs, int n_obj
     if (e->submitted) return fail(ROFT_ERR_STATE, "previous batch not stepped yet");
     HIP_TRY(hipSetDevice(e->cfg.device));
     double hp_t = e->host_prof ? host_now_us() : 0.0;
+    e->cur_submit_t0 = host_now_us();
     // bound the batches in flight (see roft_engine::lead); this also frees the batch ring slot
     if (int rc = wait_batch(e, e->batch_counter - e->lead, &e->throttled)) return rc;
+    e->cur_wait_us = host_now_us() - e->cur_submit_t0;
     HP_MARK(e, 0, hp_t);   // time blocked on the GPU
     e->backup.resize(e->objs.size());
     for (size_t i = 0; i < e->objs.size(); ++i) e->backup[i] = e->objs[i]->s;
@@ -1342,6 +1400,7 @@ int roft_frames_submit(roft_engine* e, const roft_frame_input* inputs, int n_obj
     e->cur_T = n_frames;
     e->submitted = true;
     e->device_pointers_checked = true;
+    e->cur_submit_us = host_now_us() - e->cur_submit_t0;
     return ROFT_OK;
 }
 
@@ -1434,10 +1493,20 @@ static int step_batch(roft_engine* e)
     // when its tag appears, so the first segment of a re-sync (the pose step, which reads a twist of six frames ago) and its
     // outlier test run next to the batch's mask frames instead of behind them.
     const bool cus_to_spare = 8 * a.n_obj <= device_cu_count();
-    const bool handoff = multi && T > 1 && e->handoff_mode > 0 && !(e->handoff_mode == 1 && e->throttled && !cus_to_spare) &&
+    // (round 5: keyed on the batch index, not on whether the submit call happened to wait -- see roft_engine::steady)
+    const bool steady = e->steady = (e->batch_counter - e->idle_mark) >= e->lead;
+    const bool handoff = multi && T > 1 && e->handoff_mode > 0 && e->wait_value_ok && !(e->handoff_mode == 1 && steady && !cus_to_spare) &&
                          !e->feat_dep_in_batch && !e->any_feat_now && e->arr.skf_started.p != nullptr;
-    static const int early_env = getenv("ROFT_EARLY_LANES") ? atoi(getenv("ROFT_EARLY_LANES")) : 1;   // (experiments)
-    const bool early_lanes = handoff && cus_to_spare && !e->throttled && early_env != 0;   // (bursts: in the steady state a lane is behind anyway, and at 1280x720 the early tests cost 3 %)
+    static const int early_env = getenv("ROFT_EARLY_LANES") ? atoi(getenv("ROFT_EARLY_LANES")) : 1;   // (experiments; 0 for several processes on one GPU)
+    // Early lanes spin inside their kernel for twists whose producer kernel is not even enqueued yet (it sits behind the mask
+    // chain on another stream): progress needs (i) hardware queues of their own for the four chains -- a stream set that was
+    // PROBED free of conflicts -- and (ii) CUs the lanes do not occupy: at most one object per eight CUs counted over THIS
+    // engine, which only holds when no other engine of the process works on the device (other processes: ROFT_EARLY_LANES=0).
+    // Otherwise the lanes fall back to the gate on resident velocity-filter workgroups (`handoff`), where a lane only ever
+    // waits for workgroups that run.
+    const bool early_lanes = handoff && cus_to_spare && !steady && early_env != 0 && e->streams && e->streams->conflicts == 0 &&
+                             (e->alone_on_device = alone_on_device(e->streams));   // (bursts: in the steady state a lane is behind anyway, and at 1280x720 the early tests cost 3 %)
+    const long long launches0 = e->stats.launches, evops0 = e->stats.event_ops;
 
     // ---- control blocks of the batch -> device (+ reset of the mask chain's counters), ingest of the masks delivered
     //      with the batch (tables and ingest slots of this batch's parity: the carry of the chain before stays readable).
@@ -1516,11 +1585,16 @@ static int step_batch(roft_engine* e)
     // over is worth +4 - 6 % at 8 and 32 objects in 60-step runs, +1 - 2 % in the steady state at 32, -1 % at 64): `handoff` above.
     a.handoff = handoff ? 1 : 0;
     a.skf_started = e->arr.skf_started.p;
-    e->skf_total += (unsigned long long)a.n_obj;
     e->vel_used[slot] = multi;
     launch_skf_chain(a, e->cfg.flow_weighting, sv, (multi && !full && !feat_last) ? e->ev_vel[slot] : nullptr);
     ++launches;
-    CHECK_LAUNCH("velocity filter chain");
+    if (hipError_t le = hipGetLastError()) {
+        // the filter's workgroups will never count themselves in: no lane may ever wait for them (a stream-wait on a value has
+        // no timeout) -- the hand-over is off for the rest of this engine's life
+        e->handoff_mode = 0;
+        return fail(ROFT_ERR_DEVICE, std::string("velocity filter chain: ") + hipGetErrorString(le));
+    }
+    e->skf_total += (unsigned long long)a.n_obj;   // (only once the launch is known to be enqueued: the lanes' gates wait for this count)
     tmark(e, "skf_chain", 2);
     if (feat_last) {
         launch_features(a, sv, !full ? e->ev_vel[slot] : nullptr);
@@ -1577,7 +1651,7 @@ static int step_batch(roft_engine* e)
                 // CUs to the chains; 64 objects: +5 %, and -2.5 % if a 20-frame burst did the same).  The likelihood sums are
                 // exact, so the band count changes no result.
                 OutlierLaunchOpts oo;
-                if (e->cfg.outlier_bands_per_alternative == 0 && e->throttled) oo.parts = -2;   // (-d: the automatic count / d)
+                if (e->cfg.outlier_bands_per_alternative == 0 && steady) oo.parts = -2;   // (-d: the automatic count / d)
                 launch_outlier(a, lin, sp, nullptr, &oo);
                 ++launches;
                 CHECK_LAUNCH("outlier rejection");
@@ -1588,6 +1662,17 @@ static int step_batch(roft_engine* e)
     }
     HP_MARK(e, 6, hp_t);
     if (e->host_prof) e->hp_batches++;
+    {
+        roft_batch_trace& tr = e->trace[e->batch_counter % roft_engine::kTraceRing];
+        tr = roft_batch_trace{};
+        tr.batch = e->batch_counter;
+        tr.frames = T;
+        tr.steady = steady; tr.throttled = e->throttled; tr.handoff = handoff; tr.early_lanes = early_lanes;
+        tr.outlier_parts_halved = (e->cfg.outlier_bands_per_alternative == 0 && steady) ? 1 : 0;
+        tr.launches = (int)(e->stats.launches - launches0);
+        tr.event_ops = (int)(e->stats.event_ops - evops0);
+        tr.t_submit_us = e->cur_submit_t0; tr.submit_us = e->cur_submit_us; tr.wait_us = e->cur_wait_us;
+    }
     HIP_TRY(hipGetLastError());
     return ROFT_OK;
 }
@@ -1597,7 +1682,12 @@ int roft_step(roft_engine* e)
     if (!e) return fail(ROFT_ERR_INVALID, "null engine");
     if (!e->submitted) return fail(ROFT_ERR_STATE, "roft_frame_submit must precede roft_step");
     HIP_TRY(hipSetDevice(e->cfg.device));
+    const double t_step0 = host_now_us();
     const int rc = step_batch(e);
+    {
+        roft_batch_trace& tr = e->trace[e->batch_counter % roft_engine::kTraceRing];
+        if (tr.batch == e->batch_counter) tr.step_us = host_now_us() - t_step0;
+    }
     for (HostObject* ho : e->objs) { ho->stepped_slot = ho->s.cur_slot; ho->stepped_lane = ho->s.own[ho->s.cur_slot]; }
     // (a failed step leaves the engine consistent as far as the host can tell: the batch counts as enqueued)
     const int slot = e->batch_counter % roft_engine::kBatchRing;
@@ -1615,6 +1705,11 @@ int roft_sync(roft_engine* e)
 {
     if (!e) return fail(ROFT_ERR_INVALID, "null engine");
     HIP_TRY(hipSetDevice(e->cfg.device));
+    // the batches in flight one by one, in order (their completion times go into the batch trace), then whatever else the
+    // streams carry (uploads, timing marks, reads of results)
+    if (e->multi)
+        for (int b = e->completed_batches; b < e->batch_counter; ++b)
+            if (int rc = wait_batch(e, b)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (e->multi) {
         HIP_TRY(hipStreamSynchronize(e->vel_stream));
@@ -1623,7 +1718,17 @@ int roft_sync(roft_engine* e)
     }
     e->completed_batches = e->batch_counter;
     e->completed_frames = e->frame_counter;
+    e->idle_mark = e->batch_counter;   // the device is idle: the next batches are a burst again (roft_engine::steady)
     return check_dev_error(e);
+}
+
+int roft_engine_get_batch_trace(roft_engine* e, roft_batch_trace* out, int capacity, int* n_out)
+{
+    if (!e || !out || !n_out || capacity < 0) return fail(ROFT_ERR_INVALID, "bad arguments");
+    const int n = std::min(std::min(capacity, roft_engine::kTraceRing), e->batch_counter);
+    for (int i = 0; i < n; ++i) out[i] = e->trace[(e->batch_counter - n + i) % roft_engine::kTraceRing];
+    *n_out = n;
+    return ROFT_OK;
 }
 
 int roft_get_state(roft_engine* e, int id, double pose13[13], double P12[144], double twist6[6], double Pv[36])
@@ -2313,10 +2418,21 @@ int roft_outlier_test(const roft_camera* cam, int divider, const float* depth, c
     if (!cam || !depth || !mask || !mesh || !mesh->verts || !mesh->tris || mesh->n_verts <= 0 || mesh->n_tris <= 0 || !x || !q ||
         divider <= 0 || bands < 0 || bands > kMaxOutlierParts || window_pixels < 0)
         return fail(ROFT_ERR_INVALID, "bad argument");
+    return roft_outlier_test_split(cam, divider, depth, mask, mesh, x, q, bands, vertex_cache, window_pixels, -1, L_out, samples_out, selected_out, tiles_out);
+}
+
+int roft_outlier_test_split(const roft_camera* cam, int divider, const float* depth, const uint8_t* mask, const roft_mesh* mesh,
+                            const double x[6], const double q[8], int bands, int vertex_cache, int window_pixels, int split, double L_out[2],
+                            long samples_out[2], int* selected_out, float* tiles_out)
+{
+    if (!cam || !depth || !mask || !mesh || !mesh->verts || !mesh->tris || mesh->n_verts <= 0 || mesh->n_tris <= 0 || !x || !q ||
+        divider <= 0 || bands < 0 || bands > kMaxOutlierParts || window_pixels < 0)
+        return fail(ROFT_ERR_INVALID, "bad argument");
     OutlierLaunchOpts o;
     o.parts = bands;
     o.no_vertex_cache = vertex_cache ? 0 : 1;
     o.window_pixels = window_pixels;
+    o.split = split < 0 ? -1 : (split ? 1 : 0);   // (this call only: nothing process-wide changes)
     return op_outlier(cam, divider, depth, mask, mesh, x, q, o, L_out, samples_out, selected_out, tiles_out);
 }
 

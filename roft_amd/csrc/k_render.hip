@@ -494,17 +494,52 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
                 static_assert(kMaxOutlierParts <= 8, "eight slabs per pixel");
                 const uint32_t* others = a.zmerge + slab0;
                 const size_t slab_step = 2 * a.zmerge_stride;
+                // the other groups' slabs, compacted (G - 1 pointers); the loads and the wait that makes them valid are ONE asm
+                // statement per pixel with early-clobber outputs (round 5, ADVICE: as separate statements the compiler was free to
+                // move, spill or reuse the destination registers between the load and the s_waitcnt)
+                const uint32_t* op[7];
+                {
+                    int k = 0;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p)
+                        if (p < G && p != grp && k < 7) op[k++] = others + (size_t)p * slab_step;
+                    for (; k < 7; ++k) op[k] = others;
+                }
                 for (int i = tid; i < npx; i += kFusedThreads) {
-                    uint32_t v[8];
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) {
-                        v[p] = 0x7F800000u;
-                        if (p < G && p != grp) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[p]) : "v"(others + (size_t)p * slab_step + i) : "memory");
-                    }
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
                     uint32_t m = s_z[i];
-#pragma unroll
-                    for (int p = 0; p < 8; ++p) m = min(m, v[p]);
+                    uint32_t v0, v1, v2, v3, v4, v5, v6;
+                    switch (G - 1) {   // (uniform)
+                    case 1:
+                        asm volatile("global_load_dword %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v0) : "v"(op[0] + i) : "memory");
+                        m = min(m, v0);
+                        break;
+                    case 2:
+                        asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(v0), "=&v"(v1) : "v"(op[0] + i), "v"(op[1] + i) : "memory");
+                        m = min(m, min(v0, v1));
+                        break;
+                    case 3:
+                        asm volatile("global_load_dword %0, %3, off sc1\n\tglobal_load_dword %1, %4, off sc1\n\tglobal_load_dword %2, %5, off sc1\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(op[0] + i), "v"(op[1] + i), "v"(op[2] + i) : "memory");
+                        m = min(min(m, v0), min(v1, v2));
+                        break;
+                    case 4:
+                        asm volatile("global_load_dword %0, %4, off sc1\n\tglobal_load_dword %1, %5, off sc1\n\tglobal_load_dword %2, %6, off sc1\n\t"
+                                     "global_load_dword %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(op[0] + i), "v"(op[1] + i), "v"(op[2] + i), "v"(op[3] + i) : "memory");
+                        m = min(m, min(min(v0, v1), min(v2, v3)));
+                        break;
+                    default:   // 5 .. 7 others: seven loads (the spare pointers repeat the first slab: harmless under min)
+                        asm volatile("global_load_dword %0, %7, off sc1\n\tglobal_load_dword %1, %8, off sc1\n\tglobal_load_dword %2, %9, off sc1\n\t"
+                                     "global_load_dword %3, %10, off sc1\n\tglobal_load_dword %4, %11, off sc1\n\tglobal_load_dword %5, %12, off sc1\n\t"
+                                     "global_load_dword %6, %13, off sc1\n\ts_waitcnt vmcnt(0)"
+                                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6)
+                                     : "v"(op[0] + i), "v"(op[1] + i), "v"(op[2] + i), "v"(op[3] + i), "v"(op[4] + i), "v"(op[5] + i), "v"(op[6] + i) : "memory");
+                        m = min(min(m, v0), min(min(v1, v2), min(min(v3, v4), min(v5, v6))));
+                        break;
+                    case 0: break;
+                    }
                     s_z[i] = m;
                 }
                 __syncthreads();

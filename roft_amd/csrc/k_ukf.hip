@@ -153,6 +153,7 @@ struct UkfLds {
     double meas[13];     // twist of the step [6], pose measurement x [3], q [4]
     double red[4];
     int flag;
+    int twist_timeout;   // ukf_one_step: the twist this step was told to wait for never appeared (frame-granular hand-over)
     long long t0;
     long long dbg[32];
 };
@@ -1087,7 +1088,9 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
 }
 
 // One launch = one StepDesc per object: optional prediction, then 0, 1 or 2 corrections of it.
-__device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj, int step, const UtTable& ut, UkfLds& L)
+// Returns false when the step was NOT applied: the twist it had to wait for did not appear within two seconds (the beliefs are
+// left as they were; the caller abandons the rest of the batch and the host reports ROFT_ERR_DEVICE at its next synchronisation).
+__device__ bool ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj, int step, const UtTable& ut, UkfLds& L)
 {
     ObjState& st = a.state[obj];
     // (field by field into registers: a copy of the struct, whose arrays the correction loop indexes, would live in scratch memory
@@ -1100,7 +1103,7 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
         sd.op = d.op; sd.src = d.src; sd.do_predict = d.do_predict; sd.n_corr = d.n_corr;
         sd.type0 = d.type[0]; sd.type1 = d.type[1]; sd.dst0 = d.dst[0]; sd.dst1 = d.dst[1]; sd.twist_slot = d.twist_slot;
     }
-    if (!sd.op) return;
+    if (!sd.op) return true;
     const ObjParams& prm = a.params[obj];
     const int lane = threadIdx.x;
     const int lin = c.lane, cur = c.cur_slot;
@@ -1125,13 +1128,16 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
             if (lane == 192) {
                 const long long t0 = wall_clock64();
                 unsigned spins = 0;
+                int timed_out = 0;
                 while (__hip_atomic_load(&st.twist_tag[sd.twist_slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                     __builtin_amdgcn_s_sleep(1);
                     if ((++spins & 4095u) == 0u && wall_clock64() - t0 > 200000000ll) {   // two seconds (100 MHz): give up
                         if (a.dev_error) __hip_atomic_store(a.dev_error, ROFT_DEV_ERROR_TWIST_WAIT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        timed_out = 1;
                         break;
                     }
                 }
+                L.twist_timeout = timed_out;
             }
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             if (i < 6) L.meas[i] = __longlong_as_double((long long)__hip_atomic_load(
@@ -1142,6 +1148,7 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
         if (i >= 6 && i < 13) L.meas[i] = (i < 9) ? c.pose_x[i - 6] : c.pose_q[i - 9];
     }
     __syncthreads();
+    if (a.handoff && L.twist_timeout) return false;   // (uniform: nothing of the step is applied to a belief)
 
     TICK(L, 0);
     if (sd.do_predict) {
@@ -1156,7 +1163,7 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
         if (lane < 13) d.mean[lane] = L.mean[lane];
         if (roft_object_output* row = log_row(a, c, obj))
             if (lane < 13 && sd.dst0 == cur) row->pose[lane] = L.mean[lane];
-        return;
+        return true;
     }
     TICK(L, 6);
     // square root of the predicted covariance, shared by both corrections of an outlier-rejection step
@@ -1179,6 +1186,7 @@ __device__ void ukf_one_step(const EngineArrays& a, const FrameCtrl& c, int obj,
     __syncthreads();
     if (lane < 32) st.dbg[lane] = L.dbg[lane];
 #endif
+    return true;
 }
 
 // Pose chain of a batch, one lane (BeliefSlot) per launch: one workgroup per object runs the UKF steps of the frames
@@ -1288,7 +1296,15 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
 #ifdef ROFT_UKF_WALL
         const long long w_s0 = wall_clock64();
 #endif
-        if (c.steps[step].op) ukf_one_step(a, c, obj, step, ut, L);
+        if (c.steps[step].op && !ukf_one_step(a, c, obj, step, ut, L)) {
+            // a twist never arrived (ROFT_DEV_ERROR_TWIST_WAIT is raised): no further step of this batch is applied and none waits
+            // another two seconds; the host refuses the results at its next synchronisation
+            __syncthreads();
+            t = a.T;
+            step = 0;
+            pending = false;
+            break;
+        }
 #ifdef ROFT_UKF_WALL
         if (threadIdx.x == 0 && w_steps > 0) {   // histogram of step durations (not the first step of a launch: cold)
             const long long d = wall_clock64() - w_s0;

@@ -147,6 +147,14 @@ class ROFTFilterBatch:
         L.check(L.lib().roft_engine_get_stats(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in L.EngineStats._fields_}
 
+    def batch_trace(self, n=64):
+        """The engine's record of its last (at most 64) batches, oldest first: scheduling decisions and host times
+        (roft_batch_trace in include/roft_engine.h)."""
+        arr = (L.BatchTrace * n)()
+        got = C.c_int(0)
+        L.check(L.lib().roft_engine_get_batch_trace(self._h, arr, n, C.byref(got)))
+        return [{k: getattr(arr[i], k) for k, _ in L.BatchTrace._fields_} for i in range(got.value)]
+
     def step(self):
         L.check(L.lib().roft_step(self._h))
 

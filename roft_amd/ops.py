@@ -151,12 +151,6 @@ def outlier_test(cam, divider, depth, mask, mesh, x2, q2, bands=0, vertex_cache=
     outlier_fused_kernel, the deciding pose chain segment).  x2 (2, 3), q2 (2, 4): the two alternatives.
     split: the workgroups of an alternative share its triangles (True) / the rows of its window (False); None: the library's choice.
     Returns (L[2], samples[2], selected, tiles (2, H/d, W/d) or None)."""
-    if split is not None:
-        L.check(L.lib().roft_debug_outlier_split(1 if split else 0))
-        try:
-            return outlier_test(cam, divider, depth, mask, mesh, x2, q2, bands, vertex_cache, window_pixels, tiles)
-        finally:
-            L.lib().roft_debug_outlier_split(-1)
     depth = np.ascontiguousarray(depth, np.float32)
     mask = np.ascontiguousarray(mask, np.uint8)
     x2, q2 = _f64(np.asarray(x2).reshape(6)), _f64(np.asarray(q2).reshape(8))
@@ -164,9 +158,10 @@ def outlier_test(cam, divider, depth, mask, mesh, x2, q2, bands=0, vertex_cache=
     ns = np.zeros(2, np.int64)
     sel = C.c_int(-2)
     t = np.zeros((2, cam.height // divider, cam.width // divider), np.float32) if tiles else None
-    L.check(L.lib().roft_outlier_test(C.byref(cam), divider, _p(depth), _p(mask), C.byref(mesh), _p(x2), _p(q2), bands,
-                                      1 if vertex_cache else 0, window_pixels, _p(Lv), _p(ns), C.byref(sel),
-                                      _p(t) if tiles else None))
+    # (split travels with the call -- roft_outlier_test_split -- not through a process-wide switch)
+    L.check(L.lib().roft_outlier_test_split(C.byref(cam), divider, _p(depth), _p(mask), C.byref(mesh), _p(x2), _p(q2), bands,
+                                            1 if vertex_cache else 0, window_pixels, -1 if split is None else (1 if split else 0),
+                                            _p(Lv), _p(ns), C.byref(sel), _p(t) if tiles else None))
     return Lv, ns, sel.value, t
 
 

@@ -43,8 +43,18 @@ int main(int argc, char** argv)
         model.name("object");
         model.mesh_external_path(obj_path);
         auto camera = std::make_shared<ROFT::CameraMeasurement>(std::make_shared<MemCamera>(s));
-        auto segmentation = std::make_shared<MemSegmentation>(s, 6);
-        auto flow = std::make_shared<MemFlow>(s);
+        // argv[3]: "pooled" / "rewriter" serve the recording from pinned pool buffers (the filter then hands them over in place),
+        // the latter through ONE flow matrix rewritten every frame; default: caller memory (staged by the submit call)
+        const std::string mode = argc > 3 ? argv[3] : "";
+        std::shared_ptr<RobotsIO::Utils::Segmentation> segmentation;
+        std::shared_ptr<ROFT::ImageOpticalFlowSource> flow;
+        if (mode == "pooled" || mode == "rewriter") {
+            segmentation = std::make_shared<MemSegmentationPooled>(s, 6);
+            flow = std::make_shared<MemFlowPooled>(s, mode == "rewriter");
+        } else {
+            segmentation = std::make_shared<MemSegmentation>(s, 6);
+            flow = std::make_shared<MemFlow>(s);
+        }
         auto pose = std::make_shared<MemPose>(s, 6);
         // parameter vectors as src/roft/src/main.cpp:286-325 packs the keys of config_fast_ycb.cfg
         Eigen::VectorXd p0(13), p_cov0(12), p_model(6), p_meas(12), v0(6), v_cov0(6), v_model(6), v_meas(2);

@@ -116,6 +116,38 @@ private:
     int k_ = -1;
 };
 
+// The same recording from buffers of the library's pinned pool (cv::Mat allocates image-sized buffers there): what makes
+// ROFT::ROFTFilter hand its inputs to the engine in place.  `rewrite` = ONE flow matrix rewritten every frame, the way a live
+// source with a single output buffer behaves (every cv::Mat copy shares it): the filter must not keep referring to it.
+class MemSegmentationPooled : public MemSegmentation {
+public:
+    using MemSegmentation::MemSegmentation;
+    std::pair<bool, cv::Mat> segmentation(const bool& b) override
+    {
+        auto r = MemSegmentation::segmentation(b);
+        if (r.first) r.second = r.second.clone();
+        return r;
+    }
+};
+
+class MemFlowPooled : public MemFlow {
+public:
+    MemFlowPooled(const RecordedStream& s, bool rewrite) : MemFlow(s), rewrite_(rewrite), one_(s.H, s.W, CV_32FC2) {}
+    std::tuple<bool, cv::Mat> flow(const bool& b) override
+    {
+        auto r = MemFlow::flow(b);
+        if (!std::get<0>(r)) return r;
+        if (!rewrite_) return std::make_tuple(true, std::get<1>(r).clone());
+        std::memcpy(one_.data, std::get<1>(r).data, one_.total() * one_.elemSize());
+        return std::make_tuple(true, one_);
+    }
+    bool flow_buffers_are_immutable() const override { return !rewrite_; }
+
+private:
+    bool rewrite_;
+    cv::Mat one_;
+};
+
 // poses are polled once per frame: freeze() advances the cursor and says whether this frame delivers one
 class MemPose : public RobotsIO::Utils::Transform {
 public:

@@ -32,13 +32,13 @@ def test_struct_layouts_match_header_sizes():
     # sizes the C compiler gives the ABI structs (guards the ctypes mirrors)
     import subprocess
     import tempfile
-    src = '#include <stdio.h>\n#include "roft_engine.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(roft_camera), sizeof(roft_flow), sizeof(roft_config), sizeof(roft_object_desc), sizeof(roft_frame_input), sizeof(roft_object_output));return 0;}'
+    src = '#include <stdio.h>\n#include "roft_engine.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(roft_camera), sizeof(roft_flow), sizeof(roft_config), sizeof(roft_object_desc), sizeof(roft_frame_input), sizeof(roft_object_output), sizeof(roft_batch_trace), sizeof(roft_engine_stats));return 0;}'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "s.c"), "w").write(src)
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")])
         sizes = [int(x) for x in subprocess.check_output([os.path.join(d, "s")]).split()]
     assert sizes == [C.sizeof(L.Camera), C.sizeof(L.Flow), C.sizeof(L.Config), C.sizeof(L.ObjectDesc),
-                     C.sizeof(L.FrameInput), C.sizeof(L.ObjectOutput)]
+                     C.sizeof(L.FrameInput), C.sizeof(L.ObjectOutput), C.sizeof(L.BatchTrace), C.sizeof(L.EngineStats)]
     # (the trailing ints of roft_config share one alignment slot: a field missing from the mirror would not change the size)
     src = ('#include <stdio.h>\n#include <stddef.h>\n#include "roft_engine.h"\nint main(){printf("%zu %zu %zu %zu\\n", offsetof(roft_config, device), '
            'offsetof(roft_config, max_batch_frames), offsetof(roft_config, mask_workgroups_per_object), '

@@ -232,6 +232,30 @@ def test_whole_filter_facade_equals_the_python_engine(tmp_path):
     eng.close()
 
 
+@pytest.mark.gpu
+def test_filter_facade_in_place_inputs_equal_staged_inputs(tmp_path):
+    """ROFT::ROFTFilter hands images that live in the library's pinned pool to the engine in place (zero copy) and the engine
+    keeps REFERRING to them: a flow for as long as a delayed mask can be chased through it.  cv::Mat is not copy-on-write, so a
+    source that rewrites one flow matrix every frame (a live source with a single output buffer; ROFT::ImageOpticalFlowHIP
+    before round 5) must not be referred to -- the filter copies such a flow (flow_buffers_are_immutable()).  Masks delayed by
+    six frames and chased through six flows; both pooled variants must equal the staged (HOST upload) run bit for bit."""
+    import util
+    n = 26
+    st = util.stream(41, n, 2)
+    dump_stream(str(tmp_path / "s.bin"), st, n)
+    exe = build(tmp_path, "filter_check")
+    rows = {}
+    for mode, env in (("staged", {"ROFT_FACADE_STAGED": "1"}), ("pooled", {}), ("rewriter", {})):
+        out = str(tmp_path / ("o_%s.bin" % mode))
+        r = subprocess.run([exe, str(tmp_path / "s.bin"), out, "pooled" if mode == "staged" else mode],
+                           env=dict(os.environ, ROFT_FILTER_TIMING="1", **env), capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert ("staged (HOST)" if mode == "staged" else "in-place (pinned)") in r.stdout, r.stdout
+        rows[mode] = np.fromfile(out, np.float64).reshape(n, 19)
+    assert np.array_equal(rows["pooled"], rows["staged"])
+    assert np.array_equal(rows["rewriter"], rows["staged"])
+
+
 def test_logger_probe_and_png_stand_ins(tmp_path):
     """bfl::Logger / RobotsIO::Utils::Probe(Container) / ImageFileProbe of Compat.h without a device: the log files carry
     what was logged in Eigen's default matrix format, a probe receives what set_data() hands it, and the PNG files of the

@@ -15,10 +15,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def run_bench(tmp_path, n_ranks, tag, port, extra=(), launcher=True):
+def run_bench(tmp_path, n_ranks, tag, port, extra=(), launcher=True, cpu_ref=False):
     out = str(tmp_path / ("rows_%s.npy" % tag))
-    args = ["bench.py", "--gpus", str(n_ranks), "--steps", "14", "--warmup", "4", "--objects", "5", "--no-cpu-baseline",
+    args = ["bench.py", "--gpus", str(n_ranks), "--steps", "14", "--warmup", "4", "--objects", "5", "--windows", "3",
             "--pcie-frames", "0", "--no-extras", "--no-kernel-timing", "--rehearsal-ms", "0", "--dump-rows", out] + list(extra)
+    if not cpu_ref:
+        args.append("--no-cpu-baseline")
     env = dict(os.environ, ROFT_BENCH_DEVICE="0", ROFT_BENCH_BACKEND="gloo")
     if n_ranks > 1 and launcher:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
@@ -33,8 +35,23 @@ def run_bench(tmp_path, n_ranks, tag, port, extra=(), launcher=True):
 
 def test_two_ranks_gather_what_one_rank_logs(tmp_path):
     one, rows1 = run_bench(tmp_path, 1, "one", 0)
-    two, rows2 = run_bench(tmp_path, 2, "two", 29517)
+    two, rows2 = run_bench(tmp_path, 2, "two", 29517, cpu_ref=True)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    # the line explains itself: every window's value (value = their median), the batch trace of the median window, who was there
+    for line in (one, two):
+        assert len(line["runs"]) == 3 and line["value"] == sorted(line["runs"])[1] and line["value_min"] <= line["value"] <= line["value_max"]
+        assert len(line["windows"]) == 3 and all(len(w["batches"]) == len(line["config"]["timed_batches"]) for w in line["windows"])
+        assert all(b["done_at_ms"] is not None and b["done_at_ms"] > 0 and b["steady"] == 0 for b in line["batches"])
+        assert abs(line["ms_per_step"] * line["value"] - 1e3 * 5) < 1e-6 * 5e3
+    assert one["ranks"] is None
+    rk = two["ranks"]
+    assert rk["world_size"] == 2 and rk["ranks_seen_by_all_reduce"] == 2 and rk["objects_per_gpu"] == [3, 2] and rk["first_object_of_rank"] == [0, 3]
+    assert len(rk["window_ms_per_rank"]) == 2 and all(len(w) == 3 for w in rk["window_ms_per_rank"])
+    assert abs(rk["per_gpu_rate_of_the_median_window"] - two["value"] / 2) < 1e-9 * two["value"]
+    # accuracy at N > 1: ADD-S vs ground truth over the objects of BOTH ranks, ADD-S vs the CPU path on objects of both
+    assert two["adds_vs_gt_mm"]["objects"] == 5 and one["adds_vs_gt_mm"]["objects"] == 5
+    assert abs(two["adds_vs_gt_mm"]["mean"] - one["adds_vs_gt_mm"]["mean"]) < 1e-9
+    assert two["adds_vs_cpu_ref_mm"]["objects_per_rank"] == [3, 2] and two["adds_vs_cpu_ref_mm"]["max"] < 1e-3
     assert two["config"]["objects_total"] == 5 and two["config"]["objects_per_gpu"] == 3     # block partition 3 + 2
     assert two["scaling"] == "strong" and two["cpu_baseline"] is None
     assert rows1.shape == rows2.shape == (5, 14, 19)

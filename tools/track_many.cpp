@@ -23,6 +23,7 @@
 //   ... -DROFT_WITH_RCCL -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include ... -L/opt/rocm/lib -lrccl -lamdhip64     (with --gather)
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <thread>
@@ -79,24 +80,39 @@ struct ShardRows { long n_obj = 0, frames = 0; std::vector<double> rows; };
 std::vector<ShardRows> gather_rows(const std::string& id_file, int rank, int world, int device, long n_obj, long frames, const std::vector<double>& rows)
 {
     HIP_OK(hipSetDevice(device));
+    // The id travels through ID_FILE as (job nonce, ncclUniqueId).  A file left behind by a job that crashed must never be taken for
+    // this job's: process 0 removes whatever is there before it creates its id, and the others accept a file only if it carries
+    // their job's nonce (ROFT_JOB_NONCE, the same non-zero number for every process of a job: a launcher's pid or start time) or,
+    // without a nonce, if it was written no earlier than ten minutes before they started (a leftover of an earlier job is older
+    // or, if the job before died just now, is removed by this job's process 0 within its first milliseconds).
     ncclUniqueId id;
+    unsigned long long nonce = 0;
+    if (const char* jn = std::getenv("ROFT_JOB_NONCE")) nonce = std::strtoull(jn, nullptr, 10);
     if (rank == 0) {
+        std::error_code ec;
+        std::filesystem::remove(id_file, ec);
         NCCL_OK(ncclGetUniqueId(&id));
         const std::string tmp = id_file + ".tmp";
         std::FILE* f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
+        if (!f || std::fwrite(&nonce, sizeof(nonce), 1, f) != 1 || std::fwrite(&id, sizeof(id), 1, f) != 1) throw std::runtime_error("cannot write " + tmp);
         std::fclose(f);
         std::filesystem::rename(tmp, id_file);
     } else {
         const auto t0 = std::chrono::steady_clock::now();
+        const auto oldest = std::filesystem::file_time_type::clock::now() - std::chrono::minutes(10);
         for (;;) {
-            std::FILE* f = std::fopen(id_file.c_str(), "rb");
-            if (f) {
-                const bool ok = std::fread(&id, sizeof(id), 1, f) == 1;
-                std::fclose(f);
-                if (ok) break;
+            std::error_code ec;
+            const auto written = std::filesystem::last_write_time(id_file, ec);
+            if (!ec && (nonce != 0 || written >= oldest)) {
+                std::FILE* f = std::fopen(id_file.c_str(), "rb");
+                if (f) {
+                    unsigned long long theirs = 0;
+                    const bool ok = std::fread(&theirs, sizeof(theirs), 1, f) == 1 && std::fread(&id, sizeof(id), 1, f) == 1;
+                    std::fclose(f);
+                    if (ok && theirs == nonce) break;
+                }
             }
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) throw std::runtime_error("no ncclUniqueId in " + id_file + " after 120 s");
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) throw std::runtime_error("no ncclUniqueId of this job in " + id_file + " after 120 s");
             std::this_thread::sleep_for(std::chrono::milliseconds(20));
         }
     }
