@@ -540,19 +540,22 @@ def main():
         inst, keep_i = timed_window(4000 + 1000 * n_windows, instrument=(2 if os.environ.get("ROFT_BENCH_FULL_TIMING") == "1" else 1), extra=n_extra)
         e_i = keep_i["eng"]
         tm = e_i.timing()
-        ms, cnt = tm["flow_measure"]
-        k1_live = dict(total_ms=ms, launches=cnt, avg_us=1e3 * ms / max(cnt, 1))
-        if "flow_measure_span" in tm and tm["flow_measure_span"][1]:
+        # the kernel that takes the flow measurements: the mask + measurement chain (one launch per batch), or -- images too large
+        # for it, ROFT_MASK_FUSED=0 -- the stand-alone measurement kernel
+        k1_name = "mask_flow_chain" if "mask_flow_chain" in tm else "flow_measure"
+        ms, cnt = tm[k1_name]
+        k1_live = dict(total_ms=ms, launches=cnt, avg_us=1e3 * ms / max(cnt, 1), kernel=k1_name)
+        if k1_name + "_span" in tm and tm[k1_name + "_span"][1]:
             # the same launches on the device's own 100 MHz clock: first workgroup in -> last workgroup out
-            k1_live["span_avg_us"] = 1e3 * tm["flow_measure_span"][0] / tm["flow_measure_span"][1]
-            k1_live["span_launches"] = tm["flow_measure_span"][1]
+            k1_live["span_avg_us"] = 1e3 * tm[k1_name + "_span"][0] / tm[k1_name + "_span"][1]
+            k1_live["span_launches"] = tm[k1_name + "_span"][1]
         if n_extra > 0:
             e_i.enable_timing(2)
             extra_b = [build(e_i, k0, t, keep_i["streams"], keep_i["host"]) for k0, t in extra_splits]
             run(e_i, extra_b, extra_splits, keep_i["scene"])
             e_i.sync()
             for name, (ms, cnt) in e_i.timing().items():
-                if name != "flow_measure_span":
+                if not name.endswith("_span"):
                     kernels[name] = dict(total_ms=ms, marks=cnt, avg_us=1e3 * ms / max(cnt, 1))
             e_i.enable_timing(0)
         npts_inst = e_i.get_log(0, n_timed_end)[2]
@@ -564,13 +567,15 @@ def main():
     #      reference path on a sample that holds objects of every rank
     pose_log, twist_log, npts_log, sel_log = eng.get_log(0, n_timed_end)
     pts_cache = {}
-    rng = np.random.default_rng(0)
 
     def model_points(st):
+        # 500 model points per object model, drawn with a seed of the model's own (every rank, whatever objects it holds and in
+        # whatever order it asks, scores a model on the same points)
         key = st.half_extents
         if key not in pts_cache:
             v = st.mesh[0].astype(np.float64)
-            pts_cache[key] = v[rng.choice(len(v), 500, replace=False)]
+            seed = int(sum(round(h * 1e6) * (i + 1) for i, h in enumerate(key))) & 0x7FFFFFFF
+            pts_cache[key] = v[np.random.default_rng(seed).choice(len(v), 500, replace=False)]
         return pts_cache[key]
 
     sl = slice(args.warmup, n_timed_end)
@@ -802,7 +807,8 @@ def main():
             e3.submit_batch_raw(arr, tt)
             e3.step()
             e3.sync()
-        ms_alone, n_alone = e3.timing()["flow_measure"]
+        tm3 = e3.timing()
+        ms_alone, n_alone = tm3["mask_flow_chain" if "mask_flow_chain" in tm3 else "flow_measure"]
         e3.close()
         k1_alone = dict(avg_launch_us=1e3 * ms_alone / max(n_alone, 1), launches=n_alone,
                         object_frames_per_launch=n_obj * (args.warmup + args.steps) / max(n_alone, 1))
