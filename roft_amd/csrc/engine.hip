@@ -136,11 +136,9 @@ int check_geometry(int W, int H)
         return fail(ROFT_ERR_INVALID, "image width must be a multiple of 32 and width*height a multiple of 64");
     if ((size_t)W * H >= (1u << 24))
         return fail(ROFT_ERR_INVALID, "width*height must be < 2^24 (float-accumulated sampling index, hpp:237)");
-    // LDS of the mask chain kernel: the OR target plane + a list of non-empty 64-pixel groups (any length); of the flow
-    // measurement / feature kernels: the plane + their work lists
-    const size_t plane = (size_t)(W / 32) * H * 4;
-    if (plane + 16384 + 128 > 160 * 1024 - 4096)
-        return fail(ROFT_ERR_INVALID, "mask bit plane does not fit the 160 KiB LDS of a CU");
+    // (No bound from the LDS: the mask frames work on windows of a band's rows, the flow measurement and the feature kernel read
+    //  planes that do not fit the LDS -- beyond ~1.1 Mpixel -- from memory, the general mask path lists its groups in pieces.
+    //  The reference scans any cv::Mat, ImageOpticalFlowMeasurement.hpp:231-256.)
     return ROFT_OK;
 }
 

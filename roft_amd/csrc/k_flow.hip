@@ -207,7 +207,11 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_kernel(EngineArrays
     span_out(a, slot, span_t0);
 }
 
-// Any plane size: the plane is staged in dynamic LDS, every thread walks a contiguous chunk of its words.
+// Any plane size.  LDS = true: the plane is staged in dynamic LDS, every thread walks a contiguous chunk of its words.
+// LDS = false (planes beyond the LDS, e.g. 1920 x 1080: 259 KB): the same two passes -- popcounts of the thread's chunk, then
+// its candidate items once the block scan has given the chunk its starting rank -- read the plane from memory both times (the
+// second pass finds it in the L2): no image size is refused (the reference scans any cv::Mat, hpp:231-256).
+template <bool LDS>
 __global__ __launch_bounds__(kFlowThreads) void flow_measure_lds_kernel(EngineArrays a, double depth_max, int radius)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -219,24 +223,25 @@ __global__ __launch_bounds__(kFlowThreads) void flow_measure_lds_kernel(EngineAr
         if (threadIdx.x == 0) a.npts[slot] = -1;
         return;
     }
+    const uint32_t* gplane = a.planes + plane_offset(a, obj, c.slot_prev, 1);
     uint32_t* s_plane = reinterpret_cast<uint32_t*>(smem);
-    {
-        const uint32_t* gplane = a.planes + plane_offset(a, obj, c.slot_prev, 1);
+    if (LDS) {
         for (size_t i = threadIdx.x; i < a.plane_words; i += blockDim.x) s_plane[i] = gplane[i];
         __syncthreads();
     }
+    const uint32_t* plane = LDS ? s_plane : gplane;
     const int n_words = (int)a.plane_words;
     const int per = (n_words + blockDim.x - 1) / blockDim.x;
     const int w0 = min(n_words, (int)threadIdx.x * per), w1 = min(n_words, w0 + per);
     int cnt = 0;
-    for (int w = w0; w < w1; ++w) cnt += __popc(s_plane[w]);
+    for (int w = w0; w < w1; ++w) cnt += __popc(plane[w]);
     int M;
     int rank = block_exclusive_scan(cnt, s_wave, &M);
     const int C = (M + radius - 1) / radius;
     uint2* list = (C <= kCandLds) ? s_item : reinterpret_cast<uint2*>(a.cand + (size_t)slot * a.cand_cap);
     if (cnt) {
         int ci = (rank + radius - 1) / radius, next = ci * radius;
-        for (int w = w0; w < w1; ++w) emit_word(s_plane[w], w, rank, next, ci, radius, list);
+        for (int w = w0; w < w1; ++w) emit_word(plane[w], w, rank, next, ci, radius, list);
     }
     __syncthreads();
     const int n = gather_candidates(a, c.depth_prev, c.flow[0], slot, list, C, depth_max, s_wave);
@@ -267,9 +272,15 @@ void launch_flow_measure(const EngineArrays& a, double depth_max, int radius, hi
         return;
     }
     const size_t lds = (a.plane_words * 4 + 15) & ~(size_t)15;
-    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(flow_measure_lds_kernel), 160 * 1024 - 256 - kCandLds * (int)sizeof(uint2) - 128);
-    hipExtLaunchKernelGGL(flow_measure_lds_kernel, dim3(a.n_obj, a.T), dim3(kFlowThreads), lds, s, start, stop, 0, a,
-                          depth_max, radius);
+    const size_t lds_cap = 160 * 1024 - 256 - kCandLds * sizeof(uint2) - 128;
+    if (lds <= lds_cap) {
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(flow_measure_lds_kernel<true>), (int)lds_cap);
+        hipExtLaunchKernelGGL(flow_measure_lds_kernel<true>, dim3(a.n_obj, a.T), dim3(kFlowThreads), lds, s, start, stop, 0, a,
+                              depth_max, radius);
+    } else {
+        hipExtLaunchKernelGGL(flow_measure_lds_kernel<false>, dim3(a.n_obj, a.T), dim3(kFlowThreads), 0, s, start, stop, 0, a,
+                              depth_max, radius);
+    }
 }
 
 // ---- records -> (uv, y, H) exactly as the reference assembles them (hpp:258-283) -------------

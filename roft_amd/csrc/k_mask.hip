@@ -614,6 +614,7 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
 
 constexpr int kMaskThreads = 256;   // (idle on binary masks -- every mask the reference's sources deliver: four waves find room anywhere)
 constexpr int kMaskWaves = kMaskThreads / 64;
+constexpr int kGeneralList = 16384;   // 64-pixel groups listed at a time by mask_general_kernel (64 KB of LDS)
 // One workgroup per object at the end of the batch's mask frames: the frames whose source is three-valued.
 // dynamic LDS: list of the non-empty groups
 template <int FT>
@@ -646,23 +647,30 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
             if (tid == 0) { S.n_list = 0; S.bbox[0] = INT32_MAX; S.bbox[1] = INT32_MAX; S.bbox[2] = -1; S.bbox[3] = -1; }
             __syncthreads();
             const uint2* plane2 = reinterpret_cast<const uint2*>(snz);
-            for (int g0 = 0; g0 < n_grp; g0 += kMaskThreads) {
-                const int g = g0 + tid;
-                bool ne = false;
-                if (g < n_grp) { const uint2 w = plane2[g]; ne = (w.x | w.y) != 0u; }
-                const unsigned long long b = __ballot(ne);
-                int base = 0;
-                if (lane == 0 && b) base = atomicAdd(&S.n_list, __popcll(b));
-                base = __shfl(base, 0, 64);
-                if (ne) {
-                    const int p0 = g * 64, y0 = p0 / W;
-                    s_list[base + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)y0 << 16) | (uint32_t)(p0 - y0 * W);
-                }
-            }
-            __syncthreads();
             int32_t* map = a.map + (size_t)obj * npix;
-            propagate_general<FT, kMaskWaves>(make_chase_geo(a.cam, a.ffmt), plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, map, S.bbox);
-            __syncthreads();
+            // the non-empty groups kGeneralList at a time (the list lives in LDS; an image of any size goes through in pieces,
+            // the winner map and the targets' box accumulate over them)
+            for (int c0 = 0; c0 < n_grp; c0 += kGeneralList) {
+                const int c1 = min(n_grp, c0 + kGeneralList);
+                for (int g0 = c0; g0 < c1; g0 += kMaskThreads) {
+                    const int g = g0 + tid;
+                    bool ne = false;
+                    if (g < c1) { const uint2 w = plane2[g]; ne = (w.x | w.y) != 0u; }
+                    const unsigned long long b = __ballot(ne);
+                    int base = 0;
+                    if (lane == 0 && b) base = atomicAdd(&S.n_list, __popcll(b));
+                    base = __shfl(base, 0, 64);
+                    if (ne) {
+                        const int p0 = g * 64, y0 = p0 / W;
+                        s_list[base + __popcll(b & ((1ull << lane) - 1ull))] = ((uint32_t)y0 << 16) | (uint32_t)(p0 - y0 * W);
+                    }
+                }
+                __syncthreads();
+                propagate_general<FT, kMaskWaves>(make_chase_geo(a.cam, a.ffmt), plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, map, S.bbox);
+                __syncthreads();
+                if (tid == 0) S.n_list = 0;
+                __syncthreads();
+            }
             const int bx0 = S.bbox[0], by0 = S.bbox[1], bx1 = S.bbox[2], by1 = S.bbox[3];
             // every 64-pixel output group: constant background outside the box, map samples inside
             const int wave = tid >> 6;
@@ -730,7 +738,9 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
                                per, margin, (int)win_cap);
         ++launches;
     }
-    const size_t lds_gen = ((size_t)n_grp * 4 + 15) & ~(size_t)15;
+    const size_t lds_gen = ((size_t)std::min(n_grp, kGeneralList) * 4 + 15) & ~(size_t)15;
+    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_general_kernel<ROFT_FLOW_S16C2>), kGeneralList * 4 + 16);
+    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_general_kernel<ROFT_FLOW_F32C2>), kGeneralList * 4 + 16);
     if (s16)
         hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_S16C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, stop, 0, a);
     else

@@ -38,6 +38,8 @@ constexpr int kFeatThreads = 1024;
 #define FTICK(i) do {} while (0)
 #endif
 
+// LDS = false: planes that do not fit the LDS (beyond ~1.1 Mpixel) are read from memory by both passes.
+template <bool LDS>
 __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
 {
     ROFT_RESIDENT(a, RK_FEATURES);
@@ -54,15 +56,16 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
     asm volatile("" : "+v"(feat_write), "+v"(slot_cur), "+v"(depth));   // all three fetched before the first barrier
     if (feat_write < 0) return;
     const int W = a.cam.W, wpr = a.cam.wpr;
-    uint32_t* s_plane = reinterpret_cast<uint32_t*>(smem);   // staged with coalesced 16-byte loads
-    {
-        const uint32_t* gplane = a.planes + plane_offset(a, obj, slot_cur, 1);
+    const uint32_t* gplane = a.planes + plane_offset(a, obj, slot_cur, 1);
+    uint32_t* s_stage = reinterpret_cast<uint32_t*>(smem);   // staged with coalesced 16-byte loads
+    if (LDS) {
         const size_t n4 = a.plane_words / 4;
         for (size_t i = threadIdx.x; i < n4; i += blockDim.x)
-            reinterpret_cast<uint4*>(s_plane)[i] = reinterpret_cast<const uint4*>(gplane)[i];
-        for (size_t i = n4 * 4 + threadIdx.x; i < a.plane_words; i += blockDim.x) s_plane[i] = gplane[i];
+            reinterpret_cast<uint4*>(s_stage)[i] = reinterpret_cast<const uint4*>(gplane)[i];
+        for (size_t i = n4 * 4 + threadIdx.x; i < a.plane_words; i += blockDim.x) s_stage[i] = gplane[i];
         __syncthreads();
     }
+    const uint32_t* s_plane = LDS ? s_stage : gplane;
     FTICK(0);
     uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + feat_write) * a.feat_cap;
     float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + feat_write) * a.feat_cap;
@@ -123,9 +126,14 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
 
 void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop)
 {
-    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(features_kernel), 160 * 1024 - 256 - kFeatThreads * (int)sizeof(int) - 128);
-    hipExtLaunchKernelGGL(features_kernel, dim3(a.n_obj, a.T), dim3(kFeatThreads), (uint32_t)((a.plane_words * 4 + 15) & ~(size_t)15), s,
-                          nullptr, stop, 0, a);
+    const size_t lds = (a.plane_words * 4 + 15) & ~(size_t)15;
+    const size_t lds_cap = 160 * 1024 - 256 - kFeatThreads * sizeof(int) - 128;
+    if (lds <= lds_cap) {
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(features_kernel<true>), (int)lds_cap);
+        hipExtLaunchKernelGGL(features_kernel<true>, dim3(a.n_obj, a.T), dim3(kFeatThreads), (uint32_t)lds, s, nullptr, stop, 0, a);
+    } else {
+        hipExtLaunchKernelGGL(features_kernel<false>, dim3(a.n_obj, a.T), dim3(kFeatThreads), 0, s, nullptr, stop, 0, a);
+    }
 }
 
 // ---- rasteriser ---------------------------------------------------------------------------------
