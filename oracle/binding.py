@@ -203,6 +203,23 @@ def process_noise(psd, sig_w, T):
     return Q
 
 
+def ut_weights(n, ut=(1.0, 2.0, 0.0)):
+    """{c, wm_0, wc_0, w_i} of the unscented transform over an augmented dimension n (conformance kit)."""
+    out = np.zeros(4)
+    lib().ro_ut_weights(C.c_int(n), C.byref(UT(*ut)), _p(out))
+    return out
+
+
+def sigma_points(mean, P, Qn, ut=(1.0, 2.0, 0.0)):
+    """The sigma set the oracle draws for Gaussian(9, 1 quaternion) + r noise dof: (13 + r) x (2 (12 + r) + 1)."""
+    Qn = _f64(np.atleast_2d(Qn))
+    r = Qn.shape[0]
+    sp = np.zeros((13 + r, 2 * (12 + r) + 1))
+    n = lib().ro_sigma_points(_p(_f64(mean)), _p(_f64(P)), _p(Qn), C.c_int(r), C.byref(UT(*ut)), _p(sp))
+    assert n == sp.shape[1]
+    return sp
+
+
 def ukf_predict(mean, P, Q, T, ut=(1.0, 2.0, 0.0)):
     mean, P, Q = _f64(mean), _f64(P), _f64(Q)
     mo, Po = np.zeros(13), np.zeros((12, 12))

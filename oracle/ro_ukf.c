@@ -112,6 +112,25 @@ static void quaternion_mean(const double* q, int ncols, const double* wm, double
         for (int i = 0; i < 4; i++) out[i] = -out[i];
 }
 
+/* Conformance kit (tests/ref_kit): the unscented-transform weights and the sigma set the oracle draws, so that somebody who
+ * has bfl can hold bfl::UTWeight / bfl::sigma_point against them (recalled, UNVERIFIED). */
+void ro_ut_weights(int n, const ro_ut_params* ut, double out[4])
+{
+    ut_weight w;
+    ut_weights(n, ut, &w);
+    out[0] = w.c; out[1] = w.wm[0]; out[2] = w.wc[0]; out[3] = w.wm[1];
+}
+
+int ro_sigma_points(const double mean[13], const double P[144], const double* Qn, int r, const ro_ut_params* ut,
+                    double* sp /* (13 + r) x (2 (12 + r) + 1), row-major */)
+{
+    if (r < 0 || 12 + r > MAXN) return -1;
+    ut_weight w;
+    ut_weights(12 + r, ut, &w);
+    sigma_points(mean, P, Qn, r, w.c, sp, w.ncols);
+    return w.ncols;
+}
+
 void ro_pose_process_noise(const double psd[3], const double sig_w[3], double T, double Q[81])
 {
     memset(Q, 0, sizeof(double) * 81);

@@ -476,3 +476,53 @@ def test_depth_likelihood_parity(oracle):
     assert n1 == 0 and L1 == np.finfo(np.float64).max
     L1, n1 = ops.depth_likelihood(_cam(st), depth, mask, np.zeros_like(tile), div)
     assert n1 == 0 and L1 == np.finfo(np.float64).max
+
+
+# ---------------------------------------------------------------------------------------------
+# the committed conformance vectors (tests/golden/oracle_vectors): the HIP operators against golden DATA, not only against
+# the oracle run next to them
+# ---------------------------------------------------------------------------------------------
+def test_hip_operators_against_the_committed_conformance_vectors():
+    import glob
+    import json
+    import os
+
+    def vec(c, key, dtype=np.float64):
+        return np.array([[np.nan if x is None else x for x in row] for row in c[key]], dtype=np.float64).astype(dtype)
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors", "*.json")))
+    checked = 0
+    for path in files:
+        name = os.path.basename(path)[:-5]
+        c = json.load(open(path))
+        if name.startswith("ukf_predict"):
+            m1, P1 = ops.ukf_predict(vec(c, "mean")[0], vec(c, "P"), vec(c, "Q"), c["T"][0][0], tuple(c["ut"][0]))
+            np.testing.assert_allclose(m1, vec(c, "mean_out")[0], rtol=0, atol=UKF_ATOL)
+            np.testing.assert_allclose(P1, vec(c, "P_out"), rtol=0, atol=UKF_ATOL)
+        elif name.startswith("ukf_correct"):
+            rc, m1, P1 = ops.ukf_correct(vec(c, "mean")[0], vec(c, "P"), int(c["type"][0][0]), vec(c, "meas")[0], vec(c, "Rdiag")[0], tuple(c["ut"][0]))
+            atol = 1e-6 if "beyond_pi" in name else UKF_ATOL   # (see test_ukf_correct_sigma_rotations_beyond_pi)
+            assert rc == c["status"][0][0]
+            np.testing.assert_allclose(m1, vec(c, "mean_out")[0], rtol=0, atol=atol)
+            np.testing.assert_allclose(P1, vec(c, "P_out"), rtol=0, atol=atol)
+        elif name.startswith("skf_correct"):
+            rc, x1, P1 = ops.skf_correct(vec(c, "x_pred")[0], vec(c, "P_pred"), vec(c, "y")[0], vec(c, "H"), tuple(c["Rdiag"][0]), bool(c["reweight"][0][0]))
+            assert rc == c["status"][0][0]
+            np.testing.assert_allclose(x1, vec(c, "x_out")[0], rtol=SKF_RTOL, atol=1e-12)
+            np.testing.assert_allclose(P1, vec(c, "P_out"), rtol=SKF_RTOL, atol=1e-14)
+        elif name.startswith("flow_measurement"):
+            W, H = c["width"][0][0], c["height"][0][0]
+            cam = L.Camera(W, H, *c["cam"][0])
+            n, uv, y, Hm = ops.flow_measurement(cam, vec(c, "mask", np.uint8), vec(c, "depth", np.float32), vec(c, "flow", np.float32).reshape(H, W, 2),
+                                                c["dt"][0][0], radius=c["radius"][0][0], depth_max=c["depth_max"][0][0])
+            assert n == c["n"][0][0]
+            assert np.array_equal(np.asarray(uv).reshape(-1, 2), vec(c, "uv", np.int64))
+            assert np.array_equal(y, vec(c, "y")[0]) and np.array_equal(np.asarray(Hm).reshape(-1, 6), vec(c, "H"))
+        elif name.startswith("mask_propagate"):
+            W, H = c["width"][0][0], c["height"][0][0]
+            flows = [vec(c, "flow%d" % k, np.float32).reshape(H, W, 2) for k in range(3)]
+            assert np.array_equal(ops.mask_propagate(vec(c, "mask", np.uint8), flows), vec(c, "mask_out", np.uint8))
+        else:
+            continue
+        checked += 1
+    assert checked >= 15
