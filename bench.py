@@ -849,7 +849,13 @@ def main():
         mask_px = np.mean([float((st.mask_gt[max(args.warmup - 1, 0):n_timed_end - 1] > 0).sum().item()) / args.steps for st in inst_streams])
         cand = mask_px / float(int(cfg.subsampling_radius))
         n_kept = float(np.mean(nl[ran])) if ran.any() else 0.0
-        bytes_per_obj = plane_bytes + cand * (4 + e) + n_kept * 20
+        # Declared bytes (culled form `mask + rho W H (4 + e / g^2)`, rho = fraction of TILES touched): the tile the
+        # memory system moves is the 64-byte sector, so a sampled depth (4 B) and a sampled flow element (8 / 4 B) are declared as
+        # the sector each of them lives in -- candidates are 35 mask pixels apart, 140 B of depth and 280 B of flow: no two share
+        # a sector -- + the obj bit plane (the whole mask, 1 bit / pixel) + the kept records.  `sample_bytes` is the figure rounds
+        # 2 - 4 declared (4 + e bytes per candidate): what an ideal gather engine would move, a third of what any HBM system can.
+        sample_bytes_per_obj = plane_bytes + cand * (4 + e) + n_kept * 20
+        bytes_per_obj = plane_bytes + cand * (64 + 64) + n_kept * 20
         obj_frames_per_launch = n_obj * args.steps / max(k1_live["launches"], 1)
         bytes_per_launch = bytes_per_obj * obj_frames_per_launch
         dur_s = k1_live["avg_us"] * 1e-6
@@ -858,7 +864,7 @@ def main():
         # HBM traffic of this kernel: a separate rocprofv3 --pmc pass of this same command, committed under profiles/
         # (see profiles/README.md for the gfx950 counting caveats); only quoted when the workload matches that pass
         traffic, traffic_raw, traffic_source = None, None, None
-        for tag in ("r04", "r03", "r02"):
+        for tag in ("r05", "r04", "r03", "r02"):
             pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_k1.json" % tag)
             if not os.path.exists(pmc_path):
                 continue
@@ -910,18 +916,23 @@ def main():
                         frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_raw_counter=traffic_raw, traffic_source=traffic_source,
                         frac_on_fetched_bytes=(traffic / dur_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
                         algorithmic_bytes_per_launch=bytes_per_launch, algorithmic_bytes_per_object_frame=bytes_per_obj,
+                        algorithmic_bytes_formula="W H / 8 (obj bit plane) + candidates x (64 + 64) (the depth sector and the flow sector of every "
+                                                  "candidate: SURVEY 8d's tiles touched, tile = 64-byte sector) + kept x 20 (records)",
+                        traffic_over_algorithmic=(traffic / bytes_per_launch) if traffic else None,
+                        frac_on_sample_bytes=sample_bytes_per_obj * obj_frames_per_launch / dur_s / 1e9 / HBM_PEAK_GBS,
+                        sample_bytes_per_object_frame=sample_bytes_per_obj,
                         object_frames_per_launch=obj_frames_per_launch, avg_launch_us=k1_live["avg_us"],
                         launches=k1_live["launches"],
                         dense_bytes_equivalent_per_object_frame=dense_per_obj,
-                        note="declared culled bytes: mask bit plane + sampled depth/flow + kept records (SURVEY 8d); one "
-                             "launch measures every (frame, object) of a batch; the duration is measured live with a HIP "
-                             "event pair on the kernel's own dispatch while the other chains run on their streams. The "
-                             "north-star target of 0.70 is not met: the kernel reads ~60 KB per object-frame instead of the "
-                             "dense 4 MB; every 4-byte depth and 8-byte flow sample costs a 64-byte sector, so the memory system "
-                             "moves `traffic` bytes (frac_on_fetched_bytes) for the declared ones -- the launch is bound by the RATE at which "
-                             "the memory system serves scattered sectors (measured_random_Gsectors_per_s: roft_debug_sector_rate on this box, "
-                             "x 64 B = 0.4 of the streaming peak; frac_of_measured_random_sector_rate = the kernel's gathers alone against "
-                             "it, the plane stream and the record writes not counted), not by streaming bandwidth")
+                        note="declared bytes: mask bit plane + the 64-byte sectors of the sampled depth / flow values + kept records (SURVEY 8d, "
+                             "tiles touched); one launch measures every (frame, object) of a batch; the duration is measured live with a HIP event "
+                             "pair on the kernel's own dispatch, in a window of the same shape as the timed ones (instrumented_window), while the other "
+                             "chains run on their streams.  The north-star target of 0.70 is not met: the kernel touches ~135 KB per object-frame "
+                             "instead of the dense 4 MB, a launch moves ~45 MB, and at that size it is bound by the latency of its three dependent "
+                             "round trips (plane -> candidates -> gathers -> records) and by the RATE at which the memory system serves scattered "
+                             "sectors (measured_random_Gsectors_per_s: roft_debug_sector_rate on this box, x 64 B = 0.4 of the streaming peak), not "
+                             "by streaming bandwidth; frac_on_sample_bytes is the same launch priced on 12 bytes per candidate instead of its two "
+                             "sectors (the figure of rounds 2 - 4)")
     if roofline is not None and k1_live is not None and k1_live.get("span_avg_us"):
         span_s = k1_live["span_avg_us"] * 1e-6
         roofline["kernel_span"] = dict(
@@ -958,8 +969,9 @@ def main():
             "outlier_fused": dict(per="object and test", bytes=2 * (12 * nv + 12 * nt + 8 * n_feat), mark="outlier_render_likelihood", frames_per_group=1.0),
         }
         pmc = {}
+        pmc_tag = next((t for t in ("r05", "r04") if os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc_FETCH_SIZE.csv" % t))), "r04")
         for cname in ("FETCH_SIZE", "WRITE_SIZE"):
-            path = os.path.join(ROOT, "profiles", "r04_pmc_%s.csv" % cname)
+            path = os.path.join(ROOT, "profiles", "%s_pmc_%s.csv" % (pmc_tag, cname))
             if os.path.exists(path):
                 import csv as _csv
                 for r in _csv.DictReader(open(path)):
@@ -979,10 +991,10 @@ def main():
             roofline_other[name] = ent
         roofline_other["note"] = ("declared = algorithmic bytes of the kernel (DESIGN.md section 5); durations = HIP event marks around the launch "
                                   "group in the frames behind the timed region, all chains running (mask_frames: the T frame kernels of a batch + "
-                                  "mask_general); fetch / write = profiles/r04_pmc_{FETCH,WRITE}_SIZE.csv (separate rocprofv3 --pmc passes, bytes "
+                                  "mask_general); fetch / write = profiles/%s_pmc_{FETCH,WRITE}_SIZE.csv (separate rocprofv3 --pmc passes, bytes " % pmc_tag +
                                   "per dispatch: one frame of all objects for mask_frame_kernel).  None of these kernels is bandwidth-bound: they "
                                   "are chains of dependent round trips over a few hundred KB per object (latency), the rasteriser is bound by "
-                                  "VALU issue on its CU; the CU x us budget of the pipeline is profiles/r04_cu_budget.csv")
+                                  "VALU issue on its CU; the CU x us budget of the pipeline is profiles/r04_cu_budget.csv / r05_residency_budget.csv")
     dominant = max(kernels.items(), key=lambda kv: kv[1]["total_ms"])[0] if kernels else None
     vals = sorted(w_["value"] for w_ in windows)
     # accuracy at N > 1 (window 0): ADD-S vs the CPU path over a sample with objects of EVERY rank

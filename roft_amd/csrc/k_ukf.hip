@@ -790,64 +790,48 @@ __device__ __noinline__ bool cholesky_state_sqrt(UkfLds& L, bool for_correction,
     return cholesky_rows<12>(L.cov, L.S, L.rc, L);
 }
 
+// Additive noise in closed form (round 5).  The process noise enters the motion model additively on its linear OUTPUT rows
+// ([v, w, x]' = [v, w, x] + n with v, w taken before the noise, CartesianQuaternionModel.cpp:94-103) and the augmented
+// covariance is block diagonal, so the 18 sigma columns that perturb a noise dimension are f(mean) +- sqrt(c) a_k on the linear
+// rows and f(mean) on the quaternion: in the weighted sums they are column 0 eighteen more times -- weights wm0 + 18 wi and
+// wc0 + 18 wi -- plus, in the covariance, wi sum_k 2 c a_k a_k' = Q exactly (wi = 1 / 2c, sum_k a_k a_k' = Q for ANY square root
+// of Q; the +- cross terms cancel).  The model is evaluated on the mean and the 24 state columns only (25 instead of 43), Q(T)
+// is added as it is -- no square root of Q at all --, and what changes is the rounding of sums that the reference takes over
+// 43 terms: the oracle keeps the 43 columns, the parity bar (1e-9) is unchanged.
 __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const UtTable& ut, double* warm,
                             int* warm_age, double chol_guard)
 {
     const int lane = threadIdx.x;
-    const int r = 9, n = 21;
+    const int n = 21;
     const UtW& w = ut_lookup(ut, n);
     const double sc = w.sc;
+    constexpr int kPredCols = 25;                    // the mean + 12 state dof, plus and minus
+    const double wm0 = w.wm0 + 18.0 * w.wi, wc0 = w.wc0 + 18.0 * w.wi;   // (column 0 stands for the 18 noise columns as well)
 
-    // process noise block Q(T) (CartesianQuaternionModel.cpp:127-141), padded to 10 x 10
+    // process noise block Q(T) (CartesianQuaternionModel.cpp:127-141), padded to 10 x 10: L.Q, rows / columns [v(3) w(3) x(3)]
     if (prm.q_override) {
-        for (int i = lane; i < 100; i += kUkfThreads) { L.Q[i] = 0.0; L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0; }
+        for (int i = lane; i < 100; i += kUkfThreads) L.Q[i] = 0.0;
         __syncthreads();
         for (int i = lane; i < 81; i += kUkfThreads) L.Q[(i / 9) * 10 + (i % 9)] = prm.q_override[i];
-        __syncthreads();
-        if (lane < 64) {
-            jacobi_wave(L.Q, L.VQ, 10, L);
-            if (lane < 10) L.wQ[lane] = L.Q[lane * 11];
-        }
-        __syncthreads();
     } else if (lane >= 192 && lane < 195) {
-        // Q(T) couples only (v_i, x_i): three independent symmetric 2x2 blocks, each diagonalised
-        // exactly by ONE Jacobi rotation (the same rotation the generic sweep would apply first).
-        // Three lanes of wave 3, concurrently with the square root of the state covariance on wave 0: L.VQ is the
-        // identity from the kernel's start and only these twelve entries (and L.wQ) change; the barrier that closes
-        // the square-root phase orders them before the fan-out.
+        // Q(T) couples only (v_i, x_i); three lanes of wave 3, concurrently with the square root of the state covariance on
+        // wave 0 (L.Q is zero from the kernel's start and only these fifteen entries change; the barrier that closes the
+        // square-root phase orders them before they are read)
         const int i = lane - 192;
         const double psd = L.par[3 + i];
-        const double app = psd * T;
-        const double aqq = psd * (T * T * T / 3.0);
-        const double apq = psd * (T * T / 2.0);
-        double c = 1.0, s = 0.0;
-        if (apq != 0.0) {
-            // t = sgn(tau) / (|tau| + sqrt(1 + tau^2)), tau = (aqq - app) / (2 apq), written division-free
-            const double a = aqq - app, b = 2.0 * apq;
-            const double h2 = a * a + b * b;
-            const double hyp = h2 * fast_rsqrt(h2);
-            const double sgn = ((a >= 0.0) == (b >= 0.0) || a == 0.0) ? 1.0 : -1.0;
-            const double t = sgn * fabs(b) * fast_rcp(fabs(a) + hyp);
-            c = fast_rsqrt(1.0 + t * t);
-            s = t * c;
-        }
-        // columns then rows, like the generic update
-        const double b00 = c * app - s * apq, b01 = s * app + c * apq;
-        const double b10 = c * apq - s * aqq, b11 = s * apq + c * aqq;
-        L.wQ[i] = c * b00 - s * b10;
-        L.wQ[6 + i] = s * b01 + c * b11;
-        L.wQ[3 + i] = L.par[i];
-        L.VQ[i * 10 + i] = c;       L.VQ[i * 10 + (6 + i)] = s;
-        L.VQ[(6 + i) * 10 + i] = -s; L.VQ[(6 + i) * 10 + (6 + i)] = c;
+        L.Q[i * 10 + i] = psd * T;
+        L.Q[(6 + i) * 10 + (6 + i)] = psd * (T * T * T / 3.0);
+        L.Q[i * 10 + (6 + i)] = L.Q[(6 + i) * 10 + i] = psd * (T * T / 2.0);
+        L.Q[(3 + i) * 10 + (3 + i)] = L.par[i];
     }
     TICK(L, 1);
     if (!cholesky_state_sqrt(L, false, T, chol_guard, 0.0)) decompose_state_cov(L, warm, warm_age);
     TICK(L, 2);
 
     // fan-out + motion model, lane = sigma point
-    if (lane < w.ncols) {
+    if (lane < kPredCols) {
         double d[12], dn[12];
-        sigma_perturbation(lane, r, sc, true, 0.0, L, d, dn);
+        sigma_perturbation(lane, 0, sc, false, 0.0, L, d, dn);   // (r = 0: columns 1 .. 12 add, 13 .. 24 subtract a state column)
         double v[3], wv[3], x[3], q[4];
         for (int i = 0; i < 3; ++i) {
             v[i] = L.mean[i] + d[i];
@@ -856,9 +840,9 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const UtT
         }
         quat_boxplus(L.mean + 9, d + 9, q);
         for (int i = 0; i < 3; ++i) {
-            L.Y[i * kCols + lane] = v[i] + dn[i];
-            L.Y[(3 + i) * kCols + lane] = wv[i] + dn[3 + i];
-            L.Y[(6 + i) * kCols + lane] = (x[i] + dn[6 + i]) + v[i] * T;  // v without noise (cpp:94-97)
+            L.Y[i * kCols + lane] = v[i];
+            L.Y[(3 + i) * kCols + lane] = wv[i];
+            L.Y[(6 + i) * kCols + lane] = x[i] + v[i] * T;  // v without noise (cpp:94-97)
         }
         const double norm_w = sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]) + 2.220446049250313e-16;
         double s, c;   // sin(|w| T / 2) / |w| and cos(|w| T / 2)
@@ -873,14 +857,14 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const UtT
 
     TICK(L, 3);
     // mean: the linear rows on wave 1 while wave 0 works on the quaternion rows
-    if (lane >= 64 && lane < 192) linear_means8(L.Y, 9, w.ncols, w.wm0, w.wi, lane - 64, L.ymean);   // waves 1 and 2
+    if (lane >= 64 && lane < 192) linear_means8(L.Y, 9, kPredCols, wm0, w.wi, lane - 64, L.ymean);   // waves 1 and 2
     double qm[4];
-    quaternion_mean(L.Y, 9, w.ncols, w.wm0, w.wi, qm, L);
+    quaternion_mean(L.Y, 9, kPredCols, wm0, w.wi, qm, L);
     TICK(L, 4);
     if (lane == 64)
         for (int i = 0; i < 4; ++i) L.ymean[9 + i] = qm[i];
     // deviations
-    if (lane < w.ncols) {
+    if (lane < kPredCols) {
         for (int i = 0; i < 9; ++i) L.D[i * kCols + lane] = L.Y[i * kCols + lane] - L.ymean[i];
         const double q[4] = {L.Y[9 * kCols + lane], L.Y[10 * kCols + lane], L.Y[11 * kCols + lane],
                              L.Y[12 * kCols + lane]};
@@ -891,7 +875,8 @@ __device__ void ukf_predict(UkfLds& L, const ObjParams& prm, double T, const UtT
     __syncthreads();
     if (lane < 192) {   // (whole waves: the pair sum crosses lanes) 78 distinct entries x 2 lanes
         const int e = min(lane >> 1, 77), ij = L.tri12[e], i = ij >> 8, j = ij & 0xFF;
-        const double v = weighted_dot_pair(L.D + i * kCols, L.D + j * kCols, w.ncols, w.wc0, w.wi, lane & 1);
+        double v = weighted_dot_pair(L.D + i * kCols, L.D + j * kCols, kPredCols, wc0, w.wi, lane & 1);
+        if (j < 9) v += L.Q[i * 10 + j];   // (i <= j: the linear rows carry the process noise)
         if (lane < 156) L.cov[(lane & 1) ? j * 12 + i : i * 12 + j] = v;
     }
     if (lane >= 192 && lane < 205) L.mean[lane - 192] = L.ymean[lane - 192];
@@ -918,23 +903,34 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
     const int n = 12 + r;
     const UtW& w = ut_lookup(ut, n);
     const double sc = w.sc;
+    // Additive noise in closed form (round 5, see ukf_predict): the noise of the velocity rows and of the position rows is added
+    // to the measurement function's OUTPUT (CartesianQuaternionMeasurement.cpp:381-415: `+ n`), so their 2 x n_add sigma columns
+    // are h(mean) +- sqrt(c) sigma_k e_k -- column 0 that many more times in the weighted sums, and R_kk on the diagonal of Py.
+    // Only the rotation noise of a pose measurement acts through q [+] n (:369-379) and keeps its six columns.  Columns: the
+    // mean and the 24 state columns (0 .. 24), then -- pose measurements -- +x +y +z -x -y -z of the rotation noise (25 .. 30):
+    // 25 or 31 instead of 37 or 49.  The input deviations of the noise columns are zero: they never enter Pxy.
+    const int n_add = r - (has_pose ? 3 : 0);
+    const int ncols = 25 + (has_pose ? 6 : 0);
+    const double wm0 = w.wm0 + 2.0 * n_add * w.wi, wc0 = w.wc0 + 2.0 * n_add * w.wi;
 
     // measurement vector in measurement order (velocity first)
     auto meas_at = [&](int k) -> double {
         return L.meas[has_vel ? k : 6 + k];
     };
-    if (lane < w.ncols) {
-        // measurement noise variance of this column's noise dof, measurement order (velocity first)
-        double noise_var = 0.0;
-        {
-            const int kk = (lane > 0) ? (lane - 1) % n - 12 : -1;
-            if (kk >= 0) {
-                // R_v R_w R_x R_q sit at L.par[12 ..]; without a velocity measurement the order starts at R_x
-                noise_var = L.par[(has_vel ? 12 : 18) + kk];
-            }
-        }
+    if (lane < ncols) {
         double d[12], dn[12];
-        sigma_perturbation(lane, r, sc, false, noise_var, L, d, dn);
+        sigma_perturbation(min(lane, 24), 0, sc, false, 0.0, L, d, dn);   // (r = 0: columns 1 .. 12 add, 13 .. 24 subtract a state column)
+        // rotation noise of the pose measurement (R_q sits at L.par[21 ..]): this column's rotation vector
+        double rv[3] = {0.0, 0.0, 0.0};
+        if (lane >= 25) {
+            const int k = (lane - 25) % 3;
+            const double amp = (lane < 28) ? sc : -sc;
+            const double v = amp * sqrt(fabs(L.par[21 + k]));
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { if (i == k) rv[i] = v; }
+#pragma unroll
+            for (int i = 0; i < 12; ++i) d[i] = 0.0;
+        }
 #ifdef ROFT_UKF_PROFILE
         if (lane == 0) { long long _t = clock64(); L.dbg[24] += _t - L.t0; L.t0 = _t; }
 #endif
@@ -962,15 +958,13 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
             const double p[3] = {-x[0], -x[1], -x[2]};
             const double cr[3] = {wv[1] * p[2] - wv[2] * p[1], wv[2] * p[0] - wv[0] * p[2], wv[0] * p[1] - wv[1] * p[0]};
             for (int i = 0; i < 3; ++i) {
-                L.Y[(row + i) * kCols + lane] = (v[i] + cr[i]) + dn[i];
-                L.Y[(row + 3 + i) * kCols + lane] = wv[i] + dn[3 + i];
+                L.Y[(row + i) * kCols + lane] = v[i] + cr[i];
+                L.Y[(row + 3 + i) * kCols + lane] = wv[i];
             }
             row += 6;
         }
         if (has_pose) {
-            const int off = has_vel ? 6 : 0;
-            for (int i = 0; i < 3; ++i) L.Y[(row + i) * kCols + lane] = x[i] + dn[off + i];
-            const double rv[3] = {dn[r - 3], dn[r - 2], dn[r - 1]};
+            for (int i = 0; i < 3; ++i) L.Y[(row + i) * kCols + lane] = x[i];
             double qo[4];
             quat_boxplus(q, rv, qo);
             for (int i = 0; i < 4; ++i) L.Y[(row + 3 + i) * kCols + lane] = qo[i];
@@ -980,17 +974,17 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
 
     TICK(L, 8);
     // means: the linear rows on wave 1 while wave 0 works on the quaternion rows
-    if (lane >= 64 && lane < 192) linear_means8(L.Y, nlin, w.ncols, w.wm0, w.wi, lane - 64, L.ymean);   // waves 1 and 2
+    if (lane >= 64 && lane < 192) linear_means8(L.Y, nlin, ncols, wm0, w.wi, lane - 64, L.ymean);   // waves 1 and 2
     double qm[4] = {1.0, 0.0, 0.0, 0.0};
     if (has_pose) {
-        quaternion_mean(L.Y, nlin, w.ncols, w.wm0, w.wi, qm, L);   // ends with a workgroup barrier
+        quaternion_mean(L.Y, nlin, ncols, wm0, w.wi, qm, L);   // ends with a workgroup barrier
         if (lane == 64)
             for (int i = 0; i < 4; ++i) L.ymean[nlin + i] = qm[i];
     } else {
         __syncthreads();
     }
     TICK(L, 23);
-    if (lane < w.ncols) {
+    if (lane < ncols) {
         for (int i = 0; i < nlin; ++i) L.D[i * kCols + lane] = L.Y[i * kCols + lane] - L.ymean[i];
         if (has_pose) {
             const double q[4] = {L.Y[nlin * kCols + lane], L.Y[(nlin + 1) * kCols + lane],
@@ -1011,18 +1005,22 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
     __syncthreads();
     TICK(L, 9);
     // Pxy (12 x m) on the first 12 m threads, the upper triangle of the symmetric Py (m x m) on the next
-    // m (m + 1) / 2: at most 144 + 78 threads, one pass
+    // m (m + 1) / 2: at most 144 + 78 threads, one pass.  The additive rows get their noise variance on the diagonal of Py
+    // (R_v R_w R_x R_q sit at L.par[12 ..] in measurement order; without a velocity measurement the order starts at R_x).
+    const int r_base = has_vel ? 12 : 18;
     if (m == 6) {   // 72 entries of Pxy + 21 distinct entries of Py, two lanes each (186 lanes, whole waves call)
         if (lane < 192) {
             const int e = min(lane >> 1, 92);
             const double *ar, *br;
             int o0, o1 = -1;
+            double add = 0.0;
             if (e < 72) { ar = L.X + (e / 6) * kCols; br = L.D + (e % 6) * kCols; o0 = e; }
             else {
                 const int ij = L.tri6[e - 72], i = ij >> 8, j = ij & 0xFF;
                 ar = L.D + i * kCols; br = L.D + j * kCols; o0 = i * 6 + j; o1 = j * 6 + i;
+                if (i == j && i < n_add) add = L.par[r_base + i];
             }
-            const double v = weighted_dot_pair(ar, br, w.ncols, w.wc0, w.wi, lane & 1);
+            const double v = weighted_dot_pair(ar, br, ncols, wc0, w.wi, lane & 1) + add;
             if (lane < 186) {
                 if (e < 72) { if (!(lane & 1)) L.Pxy[o0] = v; }
                 else L.Py[(lane & 1) ? o1 : o0] = v;
@@ -1032,14 +1030,15 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
         const int nxy = 12 * m, ntri = m * (m + 1) / 2;
         if (lane < nxy) {
             const int i = lane / m, j = lane % m;
-            L.Pxy[lane] = weighted_dot(L.X + i * kCols, L.D + j * kCols, w.ncols, w.wc0, w.wi);
+            L.Pxy[lane] = weighted_dot(L.X + i * kCols, L.D + j * kCols, ncols, wc0, w.wi);
         } else if (lane - nxy < ntri) {
             int u = lane - nxy, i = 0;
             while (u >= m - i) { u -= m - i; ++i; }
             const int j = i + u;
-            const double s = weighted_dot(L.D + i * kCols, L.D + j * kCols, w.ncols, w.wc0, w.wi);
-            L.Py[i * m + j] = s;
-            L.Py[j * m + i] = s;
+            double sum = weighted_dot(L.D + i * kCols, L.D + j * kCols, ncols, wc0, w.wi);
+            if (i == j && i < n_add) sum += L.par[r_base + i];
+            L.Py[i * m + j] = sum;
+            L.Py[j * m + i] = sum;
         }
     }
     __syncthreads();
@@ -1266,8 +1265,7 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
         __syncthreads();   // the next step of this workgroup reads the chosen belief
     }
     jacobi12_table(L);
-    for (int i = threadIdx.x; i < 100; i += kUkfThreads) L.VQ[i] = ((i / 10) == (i % 10)) ? 1.0 : 0.0;   // see ukf_predict
-    if (threadIdx.x < 10) L.wQ[threadIdx.x] = 0.0;
+    for (int i = threadIdx.x; i < 100; i += kUkfThreads) L.Q[i] = 0.0;   // see ukf_predict: only the entries of Q(T) are rewritten per step
     __syncthreads();
     bool pending = false;
     __shared__ FrameCtrl s_c;
