@@ -160,8 +160,9 @@ __device__ __forceinline__ void project_vertex(const float* v, const RenderPose&
     const float Y = ((P.R[3] * v[0] + P.R[4] * v[1]) + P.R[5] * v[2]) + P.t[1];
     z = ((P.R[6] * v[0] + P.R[7] * v[1]) + P.R[8] * v[2]) + P.t[2];
     if (z > 0.001f) {
-        sx = (fx * X) / z + cx;
-        sy = (fy * Y) / z + cy;
+        const float iz = 1.0f / z;   // (one reciprocal per vertex: the contract of oracle/ro_render.c)
+        sx = (fx * X) * iz + cx;
+        sy = (fy * Y) * iz + cy;
     } else {
         sx = sy = 0.0f;
     }
@@ -187,10 +188,12 @@ __device__ __forceinline__ void raster_projected(float x0, float y0, float z0, f
     if (fj1 > (float)(h - 1)) fj1 = (float)(h - 1);
     if (!(fi0 <= fi1) || !(fj0 <= fj1)) return;
     const int ia = (int)fi0, ib = (int)fi1, ja = max((int)fj0, j_lo), jb = min((int)fj1, j_hi);
-    // (the three reciprocals are only needed once a pixel centre is inside: most triangles of a fine mesh are smaller
-    //  than a pixel and cover none -- the quotients are the same wherever they are evaluated)
-    float iz0 = 0.0f, iz1 = 0.0f, iz2 = 0.0f;
-    bool have_iz = false;
+    // perspective-correct depth of a covered pixel as ONE quotient (oracle/ro_render.c):
+    //   z = area z0 z1 z2 / (w0 z1 z2 + w1 z0 z2 + w2 z0 z1)
+    // -- five multiplications per triangle, three multiply-adds and a division per pixel; no reciprocal of a vertex depth, no
+    // normalised barycentric weights (an IEEE division is ~10 instructions and the kernel is bound by instruction issue)
+    const float p12 = z1 * z2, p02 = z0 * z2, p01 = z0 * z1;
+    const float num = area * (z0 * p12);
     for (int j = ja; j <= jb; ++j) {
         const float py = (float)j + 0.5f;
         for (int i = ia; i <= ib; ++i) {
@@ -201,10 +204,8 @@ __device__ __forceinline__ void raster_projected(float x0, float y0, float z0, f
             const bool inside = (area > 0.0f) ? (w0 >= 0.0f && w1 >= 0.0f && w2 >= 0.0f)
                                               : (w0 <= 0.0f && w1 <= 0.0f && w2 <= 0.0f);
             if (!inside) continue;
-            if (!have_iz) { iz0 = 1.0f / z0; iz1 = 1.0f / z1; iz2 = 1.0f / z2; have_iz = true; }
-            const float b0 = w0 / area, b1 = w1 / area, b2 = w2 / area;
-            const float iz = (b0 * iz0 + b1 * iz1) + b2 * iz2;
-            const float z = 1.0f / iz;
+            const float den = (w0 * p12 + w1 * p02) + w2 * p01;
+            const float z = num / den;
             if (!(z > 0.0f)) continue;
             store(i, j, z);
         }
