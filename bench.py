@@ -470,7 +470,11 @@ def main():
         eng.sync()
         torch.cuda.synchronize()
         if instrument:
-            eng.timing()   # (the marks of the warm-up steps are not the timed region's)
+            # (the marks of the warm-up steps are not the timed region's -- nor part of a ROFT_DUMP_MARKS timeline)
+            dump_path = os.environ.pop("ROFT_DUMP_MARKS", None)
+            eng.timing()
+            if dump_path:
+                os.environ["ROFT_DUMP_MARKS"] = dump_path
         bcast_bytes[0] = 0
         stats0 = eng.stats()
         nb0 = stats0["batches"]
@@ -521,14 +525,18 @@ def main():
         rec, keep = timed_window(4000 + 1000 * w)
         windows.append(rec)
         if w == 0:
-            keep0 = keep   # window 0 tracks the canonical streams (seeds 4000 +): accuracy figures, --dump-rows
-        else:
-            keep["eng"].close()
+            # window 0 tracks the canonical streams (seeds 4000 +): accuracy figures, --dump-rows.  Its results are read now and the
+            # engine is closed like the others' -- a tracker whose run is over does not sit next to the next one
+            keep0 = keep
+            pose_log, twist_log, npts_log, sel_log = keep["eng"].get_log(0, n_timed_end)
+            rows0 = None if keep["gathered"] is not None else np.ascontiguousarray(keep["eng"].get_log_rows(args.warmup, args.steps).transpose(1, 0, 2))
+        keep["eng"].close()
+        if w != 0:
             del keep
     order = sorted(range(n_windows), key=lambda i: windows[i]["value"])
     med = windows[order[(n_windows - 1) // 2]]   # the median window (the lower one of an even count): a run that happened
     value = med["value"]
-    eng, streams, scene, host, gathered, cfg = (keep0[k] for k in ("eng", "streams", "scene", "host", "gathered", "cfg"))
+    streams, scene, host, gathered, cfg = (keep0[k] for k in ("streams", "scene", "host", "gathered", "cfg"))
     bcast_total = keep0["bcast"]
 
     # ---- one more window of the same shape WITH the roofline kernel's event pair (never `value`), and behind it the
@@ -565,7 +573,6 @@ def main():
 
     # ---- accuracy of window 0 (the canonical streams): ADD-S vs ground truth for EVERY object of every rank, ADD-S vs the CPU
     #      reference path on a sample that holds objects of every rank
-    pose_log, twist_log, npts_log, sel_log = eng.get_log(0, n_timed_end)
     pts_cache = {}
 
     def model_points(st):
@@ -615,7 +622,6 @@ def main():
         ranks_info = dict(all=allr, seen=int(seen.item()))
 
     if rank != 0:
-        eng.close()
         if world > 1:
             dist.barrier()  # rank 0 is timing the CPU baseline and the PCIe legs
             dist.destroy_process_group()
@@ -624,7 +630,7 @@ def main():
     if gathered is not None:
         assert tuple(gathered.shape) == (total_obj, args.steps, 19), gathered.shape
     if args.dump_rows:
-        rows_out = gathered.cpu().numpy() if gathered is not None else np.ascontiguousarray(eng.get_log_rows(args.warmup, args.steps).transpose(1, 0, 2))
+        rows_out = gathered.cpu().numpy() if gathered is not None else rows0
         np.save(args.dump_rows, rows_out)
     if world > 1:
         # cpu_baseline, the PCIe-inclusive legs and the extras are N = 1 measurements (the other ranks wait at a barrier)
@@ -1093,7 +1099,6 @@ def main():
         "stream_generation_s": gen_s[0],
     }
     print(json.dumps(out))
-    eng.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -330,7 +330,9 @@ int roft_engine_get_stats(roft_engine* e, roft_engine_stats* out);
  * The scheduling mode of a batch is a function of the batch INDEX alone: `steady` = at least <batches in flight> batches have
  * been stepped since the engine was last idle (creation / roft_sync / anything that reads results); bursts release the pose
  * lanes early (`handoff`, `early_lanes`) and spread an outlier test over all the CUs to spare, steady batches halve that
- * (`outlier_parts_halved`).  `throttled` is the MEASURED counterpart (the submit call had to wait for the in-flight bound) and
+ * (`outlier_parts_halved`); `early_lanes` is a bit mask: 1 / 2 = pose lane 0 / 1 released behind the batch's control blocks (its
+ * objects start with the first step of a re-sync replay, whose twist an earlier batch published), 4 = both lanes because the
+ * device has CUs to spare.  `throttled` is the MEASURED counterpart (the submit call had to wait for the in-flight bound) and
  * steers nothing.  Times: host steady clock in microseconds; t_done_us is when the HOST observed the batch complete (inside a
  * later submit call or roft_sync, which waits for the batches one by one in order), 0 while it has not. */
 typedef struct {

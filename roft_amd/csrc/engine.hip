@@ -401,6 +401,10 @@ struct roft_engine {
     int cur_T = 0;
     int n_segments[kNumLin] = {1, 1};     // pose chain segments per lane (1 + outlier tests of the busiest object)
     bool lin_any[kNumLin] = {false, false};   // some object has a frame on the lane in the batch
+    // per lane of the submitted batch: objects with a frame on the lane, and how many of them START with a step whose twist was
+    // published by an EARLIER batch (the first step of a re-sync replay reads the twist of pose_frames_between frames ago): such a
+    // lane can run its first segment -- and the outlier test behind it -- before this batch's velocity filter exists (step_batch)
+    int lane_objs[kNumLin] = {0, 0}, lane_old_first[kNumLin] = {0, 0};
     int relabel_wait[kNumLin] = {-1, -1};     // batch of the OTHER lane this lane's launches must follow (slots that changed lanes)
     bool any_feat = false, any_feat_now = false, had_uploads = false;
     unsigned new_mask_frames = 0;   // bit t: some object receives a mask in frame t of the batch
@@ -792,13 +796,19 @@ static void release_streams(StreamSet* s)
     if (s) s->in_use = false;
 }
 
-// true when no other engine of this process holds a stream set on the device of `mine`
+// true when no other engine of this process has work in flight on the device of `mine` (an engine that exists but is idle -- one
+// whose results are still being read -- holds no CU)
 static bool alone_on_device(const StreamSet* mine)
 {
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    for (const StreamSet* s : g_stream_sets)
-        if (s != mine && s->in_use && s->device == mine->device) return false;
-    return true;
+    bool alone = true;
+    for (const StreamSet* s : g_stream_sets) {
+        if (s == mine || !s->in_use || s->device != mine->device) continue;
+        for (hipStream_t q : {s->pose[0], s->pose[1], s->vel, s->mask})
+            if (hipStreamQuery(q) != hipSuccess) alone = false;
+    }
+    (void)hipGetLastError();   // (hipErrorNotReady is an answer, not an error)
+    return alone;
 }
 
 static int engine_setup(roft_engine* e, const roft_config* cfg)
@@ -1168,6 +1178,8 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
     int max_outliers[kNumLin] = {0, 0};
     std::vector<int> n_outliers((size_t)n_obj * kNumLin, 0);
     e->lin_any[0] = e->lin_any[1] = false;
+    e->lane_objs[0] = e->lane_objs[1] = e->lane_old_first[0] = e->lane_old_first[1] = 0;
+    std::vector<unsigned char> lane_seen((size_t)n_obj * kNumLin, 0);
     {
         // Balance of the two pose chain lanes.  A lane's launch lasts as long as its busiest object, so the lanes only
         // overlap if, in every batch, the re-sync replays of all objects are on ONE lane and the ordinary steps in
@@ -1339,6 +1351,13 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
             if (!build_pose_program(cfg, o, in, c))
                 return fail(ROFT_ERR_CAPACITY, "more buffered velocities to replay than one frame's program holds (kMaxSteps)");
             e->lin_any[c.lane] = true;
+            if (!lane_seen[(size_t)id * kNumLin + c.lane]) {
+                // the object's first frame on this lane in the batch: is its first step's twist older than the batch?
+                lane_seen[(size_t)id * kNumLin + c.lane] = 1;
+                e->lane_objs[c.lane]++;
+                const int age = (c.n_steps > 0 && c.steps[0].op) ? ((o.frame_idx - c.steps[0].twist_slot) & (kTwistRing - 1)) : 0;
+                if (age > t && c.outlier_step == 0) e->lane_old_first[c.lane]++;   // (a replay whose first step is the one the outlier test follows)
+            }
             o.last_touch[o.cur_slot] = b;
             if (c.outlier_step >= 0)
                 max_outliers[c.lane] = std::max(max_outliers[c.lane], ++n_outliers[(size_t)id * kNumLin + c.lane]);
@@ -1502,8 +1521,21 @@ static int step_batch(roft_engine* e)
     // engine, which only holds when no other engine of the process works on the device (other processes: ROFT_EARLY_LANES=0).
     // Otherwise the lanes fall back to the gate on resident velocity-filter workgroups (`handoff`), where a lane only ever
     // waits for workgroups that run.
-    const bool early_lanes = handoff && cus_to_spare && !steady && early_env != 0 && e->streams && e->streams->conflicts == 0 &&
-                             (e->alone_on_device = alone_on_device(e->streams));   // (bursts: in the steady state a lane is behind anyway, and at 1280x720 the early tests cost 3 %)
+    const bool early_ok = handoff && !steady && early_env != 0 && e->streams && e->streams->conflicts == 0 &&
+                          (e->alone_on_device = alone_on_device(e->streams));
+    const bool early_lanes = early_ok && cus_to_spare;   // (bursts: in the steady state a lane is behind anyway, and at 1280x720 the early tests cost 3 %)
+    // ... and, whatever the number of objects (round 5): a lane whose objects START the batch with the first step of a re-sync
+    // replay.  That step reads the twist of pose_frames_between frames ago -- published by an earlier batch -- and ends the lane's
+    // first segment (the outlier test follows it): segment and test need nothing of this batch but its control blocks, so in a
+    // burst they run next to the batch's mask frames instead of behind its velocity filter, and only the SECOND segment (the rest
+    // of the replay: this batch's twists) is held at the gate.  The few objects of the lane that are out of phase (a dropped
+    // pose: they start with an ordinary step) wait for their twist inside the kernel, on CUs nobody needs -- at most one per
+    // eight CUs, else the lane is not released early.
+    bool early_lane[kNumLin];
+    for (int l = 0; l < kNumLin; ++l)
+        early_lane[l] = early_lanes || (early_ok && T > 1 && e->n_segments[l] > 1 && e->lane_old_first[l] > 0 &&
+                                        8 * (e->lane_objs[l] - e->lane_old_first[l]) <= device_cu_count());
+    const bool any_early = early_lane[0] || early_lane[1];
     const long long launches0 = e->stats.launches, evops0 = e->stats.event_ops;
 
     // ---- control blocks of the batch -> device (+ reset of the mask chain's counters), ingest of the masks delivered
@@ -1517,7 +1549,7 @@ static int step_batch(roft_engine* e)
         // Events that complete with a kernel (hipExtLaunchKernelGGL stop events) cost neither the barrier packet nor
         // the host call of a hipEventRecord behind it.
         hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
-                              nullptr, (multi && (T == 1 || early_lanes)) ? e->ev_ctrl[slot] : nullptr, 0,
+                              nullptr, (multi && (T == 1 || any_early)) ? e->ev_ctrl[slot] : nullptr, 0,
                               reinterpret_cast<const uint4*>(e->stage[slot]), a, n16);
         ++launches;
     }
@@ -1618,7 +1650,7 @@ static int step_batch(roft_engine* e)
         }
         if (!e->lin_any[lin]) continue;
         const int which = lin == 0 ? 1 : 3;
-        if (multi && early_lanes) {
+        if (multi && early_lane[lin]) {
             // behind the batch's control blocks, and behind the velocity chain of the batch BEFORE (its features kernel: the sets
             // this batch's outlier tests read were buffered there or earlier)
             HIP_TRY(hipStreamWaitEvent(sp, e->ev_ctrl[slot], 0));
@@ -1639,6 +1671,12 @@ static int step_batch(roft_engine* e)
         tmark(e, nullptr, which);
         for (int seg = 0; seg < e->n_segments[lin]; ++seg) {
             const bool last = seg == e->n_segments[lin] - 1;
+            if (seg == 1 && multi && early_lane[lin] && !early_lanes) {
+                // (a lane released early for its replay's first step: what follows needs this batch's twists -- held until the
+                //  velocity filter's workgroups are resident, like a lane of a hand-over batch that was not released early)
+                HIP_TRY(hipStreamWaitValue64(sp, e->arr.skf_started.p, e->skf_total, hipStreamWaitValueGte, ~0ull));
+                ++evops;
+            }
             launch_ukf_chain(a, e->cfg.ut, seg == 0, lin, sp, (last && !full) ? e->ev_done[slot][lin] : nullptr);
             ++launches;
             CHECK_LAUNCH("pose chain segment");
@@ -1665,7 +1703,7 @@ static int step_batch(roft_engine* e)
         tr = roft_batch_trace{};
         tr.batch = e->batch_counter;
         tr.frames = T;
-        tr.steady = steady; tr.throttled = e->throttled; tr.handoff = handoff; tr.early_lanes = early_lanes;
+        tr.steady = steady; tr.throttled = e->throttled; tr.handoff = handoff; tr.early_lanes = (early_lanes ? 4 : 0) | (early_lane[0] ? 1 : 0) | (early_lane[1] ? 2 : 0);
         tr.outlier_parts_halved = (e->cfg.outlier_bands_per_alternative == 0 && steady) ? 1 : 0;
         tr.launches = (int)(e->stats.launches - launches0);
         tr.event_ops = (int)(e->stats.event_ops - evops0);

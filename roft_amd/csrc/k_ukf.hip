@@ -1210,6 +1210,7 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
     // the same SIMDs.  Highest wave priority: the chain's next instruction goes first whenever it is ready.
     __builtin_amdgcn_s_setprio(PRIO_UKF);
 #ifdef ROFT_UKF_WALL
+    const long long w_entry = wall_clock64();   // (kernel entry: dbg[26] sums entry -> first step, dbg[27] the first steps, dbg[19] counts them)
     __shared__ unsigned s_ticket;
     if (threadIdx.x == 0) {
         s_ticket = atomicAdd(reinterpret_cast<unsigned*>(&a.state[0].dbg[30 + 0]) + lin, 1u);
@@ -1304,6 +1305,11 @@ __global__ __launch_bounds__(kUkfThreads) void ukf_chain_kernel(EngineArrays a, 
             break;
         }
 #ifdef ROFT_UKF_WALL
+        if (threadIdx.x == 0 && w_steps == 0) {
+            atomicAdd(reinterpret_cast<unsigned long long*>(&st.dbg[26]), (unsigned long long)(w_s0 - w_entry));
+            atomicAdd(reinterpret_cast<unsigned long long*>(&st.dbg[27]), (unsigned long long)(wall_clock64() - w_s0));
+            atomicAdd(reinterpret_cast<unsigned long long*>(&st.dbg[19]), 1ull);
+        }
         if (threadIdx.x == 0 && w_steps > 0) {   // histogram of step durations (not the first step of a launch: cold)
             const long long d = wall_clock64() - w_s0;
             const int bin = d < 1800 ? 0 : (d < 2200 ? 1 : (d < 3000 ? 2 : 3));

@@ -3,24 +3,24 @@
 # gpurun_out/<tag>/ (copy the ones to keep into profiles/ with the tag as prefix).   usage: bash tools/collect_profiles.sh [tag]
 set -x
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 # the driver-shaped run (what BENCH_rNN.json records) three times, the default run and a long steady-state run
 for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_driver_shaped_$i.json 2> $O/bench.err; done
 timeout 300 python bench.py > $O/bench_64obj.json 2>> $O/bench.err
-timeout 300 python bench.py --steps 240 --warmup 16 --no-cpu-baseline --pcie-frames 0 --no-extras > $O/bench_steady_240.json 2>> $O/bench.err
+timeout 300 python bench.py --steps 240 --warmup 16 --windows 3 --no-cpu-baseline --pcie-frames 0 --no-extras > $O/bench_steady_240.json 2>> $O/bench.err
 timeout 900 python tools/run_baseline_configs.py --out $O/baseline_configs.json > /dev/null 2> $O/baseline.err
 # objects per GPU: the per-GPU points of the 8 / 4 / 2 / 1-GPU strong-scaling curve of config #4 (64 / 32 / 16 / 8 objects) and beyond
 python - > $O/object_sweep.json <<PY
 import json, subprocess, sys
 out = []
 for n in (8, 16, 32, 64, 128, 256):
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "60", "--warmup", "12", "--objects", str(n), "--no-cpu-baseline", "--pcie-frames", "0", "--no-extras"],
-                       capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "60", "--warmup", "12", "--objects", str(n), "--windows", "3" if n <= 64 else "1",
+                        "--no-cpu-baseline", "--pcie-frames", "0", "--no-extras"], capture_output=True, text=True, timeout=600)
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    out.append(dict(objects=n, value=d["value"], ms_per_step=d["ms_per_step"], frames_per_sec_per_object=d["frames_per_sec_per_object"],
+    out.append(dict(objects=n, value=d["value"], runs=d["runs"], ms_per_step=d["ms_per_step"], frames_per_sec_per_object=d["frames_per_sec_per_object"],
                     k1_avg_launch_us=d["roofline"]["avg_launch_us"], roofline_frac=d["roofline"]["frac"], launches_per_frame=d["launches_per_frame"],
                     kernels=d["kernels_post_run_breakdown"]))
 json.dump(dict(what="python bench.py --steps 60 --warmup 12 --objects N (one MI355X): the per-GPU load of config #4 sharded over 8 / 4 / 2 / 1 GPUs is 8 / 16 / 32 / 64 objects", runs=out), sys.stdout, indent=1)
@@ -30,22 +30,19 @@ python - > $O/object_sweep_20.json <<PY
 import json, subprocess, sys
 out = []
 for n in (8, 16, 32, 64):
-    vals = []
-    for rep in range(3):
-        r = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--objects", str(n), "--no-cpu-baseline", "--pcie-frames", "0", "--no-extras"],
-                           capture_output=True, text=True, timeout=600)
-        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-        vals.append(d["value"])
-    out.append(dict(objects=n, values=vals, median=sorted(vals)[1], frames_per_sec_per_object=sorted(vals)[1] / n, ms_per_step=d["ms_per_step"]))
-json.dump(dict(what="python bench.py --steps 20 --warmup 5 --objects N (one MI355X), three runs each", runs=out), sys.stdout, indent=1)
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--objects", str(n), "--no-cpu-baseline", "--pcie-frames", "0", "--no-extras"],
+                       capture_output=True, text=True, timeout=600)
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    out.append(dict(objects=n, values=d["runs"], median=d["value"], frames_per_sec_per_object=d["value"] / n, ms_per_step=d["ms_per_step"]))
+json.dump(dict(what="python bench.py --steps 20 --warmup 5 --objects N (one MI355X): value = median of the run's five timed windows (values)", runs=out), sys.stdout, indent=1)
 PY
 # the reference's executable over this engine: microseconds per frame at 1280x720, images read in place / staged
 timeout 600 python tools/tracker_timing.py 120 --out $O/tracker_timing.json > /dev/null 2>> $O/bench.err
 # profiler-free timelines (HIP event marks after every launch group): the driver-shaped window and the steady state
 rm -f $O/marks_20.txt $O/marks_240.txt
-ROFT_BENCH_FULL_TIMING=1 ROFT_DUMP_MARKS=$O/marks_20.txt ROFT_BENCH_EXTRA_FRAMES=0 timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-frames 0 --no-extras > /dev/null 2>> $O/bench.err
+ROFT_BENCH_FULL_TIMING=1 ROFT_DUMP_MARKS=$O/marks_20.txt ROFT_BENCH_EXTRA_FRAMES=0 timeout 300 python bench.py --steps 20 --warmup 5 --windows 1 --no-cpu-baseline --pcie-frames 0 --no-extras > /dev/null 2>> $O/bench.err
 python tools/marks_timeline.py $O/marks_20.txt --list > $O/marks_timeline_20.txt
-ROFT_BENCH_FULL_TIMING=1 ROFT_DUMP_MARKS=$O/marks_240.txt ROFT_BENCH_EXTRA_FRAMES=0 timeout 300 python bench.py --steps 240 --warmup 16 --no-cpu-baseline --pcie-frames 0 --no-extras > /dev/null 2>> $O/bench.err
+ROFT_BENCH_FULL_TIMING=1 ROFT_DUMP_MARKS=$O/marks_240.txt ROFT_BENCH_EXTRA_FRAMES=0 timeout 300 python bench.py --steps 240 --warmup 16 --windows 1 --no-cpu-baseline --pcie-frames 0 --no-extras > /dev/null 2>> $O/bench.err
 python tools/marks_timeline.py $O/marks_240.txt --from 4000 --to 9000 > $O/marks_timeline_240.txt
 python tools/marks_timeline.py $O/marks_240.txt --from 6000 --to 7400 --list | tail -n +16 >> $O/marks_timeline_240.txt
 rm -f $O/marks_20.txt $O/marks_240.txt
@@ -55,19 +52,21 @@ ROFT_BENCH_DEVICE=0 ROFT_BENCH_BACKEND=gloo timeout 600 python -m torch.distribu
 timeout 300 python tools/live_latency.py --out $O/live_latency.json > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernel stats + timeline of the driver-shaped run, chains overlapping
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 > $O/bench_under_rocprof.json 2> /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --windows 1 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 > $O/bench_under_rocprof.json 2> /dev/null
 python3 $R/tools/prof_summary.py stats $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv
-# the roofline kernel over exactly the timed launches of that run (1 warm-up batch, then 3 timed ones): compare with roofline.avg_launch_us
-python3 $R/tools/prof_summary.py window $O/stats/*/*kernel_trace.csv flow_measure_kernel 2 4 > $O/k1_timed_launches_under_rocprof.txt
+# the roofline kernel over exactly the launches that bench.py's event pairs time in that run: --windows 1 = window 0 (1 warm-up
+# batch + 4 timed), then the instrumented window (1 warm-up batch + 4 TIMED: launches 6 .. 9), then the breakdown frames:
+# compare with roofline.avg_launch_us of bench_under_rocprof.json
+python3 $R/tools/prof_summary.py window $O/stats/*/*kernel_trace.csv flow_measure_kernel 6 4 > $O/k1_timed_launches_under_rocprof.txt
 python3 $R/tools/trace_list.py $O/stats/*/*kernel_trace.csv 2 --resources > $O/pipeline_timeline.txt
 rm -rf $O/stats
 # the same kernels with the chains serialised on one stream (each kernel's duration alone), on a longer run
 export ROFT_ONE_STREAM=1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --steps 48 --warmup 7 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats1 -- python3 $R/bench.py --steps 48 --warmup 7 --windows 1 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
 unset ROFT_ONE_STREAM
 python3 $R/tools/prof_summary.py stats $O/stats1/*/*kernel_stats.csv $O/bench_kernel_stats_one_stream.csv
 rm -rf $O/stats1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python3 $R/bench.py --steps 48 --warmup 7 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats2 -- python3 $R/bench.py --steps 48 --warmup 7 --windows 1 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
 python3 $R/tools/prof_summary.py stats $O/stats2/*/*kernel_stats.csv $O/bench_kernel_stats_48.csv
 # CU x us budget of that run (48 timed + 7 warm-up + 24 breakdown frames x 64 objects; footprints: profiles/${TAG}_kernel_resources.csv,
 # made without a GPU by tools/kernel_resources.sh)
@@ -77,7 +76,7 @@ rm -rf $O/stats2
 # covers 8 frames x 64 objects in this run (24 timed frames after 8 warm-up frames, batches of 8)
 # + the L2's view of the same launches: hits, misses and read requests to the fabric (K1's gathers miss: one request each)
 for c in FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum; do
-  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc -- python3 $R/bench.py --steps 24 --warmup 8 --no-align --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc -- python3 $R/bench.py --steps 24 --warmup 8 --windows 1 --no-align --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --no-kernel-timing > /dev/null 2>&1
   python3 $R/tools/prof_summary.py pmc $O/pmc/*/*counter_collection.csv $O/pmc_$c.csv
   rm -rf $O/pmc
 done
@@ -96,7 +95,7 @@ json.dump({"objects": 64, "shape": "A", "flow": "f32", "batch": 8, "dispatches":
            # at 64 bytes -- the bit-plane read of this kernel is such a stream and is counted twice here; the 4- and 8-byte
            # sample gathers are left as counted (uncalibrated)
            "fetch_bytes_per_object_frame": raw + plane,
-           "source": "rocprofv3 --pmc FETCH_SIZE, bench.py --steps 24 --warmup 8 (tools/collect_profiles.sh), KB x 1024 / 512 object-frames per launch + 38400 B plane correction"},
+           "source": "rocprofv3 --pmc FETCH_SIZE, bench.py --steps 24 --warmup 8 --windows 1 --no-align (tools/collect_profiles.sh), KB x 1024 / 512 object-frames per launch + 38400 B plane correction"},
           open("$O/pmc_k1.json", "w"), indent=1)
 PY
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/of -- python3 $R/tools/bench_flow_producer.py > /dev/null 2>&1

@@ -48,6 +48,8 @@ for mode in ("pipelined", "one batch at a time"):
         L.lib().roft_debug_get_dbg(eng._h, o, buf)
         tot += buf[28]
         steps += buf[29]
+        fs = globals().setdefault("first_acc", [0, 0, 0])
+        fs[0] += buf[26]; fs[1] += buf[27]; fs[2] += buf[19]
         hb = globals().setdefault("hist_acc", [0, 0, 0, 0, 0, 0])
         for i in range(6): hb[i] += buf[20 + i]
         for lane in range(2):
@@ -61,6 +63,8 @@ for mode in ("pipelined", "one batch at a time"):
             lane, (first - recs[0][0]) / 100.0, skew, dur, smax, smean, nwg, wg_max, ps_max))
     print("%-20s %.1f us per frame; %d steps (%.2f per object-frame), %.2f us wall per step inside the kernel" % (
         mode, 1e6 * dt / n, steps, steps / (n * n_obj), tot / 100.0 / max(steps, 1)))
+    fs = globals().pop("first_acc")
+    print("   launches that walked a step: %d; kernel entry -> first step %.1f us, first step %.1f us (mean)" % (fs[2], fs[0] / 100.0 / max(fs[2], 1), fs[1] / 100.0 / max(fs[2], 1)))
     hb = globals().pop("hist_acc")
     print("   steps (not the first of a launch) < 18 us: %d, 18-22: %d, 22-30: %d, > 30: %d (mean %.1f us; sum of n_corr*100+type: %d)" % (hb[0], hb[1], hb[2], hb[3], hb[4] / 100.0 / max(hb[3], 1), hb[5]))
     eng.close()
