@@ -13,8 +13,8 @@ delayed masks and poses, pose re-sync, depth-render outlier rejection).  One "st
 (roft_frames_submit).  Inputs (depth, flow, masks) are resident in HBM before the timed region; the PCIe-inclusive rates
 (HOST inputs) are measured in the same run and reported beside `value`, never as it.
 
-Round 5: the timed region is run --windows times (default 5) in one invocation, every time on a FRESH engine and a FRESH,
-disjoint stream set (W warm-up steps, barrier + synchronize, exactly K timed steps, synchronize + barrier, max over ranks), with
+Round 5: the timed region is run --windows times (default 5) in one invocation, every time on a FRESH engine and on the workload's
+streams generated anew into FRESH buffers (W warm-up steps, barrier + synchronize, exactly K timed steps, synchronize + barrier, max over ranks), with
 no timing machinery of any kind inside it; `value` is the MEDIAN window (a real run: its ms_per_step, host time and batch
 trace are the top-level ones), `runs` lists all of them.  A 20-step window is 1.3 ms of GPU time in which one host thread
 enqueues ~70 launches: one window can be hit by anything that happens on the box in that millisecond, five cannot.  The
@@ -178,7 +178,7 @@ def parse():
     p.add_argument("--no-kernel-timing", action="store_true",
                    help="skip the instrumented window (roofline kernel's event pair) and the per-kernel breakdown behind it")
     p.add_argument("--windows", type=int, default=5,
-                   help="timed windows per invocation (each: fresh engine, fresh disjoint stream set, W warm-up + K timed steps); "
+                   help="timed windows per invocation (each: fresh engine, the streams generated anew into fresh buffers, W warm-up + K timed steps); "
                         "`value` is the median window")
     return p.parse_args()
 
@@ -280,16 +280,17 @@ def main():
     cam = synth.Camera.shape_a() if args.shape == "A" else synth.Camera.shape_b()
     ftype = synth.FLOW_F32C2 if args.flow == "f32" else synth.FLOW_S16C2
 
-    # The streams of a window stay resident in HBM while it runs (depth 4 B + mask 1 B per pixel, flow per grid cell); at most
-    # four sets are alive at once (window 0's for the accuracy figures, the running window's, the rehearsal's, the instrumented
-    # one): refuse a K + W that cannot fit instead of running the box out of memory.
+    # The streams of a window stay resident in HBM while it runs (depth 4 B + mask 1 B per pixel, flow per grid cell): refuse a
+    # K + W that cannot fit instead of running the box out of memory.
     g = 1 if args.flow == "f32" else 4
     flow_frame_bytes = (cam.width // g) * (cam.height // g) * (8 if args.flow == "f32" else 4)
     per_frame = cam.width * cam.height * 5 + flow_frame_bytes
-    need = per_frame * (4 * n_timed_end + n_extra) * n_obj
+    # (alive at once: window 0's set, kept for the accuracy figures, + the running window's -- or the instrumented one with its
+    #  n_extra frames; the rehearsal's set is freed before the first window)
+    need = per_frame * (2 * n_timed_end + n_extra) * n_obj
     free_b, _total_b = torch.cuda.mem_get_info(dev)
     if need > 0.8 * free_b:
-        raise SystemExit("bench.py: %d frames x %d objects of synthetic input (x 4 sets) need %.0f GB of HBM, %.0f GB are free; "
+        raise SystemExit("bench.py: %d frames x %d objects of synthetic input (two sets alive) need %.0f GB of HBM, %.0f GB are free; "
                          "lower --steps / --warmup / --objects" % (n_timed_end, n_obj, need / 1e9, free_b / 1e9))
 
     # ---- synthetic streams, generated on the GPU and left resident in HBM
@@ -522,7 +523,12 @@ def main():
     windows = []
     keep0 = None
     for w in range(n_windows):
-        rec, keep = timed_window(4000 + 1000 * w)
+        # Every window tracks the CANONICAL streams of config #4 (seeds 4000 + object index), generated anew into fresh
+        # buffers: no frame has been read by anything when its window reads it, and all windows measure the SAME workload -- the
+        # spread of `runs` is the machine's, not the data's.  (Round 5 measured windows on other seeds first: the same generator
+        # with seeds 5000 + / 6000 + tracks 15 % slower at 64 objects and 40 % slower at 16 -- different motion, different work --,
+        # which made the windows incomparable.  ROFT_BENCH_WINDOW_SEEDS=1: window i on seeds 4000 + 1000 i.)
+        rec, keep = timed_window(4000 + (1000 * w if os.environ.get("ROFT_BENCH_WINDOW_SEEDS") == "1" else 0))
         windows.append(rec)
         if w == 0:
             # window 0 tracks the canonical streams (seeds 4000 +): accuracy figures, --dump-rows.  Its results are read now and the
@@ -545,7 +551,7 @@ def main():
     k1_live = None
     inst = None
     if not args.no_kernel_timing:
-        inst, keep_i = timed_window(4000 + 1000 * n_windows, instrument=(2 if os.environ.get("ROFT_BENCH_FULL_TIMING") == "1" else 1), extra=n_extra)
+        inst, keep_i = timed_window(4000 + (1000 * n_windows if os.environ.get("ROFT_BENCH_WINDOW_SEEDS") == "1" else 0), instrument=(2 if os.environ.get("ROFT_BENCH_FULL_TIMING") == "1" else 1), extra=n_extra)
         e_i = keep_i["eng"]
         tm = e_i.timing()
         # the kernel that takes the flow measurements: the mask + measurement chain (one launch per batch), or -- images too large
@@ -1025,8 +1031,8 @@ def main():
         "data": "synthetic",
         # ---- how `value` came about: every window of this invocation (value = the median one), and the median window's own
         #      host time, host state and batch trace, so that a slow run explains itself
-        "value_is": "median of %d timed windows of exactly %d steps each (fresh engine + fresh disjoint stream set per window, no "
-                    "timing instrumentation inside)" % (n_windows, args.steps),
+        "value_is": "median of %d timed windows of exactly %d steps each (fresh engine + the workload's streams generated anew into fresh "
+                    "buffers per window, no timing instrumentation inside)" % (n_windows, args.steps),
         "runs": [w_["value"] for w_ in windows],
         "value_min": vals[0],
         "value_max": vals[-1],
@@ -1040,8 +1046,8 @@ def main():
         "timed_frames_first_touch": True,
         "method": {"windows": n_windows, "rehearsal_ms": args.rehearsal_ms,
                    "rehearsal_streams": "disjoint from every window's (seeds 20000 +, same shapes and batch cuts), once, before the first window" if args.rehearsal_ms > 0 else None,
-                   "window_streams": "window i: seeds %s + object index (window 0 = the canonical streams of config #4, SURVEY 8d); instrumented window: %d +"
-                                     % (" / ".join(str(4000 + 1000 * i) for i in range(n_windows)), 4000 + 1000 * n_windows),
+                   "window_streams": "every window (and the instrumented one): the canonical streams of config #4, seeds 4000 + object index "
+                                     "(SURVEY 8d), generated anew into fresh buffers -- first touch by the window, same workload in every window",
                    "host_spin_ms": 3.0, "host_spin": "before the W warm-up steps of every window (the window follows them behind one barrier + synchronize)",
                    "batch_cuts": "explicit --splits" if args.splits else ("full batches" if args.no_align else "batches end with the pose-arrival frame"),
                    "scheduling": "a function of the batch index since the engine was last idle (roft_batch_trace::steady), not of host timing",

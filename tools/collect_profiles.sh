@@ -54,10 +54,11 @@ cd /tmp && export TMPDIR=/tmp
 # kernel stats + timeline of the driver-shaped run, chains overlapping
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --windows 1 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 > $O/bench_under_rocprof.json 2> /dev/null
 python3 $R/tools/prof_summary.py stats $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv
-# the roofline kernel over exactly the launches that bench.py's event pairs time in that run: --windows 1 = window 0 (1 warm-up
-# batch + 4 timed), then the instrumented window (1 warm-up batch + 4 TIMED: launches 6 .. 9), then the breakdown frames:
+# the roofline kernel over exactly the launches that bench.py's event pairs time in that run: --windows 1 = window 0 (2 warm-up
+# batches (frames 0 | 1 - 4) + 4 timed), then the instrumented window (2 warm-up batches + 4 TIMED: launches 8 .. 11), then the
+# breakdown frames:
 # compare with roofline.avg_launch_us of bench_under_rocprof.json
-python3 $R/tools/prof_summary.py window $O/stats/*/*kernel_trace.csv flow_measure_kernel 6 4 > $O/k1_timed_launches_under_rocprof.txt
+python3 $R/tools/prof_summary.py window $O/stats/*/*kernel_trace.csv flow_measure_kernel 8 4 > $O/k1_timed_launches_under_rocprof.txt
 python3 $R/tools/trace_list.py $O/stats/*/*kernel_trace.csv 2 --resources > $O/pipeline_timeline.txt
 rm -rf $O/stats
 # the same kernels with the chains serialised on one stream (each kernel's duration alone), on a longer run
