@@ -796,7 +796,7 @@ def main():
             return time.perf_counter() - t1
         # (the device has idled through the CPU baseline and the host work above: no clock warm-up precedes this run)
         # fresh frames as well: a third stream set (seeds + 2000, same shapes) that nothing has read before this run
-        cold_streams, _cs = make_streams(30000, n_timed_end, zero_remote=False)
+        cold_streams, _cs = make_streams(4000, n_timed_end, zero_remote=False)   # (the canonical workload, generated anew: comparable with `value`)
         torch.cuda.synchronize()
         time.sleep(1.0)
         _c, e2 = new_engine(n_obj)
@@ -805,8 +805,8 @@ def main():
         e2.close()
         del cold_streams
         value_cold = dict(value=n_obj * args.steps / dt_cold, ms_per_step=1e3 * dt_cold / args.steps, host_enqueue_ms_per_step=1e3 * cold_host[0] / args.steps,
-                          note="a timed sequence of the same shape on a fresh engine and on FRESH frames (one more stream set, seeds "
-                               "30000 +, read by nothing before) after the device has idled (CPU baseline, host work, 1 s sleep), "
+                          note="a timed sequence of the same shape on a fresh engine and on FRESH frames (the workload's streams generated "
+                               "once more into fresh buffers, read by nothing before) after the device has idled (CPU baseline, host work, 1 s sleep), "
                                "no rehearsal of any kind and nothing of this shape run for seconds: what a short burst from an idle GPU gets")
         # the roofline kernel with the device to itself: the same frames, every batch waited for before the next one is
         # submitted (its launch then overlaps nothing but the tail of its own batch's mask chain)
