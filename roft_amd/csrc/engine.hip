@@ -1743,14 +1743,21 @@ int roft_sync(roft_engine* e)
     HIP_TRY(hipSetDevice(e->cfg.device));
     // the batches in flight one by one, in order (their completion times go into the batch trace), then whatever else the
     // streams carry (uploads, timing marks, reads of results)
-    if (e->multi)
-        for (int b = e->completed_batches; b < e->batch_counter; ++b)
+    // (only with several batches in flight: a tracker used live -- one frame submitted, stepped and read back at a time -- goes
+    //  straight to the stream synchronisations, whose wake-up is faster than an event's)
+    const int first_open = e->completed_batches, n_open = e->batch_counter - e->completed_batches;
+    if (e->multi && n_open > 1)
+        for (int b = first_open; b < e->batch_counter; ++b)
             if (int rc = wait_batch(e, b)) return rc;
     HIP_TRY(hipStreamSynchronize(e->stream));
     if (e->multi) {
         HIP_TRY(hipStreamSynchronize(e->vel_stream));
         for (int l = 0; l < kNumLin; ++l) HIP_TRY(hipStreamSynchronize(e->pose_stream[l]));
         HIP_TRY(hipStreamSynchronize(e->up_stream));
+    }
+    for (int b = std::max(first_open, e->batch_counter - roft_engine::kTraceRing); b < e->batch_counter; ++b) {
+        roft_batch_trace& tr = e->trace[b % roft_engine::kTraceRing];
+        if (tr.batch == b && tr.t_done_us == 0.0) tr.t_done_us = host_now_us();
     }
     e->completed_batches = e->batch_counter;
     e->completed_frames = e->frame_counter;
