@@ -388,3 +388,44 @@ def test_pinned_host_memory_is_read_in_place_as_device_input():
     for a, b in zip(ref, log):
         assert np.array_equal(a, b)
     assert np.array_equal(ref_masks[0], masks[0])
+
+
+def test_batch_trace_reports_a_schedule_that_depends_on_the_batch_index_only():
+    """roft_engine_get_batch_trace: the scheduling mode of a batch is a function of the number of batches stepped since the engine
+    was last idle (five: the in-flight bound) -- not of whether the submit call happened to wait --, so two runs of the same
+    sequence take the same decisions batch for batch and log the same results; roft_sync starts a new burst; the host's times and
+    the completion marks are filled in."""
+    n = 60
+    streams = [util.to_device(util.stream(580 + i, n, scale=2, device="cuda")) for i in range(3)]
+
+    def run(sync_at=None):
+        eng = make_engine(streams, max_batch_frames=6)
+        eng.enable_log(n)
+        k = 0
+        while k < n:
+            t = min(6, n - k)
+            eng.submit_batch([[util.device_frame(st, k + j) for st in streams] for j in range(t)])
+            eng.step()
+            k += t
+            if sync_at is not None and k == sync_at:
+                eng.sync()
+        log = eng.get_log(0, n)
+        tr = eng.batch_trace()
+        eng.close()
+        return log, tr
+
+    log_a, tr_a = run()
+    log_b, tr_b = run()
+    assert len(tr_a) == 10 and [b["batch"] for b in tr_a] == list(range(10)) and all(b["frames"] == 6 for b in tr_a)
+    assert [b["steady"] for b in tr_a] == [0] * 5 + [1] * 5
+    keys = ("steady", "handoff", "early_lanes", "outlier_parts_halved", "launches", "event_ops")
+    assert [[b[k] for k in keys] for b in tr_a] == [[b[k] for k in keys] for b in tr_b]
+    for x, y in zip(log_a, log_b):
+        assert np.array_equal(x, y)
+    for b in tr_a:
+        assert b["submit_us"] > 0 and b["step_us"] > 0 and b["wait_us"] >= 0 and b["t_done_us"] > b["t_submit_us"] and b["launches"] >= 8
+    # a synchronisation in the middle: the batches behind it are a burst again, and no result changes
+    log_c, tr_c = run(sync_at=36)
+    assert [b["steady"] for b in tr_c] == [0] * 5 + [1] + [0] * 4
+    for x, y in zip(log_a, log_c):
+        assert np.array_equal(x, y)
