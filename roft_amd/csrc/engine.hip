@@ -155,6 +155,7 @@ struct Arrays {
     DevBuf<int> npts;
     DevBuf<MaskRec> mrec;
     DevBuf<unsigned> mask_general;
+    DevBuf<int2> slot_span;
     DevBuf<uint32_t> feat_pix;
     DevBuf<float> feat_depth;
     DevBuf<uint32_t> zbuf;
@@ -197,6 +198,8 @@ struct Arrays {
         HIP_TRY(planes.ensure((size_t)n_obj * kPlaneSlotsTotal * 2 * a.plane_words, true));
         HIP_TRY(mrec.ensure((size_t)2 * n_obj * (kMaxBatch + 1), true));   // two tables (batch parity)
         HIP_TRY(mask_general.ensure(n_obj, true));
+        static const int spans_env = getenv("ROFT_MASK_SPANS") ? atoi(getenv("ROFT_MASK_SPANS")) : 1;   // (experiments: 0 = bands over the whole image)
+        if (spans_env) HIP_TRY(slot_span.ensure((size_t)n_obj * kPlaneSlotsTotal, true));   // (zero-filled = every span empty, like the planes)
         HIP_TRY(map.ensure((size_t)n_obj * npix, true));
         HIP_TRY(cand.ensure((size_t)n_obj * T * a.cand_cap));
         HIP_TRY(recs.ensure((size_t)n_obj * T * a.cand_cap));
@@ -209,6 +212,7 @@ struct Arrays {
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
         a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.mrec = mrec.p;
         a.mask_general = mask_general.p;
+        a.slot_span = slot_span.p;
         a.mrec_carry = mrec.p; a.slot_new = kSlotNew; a.slot_prev0 = -1; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
         a.zbuf = zbuf.p;
         a.out_log = nullptr;
@@ -381,6 +385,7 @@ struct roft_engine {
     hipEvent_t ev_up[kBatchRing] = {};     // uploads of the batch on the device
     hipEvent_t ev_ctrl[kBatchRing] = {};   // FrameCtrl blocks of the batch on the device (and the mask chain of the batch before)
     hipEvent_t ev_mask[kBatchRing] = {};   // mask chain kernel of the batch complete
+    hipEvent_t ev_prep[kBatchRing] = {};   // control blocks + ingested masks of the batch on the device (prepared on the upload stream)
     hipEvent_t ev_feat[kBatchRing] = {};   // features of the batch complete
     hipEvent_t ev_vel[kBatchRing] = {};    // twists of the batch complete
     hipEvent_t ev_done[kBatchRing][kNumLin] = {};   // pose chain of the batch complete (per lane)
@@ -832,7 +837,7 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
     for (int i = 0; i < R; ++i) {
         HIP_TRY(e->dctrl[i].ensure((size_t)cfg->max_objects * e->T_max, true));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects * e->T_max));
-        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
+        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_prep[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
             HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
     DevFlowFmt ff;
@@ -878,6 +883,9 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
                 hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->pose_stream[l], nullptr, e->ev_done[i][l], 0, flag);
             }
             HIP_TRY(hipEventRecord(e->ev_up[i], e->up_stream));
+            HIP_TRY(hipStreamWaitEvent(e->up_stream, e->ev_mask[i], 0));
+            hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->up_stream, nullptr, e->ev_prep[i], 0, flag);
+            HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_prep[i], 0));
         }
         HIP_TRY(hipGetLastError());
         for (hipStream_t q : {e->stream, e->vel_stream, e->pose_stream[0], e->pose_stream[1], e->up_stream}) HIP_TRY(hipStreamSynchronize(q));
@@ -958,7 +966,7 @@ int roft_engine_destroy(roft_engine* e)
     for (hipStream_t s : {e->stream, e->vel_stream, e->pose_stream[0], e->pose_stream[1], e->up_stream})
         if (s) (void)hipStreamSynchronize(s);
     for (int i = 0; i < R; ++i) {
-        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
+        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_prep[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
             if (ev) (void)hipEventDestroy(ev);
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
     }
@@ -1540,23 +1548,45 @@ static int step_batch(roft_engine* e)
 
     // ---- control blocks of the batch -> device (+ reset of the mask chain's counters), ingest of the masks delivered
     //      with the batch (tables and ingest slots of this batch's parity: the carry of the chain before stays readable).
-    //      (Measured and not adopted: this preparation a batch ahead on the upload stream -- 3 % slower, the chains
-    //       compete for CUs, not for the mask stream's time.)
-    if (multi && e->had_uploads) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }
-    tmark(e, nullptr, 0);
+    //      Batches: on the UPLOAD stream, so that it happens while the mask chain of the batch before is still walking -- the
+    //      mask stream is the longest serial chain of the steady state (round 5 timeline: 14 + 38 + 200 us of a 252 us period),
+    //      and the 38 us were this preparation.  What it writes was last read by the mask chain TWO batches back (tables and
+    //      ingest slots of its parity; the chain in between reads one row of them as its carry, but none of the counters
+    //      that are reset here), which it therefore waits for.  Only in the steady state (a function of the batch index): in a
+    //      burst the mask stream is not behind, and the event between the two streams is one more hop on the first batches'
+    //      critical path -- measured, one box: 120 steps +1.5 %; 20 steps -5 % and 8 objects -5 % if bursts did the same.
+    //      (Rounds 3 - 4 measured the same idea 3 % slower at 240 steps: the pose lanes were the bottleneck then.)
+    //      ROFT_PREP_AHEAD = 0 never, 2 always.
+    static const int prep_env = getenv("ROFT_PREP_AHEAD") ? atoi(getenv("ROFT_PREP_AHEAD")) : 1;   // (experiments)
+    const bool prep = multi && T > 1 && (prep_env == 2 || (prep_env == 1 && steady)) && e->up_stream != s;
+    hipStream_t sp0 = prep ? e->up_stream : s;
+    if (multi && e->had_uploads && !prep) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }   // (prep: same stream as the uploads)
+    if (prep && e->batch_counter >= 2) { HIP_TRY(hipStreamWaitEvent(sp0, e->ev_mask[(slot + R - 2) % R], 0)); ++evops; }
+    tmark(e, nullptr, prep ? 4 : 0);
     {
         const size_t n16 = sizeof(FrameCtrl) * (size_t)a.n_obj * T / 16;
         // Events that complete with a kernel (hipExtLaunchKernelGGL stop events) cost neither the barrier packet nor
         // the host call of a hipEventRecord behind it.
-        hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, s,
+        hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, sp0,
                               nullptr, (multi && (T == 1 || any_early)) ? e->ev_ctrl[slot] : nullptr, 0,
                               reinterpret_cast<const uint4*>(e->stage[slot]), a, n16);
         ++launches;
     }
     CHECK_LAUNCH("FrameCtrl upload");
-    for (int t = 0; t < T; ++t)
-        if (e->new_mask_frames & (1u << t)) { launch_mask_ingest(a, t, s); ++launches; }
-    CHECK_LAUNCH("mask ingest");
+    {
+        int last = -1;
+        for (int t = 0; t < T; ++t)
+            if (e->new_mask_frames & (1u << t)) last = t;
+        for (int t = 0; t < T; ++t)
+            if (e->new_mask_frames & (1u << t)) { launch_mask_ingest(a, t, sp0, (prep && !full && t == last) ? e->ev_prep[slot] : nullptr); ++launches; }
+        CHECK_LAUNCH("mask ingest");
+        if (prep) {
+            if (full || last < 0) { HIP_TRY(hipEventRecord(e->ev_prep[slot], sp0)); ++evops; }
+            tmark(e, "mask_prepare", 4);
+            HIP_TRY(hipStreamWaitEvent(s, e->ev_prep[slot], 0));
+            ++evops;
+        }
+    }
     HP_MARK(e, 3, hp_t);
     // ---- mask chain: every object's masks frame after frame
     tmark(e, nullptr, 0);

@@ -15,15 +15,17 @@ import run_baseline_configs as rb
 
 n_obj = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 96
-T = 8
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+first = int(sys.argv[4]) if len(sys.argv) > 4 else T   # frames of the first batch (1 with T = 6: batches end with the pose-arrival frame, like bench.py's)
 dev = torch.device("cuda", 0)
 streams = [synth.make_stream(4000 + i, n, synth.Camera.shape_a(), device=dev) for i in range(n_obj)]
 for mode in ("pipelined", "one batch at a time"):
     eng = rb.make_engine(streams, T)
     batches = []
-    for k0 in range(0, n, T):
+    cuts = [0] + list(range(first, n, T)) + [n]
+    for k0, k1 in zip(cuts[:-1], cuts[1:]):
         fl = []
-        for k in range(k0, k0 + T):
+        for k in range(k0, k1):
             frames = []
             for st in streams:
                 mi = st.mask_delivery[k]
