@@ -155,7 +155,6 @@ struct Arrays {
     DevBuf<int> npts;
     DevBuf<MaskRec> mrec;
     DevBuf<unsigned> mask_general;
-    DevBuf<int2> slot_span;
     DevBuf<uint32_t> feat_pix;
     DevBuf<float> feat_depth;
     DevBuf<uint32_t> zbuf;
@@ -198,8 +197,6 @@ struct Arrays {
         HIP_TRY(planes.ensure((size_t)n_obj * kPlaneSlotsTotal * 2 * a.plane_words, true));
         HIP_TRY(mrec.ensure((size_t)2 * n_obj * (kMaxBatch + 1), true));   // two tables (batch parity)
         HIP_TRY(mask_general.ensure(n_obj, true));
-        static const int spans_env = getenv("ROFT_MASK_SPANS") ? atoi(getenv("ROFT_MASK_SPANS")) : 1;   // (experiments: 0 = bands over the whole image)
-        if (spans_env) HIP_TRY(slot_span.ensure((size_t)n_obj * kPlaneSlotsTotal, true));   // (zero-filled = every span empty, like the planes)
         HIP_TRY(map.ensure((size_t)n_obj * npix, true));
         HIP_TRY(cand.ensure((size_t)n_obj * T * a.cand_cap));
         HIP_TRY(recs.ensure((size_t)n_obj * T * a.cand_cap));
@@ -212,7 +209,6 @@ struct Arrays {
         a.params = params.p; a.state = state.p; a.ctrl = ctrl.p; a.planes = planes.p; a.map = map.p;
         a.cand = cand.p; a.recs = recs.p; a.norms = norms.p; a.npts = npts.p; a.mrec = mrec.p;
         a.mask_general = mask_general.p;
-        a.slot_span = slot_span.p;
         a.mrec_carry = mrec.p; a.slot_new = kSlotNew; a.slot_prev0 = -1; a.feat_pix = feat_pix.p; a.feat_depth = feat_depth.p;
         a.zbuf = zbuf.p;
         a.out_log = nullptr;

@@ -119,16 +119,11 @@ __global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a, int t)
         ingest_group(reinterpret_cast<const uint4*>(c.new_mask), g,
                      reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, a.slot_new + t, 0)),
                      reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, a.slot_new + t, 1)), count, ones);
-    // the groups of a wave are consecutive: its first and last non-empty one bound the wave's part of the span
-    const unsigned long long any = __ballot(count != 0);
     for (int off = 32; off > 0; off >>= 1) { count += __shfl_xor(count, off, 64); ones += __shfl_xor(ones, off, 64); }
     if ((threadIdx.x & 63) == 0 && count) {
         MaskRec& r = a.mrec[(size_t)(t + 1) * a.n_obj + obj];
         atomicAdd(&r.new_count, count);
         if (ones) atomicAdd(&r.new_ones, ones);
-        if (a.slot_span)
-            span_add(a.slot_span + (size_t)obj * kPlaneSlotsTotal + a.slot_new + t, 2 * (g + __builtin_ctzll(any)),
-                     2 * (g + 63 - __builtin_clzll(any)) + 1);
     }
 }
 
@@ -164,8 +159,6 @@ constexpr int kFrameWaves = kFrameThreads / 64;
 struct MaskShared {
     int bbox[4];
     int n_list;
-    int far[2];                       // OrTarget::far
-    int2 span[2];                     // spans of the two candidate source planes (raw: EngineArrays::slot_span)
     unsigned long long w00[2];        // word 0 of the two candidate source planes (mask(0,0): hpp:214-215)
     const void* flows[kMaxFlowHist];
 };
@@ -209,18 +202,12 @@ struct OrTarget {
     ROFT_LDS uint32_t* win;     // LDS window (workgroup-uniform address)
     int off, words;             // first plane word of the window, its length
     uint32_t* dst;              // destination obj plane in HBM (zeroed by the frame before)
-    ROFT_LDS int* far;          // [2] first / last plane word hit OUTSIDE the window (the span of what this workgroup wrote)
     __device__ __forceinline__ void hit(int tp) const
     {
         const int wi = (tp >> 5) - off;
         const uint32_t bit = 1u << (tp & 31);
-        if ((unsigned)wi < (unsigned)words) {
-            (void)__hip_atomic_fetch_or(win + wi, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        } else {
-            (void)__hip_atomic_fetch_or(dst + (tp >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)__hip_atomic_fetch_min(far, tp >> 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            (void)__hip_atomic_fetch_max(far + 1, tp >> 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        if ((unsigned)wi < (unsigned)words) (void)__hip_atomic_fetch_or(win + wi, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else (void)__hip_atomic_fetch_or(dst + (tp >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 };
 
@@ -491,21 +478,13 @@ __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskR
     return r;
 }
 
-// Frame t of the batch, binary masks.  grid: (Q, n_obj).  The Q workgroups of an object share the 64-pixel groups of the SPAN of
-// the source plane -- first to last non-zero word, kept on the device by whoever wrote the plane (EngineArrays::slot_span) --
-// in bands of max(min_per, span / Q) groups: no workgroup is launched over image rows the object is not in (rounds 3 - 4 laid 24
-// bands over the whole image; half of them found no pixel and cost a launch slot, a round trip and 6.7 us of residency each).
-// A workgroup ORs the targets of its band's pixels into an LDS window -- the band's rows and `margin` rows above and below;
+// Frame t of the batch, binary masks.  grid: (Q, n_obj).  Workgroup q of an object owns the 64-pixel groups
+// [q, q + 1) * grp_per_wg of the source plane (a band of image rows) and the same share of the planes it copies / fills /
+// zeroes.  It ORs the targets of its pixels into an LDS window -- the band's rows and `margin` rows above and below;
 // the few pixels that fly further go to the destination plane directly -- and flushes the window's non-zero words with
-// atomicOr into the destination, which an earlier frame left zeroed (bands overlap in their margins: an order-free OR), and
-// adds the words it wrote to the destination's span.  The slot that the frame after the next one writes is zeroed over ITS
-// old span, and the next frame's span is reset (two frames ahead / one frame ahead: readers and writers of a span entry are
-// always different launches).
+// atomicOr into the destination, which the frame before left zeroed (bands overlap in their margins: an order-free OR).
 // Every workgroup of an object makes the same decisions from the same two records; workgroup 0 leaves the record of the
 // frame for the next one.  Frames whose source is three-valued are left to mask_general_kernel (bit t of mask_general).
-// Two dependent round trips: (1) control block, records, the spans and word 0 of BOTH planes the frame can read -- the last
-// propagated mask (ring slot slot_prev0 + t inside the engine) and the mask delivered with the frame (slot_new + t) --;
-// (2) the band's plane words and the span of the slot to zero.
 // dynamic LDS: [win_cap words] window | [kFrameThreads] list | [kFrameThreads] plane words of the listed groups
 #ifdef ROFT_MASK_PROFILE
 // absolute 100 MHz stamps per object: dbg[8] = 2^62 - earliest workgroup start, dbg[i] = latest workgroup passing phase i (atomicMax both)
@@ -514,20 +493,9 @@ __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskR
 #define MTICK(i) do {} while (0)
 #endif
 
-// this workgroup's share [w0, w1) of the plane words [lo, hi] (whole 4-word units, so that the 16-byte fills and copies apply)
-__device__ __forceinline__ void span_share(SlotSpan sp, size_t plane_words, int q, int nq, size_t& w0, size_t& w1)
-{
-    w0 = w1 = 0;
-    if (sp.hi < sp.lo) return;
-    const size_t lo = (size_t)sp.lo & ~(size_t)3, end = min(plane_words, ((size_t)sp.hi + 4) & ~(size_t)3);
-    const size_t per = (((end - lo + 3) / 4 + nq - 1) / nq) * 4;
-    w0 = min(end, lo + (size_t)q * per);
-    w1 = min(end, w0 + per);
-}
-
 template <int FT>
 __global__ __launch_bounds__(kFrameThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
-void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided, int min_per, int margin, int win_cap)
+void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided, int grp_per_wg, int margin, int win_cap)
 {
 #ifdef ROFT_MASK_PROFILE
     if (threadIdx.x == 0) atomicMax((unsigned long long*)&a.state[blockIdx.y].dbg[8], (unsigned long long)((1ll << 62) - wall_clock64()));
@@ -541,12 +509,16 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
     uint32_t* s_win = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_list = s_win + win_cap;
     uint2* s_words = reinterpret_cast<uint2*>(s_list + kFrameThreads);
-    const int obj = blockIdx.y, q = blockIdx.x, nq = gridDim.x;
+    const int obj = blockIdx.y, q = blockIdx.x;
     const int W = a.cam.W, H = a.cam.H, wpr = a.cam.wpr, n_grp = (W * H) >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
-    int2* const spans = a.slot_span ? a.slot_span + (size_t)obj * kPlaneSlotsTotal : nullptr;
-    const int2 span_full = make_int2(kSpanBias, (int)a.plane_words);
-    // ---- round trip 1
+    const int g0 = q * grp_per_wg, g1 = min(n_grp, g0 + grp_per_wg);
+    // the band's rows + margin = the LDS window
+    const int r_lo = max(0, (g0 * 64) / W - margin), r_hi = min(H - 1, (g1 * 64 - 1) / W + margin);
+    const int win_off = r_lo * wpr, win_words = min(win_cap, (r_hi - r_lo + 1) * wpr);
+    // ---- one round trip: control block, the two records, and (speculatively) this thread's group word of BOTH planes the
+    //      frame can read -- the last propagated mask (ring slot slot_prev0 + t inside the engine) and the mask delivered
+    //      with the frame (slot_new + t; stale but valid memory when none was delivered)
     stage_ctrl(&s_c, frame_ctrl(a, t, obj));
     if (tid >= 128 && tid < 132) {
         const int k = tid - 128;   // 0, 1: the state after the frame before; 2, 3: this frame's counters
@@ -555,112 +527,65 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
                                                       : reinterpret_cast<const uint4*>(prev)[k & 1];
     }
     const int guess_prev = a.slot_prev0 >= 0 ? (a.slot_prev0 + t) % kPlaneSlots : -1, guess_new = a.slot_new + t;
-    if (tid == 192) {
-        S.w00[0] = guess_prev >= 0 ? *reinterpret_cast<const unsigned long long*>(a.planes + plane_offset(a, obj, guess_prev, 1)) : 0ull;
-        S.w00[1] = *reinterpret_cast<const unsigned long long*>(a.planes + plane_offset(a, obj, guess_new, 1));
+    const ROFT_GLOBAL unsigned long long* pl_prev = guess_prev >= 0 ? (const ROFT_GLOBAL unsigned long long*)(a.planes + plane_offset(a, obj, guess_prev, 1)) : nullptr;
+    const ROFT_GLOBAL unsigned long long* pl_new = (const ROFT_GLOBAL unsigned long long*)(a.planes + plane_offset(a, obj, guess_new, 1));
+    unsigned long long w_prev = 0ull, w_new = 0ull;
+    if (g0 + tid < g1) {
+        if (pl_prev) w_prev = pl_prev[g0 + tid];
+        w_new = pl_new[g0 + tid];
     }
-    if (tid == 193) S.span[0] = (spans && guess_prev >= 0) ? spans[guess_prev] : span_full;
-    if (tid == 194) S.span[1] = spans ? spans[guess_new] : span_full;
-    for (int i = tid; i < win_cap; i += kFrameThreads) s_win[i] = 0u;
-    if (tid == 0) { S.n_list = 0; S.far[0] = INT32_MAX; S.far[1] = -1; }
+    if (tid == 192) { S.w00[0] = pl_prev ? pl_prev[0] : 0ull; S.w00[1] = pl_new[0]; }
+    for (int i = tid; i < win_words; i += kFrameThreads) s_win[i] = 0u;
+    if (tid == 0) S.n_list = 0;
     __syncthreads();
     MTICK(4);
     const FrameCtrl& c = s_c;
     const MaskRec r = decide_frame(s_rec[0], s_rec[1], a.slot_new + t, c, frames_between, flow_aided);
-    const uint32_t* src = a.planes + plane_offset(a, obj, r.src_slot, 1);
-    uint32_t* dst = a.planes + plane_offset(a, obj, c.slot_cur, 1);
-    int2* const dst_span = spans ? spans + c.slot_cur : nullptr;
-    if (q == 0 && tid == 0) {
-        a.mrec[(size_t)(t + 1) * a.n_obj + obj] = r;   // (every workgroup computes the same record)
-        if (spans) spans[(c.slot_cur + 1) % kPlaneSlots] = make_int2(0, 0);   // the next frame's destination: zeroed by the frame before this one
-    }
+    if (q == 0 && tid == 0) a.mrec[(size_t)(t + 1) * a.n_obj + obj] = r;   // (every workgroup computes the same record)
     if (tid < kMaxFlowHist) S.flows[tid] = (tid < r.n_flows) ? c.flow[tid] : nullptr;
     MTICK(0);
-    const bool from_guess = r.src_slot == guess_prev || r.src_slot == guess_new;
-    const int which = r.src_slot == guess_new ? 1 : 0;
-    const unsigned long long w00 = from_guess ? S.w00[which] : *reinterpret_cast<const unsigned long long*>(src);
-    const SlotSpan sspan = span_decode(from_guess ? S.span[which] : (spans ? spans[r.src_slot] : span_full));
-    const bool ones = r.mode == 2 && (w00 & 1ull);      // mask(0,0) set in a new-mask frame: every target, mapped or not, samples a set pixel
-    const bool walk = r.src_binary && r.mode != 0 && !ones && sspan.hi >= sspan.lo;
-    // the band of this workgroup: groups [g0, g1) of the source's span
-    int g0 = 0, g1 = 0;
-    if (walk) {
-        const int G0 = sspan.lo >> 1, G1 = min(n_grp, (sspan.hi >> 1) + 1);
-        const int per = max(min_per, (G1 - G0 + nq - 1) / nq);
-        g0 = min(G1, G0 + q * per);
-        g1 = min(G1, g0 + per);
-    }
-    // ---- round trip 2: the span of the slot to zero, the band's plane words
-    // the obj plane of the slot two frames ahead (one frame ahead without spans) zeroed for that frame's OR flush (nobody reads
-    // that slot any more: its last user is kPlaneSlots frames back)
-    const int zslot = (c.slot_cur + (spans ? 2 : 1)) % kPlaneSlots;
-    const SlotSpan zspan = span_decode(spans ? spans[zslot] : span_full);
-    const uint2* plane2 = reinterpret_cast<const uint2*>(src);
-    unsigned long long w_first = 0ull;
-    if (g0 + tid < g1) w_first = *reinterpret_cast<const unsigned long long*>(plane2 + g0 + tid);
-#ifdef ROFT_MASK_PROFILE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MTICK(5);
-#endif
-    {
-        size_t z0, z1;
-        span_share(zspan, a.plane_words, q, nq, z0, z1);
-        plane_fill(a.planes + plane_offset(a, obj, zslot, 1) + z0, 0u, z1 - z0);
-    }
-#ifdef ROFT_MASK_PROFILE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MTICK(6);
-#endif
+    // the obj plane of the NEXT frame's slot zeroed for that frame's OR flush (nobody reads that slot any more: its last
+    // user is kPlaneSlots frames back)
+    const size_t sh0 = (size_t)2 * g0, sh_n = (size_t)2 * (g1 - g0);   // this workgroup's share of a plane, in words
+    plane_fill(a.planes + plane_offset(a, obj, (c.slot_cur + 1) % kPlaneSlots, 1) + sh0, 0u, sh_n);
+    const uint32_t* src = a.planes + plane_offset(a, obj, r.src_slot, 1);
+    uint32_t* dst = a.planes + plane_offset(a, obj, c.slot_cur, 1);
     if (!r.src_binary) {
-        if (q == 0 && tid == 0) {
-            atomicOr(&a.mask_general[obj], 1u << t);   // three-valued source: mask_general_kernel (writes every word of both planes)
-            if (dst_span) span_add(dst_span, 0, (int)a.plane_words - 1);
-        }
+        if (q == 0 && tid == 0) atomicOr(&a.mask_general[obj], 1u << t);   // three-valued source: mask_general_kernel
         return;
     }
     if (r.mode == 0) {
-        size_t c0, c1;
-        span_share(sspan, a.plane_words, q, nq, c0, c1);
-        plane_copy(dst + c0, src + c0, c1 - c0);
-        if (q == 0 && tid == 0 && dst_span && sspan.hi >= sspan.lo) span_add(dst_span, sspan.lo, sspan.hi);
+        plane_copy(dst + sh0, src + sh0, sh_n);
         return;
     }
-    if (ones) {
-        size_t c0, c1;
-        SlotSpan all; all.lo = 0; all.hi = (int)a.plane_words - 1;
-        span_share(all, a.plane_words, q, nq, c0, c1);
-        plane_fill(dst + c0, ~0u, c1 - c0);
-        if (q == 0 && tid == 0 && dst_span) span_add(dst_span, 0, (int)a.plane_words - 1);
+    const bool from_guess = r.src_slot == guess_prev || r.src_slot == guess_new;
+    const unsigned long long w00 = from_guess ? S.w00[r.src_slot == guess_new ? 1 : 0] : *reinterpret_cast<const unsigned long long*>(src);
+    if (r.mode == 2 && (w00 & 1ull)) {
+        // mask(0,0) set in a new-mask frame: every target, mapped or not, samples a set pixel
+        plane_fill(dst + sh0, ~0u, sh_n);
         return;
     }
-    MTICK(7);
-    if (g0 >= g1) return;
-    MTICK(9);
-    // the band's rows + margin = the LDS window
-    const int r_lo = max(0, (g0 * 64) / W - margin), r_hi = min(H - 1, (g1 * 64 - 1) / W + margin);
-    const int win_off = r_lo * wpr, win_words = min(win_cap, (r_hi - r_lo + 1) * wpr);
-    MTICK(11);
     const ChaseGeo geo = make_chase_geo(a.cam, a.ffmt);
-    MTICK(12);
     OrTarget tgt;
     tgt.win = (ROFT_LDS uint32_t*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(ROFT_LDS uint32_t*)s_win);
     tgt.off = win_off;
     tgt.words = win_words;
     tgt.dst = dst;
-    tgt.far = (ROFT_LDS int*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(ROFT_LDS int*)S.far);
-    MTICK(13);
     // this workgroup's non-empty groups -> list (any order: the scatter is order-free), kFrameThreads groups at a time, then
     // their walks
+    const uint2* plane2 = reinterpret_cast<const uint2*>(src);
     for (int c0 = g0; c0 < g1; c0 += kFrameThreads) {
         const int g = c0 + tid;
         unsigned long long ww = 0ull;
-        if (g < g1) ww = (c0 == g0) ? w_first : *reinterpret_cast<const unsigned long long*>(plane2 + g);
+        if (g < g1) {
+            if (c0 == g0 && from_guess) ww = (r.src_slot == guess_new) ? w_new : w_prev;
+            else ww = *reinterpret_cast<const unsigned long long*>(plane2 + g);
+        }
         if (c0 > g0) {
             __syncthreads();   // the walks of the chunk before have read the list
             if (tid == 0) S.n_list = 0;
             __syncthreads();
         }
-        MTICK(10);
         const bool ne = ww != 0ull;
         const unsigned long long b = __ballot(ne);
         int base = 0;
@@ -679,21 +604,10 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
     }
     __syncthreads();
     MTICK(2);
-    // flush: the non-zero words of the window into the (zeroed) destination; first / last of them -> the destination's span
-    int lo = INT32_MAX, hi = -1;
+    // flush: the non-zero words of the window into the (zeroed) destination
     for (int i = tid; i < win_words; i += kFrameThreads) {
         const uint32_t v = s_win[i];
-        if (v) {
-            atomicOr(&dst[win_off + i], v);
-            lo = min(lo, win_off + i);
-            hi = win_off + i;
-        }
-    }
-    if (dst_span) {
-        for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off, 64)); hi = max(hi, __shfl_xor(hi, off, 64)); }
-        if (lane == 0 && hi >= 0) { atomicMin(&S.far[0], lo); atomicMax(&S.far[1], hi); }
-        __syncthreads();
-        if (tid == 0 && S.far[1] >= 0) span_add(dst_span, S.far[0], S.far[1]);
+        if (v) atomicOr(&dst[win_off + i], v);
     }
     MTICK(3);
 }
@@ -800,12 +714,6 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
         const int per = std::max(1, (fresh ? rows_auto_new : rows_auto) * a.cam.W / 64);
         return std::min(per, n_grp);
     };
-    // With spans (EngineArrays::slot_span) the bands are laid over the source's span, not over the image: a FIXED number of
-    // workgroups per object -- enough for an object 240 rows tall (288 on the frames that deliver a mask) at the band size
-    // above; a taller one gets taller bands -- and never more than the whole image needs.
-    static const int bands_env = getenv("ROFT_MASK_BANDS") ? atoi(getenv("ROFT_MASK_BANDS")) : 0;               // (experiments)
-    static const int bands_new_env = getenv("ROFT_MASK_BANDS_NEW") ? atoi(getenv("ROFT_MASK_BANDS_NEW")) : 0;
-    const int bands = bands_env > 0 ? bands_env : 12, bands_new = bands_new_env > 0 ? bands_new_env : 48;
     const size_t lds_cap = 160 * 1024 - 4096;   // (the kernel's static LDS -- control block, records, flow pointers -- is ~1.3 KB)
     {
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_frame_kernel<ROFT_FLOW_S16C2>), (int)lds_cap);
@@ -816,28 +724,20 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
     for (int t = 0; t < a.T; ++t) {
         const bool fresh = (new_mask_frames >> t) & 1u;
         const int per = per_for(fresh);
-        int q = (n_grp + per - 1) / per;          // bands over the whole image
-        int per_max = per;                        // the largest band a workgroup can be given
-        if (a.slot_span && a.mask_wgs <= 0 && q > (fresh ? bands_new : bands)) {
-            q = fresh ? bands_new : bands;
-            per_max = std::max(per, (n_grp + q - 1) / q);
-        }
         // LDS window: the band's rows + a margin of rows above and below (pixels that fly further are ORed into the
         // destination plane directly): 16 rows for one flow step, 48 when a new mask is chased through several
         const int margin = fresh ? 48 : 16;
         const size_t fixed = (size_t)kFrameThreads * 12;
-        size_t win_cap = ((size_t)std::min(a.cam.H, (per_max * 64 + a.cam.W - 1) / a.cam.W + 1 + 2 * margin) * a.cam.wpr + 1) & ~(size_t)1;
+        size_t win_cap = ((size_t)std::min(a.cam.H, (per * 64 + a.cam.W - 1) / a.cam.W + 1 + 2 * margin) * a.cam.wpr + 1) & ~(size_t)1;
         win_cap = std::min(win_cap, ((lds_cap - fixed) / 4) & ~(size_t)1);
         const size_t lds = win_cap * 4 + fixed;
-        const dim3 grid(q, a.n_obj);
-        // (min_per: with S = mask_workgroups_per_object the span is split into exactly S bands)
-        const int min_per = (a.slot_span && a.mask_wgs > 0) ? 1 : per;
+        const dim3 grid((n_grp + per - 1) / per, a.n_obj);
         if (s16)
             hipLaunchKernelGGL(mask_frame_kernel<ROFT_FLOW_S16C2>, grid, dim3(kFrameThreads), (uint32_t)lds, s, a, t, frames_between, flow_aided,
-                               min_per, margin, (int)win_cap);
+                               per, margin, (int)win_cap);
         else
             hipLaunchKernelGGL(mask_frame_kernel<ROFT_FLOW_F32C2>, grid, dim3(kFrameThreads), (uint32_t)lds, s, a, t, frames_between, flow_aided,
-                               min_per, margin, (int)win_cap);
+                               per, margin, (int)win_cap);
         ++launches;
     }
     const size_t lds_gen = ((size_t)std::min(n_grp, kGeneralList) * 4 + 15) & ~(size_t)15;

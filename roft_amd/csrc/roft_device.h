@@ -204,10 +204,6 @@ struct EngineArrays {
     int slot_new;            // plane slots receiving the masks ingested by this batch: slot_new + frame of the batch
     int slot_prev0;          // ring slot of the mask BEFORE frame 0 of the batch (frame t reads slot_prev0 + t, mod the ring:
                              // the flow measurement starts its plane loads without waiting for the control block), -1: unknown
-    // [n_obj][kPlaneSlotsTotal] first / last non-zero 32-bit word of every plane slot's content (a superset; SlotSpan below), kept
-    // by the kernels that write planes: the mask frames lay their bands over the source's span instead of the whole image
-    // and zero only what a slot's last content touched.  nullptr: every span is the whole plane (ROFT_MASK_SPANS=0).
-    int2* slot_span;
     unsigned* mask_general;  // [n_obj] bit t: frame t of the batch is left to mask_general_kernel (three-valued source);
                              // set by the frame kernels, read and cleared by mask_general_kernel
     int32_t* map;            // [n_obj][W*H] scatter map of the general (non-binary) mask path, all-zero between frames
@@ -356,17 +352,6 @@ __device__ inline int next_fbuf(const FrameCtrl& c, int fbuf_n, int new_count, i
     return (mode == 2) ? 0 : n;
 }
 
-// Span of a plane slot's non-zero words, stored so that zero-filled memory is the EMPTY span and both ends grow by atomicMax:
-// x = kSpanBias - first word, y = last word + 1.
-constexpr int kSpanBias = 0x7fffffff;
-struct SlotSpan { int lo, hi; };   // words, inclusive; empty: lo > hi
-__device__ inline SlotSpan span_decode(int2 v) { SlotSpan s; s.lo = kSpanBias - v.x; s.hi = v.y - 1; return s; }
-__device__ inline void span_add(int2* s, int lo, int hi)
-{
-    atomicMax(&s->x, kSpanBias - lo);
-    atomicMax(&s->y, hi + 1);
-}
-
 __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, int slot, int which)
 {
     return (((size_t)obj * kPlaneSlotsTotal + slot) * 2 + which) * a.plane_words;
@@ -374,8 +359,8 @@ __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, i
 
 // frame t's new masks -> plane slot slot_new + t, their pixel counts -> mrec row t + 1 (zeroed before: mask_reset_tables)
 void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s, hipEvent_t stop = nullptr);
-// Zeroes what the ingest kernels accumulate into: the counters of mrec rows 1 .. T and the spans of the batch's ingest slots
-// (mask_general is cleared by its only reader, mask_general_kernel: this reset may run while the chain before still sets bits).
+// Zeroes what the ingest kernels accumulate into: the counters of mrec rows 1 .. T (mask_general is cleared by its only
+// reader, mask_general_kernel: this reset may run while the chain before still sets bits).
 // (Inside the engine the control block upload kernel does this; the operator-level entry points call it.)
 void launch_mask_reset(const EngineArrays& a, hipStream_t s);
 __device__ inline void mask_reset_tables(const EngineArrays& a, size_t i)   // thread i of a grid of >= (T + 1) * n_obj threads
@@ -384,8 +369,6 @@ __device__ inline void mask_reset_tables(const EngineArrays& a, size_t i)   // t
         MaskRec& r = a.mrec[(size_t)a.n_obj + i];
         r.new_count = 0;
         r.new_ones = 0;
-        // (the ingest slots of this batch's parity: thread i <-> frame i / n_obj, object i % n_obj)
-        if (a.slot_span) a.slot_span[(i % a.n_obj) * kPlaneSlotsTotal + a.slot_new + i / a.n_obj] = make_int2(0, 0);
     }
 }
 // Mask chain of the batch (after the reset and the ingest of its new masks): one launch per frame (binary masks; many small
