@@ -255,12 +255,13 @@ void clear_ctrl(FrameCtrl& c)
 // through an SDMA copy with its cross-engine signalling.
 // Control blocks of a batch: pinned host staging -> device, and the reset of what the batch's mask chain accumulates
 // into (ingest counters, the bits of the frames left to mask_general_kernel) on the way.  (a.ctrl, a.mrec: this batch's.)
-__global__ void ctrl_upload_kernel(const uint4* __restrict__ src, EngineArrays a, size_t n16)
+__global__ void ctrl_upload_kernel(const uint4* __restrict__ src, EngineArrays a, size_t n16, int reset)
 {
     uint4* dst = reinterpret_cast<uint4*>(a.ctrl);
     const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = i0; i < n16; i += stride) dst[i] = src[i];
-    for (size_t i = i0; i < (size_t)(a.T + 1) * a.n_obj; i += stride) roft::mask_reset_tables(a, i);
+    if (reset)
+        for (size_t i = i0; i < (size_t)a.T * a.n_obj; i += stride) roft::mask_reset_tables(a, i);
 }
 
 // Diagnostics (roft_debug_probe_streams): a dispatch that cannot be placed completely keeps its hardware queue busy until its
@@ -381,6 +382,7 @@ struct roft_engine {
     hipEvent_t ev_up[kBatchRing] = {};     // uploads of the batch on the device
     hipEvent_t ev_ctrl[kBatchRing] = {};   // FrameCtrl blocks of the batch on the device (and the mask chain of the batch before)
     hipEvent_t ev_mask[kBatchRing] = {};   // mask chain kernel of the batch complete
+    hipEvent_t ev_part[kBatchRing] = {};   // the masks of the batch's frames 0 .. T - 2 complete (what its flow measurements read)
     hipEvent_t ev_prep[kBatchRing] = {};   // control blocks + ingested masks of the batch on the device (prepared on the upload stream)
     hipEvent_t ev_feat[kBatchRing] = {};   // features of the batch complete
     hipEvent_t ev_vel[kBatchRing] = {};    // twists of the batch complete
@@ -833,7 +835,7 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
     for (int i = 0; i < R; ++i) {
         HIP_TRY(e->dctrl[i].ensure((size_t)cfg->max_objects * e->T_max, true));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects * e->T_max));
-        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_prep[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
+        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_part[i], &e->ev_prep[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
             HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
     DevFlowFmt ff;
@@ -871,6 +873,8 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
         for (int i = 0; i < R; ++i) {
             hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->stream, nullptr, e->ev_ctrl[i], 0, flag);
             hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->stream, nullptr, e->ev_mask[i], 0, flag);
+            hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->stream, nullptr, e->ev_part[i], 0, flag);
+            HIP_TRY(hipStreamWaitEvent(e->vel_stream, e->ev_part[i], 0));
             hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->stream, nullptr, e->ev_feat[i], 0, flag);
             HIP_TRY(hipStreamWaitEvent(e->vel_stream, e->ev_mask[i], 0));
             hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->vel_stream, nullptr, e->ev_vel[i], 0, flag);
@@ -962,7 +966,7 @@ int roft_engine_destroy(roft_engine* e)
     for (hipStream_t s : {e->stream, e->vel_stream, e->pose_stream[0], e->pose_stream[1], e->up_stream})
         if (s) (void)hipStreamSynchronize(s);
     for (int i = 0; i < R; ++i) {
-        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_prep[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
+        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_part[i], e->ev_prep[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
             if (ev) (void)hipEventDestroy(ev);
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
     }
@@ -1565,7 +1569,7 @@ static int step_batch(roft_engine* e)
         // the host call of a hipEventRecord behind it.
         hipExtLaunchKernelGGL(ctrl_upload_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 64)), dim3(256), 0, sp0,
                               nullptr, (multi && (T == 1 || any_early)) ? e->ev_ctrl[slot] : nullptr, 0,
-                              reinterpret_cast<const uint4*>(e->stage[slot]), a, n16);
+                              reinterpret_cast<const uint4*>(e->stage[slot]), a, n16, 1);
         ++launches;
     }
     CHECK_LAUNCH("FrameCtrl upload");
@@ -1586,8 +1590,15 @@ static int step_batch(roft_engine* e)
     HP_MARK(e, 3, hp_t);
     // ---- mask chain: every object's masks frame after frame
     tmark(e, nullptr, 0);
+    // In a burst the velocity chain is released when the masks its flow measurements read are complete -- frames 0 .. T - 2: the
+    // measurement of frame t is taken inside the mask of frame t - 1 --, one mask frame (the one that chases a delivered mask
+    // through six flows, the longest) before the chain ends; the features kernel behind the velocity filter waits for the
+    // chain's end.  Not in the steady state (a function of the batch index): latency buys nothing there, and the event costs the
+    // mask stream -- the longest serial chain -- one more small launch.
+    static const int part_env = getenv("ROFT_MASK_PART_GATE") ? atoi(getenv("ROFT_MASK_PART_GATE")) : 1;   // (experiments: 0 never, 2 always)
+    const bool part_gate = multi && T > 1 && (part_env == 2 || (part_env == 1 && !steady));
     launches += launch_mask_chain(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, e->new_mask_frames, s,
-                                  (multi && !full) ? e->ev_mask[slot] : nullptr);
+                                  (multi && !full) ? e->ev_mask[slot] : nullptr, part_gate ? e->ev_part[slot] : nullptr);
     CHECK_LAUNCH("mask chain");
     tmark(e, "mask_chain", 0);
     if (multi && full) { HIP_TRY(hipEventRecord(e->ev_mask[slot], s)); ++evops; }
@@ -1610,7 +1621,7 @@ static int step_batch(roft_engine* e)
     // ---- velocity chain: the measurement of frame k needs the control blocks and the mask planes of frame k-1 --
     //      the previous batch's for a one-frame batch (ordered by the upload, which follows that batch's mask chain),
     //      this batch's mask chain otherwise
-    if (multi) { HIP_TRY(hipStreamWaitEvent(sv, T == 1 ? e->ev_ctrl[slot] : e->ev_mask[slot], 0)); ++evops; }
+    if (multi) { HIP_TRY(hipStreamWaitEvent(sv, T == 1 ? e->ev_ctrl[slot] : (part_gate ? e->ev_part[slot] : e->ev_mask[slot]), 0)); ++evops; }
     const int radius = (int)(size_t)e->cfg.subsampling_radius;
     {
         // the roofline kernel is timed by a start / stop event pair on its own dispatch: its duration as rocprofv3
@@ -1653,6 +1664,7 @@ static int step_batch(roft_engine* e)
     e->skf_total += (unsigned long long)a.n_obj;   // (only once the launch is known to be enqueued: the lanes' gates wait for this count)
     tmark(e, "skf_chain", 2);
     if (feat_last) {
+        if (part_gate) { HIP_TRY(hipStreamWaitEvent(sv, e->ev_mask[slot], 0)); ++evops; }   // (the planes of the batch's last frame)
         launch_features(a, sv, !full ? e->ev_vel[slot] : nullptr);
         ++launches;
         CHECK_LAUNCH("features");
@@ -1713,7 +1725,8 @@ static int step_batch(roft_engine* e)
                 // CUs to the chains; 64 objects: +5 %, and -2.5 % if a 20-frame burst did the same).  The likelihood sums are
                 // exact, so the band count changes no result.
                 OutlierLaunchOpts oo;
-                if (e->cfg.outlier_bands_per_alternative == 0 && steady) oo.parts = -2;   // (-d: the automatic count / d)
+                static const int steady_parts_env = getenv("ROFT_OUTLIER_STEADY_DIV") ? atoi(getenv("ROFT_OUTLIER_STEADY_DIV")) : 2;   // (experiments)
+                if (e->cfg.outlier_bands_per_alternative == 0 && steady && steady_parts_env > 1) oo.parts = -steady_parts_env;   // (-d: the automatic count / d)
                 launch_outlier(a, lin, sp, nullptr, &oo);
                 ++launches;
                 CHECK_LAUNCH("outlier rejection");

@@ -698,7 +698,8 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
     }
 }
 
-int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s, hipEvent_t stop)
+int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s, hipEvent_t stop,
+                      hipEvent_t stop_early)
 {
     const int n_grp = a.cam.W * a.cam.H / 64;
     // Groups per workgroup.  Automatic: ~3 image rows' worth of pixels more than a band of 16 rows at 640 pixels -- a workgroup
@@ -721,6 +722,16 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
     }
     int launches = 0;
     const bool s16 = a.ffmt.type == ROFT_FLOW_S16C2;
+    // the frames of objects with three-valued masks (none, normally): one workgroup per object behind the frame kernels
+    auto launch_general = [&](hipEvent_t ev) {
+        const size_t lds_gen = ((size_t)std::min(n_grp, kGeneralList) * 4 + 15) & ~(size_t)15;
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_general_kernel<ROFT_FLOW_S16C2>), kGeneralList * 4 + 16);
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_general_kernel<ROFT_FLOW_F32C2>), kGeneralList * 4 + 16);
+        if (s16)
+            hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_S16C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, ev, 0, a);
+        else
+            hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_F32C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, ev, 0, a);
+    };
     for (int t = 0; t < a.T; ++t) {
         const bool fresh = (new_mask_frames >> t) & 1u;
         const int per = per_for(fresh);
@@ -739,14 +750,12 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
             hipLaunchKernelGGL(mask_frame_kernel<ROFT_FLOW_F32C2>, grid, dim3(kFrameThreads), (uint32_t)lds, s, a, t, frames_between, flow_aided,
                                per, margin, (int)win_cap);
         ++launches;
+        // `stop_early`: the masks up to the batch's LAST BUT ONE frame are complete -- all that the flow measurements of the batch
+        // read (frame t measures inside the mask of frame t - 1); the three-valued frames so far are brought up to date for it
+        // (the kernel clears the bits it has served, the last frame sets its own again)
+        if (stop_early && t == a.T - 2) { launch_general(stop_early); ++launches; }
     }
-    const size_t lds_gen = ((size_t)std::min(n_grp, kGeneralList) * 4 + 15) & ~(size_t)15;
-    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_general_kernel<ROFT_FLOW_S16C2>), kGeneralList * 4 + 16);
-    (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_general_kernel<ROFT_FLOW_F32C2>), kGeneralList * 4 + 16);
-    if (s16)
-        hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_S16C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, stop, 0, a);
-    else
-        hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_F32C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, stop, 0, a);
+    launch_general(stop);
     return launches + 1;
 }
 

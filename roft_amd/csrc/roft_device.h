@@ -375,7 +375,8 @@ __device__ inline void mask_reset_tables(const EngineArrays& a, size_t i)   // t
 // workgroups per object, nothing persistent) and one kernel for the frames of objects with three-valued masks.
 // new_mask_frames: bit t = some object receives a mask in frame t (those frames are split finer).  Returns the number of
 // launches.
-int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s, hipEvent_t stop = nullptr);
+int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided, unsigned new_mask_frames, hipStream_t s, hipEvent_t stop = nullptr,
+                      hipEvent_t stop_early = nullptr);   // stop_early: completes with the masks of frames 0 .. T - 2
 void launch_planes_to_mask(const uint32_t* nz, const uint32_t* ob, int npix, uint8_t* mask, hipStream_t s);
 // `stop` / `start` (optional): HIP events bound to the kernel's own dispatch (hipExtLaunchKernelGGL) -- they complete
 // with the kernel, without the extra barrier packet and host call of a hipEventRecord behind it.
