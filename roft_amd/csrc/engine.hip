@@ -1556,9 +1556,12 @@ static int step_batch(roft_engine* e)
     //      burst the mask stream is not behind, and the event between the two streams is one more hop on the first batches'
     //      critical path -- measured, one box: 120 steps +1.5 %; 20 steps -5 % and 8 objects -5 % if bursts did the same.
     //      (Rounds 3 - 4 measured the same idea 3 % slower at 240 steps: the pose lanes were the bottleneck then.)
-    //      ROFT_PREP_AHEAD = 0 never, 2 always.
+    //      And only when the device is full (more than one object per eight CUs): with fewer objects a batch is a chain of
+    //      latencies at every load and the mask stream is never the longest one (60 steps, 16 / 32 objects: 5.2e5 / 9.4e5 with
+    //      the preparation ahead in steady batches, 5.8e5 / 1.02e6 without).
+    //      ROFT_PREP_AHEAD = 0 never, 2 always, 3 in every steady batch.
     static const int prep_env = getenv("ROFT_PREP_AHEAD") ? atoi(getenv("ROFT_PREP_AHEAD")) : 1;   // (experiments)
-    const bool prep = multi && T > 1 && (prep_env == 2 || (prep_env == 1 && steady)) && e->up_stream != s;
+    const bool prep = multi && T > 1 && (prep_env == 2 || (prep_env == 3 && steady) || (prep_env == 1 && steady && !cus_to_spare)) && e->up_stream != s;
     hipStream_t sp0 = prep ? e->up_stream : s;
     if (multi && e->had_uploads && !prep) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }   // (prep: same stream as the uploads)
     if (prep && e->batch_counter >= 2) { HIP_TRY(hipStreamWaitEvent(sp0, e->ev_mask[(slot + R - 2) % R], 0)); ++evops; }
@@ -1594,9 +1597,11 @@ static int step_batch(roft_engine* e)
     // measurement of frame t is taken inside the mask of frame t - 1 --, one mask frame (the one that chases a delivered mask
     // through six flows, the longest) before the chain ends; the features kernel behind the velocity filter waits for the
     // chain's end.  Not in the steady state (a function of the batch index): latency buys nothing there, and the event costs the
-    // mask stream -- the longest serial chain -- one more small launch.
-    static const int part_env = getenv("ROFT_MASK_PART_GATE") ? atoi(getenv("ROFT_MASK_PART_GATE")) : 1;   // (experiments: 0 never, 2 always)
-    const bool part_gate = multi && T > 1 && (part_env == 2 || (part_env == 1 && !steady));
+    // mask stream -- the longest serial chain -- one more small launch.  And only with CUs to spare (at most one object per eight
+    // CUs): with 64 objects the flow measurement then runs NEXT to the longest mask frame instead of behind it and takes 48 us
+    // instead of 30 for no gain in the window (1.084 / 1.072e6), while 16 objects gain 5 - 9 %.
+    static const int part_env = getenv("ROFT_MASK_PART_GATE") ? atoi(getenv("ROFT_MASK_PART_GATE")) : 1;   // (experiments: 0 never, 2 always, 3 in every burst batch)
+    const bool part_gate = multi && T > 1 && (part_env == 2 || (part_env == 3 && !steady) || (part_env == 1 && !steady && cus_to_spare));
     launches += launch_mask_chain(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, e->new_mask_frames, s,
                                   (multi && !full) ? e->ev_mask[slot] : nullptr, part_gate ? e->ev_part[slot] : nullptr);
     CHECK_LAUNCH("mask chain");

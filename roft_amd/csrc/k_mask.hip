@@ -548,6 +548,7 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
     // user is kPlaneSlots frames back)
     const size_t sh0 = (size_t)2 * g0, sh_n = (size_t)2 * (g1 - g0);   // this workgroup's share of a plane, in words
     plane_fill(a.planes + plane_offset(a, obj, (c.slot_cur + 1) % kPlaneSlots, 1) + sh0, 0u, sh_n);
+    MTICK(5);
     const uint32_t* src = a.planes + plane_offset(a, obj, r.src_slot, 1);
     uint32_t* dst = a.planes + plane_offset(a, obj, c.slot_cur, 1);
     if (!r.src_binary) {
@@ -565,6 +566,7 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
         plane_fill(dst + sh0, ~0u, sh_n);
         return;
     }
+    MTICK(6);
     const ChaseGeo geo = make_chase_geo(a.cam, a.ffmt);
     OrTarget tgt;
     tgt.win = (ROFT_LDS uint32_t*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(ROFT_LDS uint32_t*)s_win);
@@ -586,6 +588,7 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
             if (tid == 0) S.n_list = 0;
             __syncthreads();
         }
+        MTICK(7);
         const bool ne = ww != 0ull;
         const unsigned long long b = __ballot(ne);
         int base = 0;

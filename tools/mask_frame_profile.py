@@ -20,7 +20,7 @@ dev = torch.device("cuda", 0)
 cam = synth.Camera.shape_a()
 streams = [synth.make_stream(4000 + i, n, cam, flow_type=synth.FLOW_F32C2, device=dev) for i in range(n_obj)]
 eng = rb.make_engine(streams)
-names = {4: "ctrl+words landed", 0: "decided", 1: "listed", 2: "walked", 3: "flushed"}
+names = {4: "ctrl+words landed", 0: "decided", 5: "zero issued", 6: "branches", 7: "loop", 1: "listed", 2: "walked", 3: "flushed"}
 for k in range(n):
     frames = []
     for st in streams:
@@ -40,7 +40,7 @@ for k in range(n):
     t0 = ((1 << 62) - r[:, 8]).min()
     if k >= 2:
         print("frame %2d%s: " % (k, " (new mask)" if streams[0].mask_delivery[k] >= 0 else "") +
-              ", ".join("%s %.1f" % (names[i], (r[:, i].max() - t0) / 100.0) for i in (4, 0, 1, 2, 3)) +
+              ", ".join("%s %.1f" % (names[i], (r[:, i].max() - t0) / 100.0) for i in (4, 0, 5, 6, 7, 1, 2, 3)) +
               " | first wg in -> last start %.1f us" % ((((1 << 62) - r[:, 8]).max() - t0) / 100.0))
     # reset the stamps
 
