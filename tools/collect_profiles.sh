@@ -52,10 +52,10 @@ ROFT_BENCH_DEVICE=0 ROFT_BENCH_BACKEND=gloo timeout 600 python -m torch.distribu
 timeout 300 python tools/live_latency.py --out $O/live_latency.json > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernel stats + timeline of the driver-shaped run, chains overlapping
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --windows 1 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 > $O/bench_under_rocprof.json 2> /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --windows 1 --k1-windows 1 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 > $O/bench_under_rocprof.json 2> /dev/null
 python3 $R/tools/prof_summary.py stats $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv
 # the roofline kernel over exactly the launches that bench.py's event pairs time in that run: --windows 1 = window 0 (2 warm-up
-# batches (frames 0 | 1 - 4) + 4 timed), then the instrumented window (2 warm-up batches + 4 TIMED: launches 8 .. 11), then the
+# batches (frames 0 | 1 - 4) + 4 timed), then ONE instrumented window (--k1-windows 1; 2 warm-up batches + 4 TIMED: launches 8 .. 11), then the
 # breakdown frames:
 # compare with roofline.avg_launch_us of bench_under_rocprof.json
 python3 $R/tools/prof_summary.py window $O/stats/*/*kernel_trace.csv flow_measure_kernel 8 4 > $O/k1_timed_launches_under_rocprof.txt
