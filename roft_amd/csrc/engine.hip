@@ -434,6 +434,9 @@ struct roft_engine {
     // Frame-granular hand-over velocity filter -> pose lanes (EngineArrays::handoff).  handoff_mode: 0 never, 1 while the host is
     // not throttled by the in-flight bound (bursts: the pipeline is filling or draining and latency is what counts), 2 always.
     int handoff_mode = 1;
+    // ROFT_PREP_AHEAD / ROFT_MASK_PART_GATE, read when the engine is created: 0 never, 1 the default rule (a function of batch index
+    // and object count: step_batch), 2 always, 3 whenever the batch index allows it whatever the object count.  No setting changes a result.
+    int prep_mode = 1, part_mode = 1;
     bool feat_dep_in_batch = false;        // an outlier test of the batch reads features buffered by a frame of the same batch
     unsigned long long skf_total = 0;      // velocity-filter workgroups launched so far (the value the lanes' gates wait for)
     bool vel_used[kBatchRing] = {};        // the batch's velocity chain ended with ev_vel (wait_batch waits for it as well)
@@ -896,6 +899,8 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
         for (int l = 0; l < kNumLin; ++l) HIP_TRY(hipStreamSynchronize(e->pose_stream[l]));
     }
     if (const char* hm = getenv("ROFT_HANDOFF")) e->handoff_mode = atoi(hm);
+    if (const char* pm = getenv("ROFT_PREP_AHEAD")) e->prep_mode = atoi(pm);
+    if (const char* pm = getenv("ROFT_MASK_PART_GATE")) e->part_mode = atoi(pm);
     // A tool that lets only ONE kernel run at a time (rocprofv3 --pmc: counter collection serialises the dispatches) cannot run a
     // lane next to the velocity filter it waits for -- the runtime's stream-wait itself is a kernel that spins: off under it.
     else if (getenv("ROCPROF_COUNTER_COLLECTION")) e->handoff_mode = 0;
@@ -1560,7 +1565,7 @@ static int step_batch(roft_engine* e)
     //      latencies at every load and the mask stream is never the longest one (60 steps, 16 / 32 objects: 5.2e5 / 9.4e5 with
     //      the preparation ahead in steady batches, 5.8e5 / 1.02e6 without).
     //      ROFT_PREP_AHEAD = 0 never, 2 always, 3 in every steady batch.
-    static const int prep_env = getenv("ROFT_PREP_AHEAD") ? atoi(getenv("ROFT_PREP_AHEAD")) : 1;   // (experiments)
+    const int prep_env = e->prep_mode;
     const bool prep = multi && T > 1 && (prep_env == 2 || (prep_env == 3 && steady) || (prep_env == 1 && steady && !cus_to_spare)) && e->up_stream != s;
     hipStream_t sp0 = prep ? e->up_stream : s;
     if (multi && e->had_uploads && !prep) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }   // (prep: same stream as the uploads)
@@ -1600,7 +1605,7 @@ static int step_batch(roft_engine* e)
     // mask stream -- the longest serial chain -- one more small launch.  And only with CUs to spare (at most one object per eight
     // CUs): with 64 objects the flow measurement then runs NEXT to the longest mask frame instead of behind it and takes 48 us
     // instead of 30 for no gain in the window (1.084 / 1.072e6), while 16 objects gain 5 - 9 %.
-    static const int part_env = getenv("ROFT_MASK_PART_GATE") ? atoi(getenv("ROFT_MASK_PART_GATE")) : 1;   // (experiments: 0 never, 2 always, 3 in every burst batch)
+    const int part_env = e->part_mode;   // (0 never, 2 always, 3 in every burst batch)
     const bool part_gate = multi && T > 1 && (part_env == 2 || (part_env == 3 && !steady) || (part_env == 1 && !steady && cus_to_spare));
     launches += launch_mask_chain(a, e->cfg.mask_frames_between, e->cfg.flow_aided_segmentation, e->new_mask_frames, s,
                                   (multi && !full) ? e->ev_mask[slot] : nullptr, part_gate ? e->ev_part[slot] : nullptr);

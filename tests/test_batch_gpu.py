@@ -257,3 +257,25 @@ def test_outlier_bands_per_alternative_change_nothing():
                     assert np.array_equal(a, b), (split, bands)
     finally:
         L.lib().roft_debug_outlier_split(-1)
+
+
+def test_preparation_ahead_and_early_velocity_gate_change_nothing(monkeypatch):
+    """ROFT_PREP_AHEAD (control blocks, counter reset and ingest of a batch on the upload stream, behind the mask chain two batches
+    back) and ROFT_MASK_PART_GATE (velocity chain released behind the batch's last-but-one mask frame; the general-mask kernel runs
+    twice per batch then): the engine applies them by batch index and object count -- here every setting is forced, over enough
+    batches for the steady state (the sixth batch on), on streams with a three-valued mask, dropped poses, a missing flow frame and
+    an empty delivered mask -- and rows and masks stay bit for bit the same."""
+    n = 66
+    dev = [util.to_device(st) for st in awkward_streams(n)]
+    monkeypatch.setenv("ROFT_PREP_AHEAD", "0")
+    monkeypatch.setenv("ROFT_MASK_PART_GATE", "0")
+    ref, ref_masks, _ = util.run_engine_logged(make_engine, dev, n, T=6)
+    for prep, part in (("2", "0"), ("0", "2"), ("2", "2"), ("3", "3"), ("1", "1")):
+        monkeypatch.setenv("ROFT_PREP_AHEAD", prep)
+        monkeypatch.setenv("ROFT_MASK_PART_GATE", part)
+        for kw in (dict(T=6), dict(splits=[3, 1, 8, 5, 2])):
+            got, masks, _ = util.run_engine_logged(make_engine, dev, n, **kw)
+            for x, y in zip(ref, got):
+                assert np.array_equal(x, y), (prep, part, kw)
+            for x, y in zip(ref_masks, masks):
+                assert np.array_equal(x, y), (prep, part, kw)
