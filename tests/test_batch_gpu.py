@@ -126,9 +126,12 @@ def test_batch_size_is_checked_and_a_failed_submit_consumes_nothing():
         assert np.array_equal(x, y)
 
 
-def test_host_buffers_may_be_reused_when_submit_returns():
+@pytest.mark.parametrize("prep", ["1", "2"])
+def test_host_buffers_may_be_reused_when_submit_returns(prep, monkeypatch):
     """roft_frame_input: HOST buffers are copied before the submit call returns -- a live caller that refills its one
-    pinned capture buffer right after the call must get the same trajectory."""
+    pinned capture buffer right after the call must get the same trajectory.  (prep = 2: every batch prepared on the upload
+    stream, behind the copies of its own inputs -- ROFT_PREP_AHEAD.)"""
+    monkeypatch.setenv("ROFT_PREP_AHEAD", prep)
     n = 20
     st = util.stream(730, n, scale=2, device="cuda")
     dev = util.to_device(st)
