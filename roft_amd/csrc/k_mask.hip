@@ -151,7 +151,10 @@ void launch_mask_reset(const EngineArrays& a, hipStream_t s)
 // frame: each of them filled the register file of its CU for the whole batch -- 192 of 256 CUs held by a latency-bound
 // kernel, half of the chip's CU time, DESIGN.md section 5.  A workgroup here is four waves with a few KB of LDS: it fits
 // next to the filters' workgroups and is gone after a few microseconds.)
-constexpr int kFrameThreads = 256;
+#ifndef ROFT_FRAME_THREADS
+#define ROFT_FRAME_THREADS 256
+#endif
+constexpr int kFrameThreads = ROFT_FRAME_THREADS;
 constexpr int kFrameWaves = kFrameThreads / 64;
 // (64-pixel groups whose walks through the flows are in flight together in one wave -- chase_groups' NCH: a pixel's
 //  walk is a chain of dependent loads, the chains of different groups are independent)
@@ -398,6 +401,80 @@ __device__ __forceinline__ void walk_single(const ChaseGeo g, const uint32_t* li
     }
 }
 
+// The same walk for image widths that are multiples of 64 (a 64-pixel group never straddles two rows) with the bookkeeping of
+// a group on the SCALAR unit.  walk_single spends ~100 vector instructions per group -- list entry and plane words fetched from
+// LDS and broadcast group by group, the pixel's row and column, the element's offset and the 64-bit shift that isolates the
+// lane's bit recomputed per lane -- and the walk of a frame is bound by exactly that: stamps inside the kernel put the
+// processing of a round of twelve groups at 2.8 us against 1.8 us for the round trip that fetched their flow.  Here a wave
+// reads its (up to 64) list entries and plane words ONCE, one entry per lane, and takes each group's values with v_readlane:
+// row, column, element offset, the clearing of mask(0,0) and the row / column as floats are wave-uniform; what is left per lane
+// is the load, two float additions, the two clamped conversions, the bounds and bit tests and the OR.  Same arithmetic on the same
+// values, operation by operation: (float)(x0 + lane) = (float)x0 + (float)lane exactly (integers below 2^24).
+template <int FT, int MODE, int NW>
+__device__ __forceinline__ void walk_single_aligned(const ChaseGeo g, const uint32_t* list_, const uint2* words_, int n_list, bool clear00,
+                                                    const void* flow, const OrTarget tgt)
+{
+    static_assert(MODE == 1 || MODE == 2, "power-of-two grid and scale");
+    constexpr int NCH = kSingleWalks;
+    const ROFT_LDS uint32_t* const list = (const ROFT_LDS uint32_t*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(uint32_t)(uintptr_t)(const ROFT_LDS uint32_t*)list_);
+    const ROFT_LDS uint32_t* const words = (const ROFT_LDS uint32_t*)(uintptr_t)(uint32_t)__builtin_amdgcn_readfirstlane(
+        (int)(uint32_t)(uintptr_t)(const ROFT_LDS uint32_t*)reinterpret_cast<const uint32_t*>(words_));
+    const int W = g.W, H = g.H;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    constexpr uint32_t elem = (FT == ROFT_FLOW_S16C2) ? 4u : 8u;
+    const int sh = (MODE == 2) ? 0 : __builtin_ctz((unsigned)g.grid);
+    const unsigned long long fl_bits = (unsigned long long)flow;
+    const ROFT_GLOBAL unsigned char* const fl = (const ROFT_GLOBAL unsigned char*)(
+        ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fl_bits >> 32)) << 32) |
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)fl_bits));
+    // per-lane constants
+    const uint32_t lane_off = (uint32_t)(lane >> sh) * elem;          // the lane's flow element relative to the group's first
+    const uint32_t m_lo = lane < 32 ? 1u << lane : 0u, m_hi = lane < 32 ? 0u : 1u << (lane - 32);   // the lane's bit of a group's two words
+    const float lane_f = (float)lane;
+    // this wave's entries: w, w + NW, ... -- at most 64 of them (a chunk lists at most kFrameThreads groups)
+    const int my_e = wave + lane * NW;
+    uint32_t my_yx = 0u, my_lo = 0u, my_hi = 0u;
+    if (my_e < n_list) { my_yx = list[my_e]; my_lo = words[2 * my_e]; my_hi = words[2 * my_e + 1]; }
+    const int n_mine = n_list > wave ? min(64, (n_list - wave + NW - 1) / NW) : 0;   // (wave-uniform)
+    for (int u0 = 0; u0 < n_mine; u0 += NCH) {
+        uint2 raw[NCH];
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            raw[u] = make_uint2(0u, 0u);
+            if (u0 + u < n_mine) {   // (wave-uniform)
+                const uint32_t yx = (uint32_t)__builtin_amdgcn_readlane((int)my_yx, u0 + u);
+                const uint32_t y0 = yx >> 16, x0 = yx & 0xFFFFu;
+                const uint32_t off = ((y0 >> sh) * (uint32_t)g.cols + (x0 >> sh)) * elem;   // (scalar unit)
+                const ROFT_GLOBAL unsigned char* p = fl + off;
+                if (FT == ROFT_FLOW_S16C2) {
+                    raw[u] = make_uint2(*(const ROFT_GLOBAL uint32_t*)(p + lane_off), 0u);
+                } else {
+                    const unsigned long long w = *(const ROFT_GLOBAL unsigned long long*)(p + lane_off);
+                    raw[u] = make_uint2((uint32_t)w, (uint32_t)(w >> 32));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            if (u0 + u < n_mine) {
+                const uint32_t yx = (uint32_t)__builtin_amdgcn_readlane((int)my_yx, u0 + u);
+                uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)my_lo, u0 + u);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)my_hi, u0 + u);
+                if (clear00 && yx == 0u) lo &= ~1u;                      // mask_.at<uchar>(0,0) = 0
+                const float x0f = (float)(int)(yx & 0xFFFFu), y0f = (float)(int)(yx >> 16);   // (wave-uniform)
+                float dx, dy;
+                if (FT == ROFT_FLOW_S16C2) { dx = (float)(short)(raw[u].x & 0xFFFFu); dy = (float)(short)(raw[u].x >> 16); }
+                else { dx = __uint_as_float(raw[u].x); dy = __uint_as_float(raw[u].y); }
+                if (MODE == 1) { dx *= g.inv_scale; dy *= g.inv_scale; }
+                const float t_x = (x0f + lane_f) + dx, t_y = y0f + dy;
+                const int ix = trunc_clamped(t_x), iy = trunc_clamped(t_y);
+                if ((((lo & m_lo) | (hi & m_hi)) != 0u) && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H) tgt.hit(iy * W + ix);
+            }
+        }
+    }
+}
+
 // binary source: OR-scatter of the listed groups' pixels.  kBinaryWalks walks in flight per wave.
 constexpr int kBinaryWalks = 8;
 template <int FT, int NW>
@@ -405,7 +482,10 @@ __device__ __forceinline__ void propagate_binary(ChaseGeo g, const uint2* plane2
                                                  bool clear00, const void* const* flows, const OrTarget tgt, const uint2* words)
 {
     if (n_flows == 1 && words && g.mode != 0) {
-        if (g.mode == 2) walk_single<FT, 2, NW>(g, list, words, n_list, clear00, flows[0], tgt);
+        if ((g.W & 63) == 0 && n_list <= 64 * NW) {
+            if (g.mode == 2) walk_single_aligned<FT, 2, NW>(g, list, words, n_list, clear00, flows[0], tgt);
+            else walk_single_aligned<FT, 1, NW>(g, list, words, n_list, clear00, flows[0], tgt);
+        } else if (g.mode == 2) walk_single<FT, 2, NW>(g, list, words, n_list, clear00, flows[0], tgt);
         else walk_single<FT, 1, NW>(g, list, words, n_list, clear00, flows[0], tgt);
         return;
     }
@@ -493,8 +573,11 @@ __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskR
 #define MTICK(i) do {} while (0)
 #endif
 
+#ifndef ROFT_MASK_WPE
+#define ROFT_MASK_WPE 4   // (experiments: 7 forces 72 registers -- and 36 bytes of scratch in the multi-flow walk)
+#endif
 template <int FT>
-__global__ __launch_bounds__(kFrameThreads) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ __launch_bounds__(kFrameThreads) __attribute__((amdgpu_waves_per_eu(ROFT_MASK_WPE, 8)))
 void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided, int grp_per_wg, int margin, int win_cap)
 {
 #ifdef ROFT_MASK_PROFILE
