@@ -1698,13 +1698,15 @@ static int step_batch(roft_engine* e)
         }
         if (!e->lin_any[lin]) continue;
         const int which = lin == 0 ? 1 : 3;
+        // (an early lane's OUTLIER TEST waits for the velocity chain of the batch before -- its features kernel: the sets this
+        //  batch's tests read were buffered there or earlier; the pose step in front of the test needs none of that and starts
+        //  behind the control blocks alone: the features kernel runs ~35 us behind the velocity filter's last twist)
+        int wait_prev_vel = -1;
         if (multi && early_lane[lin]) {
-            // behind the batch's control blocks, and behind the velocity chain of the batch BEFORE (its features kernel: the sets
-            // this batch's outlier tests read were buffered there or earlier)
             HIP_TRY(hipStreamWaitEvent(sp, e->ev_ctrl[slot], 0));
             ++evops;
             const int pb = e->batch_counter - 1;
-            if (pb >= e->completed_batches && pb >= 0 && e->vel_used[pb % R]) { HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[pb % R], 0)); ++evops; }
+            if (pb >= e->completed_batches && pb >= 0 && e->vel_used[pb % R]) wait_prev_vel = pb % R;
         } else if (multi && handoff) {
             HIP_TRY(hipStreamWaitValue64(sp, e->arr.skf_started.p, e->skf_total, hipStreamWaitValueGte, ~0ull));
             ++evops;
@@ -1737,6 +1739,7 @@ static int step_batch(roft_engine* e)
                 OutlierLaunchOpts oo;
                 static const int steady_parts_env = getenv("ROFT_OUTLIER_STEADY_DIV") ? atoi(getenv("ROFT_OUTLIER_STEADY_DIV")) : 2;   // (experiments)
                 if (e->cfg.outlier_bands_per_alternative == 0 && steady && steady_parts_env > 1) oo.parts = -steady_parts_env;   // (-d: the automatic count / d)
+                if (wait_prev_vel >= 0) { HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[wait_prev_vel], 0)); ++evops; wait_prev_vel = -1; }
                 launch_outlier(a, lin, sp, nullptr, &oo);
                 ++launches;
                 CHECK_LAUNCH("outlier rejection");
