@@ -85,7 +85,7 @@ def test_config4_64_objects_640x480_vs_oracle():
     assert n_tests >= n_obj * 3
 
 
-N5_OBJECTS, N5_FRAMES, N5_PERIOD, N5_ORACLE = 16, 3000, 60, 66
+N5_OBJECTS, N5_FRAMES, N5_PERIOD, N5_ORACLE = 16, 3000, 60, 600
 
 
 @pytest.fixture(scope="module")
@@ -94,7 +94,7 @@ def config5_streams():
 
 
 def test_config5_16_objects_1280x720_resync_outlier_vs_oracle(config5_streams):
-    """The first 66 frames (past the point where the image loop closes) of all 16 objects against the oracle."""
+    """The first 600 frames (ten times around the image loop) of all 16 objects against the oracle."""
     from oracle import binding as ob
     n = N5_ORACLE
     log, masks, _ = util.run_engine_logged(make_engine, config5_streams, n, T=6)
