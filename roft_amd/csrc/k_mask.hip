@@ -576,8 +576,8 @@ __device__ __forceinline__ MaskRec decide_frame(const MaskRec& prev, const MaskR
 #ifndef ROFT_MASK_WPE
 #define ROFT_MASK_WPE 4   // (experiments: 7 forces 72 registers -- and 36 bytes of scratch in the multi-flow walk)
 #endif
-template <int FT>
-__global__ __launch_bounds__(kFrameThreads) __attribute__((amdgpu_waves_per_eu(ROFT_MASK_WPE, 8)))
+template <int FT, int THREADS>
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(ROFT_MASK_WPE, 8)))
 void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided, int grp_per_wg, int margin, int win_cap)
 {
 #ifdef ROFT_MASK_PROFILE
@@ -591,7 +591,7 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
     static_assert(sizeof(MaskRec) == 32, "two 16-byte loads per record");
     uint32_t* s_win = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_list = s_win + win_cap;
-    uint2* s_words = reinterpret_cast<uint2*>(s_list + kFrameThreads);
+    uint2* s_words = reinterpret_cast<uint2*>(s_list + THREADS);
     const int obj = blockIdx.y, q = blockIdx.x;
     const int W = a.cam.W, H = a.cam.H, wpr = a.cam.wpr, n_grp = (W * H) >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -603,8 +603,8 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
     //      frame can read -- the last propagated mask (ring slot slot_prev0 + t inside the engine) and the mask delivered
     //      with the frame (slot_new + t; stale but valid memory when none was delivered)
     stage_ctrl(&s_c, frame_ctrl(a, t, obj));
-    if (tid >= 128 && tid < 132) {
-        const int k = tid - 128;   // 0, 1: the state after the frame before; 2, 3: this frame's counters
+    if (tid >= THREADS / 2 && tid < THREADS / 2 + 4) {
+        const int k = tid - THREADS / 2;   // 0, 1: the state after the frame before; 2, 3: this frame's counters
         const MaskRec* prev = (t == 0) ? a.mrec_carry + obj : a.mrec + (size_t)t * a.n_obj + obj;
         reinterpret_cast<uint4*>(s_rec)[k] = (k >= 2) ? reinterpret_cast<const uint4*>(a.mrec + (size_t)(t + 1) * a.n_obj + obj)[k & 1]
                                                       : reinterpret_cast<const uint4*>(prev)[k & 1];
@@ -617,8 +617,8 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
         if (pl_prev) w_prev = pl_prev[g0 + tid];
         w_new = pl_new[g0 + tid];
     }
-    if (tid == 192) { S.w00[0] = pl_prev ? pl_prev[0] : 0ull; S.w00[1] = pl_new[0]; }
-    for (int i = tid; i < win_words; i += kFrameThreads) s_win[i] = 0u;
+    if (tid == THREADS * 3 / 4) { S.w00[0] = pl_prev ? pl_prev[0] : 0ull; S.w00[1] = pl_new[0]; }
+    for (int i = tid; i < win_words; i += THREADS) s_win[i] = 0u;
     if (tid == 0) S.n_list = 0;
     __syncthreads();
     MTICK(4);
@@ -659,7 +659,7 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
     // this workgroup's non-empty groups -> list (any order: the scatter is order-free), kFrameThreads groups at a time, then
     // their walks
     const uint2* plane2 = reinterpret_cast<const uint2*>(src);
-    for (int c0 = g0; c0 < g1; c0 += kFrameThreads) {
+    for (int c0 = g0; c0 < g1; c0 += THREADS) {
         const int g = c0 + tid;
         unsigned long long ww = 0ull;
         if (g < g1) {
@@ -686,12 +686,12 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
         __syncthreads();
         MTICK(1);
         if (S.n_list > 0) ROFT_RESIDENT_AS(a, RK_MASK_FRAME);
-        propagate_binary<FT, kFrameWaves>(geo, plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, tgt, s_words);
+        propagate_binary<FT, THREADS / 64>(geo, plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, tgt, s_words);
     }
     __syncthreads();
     MTICK(2);
     // flush: the non-zero words of the window into the (zeroed) destination
-    for (int i = tid; i < win_words; i += kFrameThreads) {
+    for (int i = tid; i < win_words; i += THREADS) {
         const uint32_t v = s_win[i];
         if (v) atomicOr(&dst[win_off + i], v);
     }
@@ -803,8 +803,10 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
     };
     const size_t lds_cap = 160 * 1024 - 4096;   // (the kernel's static LDS -- control block, records, flow pointers -- is ~1.3 KB)
     {
-        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_frame_kernel<ROFT_FLOW_S16C2>), (int)lds_cap);
-        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_frame_kernel<ROFT_FLOW_F32C2>), (int)lds_cap);
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_frame_kernel<ROFT_FLOW_S16C2, kFrameThreads>), (int)lds_cap);
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_frame_kernel<ROFT_FLOW_F32C2, kFrameThreads>), (int)lds_cap);
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_frame_kernel<ROFT_FLOW_S16C2, 128>), (int)lds_cap);
+        (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_frame_kernel<ROFT_FLOW_F32C2, 128>), (int)lds_cap);
     }
     int launches = 0;
     const bool s16 = a.ffmt.type == ROFT_FLOW_S16C2;
@@ -824,17 +826,22 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
         // LDS window: the band's rows + a margin of rows above and below (pixels that fly further are ORed into the
         // destination plane directly): 16 rows for one flow step, 48 when a new mask is chased through several
         const int margin = fresh ? 48 : 16;
-        const size_t fixed = (size_t)kFrameThreads * 12;
+        // Workgroups of TWO waves on a frame that delivers a mask: its 80 bands x n_obj workgroups exceed what the device holds at once
+        // (seven per CU by wave slots at four waves: the last one starts 33 us after the first), more than half of them find no
+        // pixel and leave after one round trip, and the others chase their groups through six flows -- six dependent round trips
+        // whatever the number of waves.  Half the waves per workgroup = twice the workgroups in flight: +1 - 3 % in runs of 60 steps
+        // and more, nothing in a 20-frame burst.  (ROFT_MASK_FRESH_THREADS=256: four waves as on every other frame.)
+        static const int fresh_threads_env = getenv("ROFT_MASK_FRESH_THREADS") ? atoi(getenv("ROFT_MASK_FRESH_THREADS")) : 128;
+        const int threads = (fresh && fresh_threads_env == 128 && kFrameThreads > 128) ? 128 : kFrameThreads;
+        const size_t fixed = (size_t)threads * 12;
         size_t win_cap = ((size_t)std::min(a.cam.H, (per * 64 + a.cam.W - 1) / a.cam.W + 1 + 2 * margin) * a.cam.wpr + 1) & ~(size_t)1;
         win_cap = std::min(win_cap, ((lds_cap - fixed) / 4) & ~(size_t)1);
         const size_t lds = win_cap * 4 + fixed;
         const dim3 grid((n_grp + per - 1) / per, a.n_obj);
-        if (s16)
-            hipLaunchKernelGGL(mask_frame_kernel<ROFT_FLOW_S16C2>, grid, dim3(kFrameThreads), (uint32_t)lds, s, a, t, frames_between, flow_aided,
-                               per, margin, (int)win_cap);
-        else
-            hipLaunchKernelGGL(mask_frame_kernel<ROFT_FLOW_F32C2>, grid, dim3(kFrameThreads), (uint32_t)lds, s, a, t, frames_between, flow_aided,
-                               per, margin, (int)win_cap);
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, dim3(threads), (uint32_t)lds, s, a, t, frames_between, flow_aided, per, margin, (int)win_cap); };
+        if (threads == 128) { if (s16) go(mask_frame_kernel<ROFT_FLOW_S16C2, 128>); else go(mask_frame_kernel<ROFT_FLOW_F32C2, 128>); }
+        else if (s16) go(mask_frame_kernel<ROFT_FLOW_S16C2, kFrameThreads>);
+        else go(mask_frame_kernel<ROFT_FLOW_F32C2, kFrameThreads>);
         ++launches;
         // `stop_early`: the masks up to the batch's LAST BUT ONE frame are complete -- all that the flow measurements of the batch
         // read (frame t measures inside the mask of frame t - 1); the three-valued frames so far are brought up to date for it

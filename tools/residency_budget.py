@@ -57,10 +57,10 @@ obj_frames = float(n_obj * (n_frames - warm))
 res = {r["kernel"].split("::")[-1]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_kernel_resources.csv")))}
 plane = cam.width * cam.height // 8
 # (kernel, threads per workgroup, dynamic LDS bytes of the launch at 640x480)
-shapes = [("mask_frame_kernel<13>", 256, 4240 + 3072), ("mask_ingest_kernel", 256, 0), ("mask_general_kernel<13>", 256, 19200),
+shapes = [("mask_frame_kernel<13, 256>", 256, 4240 + 3072), ("mask_ingest_kernel", 256, 0), ("mask_general_kernel<13>", 256, 19200),
           ("flow_measure_kernel<3>", 1024, 0), ("skf_chain_kernel", 512, 0), ("features_kernel", 1024, plane), ("ukf_chain_kernel", 256, 0),
           ("outlier_fused_kernel", 1024, 98576 + 4 * (320 * 240 // 1 + 320)),
-          ("mask_frame_kernel<13> (bands without a pixel)", 256, 4240 + 3072)]
+          ("mask_frame_kernel<13, 256> (bands without a pixel)", 256, 4240 + 3072)]   # (the two-wave workgroups of the frames that deliver a mask are counted at this share too)
 w = csv.writer(sys.stdout)
 w.writerow(["kernel", "workgroups", "resident_us_total", "mean_resident_us_per_workgroup", "cu_share_of_one_workgroup", "cu_us_per_object_frame"])
 total = 0.0
