@@ -583,7 +583,7 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
 #ifdef ROFT_MASK_PROFILE
     if (threadIdx.x == 0) atomicMax((unsigned long long*)&a.state[blockIdx.y].dbg[8], (unsigned long long)((1ll << 62) - wall_clock64()));
 #endif
-    ROFT_RESIDENT(a, RK_MASK_FRAME_EMPTY);
+    ROFT_RESIDENT(a, THREADS == 128 ? RK_MASK_FRESH_EMPTY : RK_MASK_FRAME_EMPTY);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ MaskShared S;
     __shared__ FrameCtrl s_c;
@@ -685,7 +685,7 @@ void mask_frame_kernel(EngineArrays a, int t, int frames_between, int flow_aided
         }
         __syncthreads();
         MTICK(1);
-        if (S.n_list > 0) ROFT_RESIDENT_AS(a, RK_MASK_FRAME);
+        if (S.n_list > 0) ROFT_RESIDENT_AS(a, THREADS == 128 ? RK_MASK_FRESH : RK_MASK_FRAME);
         propagate_binary<FT, THREADS / 64>(geo, plane2, s_list, S.n_list, r.n_flows, r.mode == 1, S.flows, tgt, s_words);
     }
     __syncthreads();

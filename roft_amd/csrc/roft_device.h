@@ -247,7 +247,8 @@ struct EngineArrays {
 // CU residency accounting (-DROFT_RESIDENCY builds only): every workgroup adds the time between its first instruction and the end
 // of its thread 0 to its kernel's counter -- what a workgroup really occupies its share of a CU for, early exits included.
 enum ResidencyKernel { RK_MASK_FRAME = 0, RK_MASK_INGEST, RK_MASK_GENERAL, RK_FLOW_MEASURE, RK_SKF_CHAIN, RK_FEATURES, RK_UKF_CHAIN, RK_OUTLIER,
-                       RK_MASK_FRAME_EMPTY /* the workgroups of mask_frame_kernel that found no pixel in their band (counted here INSTEAD of RK_MASK_FRAME) */, RK_COUNT };
+                       RK_MASK_FRAME_EMPTY /* the workgroups of mask_frame_kernel that found no pixel in their band (counted here INSTEAD of RK_MASK_FRAME) */,
+                       RK_MASK_FRESH, RK_MASK_FRESH_EMPTY /* the same two for the two-wave workgroups of the frames that deliver a mask */, RK_COUNT };
 #ifdef ROFT_RESIDENCY
 struct ResidencyTimer {
     unsigned long long* p;

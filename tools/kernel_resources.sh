@@ -31,7 +31,7 @@ for path in sys.argv[1:]:
             cur[k.strip()] = v.strip()
             if k.strip().startswith("LDS Size"):
                 if "device" not in cur["name"] or True:
-                    print(",".join([cur["name"], cur.get("VGPRs", ""), cur.get("AGPRs", ""), cur.get("TotalSGPRs", ""),
+                    print(",".join(['"%s"' % cur["name"] if "," in cur["name"] else cur["name"], cur.get("VGPRs", ""), cur.get("AGPRs", ""), cur.get("TotalSGPRs", ""),
                                     cur.get("ScratchSize [bytes/lane]", ""), cur.get("Occupancy [waves/SIMD]", ""), cur.get("LDS Size [bytes/block]", "")]))
                 cur = None
 PY

@@ -60,14 +60,16 @@ plane = cam.width * cam.height // 8
 shapes = [("mask_frame_kernel<13, 256>", 256, 4240 + 3072), ("mask_ingest_kernel", 256, 0), ("mask_general_kernel<13>", 256, 19200),
           ("flow_measure_kernel<3>", 1024, 0), ("skf_chain_kernel", 512, 0), ("features_kernel", 1024, plane), ("ukf_chain_kernel", 256, 0),
           ("outlier_fused_kernel", 1024, 98576 + 4 * (320 * 240 // 1 + 320)),
-          ("mask_frame_kernel<13, 256> (bands without a pixel)", 256, 4240 + 3072)]   # (the two-wave workgroups of the frames that deliver a mask are counted at this share too)
+          ("mask_frame_kernel<13, 256> (bands without a pixel)", 256, 4240 + 3072),
+          # the frames that deliver a mask: two-wave workgroups, 6-row bands with a 48-row margin (window (6 + 1 + 96) x 80 bytes)
+          ("mask_frame_kernel<13, 128>", 128, 8240 + 1536), ("mask_frame_kernel<13, 128> (bands without a pixel)", 128, 8240 + 1536)]
 w = csv.writer(sys.stdout)
 w.writerow(["kernel", "workgroups", "resident_us_total", "mean_resident_us_per_workgroup", "cu_share_of_one_workgroup", "cu_us_per_object_frame"])
 total = 0.0
 for kid, (name, threads, dyn_lds) in enumerate(shapes):
     ticks, wgs = buf[2 * kid], buf[2 * kid + 1]
     k = res.get(name.split(" (")[0]) or res.get(name.split("<")[0]) or res.get(name + "<true>")   # (features_kernel<LDS>: the plane fits the LDS at this size)
-    waves_per_simd = max(1.0, threads / 64.0 / 4.0)
+    waves_per_simd = threads / 64.0 / 4.0   # (two-wave workgroups: half a wave per SIMD on average)
     regs = (int(k["vgprs"] or 0) + int(k["agprs"] or 0) + 7) // 8 * 8
     lds = min(160.0 * 1024.0, float(k["static_lds_bytes"] or 0) + dyn_lds)
     share = min(1.0, max(waves_per_simd / 8.0, waves_per_simd * regs / 512.0, lds / (160.0 * 1024.0)))
