@@ -138,8 +138,116 @@ def cpu_baseline_multicore(streams, n_sample, n_frames, n_objects_total):
                 mean_ms_per_object_frame=1e3 * sum(r["tracker_s"] for r in res) / frames)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The line the driver parses.  The driver keeps an 8 KB tail of stdout: the line is a fixed set of numbers and short
+# identifiers (no prose, no per-window traces), strict JSON, < 4 KB at any N.  Everything else the run measured goes
+# to a side file whose path the line names (`detail`).  tests/test_host_cpu.py::test_bench_line_is_small holds this.
+# ---------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data", "inputs", "runs", "value_cold", "speedup_vs_cpu_1core", "speedup_vs_cpu_multicore",
+             "value_pcie_inclusive", "value_pcie_inclusive_shared_scene", "value_pcie_inclusive_in_place",
+             "value_pcie_inclusive_shared_scene_in_place", "launches_per_frame", "dominant_kernel")
+_CONFIG_KEYS = ("workload", "objects_per_gpu", "objects_total", "width", "height", "batch_frames", "ranks", "backend")
+_ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_on_sample_bytes", "traffic",
+                  "traffic_over_algorithmic", "algorithmic_bytes_per_object_frame", "object_frames_per_launch",
+                  "avg_launch_us", "launches", "measured_copy_GBs", "frac_of_measured_random_sector_rate")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "cpu_model")
+
+
+def _finite(x, digits=6):
+    """Numbers of the line: finite floats rounded to `digits` significant digits, anything non-finite -> None (strict JSON)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, (float, np.floating)):
+        x = float(x)
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (digits, x))
+    if isinstance(x, np.integer):
+        return int(x)
+    if isinstance(x, dict):
+        return {k: _finite(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_finite(v, digits) for v in x]
+    return str(x)
+
+
+def headline(out, detail_path=None):
+    """The compact record of a run: a whitelist of `out`'s numbers (see the block comment above)."""
+    line = {k: out.get(k) for k in _TOP_KEYS if k in out}
+    cfg = out.get("config") or {}
+    line["config"] = {k: cfg[k] for k in _CONFIG_KEYS if k in cfg}
+    rf = out.get("roofline")
+    if rf:
+        r = {k: rf.get(k) for k in _ROOFLINE_KEYS if k in rf}
+        if rf.get("kernel_span"):
+            r["kernel_span_frac"] = rf["kernel_span"].get("frac")
+            r["kernel_span_us"] = rf["kernel_span"].get("avg_us")
+        if rf.get("alone"):
+            r["alone_frac"] = rf["alone"].get("frac")
+            r["alone_us"] = rf["alone"].get("avg_launch_us")
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    ro = out.get("roofline_other")
+    if ro:
+        line["roofline_other"] = {k: {"us": v.get("avg_us_per_launch_group"), "frac": v.get("frac_of_hbm_peak")}
+                                  for k, v in ro.items() if isinstance(v, dict)}
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = {k: cb.get(k) for k in _CPU_KEYS if k in cb} if cb else None
+    cm = out.get("cpu_baseline_multicore")
+    if cm and "value" in cm:
+        line["cpu_baseline_multicore"] = {"value": cm["value"], "cores": cm["cores"], "kind": cm.get("kind", "port")}
+    for k in ("adds_vs_cpu_ref_mm", "adds_vs_gt_mm"):
+        v = out.get(k)
+        if v:
+            line[k] = {kk: vv for kk, vv in v.items() if kk in ("mean", "max", "auc", "objects")}
+    rk = out.get("ranks")
+    if rk:
+        line["ranks"] = {"world_size": rk.get("world_size"), "seen": rk.get("ranks_seen_by_all_reduce"),
+                         "objects_per_gpu": rk.get("objects_per_gpu")}
+    ss = out.get("shared_scene")
+    if ss:
+        line["shared_scene"] = {"broadcast_MB_per_step": ss.get("broadcast_MB_per_step")}
+    lv = out.get("live_latency")
+    if lv:
+        line["live_latency_us"] = {"median": lv.get("median_us"), "p99": lv.get("p99_us")}
+    if detail_path:
+        line["detail"] = detail_path
+    line = _finite(line)
+    if line.get("cpu_baseline") and isinstance(line["cpu_baseline"].get("sample"), str):
+        line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:120]
+    return line
+
+
+def emit(out, detail_path):
+    """Full record -> `detail_path` (best effort: a read-only tree must not cost the run its line); the compact line -> stdout,
+    as the LAST line of the process."""
+    written = None
+    if detail_path:
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(_finite(out, 9), f, allow_nan=False, indent=1)
+            written = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
+        except OSError as ex:
+            sys.stderr.write("bench.py: could not write %s: %s\n" % (detail_path, ex))
+    text = json.dumps(headline(out, written), allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:   # cannot happen with the whitelist above; if it ever does, drop the optional blocks, keep the contract keys
+        slim = headline(out, written)
+        for k in ("roofline_other", "live_latency_us", "adds_vs_gt_mm", "runs", "shared_scene"):
+            slim.pop(k, None)
+        text = json.dumps(slim, allow_nan=False, separators=(",", ":"))
+    sys.stdout.flush()
+    print(text, flush=True)
+    return text
+
+
 def parse():
     p = argparse.ArgumentParser()
+    p.add_argument("--json-out", default=os.path.join(ROOT, "bench_detail.json"),
+                   help="the full record of the run (windows, batch traces, method, notes); the stdout line carries the numbers only")
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=60)
     p.add_argument("--warmup", type=int, default=12)
@@ -1125,7 +1233,7 @@ def main():
         "dominant_kernel": dominant,
         "stream_generation_s": gen_s[0],
     }
-    print(json.dumps(out))
+    emit(out, args.json_out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -287,3 +287,87 @@ def test_bench_gpus_n_starts_its_own_ranks_and_relays_their_exit_code():
     assert r.returncode != 0
     # (whichever rank reports first: the launcher stops the other one as soon as one has failed)
     assert "needs GPU" in r.stderr and ("rank 0" in r.stderr or "rank 1" in r.stderr)
+
+
+def _canned_bench_record(world, n_windows=5, n_batches=40):
+    """A bench record with every block filled the way a long run fills it (many windows, long batch traces, prose notes,
+    per-rank blocks) -- the input of bench.headline()."""
+    batch = dict(frames=8, steady=True, throttled=False, handoff=True, early_lanes=2, outlier_parts_halved=False, launches=21,
+                 submit_us=123.4, wait_us=0.1, step_us=301.2, submitted_at_ms=0.1234, done_at_ms=1.2345)
+    win = dict(value=1.0954321e6, ms_per_step=0.0584321, elapsed_ms=1.1686, elapsed_ms_this_rank=1.16, host_enqueue_ms_per_step=0.04,
+               host_cpu=3, loadavg_1min=0.5, seed_base=4000, launches_per_frame=2.7, event_ops_per_frame=1.1, batches=[batch] * n_batches)
+    rf = dict(kernel="flow_measure_kernel", bound="hbm", achieved=1514.123456, peak=8000.0, unit="GB/s", frac=0.189265432,
+              frac_on_sample_bytes=0.0751234, traffic=45.8e6, traffic_raw_counter=33.3e6, traffic_source="profiles/r06_pmc_k1.json: " + "x" * 300,
+              traffic_over_algorithmic=0.92, algorithmic_bytes_per_object_frame=155362.0, algorithmic_bytes_formula="y" * 300,
+              object_frames_per_launch=320.0, avg_launch_us=32.83, launches=12, measured_copy_GBs=5280.0,
+              frac_of_measured_random_sector_rate=0.33, note="z" * 1500,
+              kernel_span=dict(avg_us=27.1, launches=12, achieved=1830.0, frac=0.229, note="n" * 400),
+              alone=dict(avg_launch_us=18.6, launches=4, object_frames_per_launch=320.0, frac=0.279, note="n" * 300))
+    other = {k: dict(declared_bytes=1e5, per="object-frame", avg_us_per_launch_group=95.0, launch_groups=4, declared_bytes_per_launch_group=5.1e7,
+                     achieved_GBs=536.0, frac_of_hbm_peak=0.067, fetch_size_bytes_per_dispatch=14.4e6, write_size_bytes_per_dispatch=8.1e6)
+             for k in ("mask_frames", "features", "outlier_fused")}
+    other["note"] = "o" * 900
+    cpu = dict(value=659.47, unit="object-frames/s", cores=1, kind="port", sample="8 objects x 32 frames of the same 640x480 streams, " + "s" * 200,
+               cpu_model="AMD EPYC 9575F 64-Core Processor", ms_per_object_frame=1.5164)
+    out = {"metric": "tracker frames/sec per object (640x480) + ADD-S vs CPU ref", "value": 1.0954321e6, "unit": "object-frames/s",
+           "n_gpus": world, "steps": 20, "warmup": 5, "ms_per_step": 0.0584321, "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic", "value_is": "v" * 200, "runs": [1.07e6, 1.08e6, 1.0954321e6, 1.1e6, 1.11e6][:n_windows],
+           "value_min": 1.07e6, "value_max": 1.11e6, "value_first_window": 1.07e6, "host_enqueue_ms_per_step": 0.04,
+           "host_state": {"cpu": 3, "loadavg_1min": 0.5, "cpus_online": 64}, "batches": [batch] * n_batches, "windows": [win] * n_windows,
+           "instrumented_window": win, "inputs": "resident in HBM", "timed_frames_first_touch": True, "method": {"note": "m" * 2000},
+           "config": {"workload": "BASELINE config #4: 640x480, CV_32FC2 flow grid 1, 64 objects in total, 8 per GPU (sharded by object, "
+                                  "no data-path collective; result rows all-gathered over RCCL at N > 1), masks+poses at 5 fps with 6-frame delay, "
+                                  "flow-aided masks, re-sync and outlier rejection on, frames submitted in batches of at most 8",
+                      "objects_per_gpu": 64 // world, "objects_total": 64, "width": 640, "height": 480, "batch_frames": 8,
+                      "timed_batches": [4, 8, 8], "ranks": world, "backend": "nccl"},
+           "ranks": None, "shared_scene": None, "frames_per_sec_per_object": 17114.0, "launches_per_frame": 2.7, "event_ops_per_frame": 1.1,
+           "roofline": rf, "roofline_other": other, "cpu_baseline": cpu if world == 1 else None,
+           "cpu_baseline_multicore": dict(value=6492.0, cores=64, kind="port", sample="c" * 300) if world == 1 else None,
+           "speedup_vs_cpu_1core": 1660.43 if world == 1 else None, "speedup_vs_cpu_multicore": 168.7 if world == 1 else None,
+           "value_pcie_inclusive": 1.14e4, "value_pcie_inclusive_shared_scene": 2.4e5, "value_pcie_inclusive_in_place": 5.4e4,
+           "value_pcie_inclusive_shared_scene_in_place": 4.4e5, "pcie_inclusive": {"note": "p" * 800}, "value_cold": 1.083e6,
+           "cold_run": {"note": "c" * 400}, "live_latency": dict(median_us=212.0, p99_us=402.0, note="l" * 200),
+           "adds_vs_gt_mm": {"mean": 7.9, "auc": 92.1, "objects": 64, "note": "a" * 100},
+           "adds_vs_cpu_ref_mm": {"mean": 1.2e-9, "max": 6.4e-9, "objects_per_rank": [1] * world},
+           "rmse_vs_gt": {"position_cm": 0.5}, "pipeline": "q" * 400, "kernels_post_run_breakdown": {"ukf_chain": dict(total_ms=1.0, marks=3, avg_us=333.0)},
+           "dominant_kernel": "ukf_chain", "stream_generation_s": 3.2}
+    if world > 1:
+        out["ranks"] = {"world_size": world, "ranks_seen_by_all_reduce": world, "objects_per_gpu": [64 // world] * world,
+                        "first_object_of_rank": list(range(0, 64, 64 // world)),
+                        "devices": [dict(rank=r, local_rank=r, device=r, name="AMD Instinct MI355X", uuid="GPU-%032x" % r) for r in range(world)],
+                        "window_ms_per_rank": [[1.1] * n_windows] * world, "per_gpu_rate_of_the_median_window": 1.3e5, "note": "r" * 300}
+    return out
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_bench_line_is_small(world, tmp_path, capsys):
+    """The driver keeps an 8 KB tail of bench.py's stdout and parses its last line (round 5's 20.7 KB line came back as
+    `parsed: null`): the line is < 4 KB of strict JSON with the contract's keys, whatever the run recorded; the full
+    record lands in the side file the line names."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    out = _canned_bench_record(world)
+    out["roofline"]["traffic"] = float("nan")   # a non-finite number must not make the line non-strict JSON
+    detail = str(tmp_path / "bench_detail.json")
+    text = bench.emit(out, detail)
+    printed = capsys.readouterr().out.strip().splitlines()
+    assert printed[-1] == text and "\n" not in text
+    assert len(text) < bench.LINE_LIMIT, len(text)
+    line = json.loads(text, parse_constant=lambda c: pytest.fail("non-strict JSON constant " + c))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["n_gpus"] == world and line["config"]["ranks"] == world and "workload" in line["config"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(line["roofline"])
+    assert line["roofline"]["traffic"] is None
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-5
+    if world == 1:
+        assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    else:
+        assert line["ranks"]["world_size"] == world and len(line["ranks"]["objects_per_gpu"]) == world
+    full = json.load(open(detail))
+    assert len(full["windows"]) == 5 and full["method"]["note"].startswith("m")   # nothing measured is lost
+    # a tree the run cannot write to costs the side file, not the line
+    text2 = bench.emit(out, "/proc/nonexistent/bench_detail.json")
+    assert len(text2) < bench.LINE_LIMIT and "detail" not in json.loads(text2)
