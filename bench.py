@@ -164,7 +164,7 @@ def _finite(x, digits=6):
         x = float(x)
         if x != x or x in (float("inf"), float("-inf")):
             return None
-        return float("%.*g" % (digits, x))
+        return float("%.*g" % (digits, x)) if digits else x
     if isinstance(x, np.integer):
         return int(x)
     if isinstance(x, dict):
@@ -229,7 +229,7 @@ def emit(out, detail_path):
     if detail_path:
         try:
             with open(detail_path, "w") as f:
-                json.dump(_finite(out, 9), f, allow_nan=False, indent=1)
+                json.dump(_finite(out, 0), f, allow_nan=False, indent=1)   # (digits 0: as measured)
             written = os.path.relpath(detail_path, ROOT) if os.path.abspath(detail_path).startswith(ROOT) else detail_path
         except OSError as ex:
             sys.stderr.write("bench.py: could not write %s: %s\n" % (detail_path, ex))

@@ -645,9 +645,34 @@ public:
     virtual bool setProperty(const std::string& /*property*/) { return false; }
 };
 
+// bfl::LinearMeasurementModel: y_hat = H x per state column, innovation = y - y_hat (what the library's class implements, so
+// that a model only states H, y and R -- the velocity filter's measurement model, tests/ref_kit/replay.cpp's RecordedLinear)
 class LinearMeasurementModel : public MeasurementModel {
 public:
     virtual Eigen::MatrixXd getMeasurementMatrix() const = 0;
+    std::pair<bool, Data> predictedMeasure(const Eigen::Ref<const Eigen::MatrixXd>& cur_states) const override
+    {
+        const Eigen::MatrixXd H = getMeasurementMatrix();
+        if (H.cols() != cur_states.rows()) return {false, Data()};
+        Eigen::MatrixXd out(H.rows(), cur_states.cols());
+        for (std::size_t i = 0; i < H.rows(); ++i)
+            for (std::size_t c = 0; c < cur_states.cols(); ++c) {
+                double s = 0.0;
+                for (std::size_t k = 0; k < H.cols(); ++k) s += H(i, k) * cur_states(k, c);
+                out(i, c) = s;
+            }
+        return {true, Data(out)};
+    }
+    std::pair<bool, Data> innovation(const Data& predicted_measurements, const Data& measurements) const override
+    {
+        const Eigen::MatrixXd* p = any::any_cast<Eigen::MatrixXd>(&predicted_measurements);
+        const Eigen::MatrixXd* m = any::any_cast<Eigen::MatrixXd>(&measurements);
+        if (!p || !m || p->rows() != m->rows()) return {false, Data()};
+        Eigen::MatrixXd out(p->rows(), p->cols());
+        for (std::size_t i = 0; i < p->rows(); ++i)
+            for (std::size_t c = 0; c < p->cols(); ++c) out(i, c) = (*m)(i, m->cols() == p->cols() ? c : 0) - (*p)(i, c);
+        return {true, Data(out)};
+    }
 };
 
 class StateModel {

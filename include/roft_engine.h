@@ -327,7 +327,8 @@ typedef struct {
 int roft_engine_get_stats(roft_engine* e, roft_engine_stats* out);
 
 /* What the engine decided for, and the host spent on, each of the last batches (a ring of 64): a slow run explains itself.
- * The scheduling mode of a batch is a function of the batch INDEX alone: `steady` = at least <batches in flight> batches have
+ * The scheduling mode of a batch is a function of the batch INDEX, the object count and the number of engines this process holds on
+ * the device (lanes are released early only by the ONLY engine of the device: a count taken at the submit, never a timing): `steady` = at least <batches in flight> batches have
  * been stepped since the engine was last idle (creation / roft_sync / anything that reads results); bursts release the pose
  * lanes early (`handoff`, `early_lanes`) and spread an outlier test over all the CUs to spare, steady batches halve that
  * (`outlier_parts_halved`); `early_lanes` is a bit mask: 1 / 2 = pose lane 0 / 1 released behind the batch's control blocks (its

@@ -110,6 +110,10 @@ def lib():
         L.ro_tracker_step.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(FrameResult)]
         L.ro_tracker_mask.restype = C.c_void_p
         L.ro_tracker_mask.argtypes = [C.c_void_p]
+        L.ro_render_depth_mode.argtypes = [C.POINTER(Mesh), C.c_void_p, C.c_void_p, C.POINTER(Camera), C.c_int, C.c_void_p, C.c_int]
+        L.ro_tracker_shadow_render.argtypes = [C.c_void_p, C.c_int]
+        L.ro_tracker_shadow_L.restype = C.c_int
+        L.ro_tracker_shadow_L.argtypes = [C.c_void_p, C.c_void_p]
         for name in ("ro_add", "ro_adds"):
             f = getattr(L, name)
             f.restype = C.c_double
@@ -251,6 +255,18 @@ def render_depth(mesh, x, q, cam, divider):
     return tile
 
 
+RENDER_CONTRACT, RENDER_V1, RENDER_GL = 0, 1, 2
+
+
+def render_depth_mode(mesh, x, q, cam, divider, mode):
+    """The rasteriser in the arithmetic of rounds 1 - 4 (RENDER_V1) or with the numerics of the reference's GL pipeline
+    (RENDER_GL): only for bounding the distance between those and the contract (ro_render.c)."""
+    x, q = _f64(x), _f64(q)
+    tile = np.zeros((cam.height // divider, cam.width // divider), np.float32)
+    lib().ro_render_depth_mode(C.byref(mesh), _p(x), _p(q), C.byref(cam), divider, _p(tile), mode)
+    return tile
+
+
 def depth_likelihood(cam, depth, mask, tile, divider):
     depth = np.ascontiguousarray(depth, np.float32)
     mask = np.ascontiguousarray(mask, np.uint8)
@@ -299,6 +315,17 @@ class Tracker:
         if rc != 0:
             raise RuntimeError("ro_tracker_step failed: %d" % rc)
         return res
+
+    def shadow_render(self, on=True):
+        """Every outlier test also scores its alternatives on RENDER_V1 and RENDER_GL renders (shadow_L)."""
+        lib().ro_tracker_shadow_render(self._h, 1 if on else 0)
+
+    def shadow_L(self):
+        """(L_v1[2], L_gl[2]) of the last step's outlier test, or None."""
+        out = np.zeros(4)
+        if not lib().ro_tracker_shadow_L(self._h, _p(out)):
+            return None
+        return out[:2].copy(), out[2:].copy()
 
     def mask(self):
         ptr = lib().ro_tracker_mask(self._h)

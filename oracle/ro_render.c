@@ -35,8 +35,27 @@
 #include <stdlib.h>
 #include <string.h>
 
-void ro_render_depth(const ro_mesh* mesh, const double x[3], const double q[4],
-                     const ro_camera* cam, int divider, float* tile)
+/* The rasteriser in three arithmetic modes.  RO_RENDER_CONTRACT is the render contract (what the HIP kernel reproduces bit for
+ * bit); the other two exist ONLY to bound how far that contract sits from (a) what rounds 1 - 4 rendered and (b) what the
+ * reference's OpenGL pipeline computes -- tests/test_render_gap_cpu.py, DESIGN.md section 3.  Never used by the product.
+ *
+ * RO_RENDER_V1: the formulation of rounds 1 - 4 (u = (fx X) / Z + cx; three reciprocals per triangle, normalised barycentric
+ *   weights, z = 1 / sum b_k / z_k).
+ * RO_RENDER_GL: the numerics of the reference's pipeline as far as the GL specification fixes them:
+ *   - per vertex z_ndc = ((f + n) / (f - n) * Z - 2 f n / (f - n)) / Z in float (the third row of SICAD.cpp:1634-1637's
+ *     projection applied to the eye-space point (X, -Y, -Z, 1); near 0.001, far 1000), window z = 0.5 z_ndc + 0.5;
+ *   - window z interpolated LINEARLY in screen space (it is affine there; plane equation in double), handed to the fragment
+ *     shader as a float gl_FragCoord.z;
+ *   - depth test LESS (SICAD.cpp:271-272) on the window z quantised to the 24-bit normalised depth buffer the reference
+ *     allocates (GL_DEPTH_COMPONENT, SICAD.cpp:260), first fragment wins ties;
+ *   - the fragment's output is shader_model.frag:33-51 in float: z = 2 z_w - 1; (2 n f) / (f + n - z (f - n))
+ *     -- at Z = 0.7 m one float ulp of z_w is 0.03 mm of depth;
+ *   - coverage by the top-left rule (a pixel centre exactly on an edge belongs to the triangle only if the edge is a left edge,
+ *     or a horizontal top edge, in image orientation).
+ *   Not modelled (implementation-defined in GL): sub-pixel snapping of vertex positions, near-plane clipping of triangles
+ *   that cross Z = 0.001 (dropped here like in the contract; no tracked object comes within a millimetre of the camera). */
+static void render_mode(const ro_mesh* mesh, const double x[3], const double q[4], const ro_camera* cam, int divider,
+                        float* tile, int mode)
 {
     const int w = cam->width / divider, h = cam->height / divider;
     const float fx = (float)(cam->fx / divider), fy = (float)(cam->fy / divider);
@@ -49,21 +68,38 @@ void ro_render_depth(const ro_mesh* mesh, const double x[3], const double q[4],
 
     const size_t npix = (size_t)w * h;
     for (size_t i = 0; i < npix; i++) tile[i] = INFINITY;
+    uint32_t* zq = NULL;   /* GL: the quantised depth buffer */
+    if (mode == RO_RENDER_GL) {
+        zq = (uint32_t*)malloc(sizeof(uint32_t) * npix);
+        for (size_t i = 0; i < npix; i++) zq[i] = 0xFFFFFFu;   /* glClear: depth 1.0 */
+    }
+    const float gl_near = 0.001f, gl_far = 1000.0f;
+    const float gl_a = (gl_far + gl_near) / (gl_far - gl_near), gl_b = (2.0f * (gl_far * gl_near)) / (gl_far - gl_near);
 
     /* camera-frame vertices and their projections */
     float* cam_z = (float*)malloc(sizeof(float) * mesh->n_verts);
     float* sx = (float*)malloc(sizeof(float) * mesh->n_verts);
     float* sy = (float*)malloc(sizeof(float) * mesh->n_verts);
+    float* zw = (float*)malloc(sizeof(float) * mesh->n_verts);
     for (int i = 0; i < mesh->n_verts; i++) {
         const float* p = mesh->verts + (size_t)3 * i;
         float X = ((R[0] * p[0] + R[1] * p[1]) + R[2] * p[2]) + t[0];
         float Y = ((R[3] * p[0] + R[4] * p[1]) + R[5] * p[2]) + t[1];
         float Z = ((R[6] * p[0] + R[7] * p[1]) + R[8] * p[2]) + t[2];
         cam_z[i] = Z;
+        zw[i] = 0.0f;
         if (Z > 0.001f) {
-            const float iZ = 1.0f / Z;
-            sx[i] = (fx * X) * iZ + cx;
-            sy[i] = (fy * Y) * iZ + cy;
+            if (mode == RO_RENDER_CONTRACT) {
+                const float iZ = 1.0f / Z;
+                sx[i] = (fx * X) * iZ + cx;
+                sy[i] = (fy * Y) * iZ + cy;
+            } else {
+                sx[i] = (fx * X) / Z + cx;
+                sy[i] = (fy * Y) / Z + cy;
+                /* clip z = -(f+n)/(f-n) * (-Z) - 2fn/(f-n), clip w = Z */
+                const float z_ndc = (gl_a * Z - gl_b) / Z;
+                zw[i] = 0.5f * z_ndc + 0.5f;
+            }
         } else {
             sx[i] = sy[i] = 0.0f;
         }
@@ -90,6 +126,14 @@ void ro_render_depth(const ro_mesh* mesh, const double x[3], const double q[4],
         const int ia = (int)fi0, ib = (int)fi1, ja = (int)fj0, jb = (int)fj1;
         const float p12 = z1 * z2, p02 = z0 * z2, p01 = z0 * z1;
         const float num = area * (z0 * p12);
+        const float iz0 = 1.0f / z0, iz1 = 1.0f / z1, iz2 = 1.0f / z2;   /* (V1) */
+        /* (GL) top-left rule: with the weights oriented so that the interior is w > 0, edge k is w_k = a_k px + b_k py + c_k;
+         * a centre ON the edge is covered iff a_k > 0 (left edge) or a_k == 0 and b_k > 0 (top edge, image rows grow downwards) */
+        const float sgn = (area > 0.0f) ? 1.0f : -1.0f;
+        const float ea[3] = {-sgn * (y2 - y1), -sgn * (y0 - y2), -sgn * (y1 - y0)};
+        const float eb[3] = {sgn * (x2 - x1), sgn * (x0 - x2), sgn * (x1 - x0)};
+        int owns[3];
+        for (int e = 0; e < 3; e++) owns[e] = (ea[e] > 0.0f) || (ea[e] == 0.0f && eb[e] > 0.0f);
         for (int j = ja; j <= jb; j++) {
             const float py = (float)j + 0.5f;
             for (int i = ia; i <= ib; i++) {
@@ -101,11 +145,34 @@ void ro_render_depth(const ro_mesh* mesh, const double x[3], const double q[4],
                 int inside = (area > 0.0f) ? (w0 >= 0.0f && w1 >= 0.0f && w2 >= 0.0f)
                                            : (w0 <= 0.0f && w1 <= 0.0f && w2 <= 0.0f);
                 if (!inside) continue;
-                float den = (w0 * p12 + w1 * p02) + w2 * p01;
-                float z = num / den;
-                if (!(z > 0.0f)) continue;
                 float* dst = tile + (size_t)j * w + i;
-                if (z < *dst) *dst = z;
+                if (mode == RO_RENDER_CONTRACT) {
+                    float den = (w0 * p12 + w1 * p02) + w2 * p01;
+                    float z = num / den;
+                    if (!(z > 0.0f)) continue;
+                    if (z < *dst) *dst = z;
+                } else if (mode == RO_RENDER_V1) {
+                    float b0 = w0 / area, b1 = w1 / area, b2 = w2 / area;
+                    float iz = (b0 * iz0 + b1 * iz1) + b2 * iz2;
+                    float z = 1.0f / iz;
+                    if (!(z > 0.0f)) continue;
+                    if (z < *dst) *dst = z;
+                } else {
+                    if ((w0 == 0.0f && !owns[0]) || (w1 == 0.0f && !owns[1]) || (w2 == 0.0f && !owns[2])) continue;
+                    /* the plane equation of window z evaluated in double (fixed-function interpolators carry more than the
+                     * depth buffer's precision), delivered to the shader as a float gl_FragCoord.z */
+                    const double dw0 = ((double)x2 - x1) * ((double)py - y1) - ((double)y2 - y1) * ((double)px - x1);
+                    const double dw1 = ((double)x0 - x2) * ((double)py - y2) - ((double)y0 - y2) * ((double)px - x2);
+                    const double dw2 = ((double)x1 - x0) * ((double)py - y0) - ((double)y1 - y0) * ((double)px - x0);
+                    const float z_w = (float)((dw0 * zw[i0] + dw1 * zw[i1] + dw2 * zw[i2]) / (dw0 + dw1 + dw2));
+                    if (!(z_w >= 0.0f && z_w <= 1.0f)) continue;   /* clipped by the depth range */
+                    const uint32_t qz = (uint32_t)floor((double)z_w * 16777215.0 + 0.5);
+                    uint32_t* zd = zq + (size_t)j * w + i;
+                    if (!(qz < *zd)) continue;   /* GL_LESS */
+                    *zd = qz;
+                    const float zn = z_w * 2.0f - 1.0f;
+                    *dst = (2.0f * gl_near * gl_far) / (gl_far + gl_near - zn * (gl_far - gl_near));
+                }
             }
         }
     }
@@ -114,6 +181,20 @@ void ro_render_depth(const ro_mesh* mesh, const double x[3], const double q[4],
     free(cam_z);
     free(sx);
     free(sy);
+    free(zw);
+    free(zq);
+}
+
+void ro_render_depth(const ro_mesh* mesh, const double x[3], const double q[4],
+                     const ro_camera* cam, int divider, float* tile)
+{
+    render_mode(mesh, x, q, cam, divider, tile, RO_RENDER_CONTRACT);
+}
+
+void ro_render_depth_mode(const ro_mesh* mesh, const double x[3], const double q[4],
+                          const ro_camera* cam, int divider, float* tile, int mode)
+{
+    render_mode(mesh, x, q, cam, divider, tile, mode);
 }
 
 double ro_depth_likelihood(const ro_camera* cam, const float* depth, const uint8_t* mask,

@@ -81,6 +81,8 @@ struct ro_tracker {
     uint8_t* buffered_seg;
     int features_initialized;
     float* tiles; /* 2 tiles */
+    int shadow, shadow_valid; /* ro_tracker_shadow_render */
+    double shadow_L[4];
 
     /* current frame */
     const float* cur_depth;
@@ -183,6 +185,14 @@ void ro_tracker_destroy(ro_tracker* t)
 }
 
 const uint8_t* ro_tracker_mask(const ro_tracker* t) { return t->seg_bin; }
+
+void ro_tracker_shadow_render(ro_tracker* t, int on) { t->shadow = on; t->shadow_valid = 0; }
+int ro_tracker_shadow_L(const ro_tracker* t, double out[4])
+{
+    if (!t->shadow_valid) return 0;
+    for (int i = 0; i < 4; i++) out[i] = t->shadow_L[i];
+    return 1;
+}
 
 static size_t flow_bytes(const ro_flow* f)
 {
@@ -486,6 +496,18 @@ static void correct_outlier_rejection(ro_tracker* t, const pose_belief* pred, in
         ro_render_depth(&t->mesh, alt[a].mean + 6, alt[a].mean + 9, &t->cfg.cam, t->divider,
                         t->tiles + a * tile_px);
         L[a] = ro_depth_likelihood(&t->cfg.cam, depth, seg, t->tiles + a * tile_px, t->divider, NULL);
+    }
+    t->shadow_valid = 0;
+    if (t->shadow) {
+        float* tmp = (float*)malloc(sizeof(float) * tile_px);
+        for (int m = 0; m < 2; m++)
+            for (int a = 0; a < 2; a++) {
+                ro_render_depth_mode(&t->mesh, alt[a].mean + 6, alt[a].mean + 9, &t->cfg.cam, t->divider, tmp,
+                                     m == 0 ? RO_RENDER_V1 : RO_RENDER_GL);
+                t->shadow_L[2 * m + a] = ro_depth_likelihood(&t->cfg.cam, depth, seg, tmp, t->divider, NULL);
+            }
+        free(tmp);
+        t->shadow_valid = 1;
     }
     int selected = (L[0] > 2.0 * L[1]) ? 1 : 0;
     if (t->res) {

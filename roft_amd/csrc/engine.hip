@@ -425,7 +425,7 @@ struct roft_engine {
     // lanes released early, outlier tests on all the CUs to spare; steady batches favour occupancy.
     int idle_mark = 0;        // batch_counter when the engine was last known idle
     bool steady = false;      // mode of the batch being stepped
-    bool alone_on_device = true;   // no other engine of this process held a stream set on the device when this one was created
+    bool alone_on_device = true;   // no other engine of this process holds a stream set on the device (asked at every submit: a count, not a timing)
     bool wait_value_ok = true;     // hipDeviceAttributeCanUseStreamWaitValue
     // trace of the last kTraceRing batches (roft_engine_get_batch_trace)
     static constexpr int kTraceRing = 64;
@@ -802,19 +802,16 @@ static void release_streams(StreamSet* s)
     if (s) s->in_use = false;
 }
 
-// true when no other engine of this process has work in flight on the device of `mine` (an engine that exists but is idle -- one
-// whose results are still being read -- holds no CU)
+// true when no other engine of this process holds a stream set on the device of `mine` -- a fact of which engines EXIST at the
+// submit (round 6, ADVICE r05: rounds 4 - 5 asked the other engines' streams whether they were busy at that instant, a host and
+// device timing that another engine could falsify a microsecond later; the launch graph is a function of the batch index, the
+// object count and this count only)
 static bool alone_on_device(const StreamSet* mine)
 {
     std::lock_guard<std::mutex> lk(g_stream_mu);
-    bool alone = true;
-    for (const StreamSet* s : g_stream_sets) {
-        if (s == mine || !s->in_use || s->device != mine->device) continue;
-        for (hipStream_t q : {s->pose[0], s->pose[1], s->vel, s->mask})
-            if (hipStreamQuery(q) != hipSuccess) alone = false;
-    }
-    (void)hipGetLastError();   // (hipErrorNotReady is an answer, not an error)
-    return alone;
+    for (const StreamSet* s : g_stream_sets)
+        if (s != mine && s->in_use && s->device == mine->device) return false;
+    return true;
 }
 
 static int engine_setup(roft_engine* e, const roft_config* cfg)
@@ -1547,7 +1544,10 @@ static int step_batch(roft_engine* e)
     bool early_lane[kNumLin];
     for (int l = 0; l < kNumLin; ++l)
         early_lane[l] = early_lanes || (early_ok && T > 1 && e->n_segments[l] > 1 && e->lane_old_first[l] > 0 &&
-                                        8 * (e->lane_objs[l] - e->lane_old_first[l]) <= device_cu_count());
+                                        8 * (e->lane_objs[l] - e->lane_old_first[l]) <= device_cu_count() &&
+                                        // (the replay-first objects wait too -- for a twist of the batch BEFORE, whose velocity filter is
+                                        //  enqueued and may still be publishing: all of the lane's workgroups together leave it half the device)
+                                        2 * e->lane_objs[l] <= device_cu_count());
     const bool any_early = early_lane[0] || early_lane[1];
     const long long launches0 = e->stats.launches, evops0 = e->stats.event_ops;
 
@@ -1772,6 +1772,13 @@ int roft_step(roft_engine* e)
     HIP_TRY(hipSetDevice(e->cfg.device));
     const double t_step0 = host_now_us();
     const int rc = step_batch(e);
+    if (rc != ROFT_OK && e->arr.mask_general.p) {
+        // A step that failed between the mask frames and mask_general_kernel (its only reader, which clears the bits it has
+        // served) leaves bits of THIS batch's frames behind; the next batch's general kernel would replay those frame indices
+        // against its own tables.  Clear them behind whatever the mask stream still carries (best effort: the device may be gone).
+        (void)hipMemsetAsync(e->arr.mask_general.p, 0, sizeof(unsigned) * (size_t)std::max(e->arr.a.n_obj, 1), e->stream);
+        (void)hipGetLastError();
+    }
     {
         roft_batch_trace& tr = e->trace[e->batch_counter % roft_engine::kTraceRing];
         if (tr.batch == e->batch_counter) tr.step_us = host_now_us() - t_step0;

@@ -1018,7 +1018,7 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
             else {
                 const int ij = L.tri6[e - 72], i = ij >> 8, j = ij & 0xFF;
                 ar = L.D + i * kCols; br = L.D + j * kCols; o0 = i * 6 + j; o1 = j * 6 + i;
-                if (i == j && i < n_add) add = L.par[r_base + i];
+                if (i == j && i < n_add) add = fabs(L.par[r_base + i]);   // |R|: what the sigma columns sqrt(|R|) of rounds 1 - 4 (and the rotation columns above) contribute
             }
             const double v = weighted_dot_pair(ar, br, ncols, wc0, w.wi, lane & 1) + add;
             if (lane < 186) {
@@ -1036,7 +1036,7 @@ __device__ int ukf_correct(UkfLds& L, int type, const UtTable& ut, PoseBelief* o
             while (u >= m - i) { u -= m - i; ++i; }
             const int j = i + u;
             double sum = weighted_dot(L.D + i * kCols, L.D + j * kCols, ncols, wc0, w.wi);
-            if (i == j && i < n_add) sum += L.par[r_base + i];
+            if (i == j && i < n_add) sum += fabs(L.par[r_base + i]);
             L.Py[i * m + j] = sum;
             L.Py[j * m + i] = sum;
         }

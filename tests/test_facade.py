@@ -1008,3 +1008,27 @@ def test_every_facade_header_compiles_on_its_own(tmp_path):
                 assert pr.returncode == 0, (units[k - len(procs) + 1 + j], err[-1500:])
             procs = []
     del src
+
+
+KIT_BIN = os.path.join(ROOT, "tests", "cpp", "_kit_build", "replay")
+
+
+@pytest.mark.gpu
+def test_conformance_kit_replays_the_vectors_through_the_class_api():
+    """tests/ref_kit/replay.cpp, FACADE build (-DROFT_KIT_FACADE, __graft_entry__.build_conformance_kit): the committed oracle
+    vectors replayed through bfl::UKFPrediction over ROFT::CartesianQuaternionModel, ROFT::UKFCorrection over
+    ROFT::CartesianQuaternionMeasurement (three measurement types, sigma rotations beyond pi) and ROFT::SKFCorrection over a
+    recorded linear model -- the reference's class API, constructor for constructor -- running on the HIP engine.  This pins
+    NOTHING (the vectors are the oracle's own): it is the kit's compiler, its I/O check and a third consumer of the vectors; with
+    real bfl only the include and link lines change."""
+    if not os.path.exists(KIT_BIN):
+        pytest.skip("tests/cpp/_kit_build/replay is built by python __graft_entry__.py")
+    r = subprocess.run([KIT_BIN, os.path.join(ROOT, "tests", "golden", "oracle_vectors")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert "DIFFERS" not in r.stdout
+    # three predictions, seven corrections of the pose filter, two of the velocity filter: mean + covariance each
+    assert sum(1 for ln in lines if ln.startswith("ukf_predict_")) == 6
+    assert sum(1 for ln in lines if ln.startswith("ukf_correct_")) == 14
+    assert sum(1 for ln in lines if ln.startswith("skf_correct")) == 4
+    assert "pins nothing" in lines[-1]

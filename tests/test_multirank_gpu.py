@@ -17,8 +17,9 @@ pytestmark = pytest.mark.gpu
 
 def run_bench(tmp_path, n_ranks, tag, port, extra=(), launcher=True, cpu_ref=False):
     out = str(tmp_path / ("rows_%s.npy" % tag))
+    detail = str(tmp_path / ("detail_%s.json" % tag))
     args = ["bench.py", "--gpus", str(n_ranks), "--steps", "14", "--warmup", "4", "--objects", "5", "--windows", "3",
-            "--pcie-frames", "0", "--no-extras", "--no-kernel-timing", "--rehearsal-ms", "0", "--dump-rows", out] + list(extra)
+            "--pcie-frames", "0", "--no-extras", "--no-kernel-timing", "--rehearsal-ms", "0", "--dump-rows", out, "--json-out", detail] + list(extra)
     if not cpu_ref:
         args.append("--no-cpu-baseline")
     env = dict(os.environ, ROFT_BENCH_DEVICE="0", ROFT_BENCH_BACKEND="gloo")
@@ -29,8 +30,21 @@ def run_bench(tmp_path, n_ranks, tag, port, extra=(), launcher=True, cpu_ref=Fal
         cmd = [sys.executable] + args
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    return json.loads(line), np.load(out)
+    # the LAST line of stdout is the compact record the driver parses (< 4 KB, strict JSON); the full record (windows, batch
+    # traces, ranks) is the side file it names -- the tests below read the full record and check the line against it
+    text = r.stdout.strip().splitlines()[-1]
+    assert len(text) < 4096, len(text)
+    line = json.loads(text, parse_constant=lambda c: pytest.fail("non-strict JSON constant " + c))
+    full = json.load(open(detail))
+    assert line["detail"] == detail
+    for k in ("metric", "unit", "n_gpus", "steps", "warmup", "scaling", "dtype", "data", "higher_is_better"):
+        assert line[k] == full[k], k
+    assert abs(line["value"] - full["value"]) <= 1e-5 * full["value"] and abs(line["ms_per_step"] - full["ms_per_step"]) <= 1e-5 * full["ms_per_step"]
+    assert line["config"]["objects_per_gpu"] == full["config"]["objects_per_gpu"] and line["config"]["ranks"] == n_ranks
+    assert (line.get("ranks") is None) == (n_ranks == 1)
+    if n_ranks > 1:
+        assert line["ranks"]["world_size"] == n_ranks and line["ranks"]["seen"] == n_ranks
+    return full, np.load(out)
 
 
 def test_two_ranks_gather_what_one_rank_logs(tmp_path):
