@@ -68,6 +68,17 @@ static void render_mode(const ro_mesh* mesh, const double x[3], const double q[4
 
     const size_t npix = (size_t)w * h;
     for (size_t i = 0; i < npix; i++) tile[i] = INFINITY;
+    /* contract, closed mesh (ro_meshclass.c): triangles that face away are not drawn -- provided every vertex is in front of the
+     * near plane (a camera inside the surface would have vertices behind it) */
+    const uint8_t* flip = NULL;
+    uint8_t* flip_own = NULL;
+    if (mode == RO_RENDER_CONTRACT) {
+        if (mesh->closed > 0) flip = mesh->tri_flip;
+        else if (mesh->closed < 0) {
+            flip_own = (uint8_t*)malloc((size_t)(mesh->n_tris > 0 ? mesh->n_tris : 1));
+            if (ro_mesh_classify(mesh->verts, mesh->n_verts, mesh->tris, mesh->n_tris, flip_own)) flip = flip_own;
+        }
+    }
     uint32_t* zq = NULL;   /* GL: the quantised depth buffer */
     if (mode == RO_RENDER_GL) {
         zq = (uint32_t*)malloc(sizeof(uint32_t) * npix);
@@ -88,6 +99,7 @@ static void render_mode(const ro_mesh* mesh, const double x[3], const double q[4
         float Z = ((R[6] * p[0] + R[7] * p[1]) + R[8] * p[2]) + t[2];
         cam_z[i] = Z;
         zw[i] = 0.0f;
+        if (!(Z > 0.001f)) flip = NULL;
         if (Z > 0.001f) {
             if (mode == RO_RENDER_CONTRACT) {
                 const float iZ = 1.0f / Z;
@@ -113,6 +125,7 @@ static void render_mode(const ro_mesh* mesh, const double x[3], const double q[4
         const float x0 = sx[i0], y0 = sy[i0], x1 = sx[i1], y1 = sy[i1], x2 = sx[i2], y2 = sy[i2];
         const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
         if (area == 0.0f || !(area == area)) continue;
+        if (flip && ((area < 0.0f) == (flip[k] != 0))) continue;   /* faces away */
         float minx = fminf(x0, fminf(x1, x2)), maxx = fmaxf(x0, fmaxf(x1, x2));
         float miny = fminf(y0, fminf(y1, y2)), maxy = fmaxf(y0, fmaxf(y1, y2));
         /* pixel centres i + 0.5 inside [min, max] */
@@ -183,6 +196,7 @@ static void render_mode(const ro_mesh* mesh, const double x[3], const double q[4
     free(sy);
     free(zw);
     free(zq);
+    free(flip_own);
 }
 
 void ro_render_depth(const ro_mesh* mesh, const double x[3], const double q[4],
