@@ -142,6 +142,13 @@ int roft_ukf_correct(const double mean[13], const double P[144], int type, const
                      const double* Rdiag, const roft_ut_params* ut, double mean_out[13],
                      double P_out[144], int* status_out);
 
+/* Is the mesh a closed orientable surface (host code, no device needed)?  *closed_out = 1 and flip_out[n_tris] (optional) = 1 for
+ * every triangle wound clockwise seen from outside, else 0 and flip_out zeroed.  The reference draws every triangle (depth test
+ * LESS, no culling: src/roft-lib/src/SICAD.cpp:271-272) and reads the NEAREST surface back; seen from outside, the nearest
+ * surface of a closed mesh faces the camera, so the renders below leave the triangles of a closed mesh that face away out (while
+ * every vertex is in front of the near plane) -- half the scan conversion.  Open, non-manifold or non-orientable meshes are drawn
+ * whole.  Rules: oracle/ro_meshclass.c. */
+int roft_mesh_classify(const roft_mesh* mesh, uint8_t* flip_out, int* closed_out);
 /* tile: (H/divider) x (W/divider) float, 0 = background.  Drawn by the rasteriser of the engine's own outlier test
  * (outlier_fused_kernel: projected vertices and the depth window in LDS). */
 int roft_render_depth(const roft_mesh* mesh, const double x[3], const double q[4],
@@ -323,6 +330,7 @@ typedef struct {
     long long launches;        /* kernel launches + memsets + copies enqueued by roft_step */
     long long event_ops;       /* cross-stream waits + explicit event records enqueued by roft_step */
     long long h2d_bytes;       /* bytes of HOST inputs uploaded by the submit calls */
+    long long h2d_copies;      /* ... in this many copies (images of consecutive frames that are consecutive in host memory go in one) */
 } roft_engine_stats;
 int roft_engine_get_stats(roft_engine* e, roft_engine_stats* out);
 

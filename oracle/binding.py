@@ -39,7 +39,8 @@ class UT(C.Structure):
 
 
 class Mesh(C.Structure):
-    _fields_ = [("verts", C.c_void_p), ("n_verts", C.c_int), ("tris", C.c_void_p), ("n_tris", C.c_int)]
+    _fields_ = [("verts", C.c_void_p), ("n_verts", C.c_int), ("tris", C.c_void_p), ("n_tris", C.c_int),
+                ("tri_flip", C.c_void_p), ("closed", C.c_int)]
 
 
 class TrackerConfig(C.Structure):
@@ -110,6 +111,8 @@ def lib():
         L.ro_tracker_step.argtypes = [C.c_void_p, C.POINTER(Frame), C.POINTER(FrameResult)]
         L.ro_tracker_mask.restype = C.c_void_p
         L.ro_tracker_mask.argtypes = [C.c_void_p]
+        L.ro_mesh_classify.restype = C.c_int
+        L.ro_mesh_classify.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.ro_render_depth_mode.argtypes = [C.POINTER(Mesh), C.c_void_p, C.c_void_p, C.POINTER(Camera), C.c_int, C.c_void_p, C.c_int]
         L.ro_tracker_shadow_render.argtypes = [C.c_void_p, C.c_int]
         L.ro_tracker_shadow_L.restype = C.c_int
@@ -243,9 +246,21 @@ def ukf_correct(mean, P, mtype, meas, rdiag, ut=(1.0, 2.0, 0.0)):
 def make_mesh(verts, tris):
     verts = np.ascontiguousarray(verts, np.float32)
     tris = np.ascontiguousarray(tris, np.int32)
-    m = Mesh(verts.ctypes.data, verts.shape[0], tris.ctypes.data, tris.shape[0])
-    m._keep = (verts, tris)
+    flip = np.zeros(max(tris.shape[0], 1), np.uint8)
+    closed = lib().ro_mesh_classify(verts.ctypes.data, verts.shape[0], tris.ctypes.data, tris.shape[0], flip.ctypes.data) if tris.shape[0] else 0
+    m = Mesh(verts.ctypes.data, verts.shape[0], tris.ctypes.data, tris.shape[0], flip.ctypes.data, closed)
+    m._keep = (verts, tris, flip)
     return m
+
+
+def mesh_classify(verts, tris):
+    """(closed, flip[n_tris]) of oracle/ro_meshclass.c: is the mesh a closed orientable surface, which triangles are wound
+    clockwise seen from outside."""
+    verts = np.ascontiguousarray(verts, np.float32)
+    tris = np.ascontiguousarray(tris, np.int32)
+    flip = np.zeros(max(tris.shape[0], 1), np.uint8)
+    closed = lib().ro_mesh_classify(verts.ctypes.data, verts.shape[0], tris.ctypes.data, tris.shape[0], flip.ctypes.data)
+    return bool(closed), flip[:tris.shape[0]]
 
 
 def render_depth(mesh, x, q, cam, divider):

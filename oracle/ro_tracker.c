@@ -33,6 +33,7 @@ struct ro_tracker {
     ro_mesh mesh;
     float* mesh_verts;
     int32_t* mesh_tris;
+    uint8_t* mesh_flip;
     int W, H, divider;
     size_t npix;
 
@@ -142,6 +143,10 @@ ro_tracker* ro_tracker_create(const ro_tracker_config* cfg, const ro_mesh* mesh)
         memcpy(t->mesh_tris, mesh->tris, sizeof(int32_t) * 3 * mesh->n_tris);
         t->mesh.verts = t->mesh_verts; t->mesh.n_verts = mesh->n_verts;
         t->mesh.tris = t->mesh_tris; t->mesh.n_tris = mesh->n_tris;
+        /* closed surface?  (ro_meshclass.c: the render then leaves out the triangles that face away) -- once per tracker */
+        t->mesh_flip = (uint8_t*)malloc((size_t)mesh->n_tris);
+        t->mesh.closed = ro_mesh_classify(t->mesh_verts, mesh->n_verts, t->mesh_tris, mesh->n_tris, t->mesh_flip);
+        t->mesh.tri_flip = t->mesh_flip;
     }
     t->of_mask = (uint8_t*)calloc(t->npix, 1);
     t->seg_bin = (uint8_t*)calloc(t->npix, 1);
@@ -177,7 +182,7 @@ void ro_tracker_destroy(ro_tracker* t)
     for (int i = 0; i < t->flow_buf_cap; i++) free(t->flow_buf[i]);
     for (int i = 0; i < 30; i++) free(t->fq_data[i]);
     free(t->flow_buf); free(t->flow_buf_desc);
-    free(t->mesh_verts); free(t->mesh_tris);
+    free(t->mesh_verts); free(t->mesh_tris); free(t->mesh_flip);
     free(t->of_mask); free(t->seg_bin); free(t->prev_seg); free(t->buffered_seg);
     free(t->prev_depth); free(t->buffered_depth); free(t->map_scratch);
     free(t->uv); free(t->y); free(t->Hm); free(t->tiles);

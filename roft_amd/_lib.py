@@ -76,7 +76,7 @@ class FrameInput(C.Structure):
 
 class EngineStats(C.Structure):
     _fields_ = [("frames", C.c_longlong), ("batches", C.c_longlong), ("launches", C.c_longlong),
-                ("event_ops", C.c_longlong), ("h2d_bytes", C.c_longlong)]
+                ("event_ops", C.c_longlong), ("h2d_bytes", C.c_longlong), ("h2d_copies", C.c_longlong)]
 
 
 class BatchTrace(C.Structure):
@@ -95,7 +95,7 @@ class ObjectOutput(C.Structure):
 ABI_SYMBOLS = [
     "roft_last_error_string", "roft_device_count", "roft_flow_measurement", "roft_kf_predict",
     "roft_skf_correct", "roft_skf_correct_points", "roft_mask_propagate", "roft_pose_process_noise", "roft_ukf_predict",
-    "roft_ukf_correct", "roft_render_depth", "roft_depth_likelihood", "roft_outlier_test", "roft_outlier_test_split", "roft_default_config",
+    "roft_ukf_correct", "roft_mesh_classify", "roft_render_depth", "roft_depth_likelihood", "roft_outlier_test", "roft_outlier_test_split", "roft_default_config",
     "roft_default_object", "roft_engine_create", "roft_engine_destroy", "roft_object_add",
     "roft_frame_submit", "roft_frames_submit", "roft_engine_retain_frames", "roft_engine_get_stats", "roft_step", "roft_sync", "roft_get_state", "roft_get_outputs", "roft_get_mask",
     "roft_engine_enable_log", "roft_engine_get_log", "roft_engine_get_log_rows", "roft_engine_stream", "roft_engine_enable_timing",

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "roft_device.h"
+#include "mesh_class.h"
 
 using namespace roft;
 
@@ -336,6 +337,7 @@ struct HostObject {
     std::vector<OwnedFlow*> owned;   // engine copies of flows that outlived the zero-copy retention window
     DevBuf<float> verts;
     DevBuf<int32_t> tris;
+    DevBuf<uint8_t> tri_flip;   // closed meshes only (mesh_class.h)
     ~HostObject() { for (auto* o : owned) delete o; }
 };
 
@@ -1011,12 +1013,19 @@ int roft_object_add(roft_engine* e, const roft_object_desc* d, int* obj_id)
     p.r_flow[1] = d->v_meas_cov_flow[1];
     auto bail = [&](int code, const std::string& msg) { delete o; return fail(code, msg); };
     if (d->mesh.n_verts > 0 && d->mesh.n_tris > 0) {
+        // closed orientable surface?  Then the outlier test's render leaves the triangles that face away out (the render
+        // contract, oracle/ro_render.c) and walks the triangles in an order that keeps alike-facing ones together
+        PreparedMesh pm;
+        prepare_mesh(d->mesh.verts, d->mesh.n_verts, d->mesh.tris, d->mesh.n_tris, pm);
         hipError_t err = o->verts.ensure((size_t)3 * d->mesh.n_verts);
         if (err == hipSuccess) err = o->tris.ensure((size_t)3 * d->mesh.n_tris);
+        if (err == hipSuccess && pm.closed) err = o->tri_flip.ensure((size_t)d->mesh.n_tris);
         if (err == hipSuccess) err = hipMemcpy(o->verts.p, d->mesh.verts, sizeof(float) * 3 * d->mesh.n_verts, hipMemcpyHostToDevice);
-        if (err == hipSuccess) err = hipMemcpy(o->tris.p, d->mesh.tris, sizeof(int32_t) * 3 * d->mesh.n_tris, hipMemcpyHostToDevice);
+        if (err == hipSuccess) err = hipMemcpy(o->tris.p, pm.tris(d->mesh.tris), sizeof(int32_t) * 3 * d->mesh.n_tris, hipMemcpyHostToDevice);
+        if (err == hipSuccess && pm.closed) err = hipMemcpy(o->tri_flip.p, pm.flip.data(), (size_t)d->mesh.n_tris, hipMemcpyHostToDevice);
         if (err != hipSuccess) return bail(ROFT_ERR_DEVICE, std::string("mesh upload: ") + hipGetErrorString(err));
         p.verts = o->verts.p; p.tris = o->tris.p;
+        p.tri_flip = pm.closed ? o->tri_flip.p : nullptr;
         p.n_verts = d->mesh.n_verts; p.n_tris = d->mesh.n_tris;
     } else if (e->cfg.outlier_rejection && e->cfg.use_pose) {
         return bail(ROFT_ERR_INVALID, "outlier rejection needs a mesh");
@@ -1153,12 +1162,10 @@ static bool build_pose_program(const roft_config& cfg, Sched& o, const roft_fram
     return !overflow;
 }
 
-// device copy of one HOST image of `frame` (uploads once per distinct host pointer and frame)
-static int stage_host(roft_engine* e, int frame, const void* host, size_t bytes, const void** dev)
+// `bytes` of the staging memory that is recycled with `frame`'s slot (bump allocation in 32 MB chunks)
+static int stage_alloc(roft_engine* e, int frame, size_t bytes, unsigned char** out)
 {
     StageFrame& sf = e->staging[frame % e->retain];
-    for (auto& pr : sf.seen)
-        if (pr.first == host) { *dev = pr.second; return ROFT_OK; }
     const size_t need = (bytes + 255) & ~(size_t)255;
     while (sf.cur < sf.chunks.size() && sf.used + need > sf.chunks[sf.cur]->n) { ++sf.cur; sf.used = 0; }
     if (sf.cur == sf.chunks.size()) {
@@ -1168,13 +1175,73 @@ static int stage_host(roft_engine* e, int frame, const void* host, size_t bytes,
         sf.chunks.push_back(c);
         sf.used = 0;
     }
-    unsigned char* d = sf.chunks[sf.cur]->p + sf.used;
+    *out = sf.chunks[sf.cur]->p + sf.used;
     sf.used += need;
+    return ROFT_OK;
+}
+
+// device copy of one HOST image of `frame` (uploads once per distinct host pointer and frame)
+static int stage_host(roft_engine* e, int frame, const void* host, size_t bytes, const void** dev)
+{
+    StageFrame& sf = e->staging[frame % e->retain];
+    for (auto& pr : sf.seen)
+        if (pr.first == host) { *dev = pr.second; return ROFT_OK; }
+    unsigned char* d = nullptr;
+    if (int rc = stage_alloc(e, frame, bytes, &d)) return rc;
     HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, e->up_stream));
     e->stats.h2d_bytes += (long long)bytes;
+    e->stats.h2d_copies++;
     e->had_uploads = true;
     sf.seen.emplace_back(host, d);
     *dev = d;
+    return ROFT_OK;
+}
+
+// HOST images of consecutive frames of a batch that are CONSECUTIVE IN HOST MEMORY (a recorded sequence held as one
+// [frames, H, W] array: frame t + 1 starts where frame t ends) are uploaded with ONE copy per run instead of one per frame --
+// a 1.2 MB copy does not reach the link's rate, a batch's worth does (round 6: the shared-scene leg of bench.py moved 26 GB/s
+// in per-frame copies against 43 GB/s in the per-object leg, whose 128 copies per frame keep the link busy by their number).
+// The run lives in the staging slot of its LAST frame (recycled after every earlier one); each frame's slot learns where its
+// image is, so that stage_host below finds it -- for every object that shows the same host pointer, too.
+static int stage_host_runs(roft_engine* e, const roft_frame_input* inputs, int n_obj, int T, size_t depth_bytes, size_t flow_bytes_)
+{
+    if (T < 2) return ROFT_OK;
+    const int frame0 = e->frame_counter;
+    for (int kind = 0; kind < 2; ++kind) {
+        const size_t bytes = kind == 0 ? depth_bytes : flow_bytes_;
+        if (bytes == 0 || (bytes & 255)) continue;   // (the pieces of a run must keep the alignment a single image gets)
+        for (int id = 0; id < n_obj; ++id) {
+            auto ptr = [&](int t) -> const unsigned char* {
+                const roft_frame_input& in = inputs[(size_t)t * n_obj + id];
+                if (in.mem_kind != ROFT_MEM_HOST) return nullptr;
+                return static_cast<const unsigned char*>(kind == 0 ? static_cast<const void*>(in.depth) : in.flow);
+            };
+            int t0 = 0;
+            while (t0 < T) {
+                int t1 = t0;
+                const unsigned char* p0 = ptr(t0);
+                if (p0)
+                    while (t1 + 1 < T && ptr(t1 + 1) == p0 + (size_t)(t1 + 1 - t0) * bytes) ++t1;
+                if (p0 && t1 > t0) {
+                    bool known = false;   // (a shared scene: an object before this one brought the run)
+                    for (auto& pr : e->staging[(frame0 + t0) % e->retain].seen)
+                        if (pr.first == p0) { known = true; break; }
+                    if (!known) {
+                        const int len = t1 - t0 + 1;
+                        unsigned char* d = nullptr;
+                        if (int rc = stage_alloc(e, frame0 + t1, (size_t)len * bytes, &d)) return rc;
+                        HIP_TRY(hipMemcpyAsync(d, p0, (size_t)len * bytes, hipMemcpyHostToDevice, e->up_stream));
+                        e->stats.h2d_bytes += (long long)((size_t)len * bytes);
+                        e->stats.h2d_copies++;
+                        e->had_uploads = true;
+                        for (int t = t0; t <= t1; ++t)
+                            e->staging[(frame0 + t) % e->retain].seen.emplace_back(p0 + (size_t)(t - t0) * bytes, d + (size_t)(t - t0) * bytes);
+                    }
+                }
+                t0 = t1 + 1;
+            }
+        }
+    }
     return ROFT_OK;
 }
 
@@ -1210,14 +1277,15 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
         }
     }
 
+    for (int t = 0; t < T; ++t) {   // the staging slots of the batch's frames are free again: every frame that could read them has ended (in-flight bound)
+        StageFrame& sf = e->staging[(e->frame_counter + t) % e->retain];
+        sf.cur = 0;
+        sf.used = 0;
+        sf.seen.clear();
+    }
+    if (int rc = stage_host_runs(e, inputs, n_obj, T, npix * sizeof(float), fbytes)) return rc;
     for (int t = 0; t < T; ++t) {
         const int frame = e->frame_counter + t;
-        {   // the staging slot of this frame is free again: every frame that could read it has ended (in-flight bound)
-            StageFrame& sf = e->staging[frame % e->retain];
-            sf.cur = 0;
-            sf.used = 0;
-            sf.seen.clear();
-        }
         for (int id = 0; id < n_obj; ++id) {
             HostObject& ho = *e->objs[id];
             Sched& o = ho.s;
@@ -2044,7 +2112,7 @@ struct OpCtx {
     hipStream_t stream = nullptr;
     Arrays arr;
     int W = 0, H = 0, ftype = 0, fgrid = 0, radius = 0;
-    DevBuf<unsigned char> b0, b1, b2, b3, b4, b5;  // generic scratch
+    DevBuf<unsigned char> b0, b1, b2, b3, b4, b5, bflip;  // generic scratch
     bool ready = false;
 
     int prepare(const roft_camera& cam, int ftype_, int fgrid_, float fscale, int radius_)
@@ -2425,12 +2493,17 @@ static int op_outlier(const roft_camera* cam, int divider, const float* depth, c
         a.tile_h = cam->height / a.cam.divider;
         a.max_verts = a.max_tris = 0;
     };
+    PreparedMesh pm;
+    prepare_mesh(mesh->verts, mesh->n_verts, mesh->tris, mesh->n_tris, pm);
     if (int rc = to_dev(c.b0, mesh->verts, (size_t)3 * mesh->n_verts, c.stream)) return rc;
-    if (int rc = to_dev(c.b1, mesh->tris, (size_t)3 * mesh->n_tris, c.stream)) return rc;
+    if (int rc = to_dev(c.b1, pm.tris(mesh->tris), (size_t)3 * mesh->n_tris, c.stream)) return rc;
+    if (pm.closed)
+        if (int rc = to_dev(c.bflip, pm.flip.data(), (size_t)mesh->n_tris, c.stream)) return rc;
     ObjParams prm;
     std::memset(&prm, 0, sizeof(prm));
     prm.verts = reinterpret_cast<const float*>(c.b0.p);
     prm.tris = reinterpret_cast<const int32_t*>(c.b1.p);
+    prm.tri_flip = pm.closed ? reinterpret_cast<const uint8_t*>(c.bflip.p) : nullptr;
     prm.n_verts = mesh->n_verts;
     prm.n_tris = mesh->n_tris;
     a.max_verts = mesh->n_verts;
@@ -2495,6 +2568,15 @@ static int op_outlier(const roft_camera* cam, int divider, const float* depth, c
     delete st;
     restore();
     HIP_TRY(err);
+    return ROFT_OK;
+}
+
+int roft_mesh_classify(const roft_mesh* mesh, uint8_t* flip_out, int* closed_out)
+{
+    if (!mesh || !mesh->verts || !mesh->tris || mesh->n_verts <= 0 || mesh->n_tris <= 0 || !closed_out) return fail(ROFT_ERR_INVALID, "bad argument");
+    std::vector<uint8_t> flip;
+    *closed_out = classify_mesh(mesh->verts, mesh->n_verts, mesh->tris, mesh->n_tris, flip) ? 1 : 0;
+    if (flip_out) std::memcpy(flip_out, flip.data(), (size_t)mesh->n_tris);
     return ROFT_OK;
 }
 

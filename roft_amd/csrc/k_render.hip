@@ -170,14 +170,21 @@ __device__ __forceinline__ void project_vertex(const float* v, const RenderPose&
 
 // Scan conversion of one projected triangle on a w x h target: `store(i, j, z)` receives every covered pixel with its
 // eye-space depth (the render contract of oracle/ro_render.c, operation by operation); rows outside [j_lo, j_hi] are
-// skipped (a strip of the target).
+// skipped (a strip of the target).  cull: 0 = draw; 1 / 2 = the mesh is a closed surface (mesh_class.h) and this triangle is
+// wound counter-clockwise (1) / clockwise (2) seen from outside: it is drawn only if it faces the camera -- a counter-clockwise
+// triangle that does has NEGATIVE screen area under the contract's projection (x right, y down, z forward).
+// The candidate pixels of the bounding box are walked as ONE loop of (columns x rows) iterations (round 6): lanes of a wave run
+// the loop in lock step, and two nested loops cost a wave max(rows) x max(columns) rounds where this one costs max(rows x
+// columns) -- a lane with a 1 x 4 box next to one with a 4 x 1 box: 4 rounds instead of 16.  The order in which a triangle's
+// pixels are visited changes nothing (nearest depth per pixel).
 template <class Store>
 __device__ __forceinline__ void raster_projected(float x0, float y0, float z0, float x1, float y1, float z1, float x2, float y2,
-                                                 float z2, int w, int h, int j_lo, int j_hi, Store store)
+                                                 float z2, int w, int h, int j_lo, int j_hi, int cull, Store store)
 {
     if (!(z0 > 0.001f && z1 > 0.001f && z2 > 0.001f)) return;
     const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
     if (area == 0.0f || !(area == area)) return;
+    if (cull && ((area < 0.0f) == (cull == 2))) return;   // faces away
     const float minx = fminf(x0, fminf(x1, x2)), maxx = fmaxf(x0, fmaxf(x1, x2));
     const float miny = fminf(y0, fminf(y1, y2)), maxy = fmaxf(y0, fmaxf(y1, y2));
     float fi0 = ceilf(minx - 0.5f), fi1 = floorf(maxx - 0.5f);
@@ -188,27 +195,29 @@ __device__ __forceinline__ void raster_projected(float x0, float y0, float z0, f
     if (fj1 > (float)(h - 1)) fj1 = (float)(h - 1);
     if (!(fi0 <= fi1) || !(fj0 <= fj1)) return;
     const int ia = (int)fi0, ib = (int)fi1, ja = max((int)fj0, j_lo), jb = min((int)fj1, j_hi);
+    if (jb < ja) return;
     // perspective-correct depth of a covered pixel as ONE quotient (oracle/ro_render.c):
     //   z = area z0 z1 z2 / (w0 z1 z2 + w1 z0 z2 + w2 z0 z1)
     // -- five multiplications per triangle, three multiply-adds and a division per pixel; no reciprocal of a vertex depth, no
     // normalised barycentric weights (an IEEE division is ~10 instructions and the kernel is bound by instruction issue)
     const float p12 = z1 * z2, p02 = z0 * z2, p01 = z0 * z1;
     const float num = area * (z0 * p12);
-    for (int j = ja; j <= jb; ++j) {
-        const float py = (float)j + 0.5f;
-        for (int i = ia; i <= ib; ++i) {
-            const float px = (float)i + 0.5f;
-            const float w0 = (x2 - x1) * (py - y1) - (y2 - y1) * (px - x1);
-            const float w1 = (x0 - x2) * (py - y2) - (y0 - y2) * (px - x2);
-            const float w2 = (x1 - x0) * (py - y0) - (y1 - y0) * (px - x0);
-            const bool inside = (area > 0.0f) ? (w0 >= 0.0f && w1 >= 0.0f && w2 >= 0.0f)
-                                              : (w0 <= 0.0f && w1 <= 0.0f && w2 <= 0.0f);
-            if (!inside) continue;
+    const float ex0 = x2 - x1, ey0 = y2 - y1, ex1 = x0 - x2, ey1 = y0 - y2, ex2 = x1 - x0, ey2 = y1 - y0;   // (the differences of the edge functions below)
+    const int n = (ib - ia + 1) * (jb - ja + 1);
+    int i = ia, j = ja;
+    for (int p = 0; p < n; ++p) {
+        const float px = (float)i + 0.5f, py = (float)j + 0.5f;
+        const float w0 = ex0 * (py - y1) - ey0 * (px - x1);
+        const float w1 = ex1 * (py - y2) - ey1 * (px - x2);
+        const float w2 = ex2 * (py - y0) - ey2 * (px - x0);
+        const bool inside = (area > 0.0f) ? (w0 >= 0.0f && w1 >= 0.0f && w2 >= 0.0f)
+                                          : (w0 <= 0.0f && w1 <= 0.0f && w2 <= 0.0f);
+        if (inside) {
             const float den = (w0 * p12 + w1 * p02) + w2 * p01;
             const float z = num / den;
-            if (!(z > 0.0f)) continue;
-            store(i, j, z);
+            if (z > 0.0f) store(i, j, z);
         }
+        if (++i > ib) { i = ia; ++j; }
     }
 }
 
@@ -338,6 +347,8 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     __shared__ long long s_hi[kFusedThreads / 64], s_lo[kFusedThreads / 64];
     __shared__ int s_cnt[kFusedThreads / 64];
     __shared__ int s_box[4];
+    __shared__ int s_behind;   // some vertex is not in front of the near plane: a closed mesh is then drawn whole too
+    __shared__ int s_nfeat[kFeatRing], s_feat_read;
     __shared__ int s_last;
     // Workgroups are handed to the XCDs round robin by their linear index; the 2 x parts workgroups of an object read the
     // same mesh (186 KB of indices + 98 KB of vertices at the bench's 15.5 k triangles): with the grid laid out as
@@ -360,6 +371,11 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     float* s_v = reinterpret_cast<float*>(smem);
     uint32_t* s_z = reinterpret_cast<uint32_t*>(smem + (((size_t)vcache_cap * 12 + 15) & ~(size_t)15));
     if (tid < 4) s_box[tid] = (tid < 2) ? INT32_MAX : -1;
+    if (tid == 0) s_behind = 0;
+    // what the sample phase needs of the control block and the object's state, fetched NOW, next to the vertices (round 6: as
+    // `c.feat_read` -> `st.n_feat[slot]` at their first use they were two more dependent round trips between the phases)
+    if (tid >= 64 && tid < 64 + kFeatRing) s_nfeat[tid - 64] = st.n_feat[tid - 64];
+    if (tid == 128) s_feat_read = c.feat_read;
 #ifdef ROFT_FUSED_PROFILE
     long long u_t0 = wall_clock64();
     if (tid < 8 && bx < 4) st.dbg[bx * 8 + tid] = 0;
@@ -369,7 +385,8 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     // them: ceil(min - 0.5) .. floor(max - 0.5) are monotone, so the box of the vertices covers every triangle)
     {
         int bi0 = INT32_MAX, bj0 = INT32_MAX, bi1 = -1, bj1 = -1;
-        constexpr int kVB = 4;   // vertices per thread whose coordinates are fetched together
+        bool behind = false;
+        constexpr int kVB = 8;   // vertices per thread whose coordinates are fetched together
         for (int vb = tid; vb < nv; vb += kVB * kFusedThreads) {
           float vc[kVB][3];
 #pragma unroll
@@ -391,9 +408,12 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
                 const float lo_j = fminf(fmaxf(ceilf(sy - 0.5f), 0.0f), (float)th), hi_j = fminf(fmaxf(floorf(sy - 0.5f), -1.0f), (float)(th - 1));
                 bi0 = min(bi0, (int)lo_i); bi1 = max(bi1, (int)hi_i);
                 bj0 = min(bj0, (int)lo_j); bj1 = max(bj1, (int)hi_j);
+            } else {
+                behind = true;
             }
           }
         }
+        if (__any(behind) && (tid & 63) == 0) atomicOr(&s_behind, 1);
         for (int off = 32; off > 0; off >>= 1) {
             bi0 = min(bi0, __shfl_xor(bi0, off, 64)); bj0 = min(bj0, __shfl_xor(bj0, off, 64));
             bi1 = max(bi1, __shfl_xor(bi1, off, 64)); bj1 = max(bj1, __shfl_xor(bj1, off, 64));
@@ -429,10 +449,10 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
         j1 = b1;
     }
     const int win_w = i1 - i0 + 1;
-    const int fslot = (c.feat_read >= 0) ? c.feat_read : 0;
+    const int fslot = (s_feat_read >= 0) ? s_feat_read : 0;
     const uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
     const float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
-    const int n = st.n_feat[fslot];
+    const int n = s_nfeat[fslot];
     LikelihoodSum err;
     int cnt = 0;
     if (win_w > 0 && j1 >= j0 && i0 >= 0 && j0 >= 0) {
@@ -447,6 +467,8 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
                 (void)__hip_atomic_fetch_min(zw + ((j - js) * win_w + (i - i0)), __float_as_uint(z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             constexpr int kTB = 8;   // triangles per thread whose vertex indices are fetched together
+            // closed mesh, everything in front of the near plane: triangles that face away are left out (the render contract)
+            const uint8_t* const flips = (prm.tri_flip && !s_behind) ? prm.tri_flip : nullptr;
             // (split: the triangles are dealt out to the workgroups of the alternative in runs of 64 -- one run per wave and
             //  fetch, so the index loads stay coalesced and neighbouring runs, which cost alike, go to different workgroups)
             const int stride = G, first = grp;
@@ -454,10 +476,13 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
             const int n_slots = split ? ((nt + 63) / 64 + stride - 1 - first) / stride * 64 : nt;        // (its runs; the last one may be short)
             for (int tb = tid; tb < n_slots; tb += kTB * kFusedThreads) {
               int idx[kTB][3];
+              int cull[kTB];
 #pragma unroll
               for (int k = 0; k < kTB; ++k) {
-                  const int32_t* tri = prm.tris + (size_t)3 * min(tri_of(min(tb + k * kFusedThreads, n_slots - 1)), nt - 1);
+                  const int t = min(tri_of(min(tb + k * kFusedThreads, n_slots - 1)), nt - 1);
+                  const int32_t* tri = prm.tris + (size_t)3 * t;
                   idx[k][0] = tri[0]; idx[k][1] = tri[1]; idx[k][2] = tri[2];
+                  cull[k] = flips ? 1 + (int)flips[t] : 0;
               }
 #pragma unroll
               for (int k = 0; k < kTB; ++k) {
@@ -473,7 +498,7 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
                     project_vertex(prm.verts + (size_t)3 * v1, P, fx, fy, cx, cy, x1, y1, z1);
                     project_vertex(prm.verts + (size_t)3 * v2, P, fx, fy, cx, cy, x2, y2, z2);
                 }
-                raster_projected(x0, y0, z0, x1, y1, z1, x2, y2, z2, tw, th, js, je, store);
+                raster_projected(x0, y0, z0, x1, y1, z1, x2, y2, z2, tw, th, js, je, cull[k], store);
               }
             }
             __syncthreads();
@@ -623,7 +648,9 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     // cache the projected vertices when they leave room for a window of 8 k pixels (a window that large or larger is
     // rendered in strips) and for the widest row of the target
     const size_t min_win = (size_t)4 * std::max(8192, a.tile_w);
-    const bool cache = vbytes + min_win <= lds_total && !(opts && opts->no_vertex_cache);
+    static const int no_vcache_env = getenv("ROFT_OUTLIER_NO_VCACHE") ? atoi(getenv("ROFT_OUTLIER_NO_VCACHE")) : 0;   // (experiments)
+    static const int win_px_env = getenv("ROFT_OUTLIER_WIN_PX") ? atoi(getenv("ROFT_OUTLIER_WIN_PX")) : 0;           // (experiments)
+    const bool cache = vbytes + min_win <= lds_total && !(opts && opts->no_vertex_cache) && !no_vcache_env;
     const int vcache_cap = cache ? a.max_verts : 0;
     int win_cap = (int)((lds_total - (cache ? vbytes : 0)) / 4);
     (void)set_max_dynamic_lds(reinterpret_cast<const void*>(outlier_fused_kernel), (int)lds_total);
@@ -640,7 +667,8 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     if (parts <= 1 || !a.zmerge || (size_t)a.n_obj * parts > a.zmerge_slabs) split = 0;
     // (a band is a fraction of the window: request only the LDS it can need, so that other chains' workgroups fit next to it)
     const int lds_parts = split ? 1 : parts;
-    const size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + lds_parts - 1) / lds_parts + (size_t)a.tile_w);
+    size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + lds_parts - 1) / lds_parts + (size_t)a.tile_w);
+    if (win_px_env > 0) win_need = std::min(win_need, (size_t)4 * std::max(win_px_env, a.tile_w));
     const size_t lds = std::min(lds_total, (((cache ? vbytes : 0) + win_need + 15) & ~(size_t)15));
     win_cap = std::min(win_cap, (int)((lds - (cache ? vbytes : 0)) / 4));
     // (operator level: a smaller window forces the strip path)

@@ -68,6 +68,10 @@ struct ObjParams {
     const int32_t* tris;
     int n_verts, n_tris;
     const double* q_override;  // operator level only: explicit 9x9 process noise (else Q(T) from the PSDs)
+    // closed-surface classification of the mesh (mesh_class.h): tri_flip[t] = 1: triangle t of `tris` is wound clockwise seen
+    // from outside; null: the mesh is not a closed orientable surface and every triangle is drawn.  (`tris` of a closed mesh is
+    // in the facing-coherent walk order, tri_flip follows it.)
+    const uint8_t* tri_flip;
 };
 
 // compact flow measurement record (what the SKF kernel consumes)

@@ -128,6 +128,16 @@ def make_mesh(verts, tris):
     return m
 
 
+def mesh_classify(verts, tris):
+    """(closed, flip[n_tris]): is the mesh a closed orientable surface, which triangles are wound clockwise seen from outside
+    (roft_mesh_classify: host code, the classification roft_object_add applies; rules in oracle/ro_meshclass.c)."""
+    m = make_mesh(verts, tris)
+    flip = np.zeros(max(m.n_tris, 1), np.uint8)
+    closed = C.c_int(-1)
+    L.check(L.lib().roft_mesh_classify(C.byref(m), _p(flip), C.byref(closed)))
+    return bool(closed.value), flip[:m.n_tris]
+
+
 def render_depth(mesh, x, q, cam, divider):
     x, q = _f64(x), _f64(q)
     tile = np.zeros((cam.height // divider, cam.width // divider), np.float32)

@@ -282,3 +282,50 @@ def test_preparation_ahead_and_early_velocity_gate_change_nothing(monkeypatch):
                 assert np.array_equal(x, y), (prep, part, kw)
             for x, y in zip(ref_masks, masks):
                 assert np.array_equal(x, y), (prep, part, kw)
+
+
+@pytest.mark.parametrize("shared", [False, True])
+def test_host_frames_that_are_consecutive_in_memory_go_up_in_one_copy(shared):
+    """Round 6: a recorded sequence held as one [frames, H, W] host array -- frame t + 1 starts where frame t ends.  A batch's
+    depth images (and its flow images) then cross the bus in ONE copy per run instead of one per frame; the bytes are the same,
+    the trajectory is the one DEVICE inputs give, and objects that show the same host pointers (a shared scene) share the run."""
+    n, T = 16, 8
+    n_obj = 3 if shared else 2
+    sts = [util.stream(760, n, scale=2, device="cuda")] * n_obj if shared else [util.stream(760 + o, n, scale=2, device="cuda") for o in range(n_obj)]
+    devs = [util.to_device(s) for s in sts]
+    ref, masks_ref, _ = util.run_engine_logged(make_engine, devs, n, T=T)
+    host = {}
+    for s in sts:
+        if id(s) not in host:
+            host[id(s)] = (s.depth.cpu().pin_memory(), s.flow.cpu().pin_memory(), s.mask_gt.cpu().pin_memory())
+    eng = make_engine(sts, max_batch_frames=T)
+    eng.enable_log(n)
+    for k0 in range(0, n, T):
+        frames = []
+        for k in range(k0, k0 + T):
+            row = []
+            for s in sts:
+                d, f, m = host[id(s)]
+                mi = s.mask_delivery[k]
+                pose = (s.pose_meas[k, :3], s.pose_meas[k, 3:]) if s.pose_valid[k] else None
+                row.append(dict(depth=d[k].data_ptr(), flow=f[k].data_ptr() if s.flow_valid[k] else None,
+                                mask=m[mi].data_ptr() if mi >= 0 else None, pose=pose, dt=s.dt, mem_kind=L.MEM_HOST))
+            frames.append(row)
+        eng.submit_batch(frames)
+        eng.step()
+    got = eng.get_log(0, n)
+    s = eng.stats()
+    eng.close()
+    for x, y in zip(ref, got):
+        assert np.array_equal(x, y)
+    distinct = 1 if shared else n_obj
+    st0 = sts[0]
+    d0, f0, m0 = host[id(st0)]
+    n_flows = int(sum(int(s_.flow_valid[:n].sum()) for s_ in (sts[:1] if shared else sts)))
+    n_masks = int(sum(int((s_.mask_delivery[:n] >= 0).sum()) for s_ in sts)) if not shared else None
+    assert s["h2d_bytes"] >= distinct * n * d0[0].numel() * 4 + n_flows * f0[0].numel() * f0.element_size()
+    # two batches: per distinct stream one depth run per batch, one flow run per batch (frame 0 has no flow: the first batch's
+    # run starts at frame 1), + the delivered masks one by one -- not 2 x 16 image copies per stream
+    masks_total = sum(int((s_.mask_delivery[:n] >= 0).sum()) for s_ in sts)
+    assert s["h2d_copies"] <= distinct * 2 * 2 + masks_total, s
+    assert s["h2d_copies"] < distinct * 2 * n

@@ -439,6 +439,57 @@ def test_render_and_outlier_test_on_a_mesh_of_the_reference(oracle):
             assert sel == 1 == (1 if ref[0][0] > 2.0 * ref[1][0] else 0), kw
 
 
+@pytest.mark.parametrize("name", ["box", "box_reversed", "box_random_windings", "box_open", "box_duplicate_triangle", "box_unwelded",
+                                  "two_components", "projective_plane"])
+def test_render_follows_the_back_face_rule_of_the_contract(oracle, name):
+    """Round 6: a mesh the classification accepts as a closed surface is rendered without the triangles that face away (and in a
+    walk order of the engine's own); open / non-manifold / non-orientable meshes are drawn whole.  Either way the tile equals
+    oracle/ro_render.c bit for bit, in every launch shape, and with the camera INSIDE the surface (a vertex behind the near plane:
+    the rule is off for that render)."""
+    import mesh_zoo
+    from roft_amd import synth
+    verts, tris, closed = mesh_zoo.zoo(14)[name]
+    if name == "projective_plane":
+        verts = (verts * 2.0).astype(np.float32)
+    assert ops.mesh_classify(verts, tris)[0] == closed == oracle.mesh_classify(verts, tris)[0]
+    omesh, mesh = oracle.make_mesh(verts, tris), ops.make_mesh(verts, tris)
+    cam = synth.Camera.shape_a()
+    ocam = util.oracle_camera(oracle, cam)
+    dcam = L.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy)
+    rng = np.random.default_rng(31)
+    poses = []
+    for _ in range(4):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        poses.append((np.array([rng.uniform(-0.12, 0.12), rng.uniform(-0.08, 0.08), rng.uniform(0.35, 0.8)]), q))
+    poses.append((np.array([0.0, 0.0, 0.02]), np.array([1.0, 0, 0, 0])))     # the camera inside the box: vertices behind it
+    poses.append((np.array([0.0, 0.0, 0.09]), np.array([1.0, 0, 0, 0])))     # just in front of it: every vertex visible, rule on
+    drawn = []
+    for x, q in poses:
+        t0 = oracle.render_depth(omesh, x, q, ocam, 2)
+        t1 = ops.render_depth(mesh, x, q, dcam, 2)
+        assert np.array_equal(t0, t1), (name, x, int((t0 != t1).sum()))
+        drawn.append(int((t0 > 0).sum()))
+    assert min(drawn[:4]) > 100, drawn     # (the two poses at the camera may leave a small mesh behind it)
+    # the outlier test on a scene of that mesh, several launch shapes
+    x, q = poses[0]
+    full = oracle.render_depth(omesh, x, q, ocam, 1)
+    depth = np.where(full > 0, full, 1.5).astype(np.float32)
+    mask = (full > 0).astype(np.uint8) * 255
+    x2 = np.stack([x + [0.02, 0.01, 0.03], x + [0.001, 0.0, 0.001]])
+    q2 = np.stack([poses[1][1], q])
+    t_ref = [oracle.render_depth(omesh, x2[k], q2[k], ocam, 2) for k in range(2)]
+    ref = [oracle.depth_likelihood(ocam, depth, mask, t_ref[k], 2) for k in range(2)]
+    for kw in (dict(bands=1), dict(bands=2), dict(bands=8), dict(bands=4, split=False), dict(bands=1, vertex_cache=False), dict(bands=2, window_pixels=320)):
+        Lv, ns, sel, tiles = ops.outlier_test(dcam, 2, depth, mask, mesh, x2, q2, **kw)
+        for k in range(2):
+            assert np.array_equal(tiles[k], t_ref[k]), (name, kw, k, int((tiles[k] != t_ref[k]).sum()))
+            assert ns[k] == ref[k][1]
+            if ref[k][1]:
+                assert abs(Lv[k] - ref[k][0]) <= LIK_RTOL * abs(ref[k][0]), (name, kw, k)
+        assert sel == (1 if ref[0][0] > 2.0 * ref[1][0] else 0)
+
+
 def test_outlier_test_no_samples(oracle):
     st = util.stream(18, 2, scale=2, mesh_n=12)
     mesh = ops.make_mesh(*st.mesh)

@@ -5,10 +5,11 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 SRC=${ROFT_SRC:-$R}
 NAME=$1; EXTRA=$2
-B=$R/build_ab/obj_$NAME; mkdir -p $B
+B=$R/build_ab/obj_$NAME; rm -rf $B; mkdir -p $B
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-pass-failed $EXTRA"
 pids=()
-for f in k_mask k_flow k_skf k_ukf k_render k_opticalflow engine flow_producer; do
+for f in k_mask k_flow k_skf k_ukf k_render k_opticalflow engine flow_producer mesh_class; do
+  [ -f $SRC/roft_amd/csrc/$f.hip ] || continue   # (a source tree of an earlier commit may lack a file)
   hipcc $FLAGS -c $SRC/roft_amd/csrc/$f.hip -o $B/$f.o &
   pids+=($!)
 done
