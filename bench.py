@@ -356,7 +356,7 @@ def main():
     dev_index = int(os.environ.get("ROFT_BENCH_DEVICE", local_rank))
     if "ROFT_BENCH_DEVICE" in os.environ and world > 1:
         # several PROCESSES on one GPU: an engine counts the CUs its early pose lanes may occupy over its own objects only
-        # (engine.hip, early_lanes) -- off, the lanes then wait for velocity-filter workgroups that are resident
+        # (engine_step.hip, early_lanes) -- off, the lanes then wait for velocity-filter workgroups that are resident
         os.environ.setdefault("ROFT_EARLY_LANES", "0")
     backend = os.environ.get("ROFT_BENCH_BACKEND", "nccl")
     if dev_index >= torch.cuda.device_count():

@@ -348,7 +348,6 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     __shared__ int s_cnt[kFusedThreads / 64];
     __shared__ int s_box[4];
     __shared__ int s_behind;   // some vertex is not in front of the near plane: a closed mesh is then drawn whole too
-    __shared__ int s_nfeat[kFeatRing], s_feat_read;
     __shared__ int s_last;
     // Workgroups are handed to the XCDs round robin by their linear index; the 2 x parts workgroups of an object read the
     // same mesh (186 KB of indices + 98 KB of vertices at the bench's 15.5 k triangles): with the grid laid out as
@@ -372,10 +371,6 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     uint32_t* s_z = reinterpret_cast<uint32_t*>(smem + (((size_t)vcache_cap * 12 + 15) & ~(size_t)15));
     if (tid < 4) s_box[tid] = (tid < 2) ? INT32_MAX : -1;
     if (tid == 0) s_behind = 0;
-    // what the sample phase needs of the control block and the object's state, fetched NOW, next to the vertices (round 6: as
-    // `c.feat_read` -> `st.n_feat[slot]` at their first use they were two more dependent round trips between the phases)
-    if (tid >= 64 && tid < 64 + kFeatRing) s_nfeat[tid - 64] = st.n_feat[tid - 64];
-    if (tid == 128) s_feat_read = c.feat_read;
 #ifdef ROFT_FUSED_PROFILE
     long long u_t0 = wall_clock64();
     if (tid < 8 && bx < 4) st.dbg[bx * 8 + tid] = 0;
@@ -386,7 +381,7 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
     {
         int bi0 = INT32_MAX, bj0 = INT32_MAX, bi1 = -1, bj1 = -1;
         bool behind = false;
-        constexpr int kVB = 8;   // vertices per thread whose coordinates are fetched together
+        constexpr int kVB = 4;   // vertices per thread whose coordinates are fetched together
         for (int vb = tid; vb < nv; vb += kVB * kFusedThreads) {
           float vc[kVB][3];
 #pragma unroll
@@ -449,10 +444,10 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
         j1 = b1;
     }
     const int win_w = i1 - i0 + 1;
-    const int fslot = (s_feat_read >= 0) ? s_feat_read : 0;
+    const int fslot = (c.feat_read >= 0) ? c.feat_read : 0;
     const uint32_t* fpix = a.feat_pix + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
     const float* fdep = a.feat_depth + ((size_t)obj * kFeatRing + fslot) * a.feat_cap;
-    const int n = s_nfeat[fslot];
+    const int n = st.n_feat[fslot];
     LikelihoodSum err;
     int cnt = 0;
     if (win_w > 0 && j1 >= j0 && i0 >= 0 && j0 >= 0) {
@@ -648,9 +643,7 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     // cache the projected vertices when they leave room for a window of 8 k pixels (a window that large or larger is
     // rendered in strips) and for the widest row of the target
     const size_t min_win = (size_t)4 * std::max(8192, a.tile_w);
-    static const int no_vcache_env = getenv("ROFT_OUTLIER_NO_VCACHE") ? atoi(getenv("ROFT_OUTLIER_NO_VCACHE")) : 0;   // (experiments)
-    static const int win_px_env = getenv("ROFT_OUTLIER_WIN_PX") ? atoi(getenv("ROFT_OUTLIER_WIN_PX")) : 0;           // (experiments)
-    const bool cache = vbytes + min_win <= lds_total && !(opts && opts->no_vertex_cache) && !no_vcache_env;
+    const bool cache = vbytes + min_win <= lds_total && !(opts && opts->no_vertex_cache);
     const int vcache_cap = cache ? a.max_verts : 0;
     int win_cap = (int)((lds_total - (cache ? vbytes : 0)) / 4);
     (void)set_max_dynamic_lds(reinterpret_cast<const void*>(outlier_fused_kernel), (int)lds_total);
@@ -667,8 +660,7 @@ void launch_outlier(const EngineArrays& a, int lin, hipStream_t s, hipEvent_t st
     if (parts <= 1 || !a.zmerge || (size_t)a.n_obj * parts > a.zmerge_slabs) split = 0;
     // (a band is a fraction of the window: request only the LDS it can need, so that other chains' workgroups fit next to it)
     const int lds_parts = split ? 1 : parts;
-    size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + lds_parts - 1) / lds_parts + (size_t)a.tile_w);
-    if (win_px_env > 0) win_need = std::min(win_need, (size_t)4 * std::max(win_px_env, a.tile_w));
+    const size_t win_need = (size_t)4 * std::max((size_t)a.tile_w, ((size_t)a.tile_w * a.tile_h + lds_parts - 1) / lds_parts + (size_t)a.tile_w);
     const size_t lds = std::min(lds_total, (((cache ? vbytes : 0) + win_need + 15) & ~(size_t)15));
     win_cap = std::min(win_cap, (int)((lds - (cache ? vbytes : 0)) / 4));
     // (operator level: a smaller window forces the strip path)

@@ -8,7 +8,7 @@ NAME=$1; EXTRA=$2
 B=$R/build_ab/obj_$NAME; rm -rf $B; mkdir -p $B
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-pass-failed $EXTRA"
 pids=()
-for f in k_mask k_flow k_skf k_ukf k_render k_opticalflow engine flow_producer mesh_class; do
+for f in k_mask k_flow k_skf k_ukf k_render k_opticalflow engine engine_submit engine_step engine_results engine_ops engine_debug flow_producer mesh_class; do
   [ -f $SRC/roft_amd/csrc/$f.hip ] || continue   # (a source tree of an earlier commit may lack a file)
   hipcc $FLAGS -c $SRC/roft_amd/csrc/$f.hip -o $B/$f.o &
   pids+=($!)

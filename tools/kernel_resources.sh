@@ -4,7 +4,7 @@
 #   bash tools/kernel_resources.sh > profiles/r04_kernel_resources.csv
 R=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
-for f in k_mask k_flow k_skf k_ukf k_render k_opticalflow engine flow_producer; do
+for f in k_mask k_flow k_skf k_ukf k_render k_opticalflow engine engine_submit engine_step engine_results engine_ops engine_debug flow_producer; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function -Wno-pass-failed -Rpass-analysis=kernel-resource-usage \
         -c $R/roft_amd/csrc/$f.hip -o $T/$f.o 2> $T/$f.ru &
 done
