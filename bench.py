@@ -1005,7 +1005,7 @@ def main():
         # HBM traffic of this kernel: a separate rocprofv3 --pmc pass of this same command, committed under profiles/
         # (see profiles/README.md for the gfx950 counting caveats); only quoted when the workload matches that pass
         traffic, traffic_raw, traffic_source = None, None, None
-        for tag in ("r05", "r04", "r03", "r02"):
+        for tag in ("r06", "r05", "r04", "r03", "r02"):
             pmc_path = os.path.join(ROOT, "profiles", "%s_pmc_k1.json" % tag)
             if not os.path.exists(pmc_path):
                 continue
@@ -1110,7 +1110,7 @@ def main():
             "outlier_fused": dict(per="object and test", bytes=2 * (12 * nv + 12 * nt + 8 * n_feat), mark="outlier_render_likelihood", frames_per_group=1.0),
         }
         pmc = {}
-        pmc_tag = next((t for t in ("r05", "r04") if os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc_FETCH_SIZE.csv" % t))), "r04")
+        pmc_tag = next((t for t in ("r06", "r05", "r04") if os.path.exists(os.path.join(ROOT, "profiles", "%s_pmc_FETCH_SIZE.csv" % t))), "r04")
         for cname in ("FETCH_SIZE", "WRITE_SIZE"):
             path = os.path.join(ROOT, "profiles", "%s_pmc_%s.csv" % (pmc_tag, cname))
             if os.path.exists(path):

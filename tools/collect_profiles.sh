@@ -3,14 +3,15 @@
 # gpurun_out/<tag>/ (copy the ones to keep into profiles/ with the tag as prefix).   usage: bash tools/collect_profiles.sh [tag]
 set -x
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-TAG=${1:-r05}
+TAG=${1:-r06}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 # the driver-shaped run (what BENCH_rNN.json records) three times, the default run and a long steady-state run
-for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 5 > $O/bench_driver_shaped_$i.json 2> $O/bench.err; done
-timeout 300 python bench.py > $O/bench_64obj.json 2>> $O/bench.err
-timeout 300 python bench.py --steps 240 --warmup 16 --windows 3 --no-cpu-baseline --pcie-frames 0 --no-extras > $O/bench_steady_240.json 2>> $O/bench.err
+# (bench.py prints the compact line the driver parses; the full record of a run is its --json-out side file: *_detail.json)
+for i in 1 2 3; do timeout 300 python bench.py --steps 20 --warmup 5 --json-out $O/bench_driver_shaped_${i}_detail.json > $O/bench_driver_shaped_$i.json 2> $O/bench.err; done
+timeout 300 python bench.py --json-out $O/bench_64obj_detail.json > $O/bench_64obj.json 2>> $O/bench.err
+timeout 300 python bench.py --steps 240 --warmup 16 --windows 3 --no-cpu-baseline --pcie-frames 0 --no-extras --json-out $O/bench_steady_240_detail.json > $O/bench_steady_240.json 2>> $O/bench.err
 timeout 900 python tools/run_baseline_configs.py --out $O/baseline_configs.json > /dev/null 2> $O/baseline.err
 # objects per GPU: the per-GPU points of the 8 / 4 / 2 / 1-GPU strong-scaling curve of config #4 (64 / 32 / 16 / 8 objects) and beyond
 python - > $O/object_sweep.json <<PY
@@ -18,8 +19,8 @@ import json, subprocess, sys
 out = []
 for n in (8, 16, 32, 64, 128, 256):
     r = subprocess.run([sys.executable, "bench.py", "--steps", "60", "--warmup", "12", "--objects", str(n), "--windows", "3" if n <= 64 else "1",
-                        "--no-cpu-baseline", "--pcie-frames", "0", "--no-extras"], capture_output=True, text=True, timeout=600)
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                        "--no-cpu-baseline", "--pcie-frames", "0", "--no-extras", "--json-out", "/tmp/roft_sweep_detail.json"], capture_output=True, text=True, timeout=600)
+    d = json.load(open("/tmp/roft_sweep_detail.json"))
     out.append(dict(objects=n, value=d["value"], runs=d["runs"], ms_per_step=d["ms_per_step"], frames_per_sec_per_object=d["frames_per_sec_per_object"],
                     k1_avg_launch_us=d["roofline"]["avg_launch_us"], roofline_frac=d["roofline"]["frac"], launches_per_frame=d["launches_per_frame"],
                     kernels=d["kernels_post_run_breakdown"]))
@@ -30,9 +31,9 @@ python - > $O/object_sweep_20.json <<PY
 import json, subprocess, sys
 out = []
 for n in (8, 16, 32, 64):
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--objects", str(n), "--no-cpu-baseline", "--pcie-frames", "0", "--no-extras"],
-                       capture_output=True, text=True, timeout=600)
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--objects", str(n), "--no-cpu-baseline", "--pcie-frames", "0", "--no-extras",
+                        "--json-out", "/tmp/roft_sweep_detail.json"], capture_output=True, text=True, timeout=600)
+    d = json.load(open("/tmp/roft_sweep_detail.json"))
     out.append(dict(objects=n, values=d["runs"], median=d["value"], frames_per_sec_per_object=d["value"] / n, ms_per_step=d["ms_per_step"]))
 json.dump(dict(what="python bench.py --steps 20 --warmup 5 --objects N (one MI355X): value = median of the run's five timed windows (values)", runs=out), sys.stdout, indent=1)
 PY
@@ -47,12 +48,12 @@ python tools/marks_timeline.py $O/marks_240.txt --from 4000 --to 9000 > $O/marks
 python tools/marks_timeline.py $O/marks_240.txt --from 6000 --to 7400 --list | tail -n +16 >> $O/marks_timeline_240.txt
 rm -f $O/marks_20.txt $O/marks_240.txt
 # the N > 1 code path executed: two ranks on this one GPU over gloo (the driver's multi-GPU runs use one GPU per rank and RCCL)
-ROFT_BENCH_DEVICE=0 ROFT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 5 > $O/bench_2ranks_one_gpu_gloo.json 2>> $O/bench.err
-ROFT_BENCH_DEVICE=0 ROFT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 20 --warmup 5 --shared-scene > $O/bench_2ranks_one_gpu_gloo_shared_scene.json 2>> $O/bench.err
+ROFT_BENCH_DEVICE=0 ROFT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 20 --warmup 5 --json-out $O/bench_2ranks_one_gpu_gloo_detail.json > $O/bench_2ranks_one_gpu_gloo.json 2>> $O/bench.err
+ROFT_BENCH_DEVICE=0 ROFT_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29513 bench.py --gpus 2 --steps 20 --warmup 5 --shared-scene --json-out $O/bench_2ranks_one_gpu_gloo_shared_scene_detail.json > $O/bench_2ranks_one_gpu_gloo_shared_scene.json 2>> $O/bench.err
 timeout 300 python tools/live_latency.py --out $O/live_latency.json > /dev/null 2>&1
 cd /tmp && export TMPDIR=/tmp
 # kernel stats + timeline of the driver-shaped run, chains overlapping
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --windows 1 --k1-windows 1 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 > $O/bench_under_rocprof.json 2> /dev/null
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 20 --warmup 5 --windows 1 --k1-windows 1 --no-cpu-baseline --pcie-frames 0 --no-extras --rehearsal-ms 0 --json-out $O/bench_under_rocprof_detail.json > $O/bench_under_rocprof.json 2> /dev/null
 python3 $R/tools/prof_summary.py stats $O/stats/*/*kernel_stats.csv $O/bench_kernel_stats.csv
 # the roofline kernel over exactly the launches that bench.py's event pairs time in that run: --windows 1 = window 0 (2 warm-up
 # batches (frames 0 | 1 - 4) + 4 timed), then ONE instrumented window (--k1-windows 1; 2 warm-up batches + 4 TIMED: launches 8 .. 11), then the
