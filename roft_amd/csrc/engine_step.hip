@@ -359,7 +359,14 @@ int step_batch(roft_engine* e)
         if (full) { HIP_TRY(hipEventRecord(e->ev_done[slot][lin], sp)); ++evops; }
     }
     HP_MARK(e, 6, hp_t);
-    if (e->host_prof) e->hp_batches++;
+    if (e->host_prof) {
+        e->hp_batches++;
+        // ROFT_HOST_PROF=1+: the host's time in this step, batch by batch (a burst's first batches are not its later ones)
+        static const bool per_batch = getenv("ROFT_HOST_PROF") && getenv("ROFT_HOST_PROF")[0] == '1' && getenv("ROFT_HOST_PROF")[1] == '+';
+        if (per_batch)
+            std::fprintf(stderr, "[roft host batch %d T=%d] ctrl %.1f mask %.1f vel %.1f lanes %.1f us (cumulative)\n", e->batch_counter, T,
+                         e->hp_acc[3], e->hp_acc[4], e->hp_acc[5], e->hp_acc[6]);
+    }
     {
         roft_batch_trace& tr = e->trace[e->batch_counter % roft_engine::kTraceRing];
         tr = roft_batch_trace{};
