@@ -627,6 +627,11 @@ int roft_object_add(roft_engine* e, const roft_object_desc* d, int* obj_id)
     p.r_flow[1] = d->v_meas_cov_flow[1];
     auto bail = [&](int code, const std::string& msg) { delete o; return fail(code, msg); };
     if (d->mesh.n_verts > 0 && d->mesh.n_tris > 0) {
+        if (!d->mesh.verts || !d->mesh.tris) return bail(ROFT_ERR_INVALID, "mesh: null vertex or triangle array");
+        for (size_t i = 0; i < (size_t)3 * d->mesh.n_tris; ++i)   // (the rasteriser indexes the vertex array with these)
+            if (d->mesh.tris[i] < 0 || d->mesh.tris[i] >= d->mesh.n_verts)
+                return bail(ROFT_ERR_INVALID, "mesh: triangle " + std::to_string(i / 3) + " refers to vertex " + std::to_string(d->mesh.tris[i]) +
+                                                  " of " + std::to_string(d->mesh.n_verts));
         // closed orientable surface?  Then the outlier test's render leaves the triangles that face away out (the render
         // contract, oracle/ro_render.c) and walks the triangles in an order that keeps alike-facing ones together
         PreparedMesh pm;

@@ -393,6 +393,8 @@ static int op_outlier(const roft_camera* cam, int divider, const float* depth, c
         a.tile_h = cam->height / a.cam.divider;
         a.max_verts = a.max_tris = 0;
     };
+    for (size_t i = 0; i < (size_t)3 * mesh->n_tris; ++i)
+        if (mesh->tris[i] < 0 || mesh->tris[i] >= mesh->n_verts) return fail(ROFT_ERR_INVALID, "mesh: a triangle refers to a vertex outside the vertex array");
     PreparedMesh pm;
     prepare_mesh(mesh->verts, mesh->n_verts, mesh->tris, mesh->n_tris, pm);
     if (int rc = to_dev(c.b0, mesh->verts, (size_t)3 * mesh->n_verts, c.stream)) return rc;

@@ -429,3 +429,79 @@ def test_batch_trace_reports_a_schedule_that_depends_on_the_batch_index_only():
     assert [b["steady"] for b in tr_c] == [0] * 5 + [1] + [0] * 4
     for x, y in zip(log_a, log_c):
         assert np.array_equal(x, y)
+
+
+def test_lanes_are_released_early_only_by_the_only_engine_of_the_device():
+    """whether a burst batch releases its pose lanes early (they then spin for twists whose producer is not even
+    enqueued) is decided from a COUNT -- the stream sets this process holds on the device when the batch is submitted --, never
+    from whether another engine happens to be busy at that instant.  One engine alone: early lanes in its burst batches.  Two
+    engines in one process, stepped alternately in batches: none in either, and both log what each logs alone, bit for bit."""
+    n = 36
+    sa = [util.to_device(util.stream(590 + i, n, scale=2, device="cuda")) for i in range(2)]
+    sb = [util.to_device(util.stream(595 + i, n, scale=2, device="cuda")) for i in range(3)]
+
+    def batches(eng, streams, k0, t):
+        eng.submit_batch([[util.device_frame(st, k0 + j) for st in streams] for j in range(t)])
+        eng.step()
+
+    def alone(streams):
+        eng = make_engine(streams, max_batch_frames=6)
+        eng.enable_log(n)
+        for k0 in range(0, n, 6):
+            batches(eng, streams, k0, 6)
+        log, tr = eng.get_log(0, n), eng.batch_trace()
+        eng.close()
+        return log, tr
+
+    log_a, tr_a = alone(sa)
+    log_b, tr_b = alone(sb)
+    # (bursts of the only engine release lanes early -- on a stream set whose four chains were probed onto hardware queues of their
+    #  own, which is what a fresh process gets; a set with conflicts never does, and then there is nothing to compare)
+    early_alone = any(b["early_lanes"] for b in tr_a) and any(b["early_lanes"] for b in tr_b)
+    ea, eb = make_engine(sa, max_batch_frames=6), make_engine(sb, max_batch_frames=6)
+    ea.enable_log(n)
+    eb.enable_log(n)
+    for k0 in range(0, n, 6):
+        batches(ea, sa, k0, 6)
+        batches(eb, sb, k0, 6)
+    got_a, got_b = ea.get_log(0, n), eb.get_log(0, n)
+    tr2_a, tr2_b = ea.batch_trace(), eb.batch_trace()
+    eb.close()
+    # ... and once the other engine is gone, the remaining one is alone again: a new burst releases its lanes early
+    ea.sync()
+    more = [util.to_device(util.stream(590 + i, n + 12, scale=2, device="cuda")) for i in range(2)]
+    for k0 in range(n, n + 12, 6):
+        batches(ea, more, k0, 6)
+    tr3_a = ea.batch_trace()
+    ea.close()
+    assert not any(b["early_lanes"] for b in tr2_a) and not any(b["early_lanes"] for b in tr2_b)
+    if early_alone:
+        assert any(b["early_lanes"] for b in tr3_a if b["batch"] >= n // 6)
+    for x, y in zip(log_a, got_a):
+        assert np.array_equal(x, y)
+    for x, y in zip(log_b, got_b):
+        assert np.array_equal(x, y)
+
+
+def test_a_mesh_whose_triangles_point_outside_its_vertices_is_refused():
+    """roft_object_add / roft_render_depth: the rasteriser indexes the vertex array with the triangles' entries -- an index outside
+    of it is refused at the boundary (ROFT_ERR_INVALID with the triangle named), not read."""
+    from roft_amd import engine as E
+    from roft_amd import ops
+    st = util.stream(597, 2, scale=2)
+    verts, tris = st.mesh
+    bad = tris.copy()
+    bad[5, 1] = len(verts)
+    cfg = E.default_config(st.camera.width, st.camera.height, st.flow_type, max_objects=1)
+    eng = E.ROFTFilterBatch(cfg)
+    with pytest.raises(L.RoftError) as ei:
+        eng.add_object(E.default_object(), verts, bad)
+    assert "triangle 5" in str(ei.value)
+    bad[5, 1] = -1
+    with pytest.raises(L.RoftError):
+        eng.add_object(E.default_object(), verts, bad)
+    eng.add_object(E.default_object(), verts, tris)     # the engine is usable afterwards
+    eng.close()
+    cam = L.Camera(st.camera.width, st.camera.height, st.camera.fx, st.camera.fy, st.camera.cx, st.camera.cy)
+    with pytest.raises(L.RoftError):
+        ops.render_depth(ops.make_mesh(verts, bad), st.gt.x[0], st.gt.q[0], cam, 2)
