@@ -181,7 +181,19 @@ int step_batch(roft_engine* e)
     if (multi && e->had_uploads && !prep) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }   // (prep: same stream as the uploads)
     if (prep && e->batch_counter >= 2) { HIP_TRY(hipStreamWaitEvent(sp0, e->ev_mask[(slot + R - 2) % R], 0)); ++evops; }
     tmark(e, nullptr, prep ? 4 : 0);
-    {
+    // Bursts and engines with CUs to spare (no preparation ahead): control blocks and the ingest of the delivered masks in ONE
+    // launch -- on the mask stream they and the first mask frame were three dependent launches (27 - 35 us in front of the frame).
+    static const int fuse_env = getenv("ROFT_CTRL_INGEST") ? atoi(getenv("ROFT_CTRL_INGEST")) : 1;   // (experiments: 0 = two launches)
+    bool fused = false;
+    if (fuse_env && !prep && e->new_mask_frames && !e->timing) {
+        const size_t n16 = sizeof(FrameCtrl) * (size_t)a.n_obj * T / 16;
+        fused = launch_ctrl_ingest(e->stage[slot], a, n16, e->new_mask_frames, sp0, (multi && (T == 1 || any_early)) ? e->ev_ctrl[slot] : nullptr);
+        if (fused) {
+            ++launches;
+            CHECK_LAUNCH("FrameCtrl upload + mask ingest");
+        }
+    }
+    if (!fused) {
         const size_t n16 = sizeof(FrameCtrl) * (size_t)a.n_obj * T / 16;
         // Events that complete with a kernel (hipExtLaunchKernelGGL stop events) cost neither the barrier packet nor
         // the host call of a hipEventRecord behind it.
@@ -191,7 +203,7 @@ int step_batch(roft_engine* e)
         ++launches;
     }
     CHECK_LAUNCH("FrameCtrl upload");
-    {
+    if (!fused) {
         int last = -1;
         for (int t = 0; t < T; ++t)
             if (e->new_mask_frames & (1u << t)) last = t;
@@ -394,6 +406,16 @@ int roft_step(roft_engine* e)
         // served) leaves bits of THIS batch's frames behind; the next batch's general kernel would replay those frame indices
         // against its own tables.  Clear them behind whatever the mask stream still carries (best effort: the device may be gone).
         (void)hipMemsetAsync(e->arr.mask_general.p, 0, sizeof(unsigned) * (size_t)std::max(e->arr.a.n_obj, 1), e->stream);
+        // ... and the ingest counters of both mask tables: the chain's last kernel, which leaves them zeroed for the batch that
+        // uses a table next (ctrl_ingest_kernel adds to them without a reset of its own), may not have run
+        if (e->arr.mrec.p) {
+            EngineArrays a2 = e->arr.a;
+            a2.T = kMaxBatch;
+            for (int par = 0; par < 2; ++par) {
+                a2.mrec = e->arr.mrec.p + (size_t)par * (kMaxBatch + 1) * a2.n_obj;
+                launch_mask_reset(a2, e->stream);
+            }
+        }
         (void)hipGetLastError();
     }
     {

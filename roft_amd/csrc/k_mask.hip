@@ -127,6 +127,61 @@ __global__ __launch_bounds__(256) void mask_ingest_kernel(EngineArrays a, int t)
     }
 }
 
+// Control blocks of a batch AND the ingest of the masks it delivers in ONE launch (round 6; bursts: on the mask stream the control
+// block upload, the ingest and the first mask frame were three dependent launches, 27 - 35 us before the first frame could
+// start).  Blocks [0, copy_blocks): the pinned staging block -> a.ctrl.  The other blocks: one 256-pixel-group chunk of one object
+// of one delivering frame each; they read the two control fields they need (has_new_mask, new_mask) from the STAGING block, not
+// from the device copy the first blocks are writing.  The counters the ingest adds to are zeroed by the mask chain that used
+// their table last (mask_general_kernel, final launch; mask_reset_tables at allocation), not here: nothing in this kernel depends
+// on anything else in it.
+__global__ __launch_bounds__(256) void ctrl_ingest_kernel(const uint4* __restrict__ src, EngineArrays a, size_t n16, int copy_blocks,
+                                                          int chunks, unsigned frames_packed)
+{
+    if ((int)blockIdx.x < copy_blocks) {
+        uint4* dst = reinterpret_cast<uint4*>(a.ctrl);
+        const size_t stride = (size_t)copy_blocks * blockDim.x;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+        return;
+    }
+    ROFT_RESIDENT(a, RK_MASK_INGEST);
+    const int w = (int)blockIdx.x - copy_blocks;
+    const int chunk = w % chunks, rest = w / chunks, obj = rest % a.n_obj, fi = rest / a.n_obj;
+    const int t = (int)((frames_packed >> (4 * fi)) & 15u);   // the fi-th delivering frame of the batch
+    const FrameCtrl& c = reinterpret_cast<const FrameCtrl*>(src)[(size_t)t * a.n_obj + obj];
+    if (!c.has_new_mask) return;
+    const int n_grp = (a.cam.W * a.cam.H) >> 6;
+    const int g = chunk * blockDim.x + threadIdx.x;
+    int count = 0, ones = 0;
+    if (g < n_grp)
+        ingest_group(reinterpret_cast<const uint4*>(c.new_mask), g,
+                     reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, a.slot_new + t, 0)),
+                     reinterpret_cast<uint2*>(a.planes + plane_offset(a, obj, a.slot_new + t, 1)), count, ones);
+    for (int off = 32; off > 0; off >>= 1) { count += __shfl_xor(count, off, 64); ones += __shfl_xor(ones, off, 64); }
+    if ((threadIdx.x & 63) == 0 && count) {
+        MaskRec& r = a.mrec[(size_t)(t + 1) * a.n_obj + obj];
+        atomicAdd(&r.new_count, count);
+        if (ones) atomicAdd(&r.new_ones, ones);
+    }
+}
+
+// returns false when the batch's delivering frames do not fit the packed argument (more than eight: never with T <= 8)
+bool launch_ctrl_ingest(const void* staging, const EngineArrays& a, size_t n16, unsigned new_mask_frames, hipStream_t s, hipEvent_t stop)
+{
+    unsigned packed = 0;
+    int n_frames = 0;
+    for (int t = 0; t < a.T && t < 16; ++t)
+        if (new_mask_frames & (1u << t)) {
+            if (n_frames >= 8) return false;
+            packed |= (unsigned)t << (4 * n_frames++);
+        }
+    const int n_grp = a.cam.W * a.cam.H / 64, chunks = (n_grp + 255) / 256;
+    const int copy_blocks = (int)std::min<size_t>((n16 + 255) / 256, 64);
+    const unsigned grid = (unsigned)copy_blocks + (unsigned)n_frames * (unsigned)a.n_obj * (unsigned)chunks;
+    hipExtLaunchKernelGGL(ctrl_ingest_kernel, dim3(grid), dim3(256), 0, s, nullptr, stop, 0, reinterpret_cast<const uint4*>(staging), a, n16,
+                          copy_blocks, chunks, packed);
+    return true;
+}
+
 void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s, hipEvent_t stop)
 {
     const int n_grp = a.cam.W * a.cam.H / 64;
@@ -704,7 +759,7 @@ constexpr int kGeneralList = 16384;   // 64-pixel groups listed at a time by mas
 // One workgroup per object at the end of the batch's mask frames: the frames whose source is three-valued.
 // dynamic LDS: list of the non-empty groups
 template <int FT>
-__global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays a)
+__global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays a, int final_launch)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ MaskShared S;
@@ -713,6 +768,14 @@ __global__ __launch_bounds__(kMaskThreads) void mask_general_kernel(EngineArrays
     const int W = a.cam.W, H = a.cam.H, npix = W * H, n_grp = npix >> 6;
     const int tid = threadIdx.x, lane = tid & 63;
     ROFT_RESIDENT(a, RK_MASK_GENERAL);
+    // The chain is through with this batch's ingest counters (rows 1 .. T of its table, read by the frame kernels' decisions): left
+    // zeroed for the batch that uses the table next, whose ingest may then share a launch with its control block upload
+    // (ctrl_ingest_kernel).  Only the LAST launch of a chain does this (the early one runs in front of the last frame).
+    if (final_launch && tid < a.T) {
+        MaskRec& r0 = a.mrec[(size_t)(tid + 1) * a.n_obj + obj];
+        r0.new_count = 0;
+        r0.new_ones = 0;
+    }
     const unsigned todo = a.mask_general[obj];
     if (!todo) return;   // (almost always 0: every mask the reference's sources deliver is binary)
     __syncthreads();
@@ -811,14 +874,14 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
     int launches = 0;
     const bool s16 = a.ffmt.type == ROFT_FLOW_S16C2;
     // the frames of objects with three-valued masks (none, normally): one workgroup per object behind the frame kernels
-    auto launch_general = [&](hipEvent_t ev) {
+    auto launch_general = [&](hipEvent_t ev, int final_launch) {
         const size_t lds_gen = ((size_t)std::min(n_grp, kGeneralList) * 4 + 15) & ~(size_t)15;
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_general_kernel<ROFT_FLOW_S16C2>), kGeneralList * 4 + 16);
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(mask_general_kernel<ROFT_FLOW_F32C2>), kGeneralList * 4 + 16);
         if (s16)
-            hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_S16C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, ev, 0, a);
+            hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_S16C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, ev, 0, a, final_launch);
         else
-            hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_F32C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, ev, 0, a);
+            hipExtLaunchKernelGGL(mask_general_kernel<ROFT_FLOW_F32C2>, dim3(a.n_obj), dim3(kMaskThreads), (uint32_t)lds_gen, s, nullptr, ev, 0, a, final_launch);
     };
     for (int t = 0; t < a.T; ++t) {
         const bool fresh = (new_mask_frames >> t) & 1u;
@@ -846,9 +909,9 @@ int launch_mask_chain(const EngineArrays& a, int frames_between, int flow_aided,
         // `stop_early`: the masks up to the batch's LAST BUT ONE frame are complete -- all that the flow measurements of the batch
         // read (frame t measures inside the mask of frame t - 1); the three-valued frames so far are brought up to date for it
         // (the kernel clears the bits it has served, the last frame sets its own again)
-        if (stop_early && t == a.T - 2) { launch_general(stop_early); ++launches; }
+        if (stop_early && t == a.T - 2) { launch_general(stop_early, 0); ++launches; }
     }
-    launch_general(stop);
+    launch_general(stop, 1);
     return launches + 1;
 }
 

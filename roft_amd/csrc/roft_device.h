@@ -364,6 +364,9 @@ __host__ __device__ inline size_t plane_offset(const EngineArrays& a, int obj, i
 
 // frame t's new masks -> plane slot slot_new + t, their pixel counts -> mrec row t + 1 (zeroed before: mask_reset_tables)
 void launch_mask_ingest(const EngineArrays& a, int t, hipStream_t s, hipEvent_t stop = nullptr);
+// the batch's control blocks (pinned staging -> a.ctrl) and the ingest of every mask it delivers in ONE launch; the ingest counters
+// must be zero (they are: mask_general_kernel's final launch leaves them so).  false: not launched (too many delivering frames)
+bool launch_ctrl_ingest(const void* staging, const EngineArrays& a, size_t n16, unsigned new_mask_frames, hipStream_t s, hipEvent_t stop = nullptr);
 // Zeroes what the ingest kernels accumulate into: the counters of mrec rows 1 .. T (mask_general is cleared by its only
 // reader, mask_general_kernel: this reset may run while the chain before still sets bits).
 // (Inside the engine the control block upload kernel does this; the operator-level entry points call it.)
