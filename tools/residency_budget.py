@@ -2,7 +2,7 @@
 """CU x microseconds per object-frame of every kernel of the pipeline, measured: a library built with -DROFT_RESIDENCY
 (bash tools/build_variant.sh resid -DROFT_RESIDENCY; ROFT_LIB_SO=build_ab/resid.so) makes every workgroup add the time it was
 resident (first instruction -> end of its thread 0, early exits included) to its kernel's counter; x the share of a CU one
-workgroup occupies (wave slots, registers, LDS: profiles/r05_kernel_resources.csv + the launch shapes of the 640x480 workload) =
+workgroup occupies (wave slots, registers, LDS: profiles/r06_kernel_resources.csv + the launch shapes of the 640x480 workload) =
 CU x us.  Workload: BASELINE config #4 as bench.py tracks it (64 objects, six-frame batches ending with the pose arrival), all
 chains running.     python tools/residency_budget.py [frames] [--objects N] > profiles/r05_residency_budget.csv"""
 import csv
@@ -54,7 +54,7 @@ run(warm, n_frames)
 L.check(L.lib().roft_debug_get_residency(eng._h, buf))
 eng.close()
 obj_frames = float(n_obj * (n_frames - warm))
-res = {r["kernel"].split("::")[-1]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r05_kernel_resources.csv")))}
+res = {r["kernel"].split("::")[-1]: r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r06_kernel_resources.csv")))}
 plane = cam.width * cam.height // 8
 # (kernel, threads per workgroup, dynamic LDS bytes of the launch at 640x480)
 shapes = [("mask_frame_kernel<13, 256>", 256, 4240 + 3072), ("mask_ingest_kernel", 256, 0), ("mask_general_kernel<13>", 256, 19200),
