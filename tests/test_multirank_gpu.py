@@ -101,3 +101,35 @@ def test_gpus_n_without_a_launcher_starts_the_ranks_itself(tmp_path):
     assert rows2.shape == (5, 14, 19) and np.isfinite(rows2).all()
     one, rows1 = run_bench(tmp_path, 1, "self1", 0)
     assert np.array_equal(rows1, rows2)
+
+
+def test_the_drivers_command_prints_one_small_parseable_line(tmp_path):
+    """`python3 bench.py --gpus 1 --steps 20 --warmup 5` -- exactly what the driver runs and records as BENCH_rNN.json -- with every
+    leg on (CPU baselines, PCIe legs, cold run, instrumented windows): stdout is ONE line, under 4 KB, strict JSON, with the
+    contract's keys, `roofline` and `cpu_baseline` filled in; the side file holds the rest.  (Round 5's line was 20.7 KB and came
+    back as `parsed: null`.)"""
+    detail = str(tmp_path / "detail.json")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "20", "--warmup", "5", "--json-out", detail],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1 and len(r.stdout.encode()) < 4096, (len(lines), len(r.stdout))
+    tail = r.stdout.encode()[-8192:].decode()       # what the driver keeps
+    d = json.loads(tail.strip().splitlines()[-1], parse_constant=lambda c: pytest.fail("non-strict JSON constant " + c))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "object-frames/s" and d["dtype"] == "f64"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["data"] == "synthetic"
+    assert d["config"]["objects_total"] == 64 and d["config"]["width"] == 640 and d["config"]["height"] == 480 and "workload" in d["config"]
+    assert abs(d["value"] * d["ms_per_step"] - 64e3) < 1e-3 * 64e3 and len(d["runs"]) == 5
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and 0.02 < rf["frac"] < 0.7
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 and rf["avg_launch_us"] > 5 and rf["launches"] >= 4
+    cb = d["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["kind"] == "port" and cb["unit"] == "object-frames/s" and 100 < cb["value"] < 1e5 and cb["sample"]
+    assert d["value"] > 50 * cb["value"]
+    assert d["adds_vs_cpu_ref_mm"]["max"] < 1e-3
+    full = json.load(open(detail))
+    assert len(full["windows"]) == 5 and full["roofline"]["note"] and full["cpu_baseline_multicore"]
