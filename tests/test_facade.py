@@ -679,6 +679,36 @@ def test_reference_tracker_runs_on_this_engine(tmp_path, capsys, shape):
     # six significant digits per value in the C++ logs
     assert np.allclose(logs["pose_estimate"], est, rtol=2e-5, atol=1e-6), np.abs(logs["pose_estimate"] - est).max()
     assert np.allclose(logs["velocity_estimate"], vel, rtol=2e-5, atol=1e-6), np.abs(logs["velocity_estimate"] - vel).max()
+    # ... and against the CPU ORACLE (round 6; the comparison above is engine against engine -- an API test): the same sequence
+    # directory, read frame by frame through roft_amd.io, through oracle/ro_tracker.c with the configuration this command line
+    # amounts to (test/test.sh's settings = the oracle's defaults; the initial pose and the camera as passed).  What the reference's
+    # executable logged over the HIP engine must be the oracle's trajectory to the six digits bfl::Logger prints.
+    if shape in ("A_f32_grid1", "B_s16_grid4", "A_from_first_detection"):
+        from oracle import binding as ob
+        seq = io.Sequence(root, obj_name, flow_set="analytic", mask_set="gt", pose_set="dope", width=c.width, height=c.height, delayed=True, first_frame=first)
+        ocfg = ob.default_config(640 if c.width in (640, 320, 160) else 1280, c.height)
+        ocfg.cam.width, ocfg.cam.height = c.width, c.height
+        ocfg.cam.fx, ocfg.cam.fy, ocfg.cam.cx, ocfg.cam.cy = c.fx, c.fy, c.cx, c.cy
+        for i in range(6):
+            ocfg.p_mean0[i] = 0.0
+        for i in range(3):
+            ocfg.p_mean0[6 + i] = float(m0[6 + i])
+        q0 = io.axis_angle_to_quat(np.asarray(axis, float), float(angle))
+        for i in range(4):
+            ocfg.p_mean0[9 + i] = float(q0[i])
+        verts_o, tris_o = io.load_obj(mesh)
+        trk = ob.Tracker(ocfg, verts_o, tris_o)
+        ref_pose, ref_vel = [], []
+        for k in range(first, len(seq)):
+            fr = seq.frame(k)
+            res = trk.step(fr["dt"] if fr["dt"] > 0 else st.dt, fr["depth"], fr["flow"], fr["mask"], fr["pose"])
+            ref_pose.append(io.pose_log_row(np.array(res.pose)))
+            ref_vel.append(np.array(res.twist))
+        trk.close()
+        ref_pose, ref_vel = np.array(ref_pose), np.array(ref_vel)
+        assert ref_pose.shape == logs["pose_estimate"].shape
+        assert np.allclose(logs["pose_estimate"], ref_pose, rtol=2e-5, atol=2e-6), np.abs(logs["pose_estimate"] - ref_pose).max()
+        assert np.allclose(logs["velocity_estimate"], ref_vel, rtol=2e-5, atol=2e-6), np.abs(logs["velocity_estimate"] - ref_vel).max()
 
 
 def test_queue_handler_and_mesh_resource(tmp_path):
