@@ -33,6 +33,22 @@ def zoo(n=6):
     # the real projective plane on six vertices: every edge in exactly two triangles, not orientable
     rp2 = np.array([[1, 2, 3], [1, 2, 4], [1, 3, 5], [1, 4, 6], [1, 5, 6], [2, 3, 6], [2, 4, 5], [2, 5, 6], [3, 4, 5], [3, 4, 6]], np.int32) - 1
     out["projective_plane"] = (rng.normal(size=(6, 3)).astype(np.float32) * 0.05, rp2, False)
+    # a torus (genus 1: closed and orientable, not simply connected) with every second quad split the other way, and the same
+    # surface without one ring of quads (open)
+    nu, nv_, R0, r0 = 4 * n, 2 * n, 0.07, 0.025
+    uu, vv = np.meshgrid(np.arange(nu) * 2 * np.pi / nu, np.arange(nv_) * 2 * np.pi / nv_, indexing="ij")
+    tv = np.stack([(R0 + r0 * np.cos(vv)) * np.cos(uu), (R0 + r0 * np.cos(vv)) * np.sin(uu), r0 * np.sin(vv)], -1).reshape(-1, 3).astype(np.float32)
+    tt = []
+    for i in range(nu):
+        for j in range(nv_):
+            a, b, c, d = i * nv_ + j, ((i + 1) % nu) * nv_ + j, ((i + 1) % nu) * nv_ + (j + 1) % nv_, i * nv_ + (j + 1) % nv_
+            tt += [[a, b, c], [a, c, d]] if (i + j) % 2 == 0 else [[a, b, d], [b, c, d]]
+    tt = np.array(tt, np.int32)
+    out["torus"] = (tv, tt, True)
+    out["torus_open"] = (tv, np.ascontiguousarray(tt[2 * nv_:]), False)
+    # a hollow box: an outer shell and an inner one wound towards the cavity (two closed components, one inside the other)
+    vin = (v * 0.6).astype(np.float32)
+    out["hollow_box"] = (np.concatenate([v, vin]), np.ascontiguousarray(np.concatenate([t, t[:, ::-1] + len(v)]).astype(np.int32)), True)
     v_nan = v.copy()
     v_nan[3, 1] = np.nan
     out["box_nan_vertex"] = (v_nan, t, False)

@@ -54,7 +54,7 @@ def test_the_bench_mesh_and_the_references_cracker_box_are_closed():
         assert co and ce and np.array_equal(fo, fe)
 
 
-@pytest.mark.parametrize("name", ["box", "box_reversed", "box_random_windings", "box_unwelded", "two_components"])
+@pytest.mark.parametrize("name", ["box", "box_reversed", "box_random_windings", "box_unwelded", "two_components", "torus", "hollow_box"])
 def test_leaving_out_the_triangles_that_face_away_does_not_change_the_render(name):
     """Oracle against oracle: the contract's render of a closed mesh (triangles facing away left out) against the same mesh drawn
     whole.  Equal in exact arithmetic; in float arithmetic a pixel centre within rounding of an edge may differ -- none does here

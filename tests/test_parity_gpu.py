@@ -440,7 +440,7 @@ def test_render_and_outlier_test_on_a_mesh_of_the_reference(oracle):
 
 
 @pytest.mark.parametrize("name", ["box", "box_reversed", "box_random_windings", "box_open", "box_duplicate_triangle", "box_unwelded",
-                                  "two_components", "projective_plane"])
+                                  "two_components", "projective_plane", "torus", "torus_open", "hollow_box"])
 def test_render_follows_the_back_face_rule_of_the_contract(oracle, name):
     """Round 6: a mesh the classification accepts as a closed surface is rendered without the triangles that face away (and in a
     walk order of the engine's own); open / non-manifold / non-orientable meshes are drawn whole.  Either way the tile equals
