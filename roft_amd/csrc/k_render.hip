@@ -461,26 +461,26 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
             };
             constexpr int kTB = 8;   // triangles per thread whose vertex indices are fetched together
             // closed mesh, everything in front of the near plane: triangles that face away are left out (the render contract)
-            const uint8_t* const flips = (prm.tri_flip && !s_behind) ? prm.tri_flip : nullptr;
+            const uint8_t* const flips = (prm.tri_flip && !s_behind && nv < (1 << 30)) ? prm.tri_flip : nullptr;   // (the cull code rides in an index's top bits)
             // (split: the triangles are dealt out to the workgroups of the alternative in runs of 64 -- one run per wave and
             //  fetch, so the index loads stay coalesced and neighbouring runs, which cost alike, go to different workgroups)
             const int stride = G, first = grp;
             auto tri_of = [=](int slot) { return ((slot >> 6) * stride + first) * 64 + (slot & 63); };   // slot: this workgroup's own numbering
             const int n_slots = split ? ((nt + 63) / 64 + stride - 1 - first) / stride * 64 : nt;        // (its runs; the last one may be short)
             for (int tb = tid; tb < n_slots; tb += kTB * kFusedThreads) {
-              int idx[kTB][3];
-              int cull[kTB];
+              int idx[kTB][3];   // (idx[k][0] carries the triangle's cull code in its two top bits: no registers of its own)
 #pragma unroll
               for (int k = 0; k < kTB; ++k) {
                   const int t = min(tri_of(min(tb + k * kFusedThreads, n_slots - 1)), nt - 1);
                   const int32_t* tri = prm.tris + (size_t)3 * t;
                   idx[k][0] = tri[0]; idx[k][1] = tri[1]; idx[k][2] = tri[2];
-                  cull[k] = flips ? 1 + (int)flips[t] : 0;
+                  if (flips) idx[k][0] |= (1 + (int)flips[t]) << 30;
               }
 #pragma unroll
               for (int k = 0; k < kTB; ++k) {
                 if (tb + k * kFusedThreads >= n_slots || tri_of(tb + k * kFusedThreads) >= nt) break;
-                const int v0 = idx[k][0], v1 = idx[k][1], v2 = idx[k][2];
+                const int cull_k = (int)((unsigned)idx[k][0] >> 30);
+                const int v0 = idx[k][0] & 0x3FFFFFFF, v1 = idx[k][1], v2 = idx[k][2];
                 float x0, y0, z0, x1, y1, z1, x2, y2, z2;
                 if (cached) {
                     x0 = s_v[3 * v0]; y0 = s_v[3 * v0 + 1]; z0 = s_v[3 * v0 + 2];
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(kFusedThreads) void outlier_fused_kernel(EngineArra
                     project_vertex(prm.verts + (size_t)3 * v1, P, fx, fy, cx, cy, x1, y1, z1);
                     project_vertex(prm.verts + (size_t)3 * v2, P, fx, fy, cx, cy, x2, y2, z2);
                 }
-                raster_projected(x0, y0, z0, x1, y1, z1, x2, y2, z2, tw, th, js, je, cull[k], store);
+                raster_projected(x0, y0, z0, x1, y1, z1, x2, y2, z2, tw, th, js, je, cull_k, store);
               }
             }
             __syncthreads();
