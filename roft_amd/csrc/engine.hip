@@ -587,6 +587,7 @@ int roft_engine_destroy(roft_engine* e)
         for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_part[i], e->ev_prep[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
             if (ev) (void)hipEventDestroy(ev);
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
+        if (e->gather_tab[i]) (void)hipHostFree(e->gather_tab[i]);
     }
     release_streams(e->streams);   // (idle: synchronised above)
     for (auto* o : e->objs) delete o;

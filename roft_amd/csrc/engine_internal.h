@@ -283,6 +283,10 @@ struct StreamSet {
     int conflicts = 0;     // pairs of busy streams on one hardware queue when the set was created (-1: not probed)
 };
 
+struct GatherItem { const void* src; void* dst; size_t bytes; };   // one small pinned HOST image -> its staging copy
+constexpr int kGatherCap = 8192;                                    // items per batch (8 frames x 1024 objects)
+constexpr size_t kGatherMaxBytes = (size_t)2 << 20;                 // larger images go through the copy engine
+
 struct roft_engine {
     roft_config cfg{};
     Arrays arr;
@@ -306,6 +310,10 @@ struct roft_engine {
     int retain = ROFT_RETAIN_FRAMES;
     DevBuf<FrameCtrl> dctrl[kBatchRing];
     FrameCtrl* stage[kBatchRing] = {};     // pinned staging blocks
+    // Small HOST images in PINNED memory (the per-object masks of a delivery: 64 buffers of 300 KB) are not copied one
+    // hipMemcpyAsync each but fetched by ONE kernel over the bus (engine_submit.hip, gather_copy_kernel): what to fetch, per batch
+    std::vector<GatherItem> gather;                    // collected by stage_host during a submit
+    GatherItem* gather_tab[kBatchRing] = {};           // pinned tables the kernel reads (kGatherCap entries each; allocated on first use)
     hipEvent_t ev_up[kBatchRing] = {};     // uploads of the batch on the device
     hipEvent_t ev_ctrl[kBatchRing] = {};   // FrameCtrl blocks of the batch on the device (and the mask chain of the batch before)
     hipEvent_t ev_mask[kBatchRing] = {};   // mask chain kernel of the batch complete

@@ -133,6 +133,48 @@ static int stage_alloc(roft_engine* e, int frame, size_t bytes, unsigned char** 
     return ROFT_OK;
 }
 
+// Many small HOST images -> their staging copies in ONE launch: workgroup (x, y) copies 16-byte units x, x + gridDim.x, ... of item y.
+// The sources are PINNED host buffers the device can address (stage_host checks); a 300 KB hipMemcpyAsync costs ~11 us of
+// which 6 are the transfer, and a delivery brings one mask per object: 64 copies = 0.7 ms per six frames in the shared-scene leg
+// of bench.py (28 GB/s), against one kernel that keeps the link busy.
+__global__ __launch_bounds__(256) void gather_copy_kernel(const GatherItem* __restrict__ tab)
+{
+    const GatherItem it = tab[blockIdx.y];
+    const uint4* src = reinterpret_cast<const uint4*>(it.src);
+    uint4* dst = reinterpret_cast<uint4*>(it.dst);
+    const size_t n16 = it.bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// the items collected by stage_host during this submit -> one launch on the upload stream (before the submit waits for its uploads)
+static int flush_gather(roft_engine* e)
+{
+    if (e->gather.empty()) return ROFT_OK;
+    const int slot = e->batch_counter % roft_engine::kBatchRing;
+    if (!e->gather_tab[slot]) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->gather_tab[slot]), sizeof(GatherItem) * kGatherCap, hipHostMallocMapped));
+    const size_t n = e->gather.size();
+    std::memcpy(e->gather_tab[slot], e->gather.data(), sizeof(GatherItem) * n);
+    size_t largest = 0;
+    for (const GatherItem& g : e->gather) largest = std::max(largest, g.bytes);
+    const unsigned gx = (unsigned)std::max<size_t>(1, std::min<size_t>(32, (largest / 16 + 2047) / 2048));   // ~8 units per thread
+    hipLaunchKernelGGL(gather_copy_kernel, dim3(gx, (unsigned)n), dim3(256), 0, e->up_stream, e->gather_tab[slot]);
+    e->gather.clear();
+    if (hipError_t le = hipGetLastError()) return fail(ROFT_ERR_DEVICE, std::string("gather copy of HOST inputs: ") + hipGetErrorString(le));
+    e->stats.h2d_copies++;
+    return ROFT_OK;
+}
+
+// the device address of a PINNED host buffer the GPU can read in place, or null (pageable memory, or not identity-mapped)
+static const void* pinned_device_pointer(const void* host)
+{
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (attr.type != hipMemoryTypeHost) return nullptr;
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<void*>(host), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return dp;
+}
+
 // device copy of one HOST image of `frame` (uploads once per distinct host pointer and frame)
 static int stage_host(roft_engine* e, int frame, const void* host, size_t bytes, const void** dev)
 {
@@ -141,6 +183,17 @@ static int stage_host(roft_engine* e, int frame, const void* host, size_t bytes,
         if (pr.first == host) { *dev = pr.second; return ROFT_OK; }
     unsigned char* d = nullptr;
     if (int rc = stage_alloc(e, frame, bytes, &d)) return rc;
+    static const int gather_env = getenv("ROFT_GATHER_COPY") ? atoi(getenv("ROFT_GATHER_COPY")) : 1;   // (experiments: 0 = one copy per image)
+    const void* dp = nullptr;
+    if (gather_env && bytes <= kGatherMaxBytes && (bytes & 15) == 0 && (reinterpret_cast<uintptr_t>(host) & 15) == 0 &&
+        (int)e->gather.size() < kGatherCap && (dp = pinned_device_pointer(host)) != nullptr) {
+        e->gather.push_back(GatherItem{dp, d, bytes});   // fetched by flush_gather's one launch
+        e->stats.h2d_bytes += (long long)bytes;
+        e->had_uploads = true;
+        sf.seen.emplace_back(host, d);
+        *dev = d;
+        return ROFT_OK;
+    }
     HIP_TRY(hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, e->up_stream));
     e->stats.h2d_bytes += (long long)bytes;
     e->stats.h2d_copies++;
@@ -429,7 +482,10 @@ int roft_frames_submit(roft_engine* e, const roft_frame_input* inputs, int n_obj
     e->any_feat = e->any_feat_now = e->had_uploads = false;
     e->feat_dep_in_batch = false;
     e->new_mask_frames = 0;
-    const int rc = submit_frames(e, inputs, n_objects, n_frames);
+    e->gather.clear();
+    int rc = submit_frames(e, inputs, n_objects, n_frames);
+    if (rc == ROFT_OK) rc = flush_gather(e);
+    e->gather.clear();
     HP_MARK(e, 1, hp_t);
     int rc2 = ROFT_OK;
     if (e->had_uploads) {
