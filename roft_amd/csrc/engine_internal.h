@@ -345,6 +345,7 @@ struct roft_engine {
     int lane_objs[kNumLin] = {0, 0}, lane_old_first[kNumLin] = {0, 0};
     int relabel_wait[kNumLin] = {-1, -1};     // batch of the OTHER lane this lane's launches must follow (slots that changed lanes)
     bool any_feat = false, any_feat_now = false, had_uploads = false;
+    unsigned feat_frames = 0;              // bit t: some object buffers outlier-rejection features in frame t of the batch
     unsigned new_mask_frames = 0;   // bit t: some object receives a mask in frame t of the batch
     int prev_T = 0;                 // frames of the batch stepped before
     int batch_counter = 0, frame_counter = 0;

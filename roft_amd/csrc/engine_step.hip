@@ -242,7 +242,7 @@ int step_batch(roft_engine* e)
     const bool feat_on_vel = multi && T > 1;
     const bool want_ev_feat = multi && e->any_feat && !feat_on_vel && (T > 1 || e->any_feat_now);
     if (e->any_feat && !feat_on_vel) {
-        launch_features(a, s, (want_ev_feat && !full) ? e->ev_feat[slot] : nullptr);
+        launch_features(a, s, (want_ev_feat && !full) ? e->ev_feat[slot] : nullptr, e->feat_frames);
         ++launches;
         CHECK_LAUNCH("features");
         tmark(e, "features", 0);
@@ -297,7 +297,7 @@ int step_batch(roft_engine* e)
     tmark(e, "skf_chain", 2);
     if (feat_last) {
         if (part_gate) { HIP_TRY(hipStreamWaitEvent(sv, e->ev_mask[slot], 0)); ++evops; }   // (the planes of the batch's last frame)
-        launch_features(a, sv, !full ? e->ev_vel[slot] : nullptr);
+        launch_features(a, sv, !full ? e->ev_vel[slot] : nullptr, e->feat_frames);
         ++launches;
         CHECK_LAUNCH("features");
         tmark(e, "features", 2);

@@ -450,6 +450,7 @@ static int submit_frames(roft_engine* e, const roft_frame_input* inputs, int n_o
             if (c.feat_write >= 0) {
                 e->feat_batch[(size_t)id * kFeatRing + c.feat_write] = b;
                 e->any_feat = true;
+                e->feat_frames |= 1u << t;
                 // a feature set is re-used only when the batch that read or wrote it last has ended
                 const int last = o.feat_use[c.feat_write];
                 if (last >= 0 && last < b) { if (int rc = wait_batch(e, last)) return rc; }
@@ -480,6 +481,7 @@ int roft_frames_submit(roft_engine* e, const roft_frame_input* inputs, int n_obj
     e->backup.resize(e->objs.size());
     for (size_t i = 0; i < e->objs.size(); ++i) e->backup[i] = e->objs[i]->s;
     e->any_feat = e->any_feat_now = e->had_uploads = false;
+    e->feat_frames = 0;
     e->feat_dep_in_batch = false;
     e->new_mask_frames = 0;
     e->gather.clear();

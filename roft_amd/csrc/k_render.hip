@@ -39,15 +39,16 @@ constexpr int kFeatThreads = 1024;
 #endif
 
 // LDS = false: planes that do not fit the LDS (beyond ~1.1 Mpixel) are read from memory by both passes.
+// grid: (n_obj, frames listed in `frames_packed`: four bits per frame index, the batch's frames that buffer features for some object)
 template <bool LDS>
-__global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
+__global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a, unsigned frames_packed)
 {
     ROFT_RESIDENT(a, RK_FEATURES);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_wave[16];
     __shared__ int s_chunk[kFeatThreads];
     const int obj = blockIdx.x;
-    const FrameCtrl& c = frame_ctrl(a, blockIdx.y, obj);   // grid: (n_obj, frames of the batch)
+    const FrameCtrl& c = frame_ctrl(a, (int)((frames_packed >> (4 * blockIdx.y)) & 15u), obj);
 #ifdef ROFT_FEAT_PROFILE
     long long f_t0 = wall_clock64();
 #endif
@@ -124,15 +125,23 @@ __global__ __launch_bounds__(kFeatThreads) void features_kernel(EngineArrays a)
     if (threadIdx.x == 0) a.state[obj].n_feat[feat_write] = n;
 }
 
-void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop)
+// feat_frames: bit t = some object buffers features in frame t of the batch (0: every frame -- the operator level).  Only those
+// frames get workgroups (round 6: a 1024-thread workgroup with the plane's 38 KB of LDS needs a place on a CU even to find out
+// that its frame has nothing to do, and five of a batch's six frames have not).
+void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop, unsigned feat_frames)
 {
+    unsigned packed = 0;
+    int n_frames = 0;
+    for (int t = 0; t < a.T && t < 8; ++t)
+        if (feat_frames == 0 || (feat_frames & (1u << t))) packed |= (unsigned)t << (4 * n_frames++);
+    if (n_frames == 0) n_frames = 1;   // (a.T == 0 cannot happen; the launch carries the caller's stop event: never skipped)
     const size_t lds = (a.plane_words * 4 + 15) & ~(size_t)15;
     const size_t lds_cap = 160 * 1024 - 256 - kFeatThreads * sizeof(int) - 128;
     if (lds <= lds_cap) {
         (void)set_max_dynamic_lds(reinterpret_cast<const void*>(features_kernel<true>), (int)lds_cap);
-        hipExtLaunchKernelGGL(features_kernel<true>, dim3(a.n_obj, a.T), dim3(kFeatThreads), (uint32_t)lds, s, nullptr, stop, 0, a);
+        hipExtLaunchKernelGGL(features_kernel<true>, dim3(a.n_obj, n_frames), dim3(kFeatThreads), (uint32_t)lds, s, nullptr, stop, 0, a, packed);
     } else {
-        hipExtLaunchKernelGGL(features_kernel<false>, dim3(a.n_obj, a.T), dim3(kFeatThreads), 0, s, nullptr, stop, 0, a);
+        hipExtLaunchKernelGGL(features_kernel<false>, dim3(a.n_obj, n_frames), dim3(kFeatThreads), 0, s, nullptr, stop, 0, a, packed);
     }
 }
 

@@ -406,7 +406,7 @@ void launch_kf_predict(const double* x, const double* P, const double* qdiag, do
 // step (then launch_outlier and another segment follow) or to the end of the batch.
 // Of every object only the frames of lane `lin` are walked.
 void launch_ukf_chain(const EngineArrays& a, roft_ut_params ut, bool first_segment, int lin, hipStream_t s, hipEvent_t stop = nullptr);
-void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr);   // after the mask chain of the batch
+void launch_features(const EngineArrays& a, hipStream_t s, hipEvent_t stop = nullptr, unsigned feat_frames = 0);   // after the mask chain of the batch; feat_frames: bit t = frame t buffers features (0: all frames)
 // Operator-level overrides of the outlier test's launch shape (roft_render_depth / roft_outlier_test: the parity tests drive
 // the engine's kernel through every configuration); the engine passes none.
 struct OutlierLaunchOpts {
