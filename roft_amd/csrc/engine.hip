@@ -451,7 +451,7 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
     for (int i = 0; i < R; ++i) {
         HIP_TRY(e->dctrl[i].ensure((size_t)cfg->max_objects * e->T_max, true));
         HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&e->stage[i]), sizeof(FrameCtrl) * cfg->max_objects * e->T_max));
-        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_part[i], &e->ev_prep[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_done[i][0], &e->ev_done[i][1]})
+        for (hipEvent_t* ev : {&e->ev_up[i], &e->ev_ctrl[i], &e->ev_mask[i], &e->ev_part[i], &e->ev_prep[i], &e->ev_feat[i], &e->ev_vel[i], &e->ev_skf[i], &e->ev_done[i][0], &e->ev_done[i][1]})
             HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     }
     DevFlowFmt ff;
@@ -494,6 +494,8 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
             hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->stream, nullptr, e->ev_feat[i], 0, flag);
             HIP_TRY(hipStreamWaitEvent(e->vel_stream, e->ev_mask[i], 0));
             hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->vel_stream, nullptr, e->ev_vel[i], 0, flag);
+            hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->vel_stream, nullptr, e->ev_skf[i], 0, flag);
+            HIP_TRY(hipStreamWaitEvent(e->pose_stream[i & 1], e->ev_skf[i], 0));
             for (int l = 0; l < kNumLin; ++l) {
                 HIP_TRY(hipStreamWaitEvent(e->pose_stream[l], (i & 1) ? e->ev_vel[i] : e->ev_ctrl[i], 0));
                 hipExtLaunchKernelGGL(probe_tiny_kernel, dim3(1), dim3(64), 0, e->pose_stream[l], nullptr, e->ev_done[i][l], 0, flag);
@@ -584,7 +586,7 @@ int roft_engine_destroy(roft_engine* e)
     for (hipStream_t s : {e->stream, e->vel_stream, e->pose_stream[0], e->pose_stream[1], e->up_stream})
         if (s) (void)hipStreamSynchronize(s);
     for (int i = 0; i < R; ++i) {
-        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_part[i], e->ev_prep[i], e->ev_feat[i], e->ev_vel[i], e->ev_done[i][0], e->ev_done[i][1]})
+        for (hipEvent_t ev : {e->ev_up[i], e->ev_ctrl[i], e->ev_mask[i], e->ev_part[i], e->ev_prep[i], e->ev_feat[i], e->ev_vel[i], e->ev_skf[i], e->ev_done[i][0], e->ev_done[i][1]})
             if (ev) (void)hipEventDestroy(ev);
         if (e->stage[i]) (void)hipHostFree(e->stage[i]);
         if (e->gather_tab[i]) (void)hipHostFree(e->gather_tab[i]);

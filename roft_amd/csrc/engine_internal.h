@@ -320,7 +320,8 @@ struct roft_engine {
     hipEvent_t ev_part[kBatchRing] = {};   // the masks of the batch's frames 0 .. T - 2 complete (what its flow measurements read)
     hipEvent_t ev_prep[kBatchRing] = {};   // control blocks + ingested masks of the batch on the device (prepared on the upload stream)
     hipEvent_t ev_feat[kBatchRing] = {};   // features of the batch complete
-    hipEvent_t ev_vel[kBatchRing] = {};    // twists of the batch complete
+    hipEvent_t ev_vel[kBatchRing] = {};    // the batch's velocity chain complete (velocity filter AND the feature kernel behind it)
+    hipEvent_t ev_skf[kBatchRing] = {};    // twists of the batch complete (the velocity filter alone: what a pose lane waits for)
     hipEvent_t ev_done[kBatchRing][kNumLin] = {};   // pose chain of the batch complete (per lane)
     bool done_used[kBatchRing][kNumLin] = {};       // ... the lane had work in that batch
     bool multi = false;

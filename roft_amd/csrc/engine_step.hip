@@ -7,7 +7,7 @@
 //  (1) Every cross-stream dependency of a batch is an EVENT recorded behind the producer (the stop event of its last kernel) and
 //      waited for by the consumer's stream before the consumer's first kernel: ev_up (HOST copies) -> mask / velocity stream;
 //      ev_prep (control blocks + ingest prepared on the upload stream) -> mask stream; ev_mask / ev_part (mask frames) -> velocity
-//      stream and the features kernel; ev_vel (velocity filter + features) -> pose lanes; ev_done[lane] -> host (in-flight bound,
+//      stream and the features kernel; ev_skf (velocity filter) | ev_vel (+ the features behind it) -> pose lanes; ev_done[lane] -> host (in-flight bound,
 //      roft_sync).  Events only point from work enqueued EARLIER to work enqueued later, batch by batch and chain by chain in the
 //      fixed order of step_batch: the wait-for graph is acyclic by construction.
 //  (2) The only waits INSIDE kernels are the frame-granular hand-over (a pose lane's step waits for the tag of the twist it needs,
@@ -285,7 +285,11 @@ int step_batch(roft_engine* e)
     a.handoff = handoff ? 1 : 0;
     a.skf_started = e->arr.skf_started.p;
     e->vel_used[slot] = multi;
-    launch_skf_chain(a, e->cfg.flow_weighting, sv, (multi && !full && !feat_last) ? e->ev_vel[slot] : nullptr);
+    // (with the feature kernel behind it the filter's own stop event is ev_skf: a lane that waits for the batch's twists does not
+    //  wait for the features as well -- 39 us at 64 objects --, which its tests read from sets buffered by EARLIER batches; round 6)
+    static const int skf_ev_env = getenv("ROFT_LANES_WAIT_SKF") ? atoi(getenv("ROFT_LANES_WAIT_SKF")) : 1;   // (experiments: 0 = wait for ev_vel)
+    const bool lanes_wait_skf = multi && feat_last && skf_ev_env != 0 && !e->feat_dep_in_batch && !e->any_feat_now;
+    launch_skf_chain(a, e->cfg.flow_weighting, sv, (multi && !full) ? (feat_last ? (lanes_wait_skf ? e->ev_skf[slot] : nullptr) : e->ev_vel[slot]) : nullptr);
     ++launches;
     if (hipError_t le = hipGetLastError()) {
         // the filter's workgroups will never count themselves in: no lane may ever wait for them (a stream-wait on a value has
@@ -295,6 +299,7 @@ int step_batch(roft_engine* e)
     }
     e->skf_total += (unsigned long long)a.n_obj;   // (only once the launch is known to be enqueued: the lanes' gates wait for this count)
     tmark(e, "skf_chain", 2);
+    if (lanes_wait_skf && full) { HIP_TRY(hipEventRecord(e->ev_skf[slot], sv)); ++evops; }
     if (feat_last) {
         if (part_gate) { HIP_TRY(hipStreamWaitEvent(sv, e->ev_mask[slot], 0)); ++evops; }   // (the planes of the batch's last frame)
         launch_features(a, sv, !full ? e->ev_vel[slot] : nullptr, e->feat_frames);
@@ -333,7 +338,7 @@ int step_batch(roft_engine* e)
             HIP_TRY(hipStreamWaitValue64(sp, e->arr.skf_started.p, e->skf_total, hipStreamWaitValueGte, ~0ull));
             ++evops;
         } else if (multi) {
-            HIP_TRY(hipStreamWaitEvent(sp, e->ev_vel[slot], 0));
+            HIP_TRY(hipStreamWaitEvent(sp, lanes_wait_skf ? e->ev_skf[slot] : e->ev_vel[slot], 0));
             ++evops;
             // The pose chain reads mask-chain products only through the feature ring.  With one-frame batches the set an
             // outlier test reads was buffered by an earlier batch -- covered by ev_vel, since the velocity chain waited for
