@@ -121,6 +121,8 @@ int wait_batch(roft_engine* e, int b, bool* waited)
         (void)hipGetLastError();
         HIP_TRY(hipEventSynchronize(e->ev_vel[b % roft_engine::kBatchRing]));
     }
+    // (... or before the features kernel behind the batch's mask frames does, which reads the batch's depth images)
+    if (e->feat_used[b % roft_engine::kBatchRing]) HIP_TRY(hipEventSynchronize(e->ev_feat[b % roft_engine::kBatchRing]));
     for (int l = 0; l < kNumLin; ++l)
         if (e->done_used[b % roft_engine::kBatchRing][l]) {
             if (waited && hipEventQuery(e->ev_done[b % roft_engine::kBatchRing][l]) == hipErrorNotReady) *waited = true;
@@ -516,6 +518,8 @@ static int engine_setup(roft_engine* e, const roft_config* cfg)
     if (const char* hm = getenv("ROFT_HANDOFF")) e->handoff_mode = atoi(hm);
     if (const char* pm = getenv("ROFT_PREP_AHEAD")) e->prep_mode = atoi(pm);
     if (const char* pm = getenv("ROFT_MASK_PART_GATE")) e->part_mode = atoi(pm);
+    if (const char* pm = getenv("ROFT_FEAT_ON_MASK")) e->feat_mask_mode = atoi(pm);
+    if (const char* pm = getenv("ROFT_LANES_WAIT_SKF")) e->lanes_wait_skf = atoi(pm);
     // A tool that lets only ONE kernel run at a time (rocprofv3 --pmc: counter collection serialises the dispatches) cannot run a
     // lane next to the velocity filter it waits for -- the runtime's stream-wait itself is a kernel that spins: off under it.
     else if (getenv("ROCPROF_COUNTER_COLLECTION")) e->handoff_mode = 0;

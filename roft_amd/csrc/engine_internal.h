@@ -374,9 +374,12 @@ struct roft_engine {
     // ROFT_PREP_AHEAD / ROFT_MASK_PART_GATE, read when the engine is created: 0 never, 1 the default rule (a function of batch index
     // and object count: step_batch), 2 always, 3 whenever the batch index allows it whatever the object count.  No setting changes a result.
     int prep_mode = 1, part_mode = 1;
+    int feat_mask_mode = 1;     // features kernel on the mask stream: 0 never, 1 at most one object per sixteen CUs, 2 always (ROFT_FEAT_ON_MASK)
+    int lanes_wait_skf = 1;     // pose lanes without hand-over wait for the velocity filter's own event (ROFT_LANES_WAIT_SKF=0: for the features too)
     bool feat_dep_in_batch = false;        // an outlier test of the batch reads features buffered by a frame of the same batch
     unsigned long long skf_total = 0;      // velocity-filter workgroups launched so far (the value the lanes' gates wait for)
     bool vel_used[kBatchRing] = {};        // the batch's velocity chain ended with ev_vel (wait_batch waits for it as well)
+    bool feat_used[kBatchRing] = {};       // the batch's feature kernel ran on the mask stream and ended with ev_feat (wait_batch waits for it as well)
     std::vector<int> feat_batch;           // [objects][kFeatRing] batch that last wrote each feature set (-1: none)
     // timing
     bool timing = false;

@@ -239,8 +239,12 @@ int step_batch(roft_engine* e)
     // and the pose lanes wait for its end anyway, so the features cost the mask chain (the longest one) nothing and need
     // no event of their own.  One-frame submits: on the mask chain's stream; the pose chain waits for them only when a
     // test reads a set buffered in this very frame (older sets are covered by the velocity chain's wait on that stream).
-    const bool feat_on_vel = multi && T > 1;
+    // ... and so do batches of an engine with MANY CUs to spare (at most one object per sixteen CUs): there a batch is a chain of
+    // latencies on every stream and the velocity stream's -- flow measurement, T filter steps, features -- is the longest, not the
+    // mask stream's (round 6, 120 steps: 8 objects 3.46e5 -> 3.64e5, 16 objects 6.46e5 -> 6.62e5; 32 objects -4 %, 64 objects -7.5 %).
+    const bool feat_on_vel = multi && T > 1 && !(e->feat_mask_mode == 2 || (e->feat_mask_mode == 1 && 16 * a.n_obj <= device_cu_count()));
     const bool want_ev_feat = multi && e->any_feat && !feat_on_vel && (T > 1 || e->any_feat_now);
+    e->feat_used[slot] = want_ev_feat;
     if (e->any_feat && !feat_on_vel) {
         launch_features(a, s, (want_ev_feat && !full) ? e->ev_feat[slot] : nullptr, e->feat_frames);
         ++launches;
@@ -287,8 +291,7 @@ int step_batch(roft_engine* e)
     e->vel_used[slot] = multi;
     // (with the feature kernel behind it the filter's own stop event is ev_skf: a lane that waits for the batch's twists does not
     //  wait for the features as well -- 39 us at 64 objects --, which its tests read from sets buffered by EARLIER batches; round 6)
-    static const int skf_ev_env = getenv("ROFT_LANES_WAIT_SKF") ? atoi(getenv("ROFT_LANES_WAIT_SKF")) : 1;   // (experiments: 0 = wait for ev_vel)
-    const bool lanes_wait_skf = multi && feat_last && skf_ev_env != 0 && !e->feat_dep_in_batch && !e->any_feat_now;
+    const bool lanes_wait_skf = multi && feat_last && e->lanes_wait_skf != 0 && !e->feat_dep_in_batch && !e->any_feat_now;
     launch_skf_chain(a, e->cfg.flow_weighting, sv, (multi && !full) ? (feat_last ? (lanes_wait_skf ? e->ev_skf[slot] : nullptr) : e->ev_vel[slot]) : nullptr);
     ++launches;
     if (hipError_t le = hipGetLastError()) {

@@ -284,6 +284,32 @@ def test_preparation_ahead_and_early_velocity_gate_change_nothing(monkeypatch):
                 assert np.array_equal(x, y), (prep, part, kw)
 
 
+def test_where_the_feature_kernel_runs_and_what_the_lanes_wait_for_change_nothing(monkeypatch):
+    """Round 6: the features kernel of a batch runs behind the velocity filter (ROFT_FEAT_ON_MASK=0) or behind the batch's mask frames
+    (2; the default chooses by object count), and pose lanes that are not handed their twists frame by frame (ROFT_HANDOFF=0) wait for
+    the velocity filter alone or for the features behind it as well (ROFT_LANES_WAIT_SKF=1 / 0).  Engines read the switches when they
+    are created; every combination gives the rows and masks of the first one, bit for bit, on the awkward streams -- incl. an object
+    with a pose (and so an outlier test and a feature set) on every frame."""
+    n = 42
+    dev = [util.to_device(st) for st in awkward_streams(n)]
+    ref = None
+    for feat in ("0", "2"):
+        for handoff in ("0", "2"):
+            for skf in ("0", "1"):
+                monkeypatch.setenv("ROFT_FEAT_ON_MASK", feat)
+                monkeypatch.setenv("ROFT_HANDOFF", handoff)
+                monkeypatch.setenv("ROFT_LANES_WAIT_SKF", skf)
+                for kw in (dict(T=6), dict(splits=[3, 1, 8, 5, 2])):
+                    got = util.run_engine_logged(make_engine, dev, n, **kw)
+                    if ref is None:
+                        ref = got
+                        continue
+                    for x, y in zip(ref[0], got[0]):
+                        assert np.array_equal(x, y), (feat, handoff, skf, kw)
+                    for x, y in zip(ref[1], got[1]):
+                        assert np.array_equal(x, y), (feat, handoff, skf, kw)
+
+
 @pytest.mark.parametrize("shared", [False, True])
 def test_host_frames_that_are_consecutive_in_memory_go_up_in_one_copy(shared):
     """Round 6: a recorded sequence held as one [frames, H, W] host array -- frame t + 1 starts where frame t ends.  A batch's
