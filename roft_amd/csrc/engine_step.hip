@@ -179,7 +179,12 @@ int step_batch(roft_engine* e)
     const bool prep = multi && T > 1 && (prep_env == 2 || (prep_env == 3 && steady) || (prep_env == 1 && steady && !cus_to_spare)) && e->up_stream != s;
     hipStream_t sp0 = prep ? e->up_stream : s;
     if (multi && e->had_uploads && !prep) { HIP_TRY(hipStreamWaitEvent(s, e->ev_up[slot], 0)); ++evops; }   // (prep: same stream as the uploads)
-    if (prep && e->batch_counter >= 2) { HIP_TRY(hipStreamWaitEvent(sp0, e->ev_mask[(slot + R - 2) % R], 0)); ++evops; }
+    if (prep && e->batch_counter >= 2) {
+        HIP_TRY(hipStreamWaitEvent(sp0, e->ev_mask[(slot + R - 2) % R], 0));
+        ++evops;
+        // (... and for the feature kernel behind that mask chain, where there was one: it reads the control blocks of its batch)
+        if (e->feat_used[(slot + R - 2) % R]) { HIP_TRY(hipStreamWaitEvent(sp0, e->ev_feat[(slot + R - 2) % R], 0)); ++evops; }
+    }
     tmark(e, nullptr, prep ? 4 : 0);
     // Bursts and engines with CUs to spare (no preparation ahead): control blocks and the ingest of the delivered masks in ONE
     // launch -- on the mask stream they and the first mask frame were three dependent launches (27 - 35 us in front of the frame).
@@ -244,13 +249,16 @@ int step_batch(roft_engine* e)
     // mask stream's (round 6, 120 steps: 8 objects 3.46e5 -> 3.64e5, 16 objects 6.46e5 -> 6.62e5; 32 objects -4 %, 64 objects -7.5 %).
     const bool feat_on_vel = multi && T > 1 && !(e->feat_mask_mode == 2 || (e->feat_mask_mode == 1 && 16 * a.n_obj <= device_cu_count()));
     const bool want_ev_feat = multi && e->any_feat && !feat_on_vel && (T > 1 || e->any_feat_now);
-    e->feat_used[slot] = want_ev_feat;
+    // (a feature kernel on the mask stream always ends with ev_feat -- a stop event costs nothing --: wait_batch waits for it, and so
+    //  does a preparation ahead that rewrites the control blocks it reads; the LANES wait for it only when they need this batch's sets)
+    const bool rec_ev_feat = multi && e->any_feat && !feat_on_vel;
+    e->feat_used[slot] = rec_ev_feat;
     if (e->any_feat && !feat_on_vel) {
-        launch_features(a, s, (want_ev_feat && !full) ? e->ev_feat[slot] : nullptr, e->feat_frames);
+        launch_features(a, s, (rec_ev_feat && !full) ? e->ev_feat[slot] : nullptr, e->feat_frames);
         ++launches;
         CHECK_LAUNCH("features");
         tmark(e, "features", 0);
-        if (want_ev_feat && full) { HIP_TRY(hipEventRecord(e->ev_feat[slot], s)); ++evops; }
+        if (rec_ev_feat && full) { HIP_TRY(hipEventRecord(e->ev_feat[slot], s)); ++evops; }
     }
     HP_MARK(e, 4, hp_t);
 

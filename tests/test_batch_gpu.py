@@ -293,21 +293,24 @@ def test_where_the_feature_kernel_runs_and_what_the_lanes_wait_for_change_nothin
     n = 42
     dev = [util.to_device(st) for st in awkward_streams(n)]
     ref = None
-    for feat in ("0", "2"):
-        for handoff in ("0", "2"):
-            for skf in ("0", "1"):
-                monkeypatch.setenv("ROFT_FEAT_ON_MASK", feat)
-                monkeypatch.setenv("ROFT_HANDOFF", handoff)
-                monkeypatch.setenv("ROFT_LANES_WAIT_SKF", skf)
-                for kw in (dict(T=6), dict(splits=[3, 1, 8, 5, 2])):
-                    got = util.run_engine_logged(make_engine, dev, n, **kw)
-                    if ref is None:
-                        ref = got
-                        continue
-                    for x, y in zip(ref[0], got[0]):
-                        assert np.array_equal(x, y), (feat, handoff, skf, kw)
-                    for x, y in zip(ref[1], got[1]):
-                        assert np.array_equal(x, y), (feat, handoff, skf, kw)
+    combos = [(feat, handoff, skf, "1") for feat in ("0", "2") for handoff in ("0", "2") for skf in ("0", "1")]
+    # ... and with every batch prepared ahead on the upload stream, which rewrites the control blocks a feature kernel two batches back
+    # has read: behind the mask frames that kernel ends after the event the preparation used to wait for
+    combos += [("2", "0", "1", "2"), ("2", "2", "1", "2")]
+    for feat, handoff, skf, prep in combos:
+        monkeypatch.setenv("ROFT_FEAT_ON_MASK", feat)
+        monkeypatch.setenv("ROFT_HANDOFF", handoff)
+        monkeypatch.setenv("ROFT_LANES_WAIT_SKF", skf)
+        monkeypatch.setenv("ROFT_PREP_AHEAD", prep)
+        for kw in (dict(T=6), dict(splits=[3, 1, 8, 5, 2])):
+            got = util.run_engine_logged(make_engine, dev, n, **kw)
+            if ref is None:
+                ref = got
+                continue
+            for x, y in zip(ref[0], got[0]):
+                assert np.array_equal(x, y), (feat, handoff, skf, prep, kw)
+            for x, y in zip(ref[1], got[1]):
+                assert np.array_equal(x, y), (feat, handoff, skf, prep, kw)
 
 
 @pytest.mark.parametrize("shared", [False, True])
