@@ -7,13 +7,15 @@
 //  (1) Every cross-stream dependency of a batch is an EVENT recorded behind the producer (the stop event of its last kernel) and
 //      waited for by the consumer's stream before the consumer's first kernel: ev_up (HOST copies) -> mask / velocity stream;
 //      ev_prep (control blocks + ingest prepared on the upload stream) -> mask stream; ev_mask / ev_part (mask frames) -> velocity
-//      stream and the features kernel; ev_skf (velocity filter) | ev_vel (+ the features behind it) -> pose lanes; ev_done[lane] -> host (in-flight bound,
-//      roft_sync).  Events only point from work enqueued EARLIER to work enqueued later, batch by batch and chain by chain in the
+//      stream and the features kernel; ev_skf (velocity filter) | ev_vel (+ the features behind it) -> pose lanes; ev_feat (a feature
+//      kernel that ran on the MASK stream: one-frame submits, engines with few objects) -> the lanes whose tests read this batch's
+//      sets, the preparation ahead two batches on (it rewrites the control blocks that kernel reads), the host; ev_done[lane] -> host
+//      (in-flight bound, roft_sync).  Events only point from work enqueued EARLIER to work enqueued later, batch by batch and chain by chain in the
 //      fixed order of step_batch: the wait-for graph is acyclic by construction.
 //  (2) The only waits INSIDE kernels are the frame-granular hand-over (a pose lane's step waits for the tag of the twist it needs,
 //      k_ukf.hip ukf_one_step; the velocity filter publishes value then tag, k_skf.hip).  A lane kernel is released in one of
 //      three ways, each of which guarantees that what it waits for RUNS:
-//        (a) behind ev_vel: the velocity filter of the batch has ended -- nothing is waited for in the kernel;
+//        (a) behind ev_skf / ev_vel: the velocity filter of the batch has ended -- nothing is waited for in the kernel;
 //        (b) `handoff`: behind a hipStreamWaitValue64 on skf_started >= (all velocity-filter workgroups of the batch): every
 //            producer workgroup is RESIDENT on a CU when the lane starts, so the lane only waits for workgroups that run;
 //        (c) `early_lane`: behind the batch's control blocks only, while the producer may not even be enqueued.  Progress then
@@ -27,7 +29,7 @@
 //  (3) The outlier test's workgroups that share an alternative (k_render.hip) never wait for each other: each writes its slab,
 //      counts itself in and EXITS unless it is the last to arrive; the last one merges.  No co-residency is needed.
 //  (4) The mask frames hand over through kernel boundaries only (one launch per frame): no barrier among workgroups in memory.
-//  (5) The host blocks in exactly two places: roft_frames_submit on ev_done / ev_vel of batch b - lead (the in-flight bound that
+//  (5) The host blocks in exactly two places: roft_frames_submit on ev_done / ev_vel / ev_feat of batch b - lead (the in-flight bound that
 //      sizes every ring), and roft_sync.  Both wait for events of work already enqueued.
 #include "engine_internal.h"
 
